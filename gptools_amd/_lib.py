@@ -1,0 +1,279 @@
+"""ctypes binding of ``libgpt_hip.so`` (C ABI declared in ``include/gpt_hip.h``).
+
+This is the only route from the Python host code to the GPU.  There is no CPU fallback: if the
+shared library is missing or no HIP device is usable, every entry point raises.
+"""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpt_hip.so")
+
+GPT_OK = 0
+GPT_E_ARG, GPT_E_VALUE, GPT_E_NOTIMPL, GPT_E_HIP, GPT_E_NOMEM, GPT_E_STATE = -1, -2, -3, -4, -5, -6
+KERNEL_SE, KERNEL_M52, KERNEL_DIAGNOISE, KERNEL_ZERO = 0, 1, 2, 3
+MAX_DIM = 16
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+_i64 = C.c_int64
+
+# name -> (restype, argtypes); mirrors include/gpt_hip.h one to one
+SIGNATURES = {
+    "gpt_version": (C.c_int, []),
+    "gpt_last_error": (C.c_char_p, []),
+    "gpt_ctx_create": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
+    "gpt_ctx_destroy": (C.c_int, [_vp]),
+    "gpt_ctx_set_option": (C.c_int, [_vp, C.c_char_p, _i64]),
+    "gpt_ctx_synchronize": (C.c_int, [_vp]),
+    "gpt_ctx_stream": (_vp, [_vp]),
+    "gpt_kpairs": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, _dp, _ip, _ip, _i64, C.c_int, C.c_int, C.c_int, _ip, _dp]),
+    "gpt_kbuild": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, _ip, _i64, _dp, _ip, _i64, C.c_int, C.c_int, _ip, _dp]),
+    "gpt_set_data": (C.c_int, [_vp, _dp, _ip, _i64, C.c_int]),
+    "gpt_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, C.c_double, _dp, _dp]),
+    "gpt_fit_matrix": (C.c_int, [_vp, _dp, _i64, _dp, _dp, _dp]),
+    "gpt_get_L": (C.c_int, [_vp, _dp]),
+    "gpt_get_alpha": (C.c_int, [_vp, _dp]),
+    "gpt_predict": (C.c_int, [_vp, _dp, _ip, _i64, C.c_int, _dp, _ip, _dp, _dp, _dp]),
+    "gpt_solve_L": (C.c_int, [_vp, _dp, _i64]),
+    "gpt_cho_solve": (C.c_int, [_vp, _dp, _i64]),
+    "gpt_last_timings": (C.c_int, [_vp, _dp, C.c_int]),
+    "gpt_potrf_host": (C.c_int, [_vp, _dp, _i64]),
+    "gpt_gemm_nt_host": (C.c_int, [_vp, _i64, _i64, _i64, C.c_double, _dp, _dp, C.c_double, _dp]),
+    "gpt_dev_kbuild": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _vp, _i64, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int,
+                                 _ip, C.c_int, _i64, _i64, _vp, C.c_double, C.c_double, _vp, _i64]),
+    "gpt_dev_gemm_nt": (C.c_int, [_vp, _i64, _i64, _i64, C.c_double, _vp, _i64, _vp, _i64, C.c_double, _vp, _i64, C.c_int]),
+    "gpt_dev_potrf_panel": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64]),
+    "gpt_dev_potrf": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
+    "gpt_dev_trsm_rlt": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class GPTBackendError(RuntimeError):
+    """The HIP backend is missing or failed; there is deliberately no CPU fallback."""
+
+
+def build(verbose=False):
+    """Compile ``libgpt_hip.so`` for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise GPTBackendError("building libgpt_hip.so failed")
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library and declare every prototype; raises if it is absent."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise GPTBackendError(
+                    "%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(gptools_amd has no CPU fallback)" % LIB_PATH)
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)          # AttributeError if the export is missing
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().gpt_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    """Map a C status to the exception the reference would raise at the same place."""
+    if rc == GPT_OK:
+        return
+    msg = last_error()
+    if rc > 0:
+        raise np.linalg.LinAlgError(msg or "%d-th leading minor of the array is not positive definite" % rc)
+    if rc in (GPT_E_ARG, GPT_E_VALUE):
+        raise ValueError(msg)
+    if rc == GPT_E_NOTIMPL:
+        raise NotImplementedError(msg)
+    if rc == GPT_E_NOMEM:
+        raise MemoryError(msg)
+    raise GPTBackendError("libgpt_hip: %s (code %d)" % (msg, rc))
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+class Context(object):
+    """One GPU + stream; owns the device-resident X, n, K_tot/L, invd, alpha."""
+
+    def __init__(self, device=0, stream=None):
+        lib = load()
+        h = _vp()
+        check(lib.gpt_ctx_create(int(device), _vp(stream) if stream else None, C.byref(h)))
+        self._h = h
+        self._lib = lib
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gpt_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise GPTBackendError("context already destroyed")
+        return self._h
+
+    def set_option(self, key, value):
+        check(self._lib.gpt_ctx_set_option(self.handle, key.encode(), int(value)))
+
+    def synchronize(self):
+        check(self._lib.gpt_ctx_synchronize(self.handle))
+
+    @property
+    def stream(self):
+        return self._lib.gpt_ctx_stream(self.handle)
+
+    # ---- Kernel.__call__ / compute_Kij -------------------------------------------------------
+    def kpairs(self, kernel_id, params, Xi, Xj, ni, nj, hyper_deriv=None, symmetric=False, noise_n=None):
+        params, Xi, Xj, ni, nj = f64(params), f64(Xi), f64(Xj), i32(ni), i32(nj)
+        if Xi.ndim != 2 or Xi.shape != Xj.shape or ni.shape != Xi.shape or nj.shape != Xi.shape:
+            raise ValueError("Lengths/widths of Xi, Xj, ni, nj don't match")
+        M, D = Xi.shape
+        out = np.empty(M, dtype=np.float64)
+        nn = None if noise_n is None else i32(noise_n)
+        check(self._lib.gpt_kpairs(self.handle, kernel_id, dptr(params), len(params), dptr(Xi), dptr(Xj), iptr(ni),
+                                   iptr(nj), M, D, -1 if hyper_deriv is None else int(hyper_deriv),
+                                   int(bool(symmetric)), iptr(nn), dptr(out)))
+        return out
+
+    def kbuild(self, kernel_id, params, Xi, ni, Xj=None, nj=None, hyper_deriv=None, noise_n=None):
+        params, Xi, ni = f64(params), f64(Xi), i32(ni)
+        M, D = Xi.shape
+        if Xj is None:
+            Xj_, nj_, P = None, None, M
+        else:
+            Xj_, nj_ = f64(Xj), i32(nj)
+            P = Xj_.shape[0]
+        out = np.empty((M, P), dtype=np.float64)
+        nn = None if noise_n is None else i32(noise_n)
+        check(self._lib.gpt_kbuild(self.handle, kernel_id, dptr(params), len(params), dptr(Xi), iptr(ni), M,
+                                   dptr(Xj_), iptr(nj_), P, D, -1 if hyper_deriv is None else int(hyper_deriv),
+                                   iptr(nn), dptr(out)))
+        return out
+
+    # ---- fit / state ---------------------------------------------------------------------------
+    def set_data(self, X, n):
+        X, n = f64(X), i32(n)
+        check(self._lib.gpt_set_data(self.handle, dptr(X), iptr(n), X.shape[0], X.shape[1]))
+
+    def fit(self, kernel_id, params, noise_var, y, err_y, diag_add):
+        params, y, err_y = f64(params), f64(y), f64(err_y)
+        ll = C.c_double()
+        ld = C.c_double()
+        check(self._lib.gpt_fit(self.handle, kernel_id, dptr(params), len(params), float(noise_var), dptr(y),
+                                dptr(err_y), float(diag_add), C.byref(ll), C.byref(ld)))
+        return ll.value, ld.value
+
+    def fit_matrix(self, K_tot, y):
+        K_tot, y = f64(K_tot), f64(y)
+        ll = C.c_double()
+        ld = C.c_double()
+        check(self._lib.gpt_fit_matrix(self.handle, dptr(K_tot), K_tot.shape[0], dptr(y), C.byref(ll), C.byref(ld)))
+        return ll.value, ld.value
+
+    def get_L(self, N):
+        L = np.empty((N, N), dtype=np.float64)
+        check(self._lib.gpt_get_L(self.handle, dptr(L)))
+        return L
+
+    def get_alpha(self, N):
+        a = np.empty(N, dtype=np.float64)
+        check(self._lib.gpt_get_alpha(self.handle, dptr(a)))
+        return a
+
+    def predict(self, Xstar, nstar, want, noise_params=None, noise_n=None):
+        Xstar, nstar = f64(Xstar), i32(nstar)
+        M = Xstar.shape[0]
+        mean = np.empty(M)
+        std = np.empty(M) if want >= 1 else None
+        cov = np.empty((M, M)) if want == 2 else None
+        npar = None if noise_params is None else f64(noise_params)
+        nn = None if noise_n is None else i32(noise_n)
+        check(self._lib.gpt_predict(self.handle, dptr(Xstar), iptr(nstar), M, int(want), dptr(npar), iptr(nn),
+                                    dptr(mean), dptr(std), dptr(cov)))
+        return mean, std, cov
+
+    def solve_L(self, B):
+        B2 = np.array(B, dtype=np.float64, order="C")
+        shp = B2.shape
+        B2 = np.ascontiguousarray(B2.reshape(shp[0], -1))
+        check(self._lib.gpt_solve_L(self.handle, dptr(B2), B2.shape[1]))
+        return B2.reshape(shp)
+
+    def cho_solve(self, B):
+        B2 = np.array(B, dtype=np.float64, order="C")
+        shp = B2.shape
+        B2 = np.ascontiguousarray(B2.reshape(shp[0], -1))
+        check(self._lib.gpt_cho_solve(self.handle, dptr(B2), B2.shape[1]))
+        return B2.reshape(shp)
+
+    def last_timings(self):
+        out = np.zeros(5)
+        self._lib.gpt_last_timings(self.handle, dptr(out), 5)
+        return dict(upload=out[0], kbuild=out[1], potrf=out[2], tail=out[3], total=out[4])
+
+    def potrf_host(self, A):
+        L = np.array(A, dtype=np.float64, order="C")
+        check(self._lib.gpt_potrf_host(self.handle, dptr(L), L.shape[0]))
+        return L
+
+    def gemm_nt_host(self, alpha, A, B, beta, Cm):
+        A, B = f64(A), f64(B)
+        Cm = np.array(Cm, dtype=np.float64, order="C")
+        check(self._lib.gpt_gemm_nt_host(self.handle, A.shape[0], B.shape[0], A.shape[1], float(alpha), dptr(A),
+                                         dptr(B), float(beta), dptr(Cm)))
+        return Cm
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    """Process-wide lazily created context (one per device, re-created after fork)."""
+    key = (os.getpid(), int(device))
+    ctx = _default_ctx.get(key)
+    if ctx is None:
+        ctx = Context(device)
+        _default_ctx[key] = ctx
+    return ctx

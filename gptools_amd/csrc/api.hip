@@ -1,0 +1,880 @@
+// api.hip -- C ABI (include/gpt_hip.h) and host-side orchestration for libgpt_hip.so.
+//
+// Host logic restated here (not kernels): the blocked right-looking Cholesky with a recursive
+// panel and one-panel look-ahead on a second, high-priority HIP stream; the padded / augmented
+// matrix layout; GaussianProcess.compute_K_L_alpha_ll (ref: gptools/gaussian_process.py:1418-1469)
+// and GaussianProcess.predict (ref: gptools/gaussian_process.py:965-1006) sequencing.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+#include <new>
+#include <vector>
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void gpt_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *gpt_last_error(void) { return g_err; }
+extern "C" int gpt_version(void) { return 100; }
+
+#define GPT_TRY(expr)          \
+    do {                       \
+        int rc_ = (expr);      \
+        if (rc_ != GPT_OK) return rc_; \
+    } while (0)
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+enum { SLOT_XI = 0, SLOT_XJ, SLOT_NI, SLOT_NJ, SLOT_OUT, SLOT_KST, SLOT_KSS, SLOT_XS, SLOT_NS, SLOT_VEC, SLOT_VEC2,
+       SLOT_RHS, SLOT_LOW, SLOT_COUNT };
+
+struct gpt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipStream_t panel_stream = nullptr;
+    std::vector<hipEvent_t> events;       // sync-only events (look-ahead fork/join)
+    hipEvent_t tev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // options
+    int64_t nb_outer = 256;
+    int lookahead = 1;
+    int use_graph = 0;
+    int timing = 0;
+    int tile = 0;
+    // resident training inputs
+    int64_t N = 0;
+    int D = 0;
+    double *dX = nullptr;
+    int32_t *dn = nullptr;
+    // factorisation state
+    int64_t NP = 0;            // padded order (multiple of 128, > N)
+    double *dA = nullptr;      // NP x NP, row-major, lower triangle meaningful
+    double *d_invd = nullptr;  // (NP/16) x 16 x 16
+    int32_t *d_info = nullptr;
+    double *d_y = nullptr, *d_erry = nullptr, *d_scal = nullptr, *d_alpha = nullptr;
+    double *h_scal = nullptr;  // pinned
+    int32_t *h_info = nullptr; // pinned
+    bool factored = false, alpha_valid = false, have_kernel = false;
+    KParams kp;
+    double timings[5] = {0, 0, 0, 0, 0};
+    // graph cache for the factorisation
+    hipGraphExec_t gexec = nullptr;
+    int64_t g_n = 0, g_nb = 0;
+    int g_la = 0;
+    double *g_A = nullptr;
+    DevBuf slots[SLOT_COUNT];
+};
+
+static int ensure(gpt_ctx *c, int slot, size_t bytes, void **out)
+{
+    DevBuf &b = c->slots[slot];
+    if (b.cap < bytes) {
+        if (b.p) GPT_HIP_CHECK(hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+        const size_t want = bytes + bytes / 8 + 256;
+        GPT_HIP_CHECK(hipMalloc(&b.p, want));
+        b.cap = want;
+    }
+    *out = b.p;
+    return GPT_OK;
+}
+
+static hipEvent_t get_event(gpt_ctx *c, size_t idx)
+{
+    while (c->events.size() <= idx) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        c->events.push_back(e);
+    }
+    return c->events[idx];
+}
+
+// ------------------------------------------------------------------------------------------------
+static int make_kparams(int kernel_id, const double *params, int nparams, int D, int hyper_deriv, int symmetric,
+                        const int32_t *noise_n, KParams *kp)
+{
+    if (D < 1 || D > GPT_MAX_DIM) {
+        gpt_set_error("num_dim %d out of range [1, %d]", D, GPT_MAX_DIM);
+        return GPT_E_ARG;
+    }
+    memset(kp, 0, sizeof(*kp));
+    kp->kernel_id = kernel_id;
+    kp->D = D;
+    kp->hyper_deriv = hyper_deriv < 0 ? -1 : hyper_deriv;
+    kp->symmetric = symmetric ? 1 : 0;
+    if (kernel_id == GPT_KERNEL_SE || kernel_id == GPT_KERNEL_M52) {
+        if (nparams != D + 1) {
+            gpt_set_error("kernel %d expects %d params, got %d", kernel_id, D + 1, nparams);
+            return GPT_E_ARG;
+        }
+        if (kernel_id == GPT_KERNEL_M52 && hyper_deriv >= 0) {
+            gpt_set_error("Hyperparameter derivatives have not been implemented!");
+            return GPT_E_NOTIMPL;
+        }
+        if (hyper_deriv >= nparams) {
+            gpt_set_error("hyper_deriv %d out of range", hyper_deriv);
+            return GPT_E_ARG;
+        }
+        kp->sigma = params[0];
+        for (int d = 0; d < D; d++) {
+            const double l = params[1 + d];
+            kp->l[d] = l;
+            kp->inv_l[d] = 1.0 / l;
+            kp->inv_var[d] = 1.0 / (l * l);
+        }
+    } else if (kernel_id == GPT_KERNEL_DIAGNOISE || kernel_id == GPT_KERNEL_ZERO) {
+        if (nparams != 1) {
+            gpt_set_error("noise kernels expect 1 param, got %d", nparams);
+            return GPT_E_ARG;
+        }
+        if (hyper_deriv > 0) {
+            gpt_set_error("hyper_deriv %d out of range", hyper_deriv);
+            return GPT_E_ARG;
+        }
+        kp->sigma = params[0];
+        for (int d = 0; d < D; d++) kp->noise_n[d] = noise_n ? noise_n[d] : 0;
+    } else {
+        gpt_set_error("unknown kernel_id %d", kernel_id);
+        return GPT_E_ARG;
+    }
+    return GPT_OK;
+}
+
+// Matern52 accepts only derivative orders summing to <= 1 per point (ref: kernel/matern.py:545-546).
+static int check_m52_orders(const int32_t *n, int64_t M, int D)
+{
+    for (int64_t i = 0; i < M; i++) {
+        long s = 0;
+        for (int d = 0; d < D; d++) s += n[i * D + d];
+        if (s > 1) {
+            gpt_set_error("Matern52Kernel only supports 0th and 1st order derivatives");
+            return GPT_E_VALUE;
+        }
+    }
+    return GPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense drivers on device data
+// ------------------------------------------------------------------------------------------------
+static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A,
+                   int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri)
+{
+    return launch_gemm_nt(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, c->tile);
+}
+
+// Factor the block column Ap (m x w, diag block on top): recursive halving down to 128 columns.
+static int panel_rec(gpt_ctx *c, hipStream_t st, double *Ap, int64_t lda, int64_t m, int64_t w, double *invd,
+                     int32_t *info, int64_t base)
+{
+    if (w == 128) {
+        GPT_TRY(launch_potf2_diag(st, Ap, lda, invd, info, base));
+        return launch_trsm_panel(st, m - 128, Ap, lda, invd, Ap + 128 * lda, lda);
+    }
+    const int64_t h = (w / 256) * 128 > 0 ? (w / 256) * 128 : 128;
+    GPT_TRY(panel_rec(c, st, Ap, lda, m, h, invd, info, base));
+    GPT_TRY(gemm_nt(c, st, m - h, w - h, h, -1.0, Ap + h * lda, lda, Ap + h * lda, lda, 1.0, Ap + h * lda + h, lda, 1));
+    return panel_rec(c, st, Ap + h * lda + h, lda, m - h, w - h, invd + (h / 16) * 256, info, base + h);
+}
+
+static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *invd, int32_t *info)
+{
+    if (n % 128) {
+        gpt_set_error("potrf: n must be a multiple of 128 (n=%lld)", (long long)n);
+        return GPT_E_ARG;
+    }
+    const int64_t nbo = c->nb_outer;
+    const int64_t nblk = (n + nbo - 1) / nbo;
+    hipStream_t S = c->stream, P = c->panel_stream;
+    const bool la = c->lookahead && nblk > 1;
+    if (!la) {
+        for (int64_t k = 0; k < nblk; k++) {
+            const int64_t c0 = k * nbo, w = (n - c0 < nbo) ? n - c0 : nbo, m = n - c0;
+            GPT_TRY(panel_rec(c, S, A + c0 * lda + c0, lda, m, w, invd + (c0 / 16) * 256, info, c0));
+            const int64_t r0 = c0 + w;
+            if (r0 < n)
+                GPT_TRY(gemm_nt(c, S, n - r0, n - r0, w, -1.0, A + r0 * lda + c0, lda, A + r0 * lda + c0, lda, 1.0,
+                                A + r0 * lda + r0, lda, 1));
+        }
+        return GPT_OK;
+    }
+    // ---- look-ahead: panel k+1 is factored on P while S applies panel k to the rest ----
+    hipEvent_t e_start = get_event(c, 0);
+    if (!e_start) return GPT_E_HIP;
+    GPT_HIP_CHECK(hipEventRecord(e_start, S));
+    GPT_HIP_CHECK(hipStreamWaitEvent(P, e_start, 0));
+    {
+        const int64_t w = (n < nbo) ? n : nbo;
+        GPT_TRY(panel_rec(c, P, A, lda, n, w, invd, info, 0));
+    }
+    hipEvent_t e_panel = get_event(c, 1);
+    GPT_HIP_CHECK(hipEventRecord(e_panel, P));
+    for (int64_t k = 0; k + 1 < nblk; k++) {
+        const int64_t c0 = k * nbo, w = nbo;
+        const int64_t n0 = c0 + w;                                   // first column of block k+1
+        const int64_t w1 = (n - n0 < nbo) ? n - n0 : nbo;
+        const int64_t r0 = n0 + w1;                                   // first column after block k+1
+        // P: bring block column k+1 up to date with panel k, then factor it
+        if (k > 0) {
+            hipEvent_t e_upd_prev = get_event(c, 2 + 2 * (k - 1) + 1);
+            GPT_HIP_CHECK(hipStreamWaitEvent(P, e_upd_prev, 0));
+        }
+        GPT_TRY(gemm_nt(c, P, n - n0, w1, w, -1.0, A + n0 * lda + c0, lda, A + n0 * lda + c0, lda, 1.0,
+                        A + n0 * lda + n0, lda, 1));
+        // S: apply panel k to everything right of block k+1
+        GPT_HIP_CHECK(hipStreamWaitEvent(S, e_panel, 0));
+        if (r0 < n)
+            GPT_TRY(gemm_nt(c, S, n - r0, n - r0, w, -1.0, A + r0 * lda + c0, lda, A + r0 * lda + c0, lda, 1.0,
+                            A + r0 * lda + r0, lda, 1));
+        hipEvent_t e_upd = get_event(c, 2 + 2 * k + 1);
+        GPT_HIP_CHECK(hipEventRecord(e_upd, S));
+        GPT_TRY(panel_rec(c, P, A + n0 * lda + n0, lda, n - n0, w1, invd + (n0 / 16) * 256, info, n0));
+        e_panel = get_event(c, 2 + 2 * (k + 1));
+        GPT_HIP_CHECK(hipEventRecord(e_panel, P));
+    }
+    GPT_HIP_CHECK(hipStreamWaitEvent(S, e_panel, 0));
+    return GPT_OK;
+}
+
+static int potrf_run(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *invd, int32_t *info)
+{
+    if (!c->use_graph) return potrf_enqueue(c, n, A, lda, invd, info);
+    if (c->gexec && (c->g_n != n || c->g_nb != c->nb_outer || c->g_la != c->lookahead || c->g_A != A)) {
+        hipGraphExecDestroy(c->gexec);
+        c->gexec = nullptr;
+    }
+    if (!c->gexec) {
+        hipGraph_t graph = nullptr;
+        GPT_HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+        int rc = potrf_enqueue(c, n, A, lda, invd, info);
+        hipError_t e = hipStreamEndCapture(c->stream, &graph);
+        if (rc != GPT_OK) {
+            if (graph) hipGraphDestroy(graph);
+            return rc;
+        }
+        GPT_HIP_CHECK(e);
+        GPT_HIP_CHECK(hipGraphInstantiate(&c->gexec, graph, nullptr, nullptr, 0));
+        hipGraphDestroy(graph);
+        c->g_n = n;
+        c->g_nb = c->nb_outer;
+        c->g_la = c->lookahead;
+        c->g_A = A;
+    }
+    GPT_HIP_CHECK(hipGraphLaunch(c->gexec, c->stream));
+    return GPT_OK;
+}
+
+// B (m x n) <- B L^-T, n a multiple of 128
+static int trsm_rlt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, const double *L, int64_t ldl, const double *invd,
+                    double *B, int64_t ldb)
+{
+    if (n == 128) return launch_trsm_panel(st, m, L, ldl, invd, B, ldb);
+    const int64_t h = (n / 256) * 128 > 0 ? (n / 256) * 128 : 128;
+    GPT_TRY(trsm_rlt(c, st, m, h, L, ldl, invd, B, ldb));
+    GPT_TRY(gemm_nt(c, st, m, n - h, h, -1.0, B, ldb, L + h * ldl, ldl, 1.0, B + h, ldb, 0));
+    return trsm_rlt(c, st, m, n - h, L + h * ldl + h, ldl, invd + (h / 16) * 256, B + h, ldb);
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+extern "C" int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out)
+{
+    if (!out) return GPT_E_ARG;
+    int ndev = 0;
+    GPT_HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0 || device_id < 0 || device_id >= ndev) {
+        gpt_set_error("no such HIP device %d (count %d)", device_id, ndev);
+        return GPT_E_HIP;
+    }
+    GPT_HIP_CHECK(hipSetDevice(device_id));
+    gpt_ctx *c = new (std::nothrow) gpt_ctx();
+    if (!c) return GPT_E_NOMEM;
+    c->device = device_id;
+    int lo = 0, hi = 0;
+    GPT_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        GPT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    GPT_HIP_CHECK(hipStreamCreateWithPriority(&c->panel_stream, hipStreamNonBlocking, hi));
+    for (int i = 0; i < 5; i++) GPT_HIP_CHECK(hipEventCreate(&c->tev[i]));
+    GPT_HIP_CHECK(hipMalloc(&c->d_info, sizeof(int32_t)));
+    GPT_HIP_CHECK(hipMalloc(&c->d_scal, 4 * sizeof(double)));
+    GPT_HIP_CHECK(hipHostMalloc((void **)&c->h_scal, 4 * sizeof(double), hipHostMallocDefault));
+    GPT_HIP_CHECK(hipHostMalloc((void **)&c->h_info, sizeof(int32_t), hipHostMallocDefault));
+    *out = c;
+    return GPT_OK;
+}
+
+static void free_factor(gpt_ctx *c)
+{
+    if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+    if (c->dA) hipFree(c->dA);
+    if (c->d_invd) hipFree(c->d_invd);
+    if (c->d_y) hipFree(c->d_y);
+    if (c->d_erry) hipFree(c->d_erry);
+    if (c->d_alpha) hipFree(c->d_alpha);
+    c->dA = c->d_invd = c->d_y = c->d_erry = c->d_alpha = nullptr;
+    c->NP = 0;
+    c->factored = c->alpha_valid = false;
+}
+
+extern "C" int gpt_ctx_destroy(gpt_ctx *c)
+{
+    if (!c) return GPT_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->panel_stream);
+    free_factor(c);
+    if (c->dX) hipFree(c->dX);
+    if (c->dn) hipFree(c->dn);
+    for (auto &b : c->slots)
+        if (b.p) hipFree(b.p);
+    for (auto e : c->events) hipEventDestroy(e);
+    for (int i = 0; i < 5; i++)
+        if (c->tev[i]) hipEventDestroy(c->tev[i]);
+    if (c->d_info) hipFree(c->d_info);
+    if (c->d_scal) hipFree(c->d_scal);
+    if (c->h_scal) hipHostFree(c->h_scal);
+    if (c->h_info) hipHostFree(c->h_info);
+    hipStreamDestroy(c->panel_stream);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+    return GPT_OK;
+}
+
+extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
+{
+    if (!c || !key) return GPT_E_ARG;
+    if (!strcmp(key, "nb_outer")) {
+        if (value < 128 || value % 128) {
+            gpt_set_error("nb_outer must be a positive multiple of 128");
+            return GPT_E_ARG;
+        }
+        c->nb_outer = value;
+    } else if (!strcmp(key, "lookahead")) c->lookahead = value ? 1 : 0;
+    else if (!strcmp(key, "graph")) c->use_graph = value ? 1 : 0;
+    else if (!strcmp(key, "timing")) c->timing = value ? 1 : 0;
+    else if (!strcmp(key, "tile")) {
+        if (value != 0 && value != 64 && value != 128) {
+            gpt_set_error("tile must be 0, 64 or 128");
+            return GPT_E_ARG;
+        }
+        c->tile = (int)value;
+    } else {
+        gpt_set_error("unknown option '%s'", key);
+        return GPT_E_ARG;
+    }
+    return GPT_OK;
+}
+
+extern "C" int gpt_ctx_synchronize(gpt_ctx *c)
+{
+    if (!c) return GPT_E_ARG;
+    GPT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GPT_OK;
+}
+
+extern "C" void *gpt_ctx_stream(gpt_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+#define CTX_ENTER(c)                          \
+    do {                                      \
+        if (!(c)) {                           \
+            gpt_set_error("null context");    \
+            return GPT_E_ARG;                 \
+        }                                     \
+        GPT_HIP_CHECK(hipSetDevice((c)->device)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Kernel.__call__ / compute_Kij
+// ------------------------------------------------------------------------------------------------
+extern "C" int gpt_kpairs(gpt_ctx *c, int kernel_id, const double *params, int nparams, const double *Xi,
+                          const double *Xj, const int32_t *ni, const int32_t *nj, int64_t M, int D,
+                          int hyper_deriv, int symmetric, const int32_t *noise_n, double *out)
+{
+    CTX_ENTER(c);
+    if (M < 0 || !params || (M > 0 && (!Xi || !Xj || !ni || !nj || !out))) return GPT_E_ARG;
+    KParams kp;
+    GPT_TRY(make_kparams(kernel_id, params, nparams, D, hyper_deriv, symmetric, noise_n, &kp));
+    if (kernel_id == GPT_KERNEL_M52) {
+        GPT_TRY(check_m52_orders(ni, M, D));
+        GPT_TRY(check_m52_orders(nj, M, D));
+    }
+    if (M == 0) return GPT_OK;
+    double *dXi, *dXj, *dout;
+    int32_t *dni, *dnj;
+    const size_t xb = (size_t)M * D * sizeof(double), nb = (size_t)M * D * sizeof(int32_t);
+    GPT_TRY(ensure(c, SLOT_XI, xb, (void **)&dXi));
+    GPT_TRY(ensure(c, SLOT_XJ, xb, (void **)&dXj));
+    GPT_TRY(ensure(c, SLOT_NI, nb, (void **)&dni));
+    GPT_TRY(ensure(c, SLOT_NJ, nb, (void **)&dnj));
+    GPT_TRY(ensure(c, SLOT_OUT, (size_t)M * sizeof(double), (void **)&dout));
+    hipStream_t st = c->stream;
+    GPT_HIP_CHECK(hipMemcpyAsync(dXi, Xi, xb, hipMemcpyHostToDevice, st));
+    GPT_HIP_CHECK(hipMemcpyAsync(dXj, Xj, xb, hipMemcpyHostToDevice, st));
+    GPT_HIP_CHECK(hipMemcpyAsync(dni, ni, nb, hipMemcpyHostToDevice, st));
+    GPT_HIP_CHECK(hipMemcpyAsync(dnj, nj, nb, hipMemcpyHostToDevice, st));
+    GPT_TRY(launch_kpairs(st, kp, dXi, dXj, dni, dnj, M, dout));
+    GPT_HIP_CHECK(hipMemcpyAsync(out, dout, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, st));
+    GPT_HIP_CHECK(hipStreamSynchronize(st));
+    return GPT_OK;
+}
+
+extern "C" int gpt_kbuild(gpt_ctx *c, int kernel_id, const double *params, int nparams, const double *Xi,
+                          const int32_t *ni, int64_t M, const double *Xj, const int32_t *nj, int64_t P, int D,
+                          int hyper_deriv, const int32_t *noise_n, double *K_out)
+{
+    CTX_ENTER(c);
+    const int symmetric = (Xj == nullptr);
+    if (symmetric) {
+        Xj = Xi;
+        nj = ni;
+        P = M;
+    }
+    if (M < 0 || P < 0 || !params) return GPT_E_ARG;
+    KParams kp;
+    GPT_TRY(make_kparams(kernel_id, params, nparams, D, hyper_deriv, symmetric, noise_n, &kp));
+    if (kernel_id == GPT_KERNEL_M52) {
+        GPT_TRY(check_m52_orders(ni, M, D));
+        GPT_TRY(check_m52_orders(nj, P, D));
+    }
+    if (M == 0 || P == 0) return GPT_OK;
+    if (!Xi || !ni || !Xj || !nj || !K_out) return GPT_E_ARG;
+    double *dXi, *dXj, *dK;
+    int32_t *dni, *dnj;
+    GPT_TRY(ensure(c, SLOT_XI, (size_t)M * D * sizeof(double), (void **)&dXi));
+    GPT_TRY(ensure(c, SLOT_NI, (size_t)M * D * sizeof(int32_t), (void **)&dni));
+    GPT_TRY(ensure(c, SLOT_XJ, (size_t)P * D * sizeof(double), (void **)&dXj));
+    GPT_TRY(ensure(c, SLOT_NJ, (size_t)P * D * sizeof(int32_t), (void **)&dnj));
+    GPT_TRY(ensure(c, SLOT_OUT, (size_t)M * P * sizeof(double), (void **)&dK));
+    hipStream_t st = c->stream;
+    GPT_HIP_CHECK(hipMemcpyAsync(dXi, Xi, (size_t)M * D * sizeof(double), hipMemcpyHostToDevice, st));
+    GPT_HIP_CHECK(hipMemcpyAsync(dni, ni, (size_t)M * D * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    GPT_HIP_CHECK(hipMemcpyAsync(dXj, Xj, (size_t)P * D * sizeof(double), hipMemcpyHostToDevice, st));
+    GPT_HIP_CHECK(hipMemcpyAsync(dnj, nj, (size_t)P * D * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    GPT_TRY(launch_kbuild(st, kp, dXi, dni, M, dXj, dnj, P, 0, 0, 0, nullptr, 0.0, 0.0, dK, P));
+    GPT_HIP_CHECK(hipMemcpyAsync(K_out, dK, (size_t)M * P * sizeof(double), hipMemcpyDeviceToHost, st));
+    GPT_HIP_CHECK(hipStreamSynchronize(st));
+    return GPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// data residency + fit
+// ------------------------------------------------------------------------------------------------
+extern "C" int gpt_set_data(gpt_ctx *c, const double *X, const int32_t *n, int64_t N, int D)
+{
+    CTX_ENTER(c);
+    if (N <= 0 || !X || !n || D < 1 || D > GPT_MAX_DIM) {
+        gpt_set_error("set_data: bad arguments (N=%lld, D=%d)", (long long)N, D);
+        return GPT_E_ARG;
+    }
+    GPT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->dX) hipFree(c->dX);
+    if (c->dn) hipFree(c->dn);
+    c->dX = nullptr;
+    c->dn = nullptr;
+    GPT_HIP_CHECK(hipMalloc(&c->dX, (size_t)N * D * sizeof(double)));
+    GPT_HIP_CHECK(hipMalloc(&c->dn, (size_t)N * D * sizeof(int32_t)));
+    GPT_HIP_CHECK(hipMemcpyAsync(c->dX, X, (size_t)N * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    GPT_HIP_CHECK(hipMemcpyAsync(c->dn, n, (size_t)N * D * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    GPT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->N = N;
+    c->D = D;
+    c->factored = false;
+    c->alpha_valid = false;
+    c->have_kernel = false;
+    return GPT_OK;
+}
+
+static int ensure_factor_storage(gpt_ctx *c, int64_t N)
+{
+    const int64_t NP = round_up(N + 1, 128);
+    if (c->NP == NP && c->dA) return GPT_OK;
+    GPT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    free_factor(c);
+    GPT_HIP_CHECK(hipMalloc(&c->dA, (size_t)NP * NP * sizeof(double)));
+    GPT_HIP_CHECK(hipMalloc(&c->d_invd, (size_t)(NP / 16) * 256 * sizeof(double)));
+    GPT_HIP_CHECK(hipMalloc(&c->d_y, (size_t)NP * sizeof(double)));
+    GPT_HIP_CHECK(hipMalloc(&c->d_erry, (size_t)NP * sizeof(double)));
+    GPT_HIP_CHECK(hipMalloc(&c->d_alpha, (size_t)NP * sizeof(double)));
+    c->NP = NP;
+    return GPT_OK;
+}
+
+// Factor the (already assembled, lower) N x N matrix in dA, with y in d_y; produce ll terms.
+static int factor_and_ll(gpt_ctx *c, int64_t N, double *ll_data_out, double *logdet_half_out)
+{
+    hipStream_t st = c->stream;
+    const int64_t NP = c->NP;
+    GPT_HIP_CHECK(hipMemsetAsync(c->d_info, 0, sizeof(int32_t), st));
+    GPT_TRY(launch_fill_pad(st, c->dA, NP, N, NP, c->d_y, 1e300));
+    if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[2], st));
+    GPT_TRY(potrf_run(c, NP, c->dA, NP, c->d_invd, c->d_info));
+    if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[3], st));
+    GPT_TRY(launch_logdet_dot(st, c->dA, NP, N, c->d_scal));
+    GPT_HIP_CHECK(hipMemcpyAsync(c->h_scal, c->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    GPT_HIP_CHECK(hipMemcpyAsync(c->h_info, c->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[4], st));
+    GPT_HIP_CHECK(hipStreamSynchronize(st));
+    if (c->timing) {
+        float ms = 0;
+        for (int i = 0; i < 4; i++) {
+            hipEventElapsedTime(&ms, c->tev[i], c->tev[i + 1]);
+            c->timings[i] = ms;
+        }
+        hipEventElapsedTime(&ms, c->tev[0], c->tev[4]);
+        c->timings[4] = ms;
+    }
+    c->alpha_valid = false;
+    const int32_t info = *c->h_info;
+    if (info != 0) {
+        c->factored = false;
+        if (info > N) {          // only the augmented / padding pivots failed: z.z overflowed
+            gpt_set_error("factorisation failed in the augmented row (non-finite data?)");
+            return (int)N;
+        }
+        gpt_set_error("%d-th leading minor of the array is not positive definite", (int)info);
+        return (int)info;
+    }
+    c->factored = true;
+    const double logdet_half = c->h_scal[0], zz = c->h_scal[1];
+    if (logdet_half_out) *logdet_half_out = logdet_half;
+    if (ll_data_out) *ll_data_out = -0.5 * zz - logdet_half - 0.5 * (double)N * log(2.0 * M_PI);
+    return GPT_OK;
+}
+
+extern "C" int gpt_fit(gpt_ctx *c, int kernel_id, const double *params, int nparams, double noise_var,
+                       const double *y, const double *err_y, double diag_add, double *ll_data_out,
+                       double *logdet_half_out)
+{
+    CTX_ENTER(c);
+    if (!c->dX) {
+        gpt_set_error("gpt_fit: call gpt_set_data first");
+        return GPT_E_STATE;
+    }
+    if (!params || !y || !err_y) return GPT_E_ARG;
+    if (kernel_id != GPT_KERNEL_SE && kernel_id != GPT_KERNEL_M52) {
+        gpt_set_error("gpt_fit: kernel_id must be SE or Matern52");
+        return GPT_E_ARG;
+    }
+    const int64_t N = c->N;
+    KParams kp;
+    GPT_TRY(make_kparams(kernel_id, params, nparams, c->D, -1, 1, nullptr, &kp));
+    GPT_TRY(ensure_factor_storage(c, N));
+    hipStream_t st = c->stream;
+    c->factored = false;
+    if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[0], st));
+    GPT_HIP_CHECK(hipMemcpyAsync(c->d_y, y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, st));
+    GPT_HIP_CHECK(hipMemcpyAsync(c->d_erry, err_y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, st));
+    if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[1], st));
+    GPT_TRY(launch_kbuild(st, kp, c->dX, c->dn, N, c->dX, c->dn, N, 1, 0, 0, c->d_erry, noise_var, diag_add, c->dA,
+                          c->NP));
+    c->kp = kp;
+    c->have_kernel = true;
+    return factor_and_ll(c, N, ll_data_out, logdet_half_out);
+}
+
+extern "C" int gpt_fit_matrix(gpt_ctx *c, const double *K_tot, int64_t N, const double *y, double *ll_data_out,
+                              double *logdet_half_out)
+{
+    CTX_ENTER(c);
+    if (!K_tot || !y || N <= 0) return GPT_E_ARG;
+    GPT_TRY(ensure_factor_storage(c, N));
+    hipStream_t st = c->stream;
+    c->factored = false;
+    c->have_kernel = false;
+    c->N = N;
+    if (c->timing) {
+        GPT_HIP_CHECK(hipEventRecord(c->tev[0], st));
+        GPT_HIP_CHECK(hipEventRecord(c->tev[1], st));
+    }
+    GPT_HIP_CHECK(hipMemcpyAsync(c->d_y, y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, st));
+    GPT_HIP_CHECK(hipMemcpy2DAsync(c->dA, (size_t)c->NP * sizeof(double), K_tot, (size_t)N * sizeof(double),
+                                   (size_t)N * sizeof(double), (size_t)N, hipMemcpyHostToDevice, st));
+    return factor_and_ll(c, N, ll_data_out, logdet_half_out);
+}
+
+extern "C" int gpt_last_timings(gpt_ctx *c, double *out_ms, int n)
+{
+    if (!c || !out_ms) return GPT_E_ARG;
+    const int cnt = n < 5 ? n : 5;
+    for (int i = 0; i < cnt; i++) out_ms[i] = c->timings[i];
+    return cnt;
+}
+
+#define NEED_FACTOR(c)                                                        \
+    do {                                                                      \
+        if (!(c)->factored) {                                                 \
+            gpt_set_error("no valid factorisation resident (call gpt_fit)");  \
+            return GPT_E_STATE;                                               \
+        }                                                                     \
+    } while (0)
+
+extern "C" int gpt_get_L(gpt_ctx *c, double *L_out)
+{
+    CTX_ENTER(c);
+    NEED_FACTOR(c);
+    if (!L_out) return GPT_E_ARG;
+    const int64_t N = c->N;
+    double *dlow;
+    GPT_TRY(ensure(c, SLOT_LOW, (size_t)N * N * sizeof(double), (void **)&dlow));
+    GPT_TRY(launch_extract_lower(c->stream, c->dA, c->NP, N, dlow, N));
+    GPT_HIP_CHECK(hipMemcpyAsync(L_out, dlow, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    GPT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GPT_OK;
+}
+
+// alpha = L^-T z with z = the augmented row (z = L^-1 y)
+static int ensure_alpha(gpt_ctx *c)
+{
+    if (c->alpha_valid) return GPT_OK;
+    const int64_t N = c->N, n128 = round_up(N, 128);
+    hipStream_t st = c->stream;
+    GPT_HIP_CHECK(hipMemsetAsync(c->d_alpha, 0, (size_t)c->NP * sizeof(double), st));
+    GPT_HIP_CHECK(hipMemcpyAsync(c->d_alpha, c->dA + N * c->NP, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, st));
+    GPT_TRY(launch_trsv_lt(st, n128, c->dA, c->NP, c->d_invd, c->d_alpha));
+    c->alpha_valid = true;
+    return GPT_OK;
+}
+
+extern "C" int gpt_get_alpha(gpt_ctx *c, double *alpha_out)
+{
+    CTX_ENTER(c);
+    NEED_FACTOR(c);
+    if (!alpha_out) return GPT_E_ARG;
+    GPT_TRY(ensure_alpha(c));
+    GPT_HIP_CHECK(hipMemcpyAsync(alpha_out, c->d_alpha, (size_t)c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    GPT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// predict
+// ------------------------------------------------------------------------------------------------
+extern "C" int gpt_predict(gpt_ctx *c, const double *Xstar, const int32_t *nstar, int64_t M, int want,
+                           const double *noise_params, const int32_t *noise_n, double *mean_out, double *std_out,
+                           double *cov_out)
+{
+    CTX_ENTER(c);
+    NEED_FACTOR(c);
+    if (!c->have_kernel) {
+        gpt_set_error("gpt_predict needs a factorisation produced by gpt_fit");
+        return GPT_E_STATE;
+    }
+    if (M <= 0 || !Xstar || !nstar || !mean_out || want < 0 || want > 2 || (want == 1 && !std_out) ||
+        (want == 2 && !cov_out)) {
+        gpt_set_error("gpt_predict: bad arguments");
+        return GPT_E_ARG;
+    }
+    if (M > 65535 * 32) return GPT_E_ARG;
+    const int D = c->D;
+    const int64_t N = c->N, NP = c->NP, n128 = round_up(N, 128), MP = round_up(M, 64);
+    if (c->kp.kernel_id == GPT_KERNEL_M52) GPT_TRY(check_m52_orders(nstar, M, D));
+    hipStream_t st = c->stream;
+    double *dXs, *dKst, *dmean;
+    int32_t *dns;
+    GPT_TRY(ensure(c, SLOT_XS, (size_t)M * D * sizeof(double), (void **)&dXs));
+    GPT_TRY(ensure(c, SLOT_NS, (size_t)M * D * sizeof(int32_t), (void **)&dns));
+    GPT_TRY(ensure(c, SLOT_KST, (size_t)MP * n128 * sizeof(double), (void **)&dKst));
+    GPT_TRY(ensure(c, SLOT_VEC, (size_t)MP * 2 * sizeof(double), (void **)&dmean));
+    double *dvar = dmean + MP;
+    GPT_HIP_CHECK(hipMemcpyAsync(dXs, Xstar, (size_t)M * D * sizeof(double), hipMemcpyHostToDevice, st));
+    GPT_HIP_CHECK(hipMemcpyAsync(dns, nstar, (size_t)M * D * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    KParams kp = c->kp;
+    kp.symmetric = 0;
+    kp.hyper_deriv = -1;
+    // Kstar^T: row a = test point a, column i = training point i  (k is symmetric under swapping its
+    // two (point, derivative-order) arguments, so this equals Kstar[i][a] of ref :966)
+    GPT_TRY(launch_zero2d(st, MP, n128, dKst, n128));
+    GPT_TRY(launch_kbuild(st, kp, dXs, dns, M, c->dX, c->dn, N, 0, 0, 0, nullptr, 0.0, 0.0, dKst, n128));
+    GPT_TRY(ensure_alpha(c));
+    GPT_TRY(launch_gemv_n(st, M, N, dKst, n128, c->d_alpha, dmean));
+    GPT_HIP_CHECK(hipMemcpyAsync(mean_out, dmean, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (want >= 1) {
+        GPT_TRY(trsm_rlt(c, st, MP, n128, c->dA, NP, c->d_invd, dKst, n128));     // V' = Kstar^T L^-T
+        KParams kn;
+        if (noise_params) GPT_TRY(make_kparams(GPT_KERNEL_DIAGNOISE, noise_params, 1, D, -1, 1, noise_n, &kn));
+        if (want == 1) {
+            double *dkd;
+            GPT_TRY(ensure(c, SLOT_VEC2, (size_t)M * sizeof(double), (void **)&dkd));
+            KParams ks = c->kp;
+            ks.symmetric = 1;
+            ks.hyper_deriv = -1;
+            GPT_TRY(launch_kpairs(st, ks, dXs, dXs, dns, dns, M, dkd));
+            GPT_TRY(launch_rowsumsq_sub(st, M, n128, dKst, n128, dkd, dvar));
+            GPT_HIP_CHECK(hipMemcpyAsync(std_out, dvar, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, st));
+            GPT_HIP_CHECK(hipStreamSynchronize(st));
+            double nv = 0.0;
+            for (int64_t a = 0; a < M; a++) {
+                if (noise_params) {          // diagonal of the symmetric noise term (ref: noise.py:103-104)
+                    bool hit = true;
+                    for (int d = 0; d < D; d++) hit = hit && nstar[a * D + d] == kn.noise_n[d];
+                    nv = hit ? noise_params[0] * noise_params[0] : 0.0;
+                }
+                std_out[a] = sqrt(std_out[a] + nv);
+            }
+            return GPT_OK;
+        }
+        double *dcov;
+        GPT_TRY(ensure(c, SLOT_KSS, (size_t)MP * MP * sizeof(double), (void **)&dcov));
+        KParams ks = c->kp;
+        ks.symmetric = 1;
+        ks.hyper_deriv = -1;
+        GPT_TRY(launch_zero2d(st, MP, MP, dcov, MP));
+        GPT_TRY(launch_kbuild(st, ks, dXs, dns, M, dXs, dns, M, 0, 0, 0, nullptr, 0.0, 0.0, dcov, MP));
+        if (noise_params) GPT_TRY(launch_add_noise_sym(st, kn, dXs, dns, M, dcov, MP));
+        GPT_TRY(gemm_nt(c, st, MP, MP, n128, -1.0, dKst, n128, dKst, n128, 1.0, dcov, MP, 0));
+        GPT_HIP_CHECK(hipMemcpy2DAsync(cov_out, (size_t)M * sizeof(double), dcov, (size_t)MP * sizeof(double),
+                                       (size_t)M * sizeof(double), (size_t)M, hipMemcpyDeviceToHost, st));
+        GPT_HIP_CHECK(hipStreamSynchronize(st));
+        if (std_out)
+            for (int64_t a = 0; a < M; a++) std_out[a] = sqrt(cov_out[a * M + a]);
+        return GPT_OK;
+    }
+    GPT_HIP_CHECK(hipStreamSynchronize(st));
+    return GPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic solves against the resident factor
+// ------------------------------------------------------------------------------------------------
+static int solve_common(gpt_ctx *c, double *B, int64_t nrhs, bool full)
+{
+    CTX_ENTER(c);
+    NEED_FACTOR(c);
+    if (!B || nrhs <= 0) return GPT_E_ARG;
+    const int64_t N = c->N, n128 = round_up(N, 128), RP = round_up(nrhs, 64);
+    hipStream_t st = c->stream;
+    double *dBt;
+    GPT_TRY(ensure(c, SLOT_RHS, (size_t)RP * n128 * sizeof(double), (void **)&dBt));
+    std::vector<double> Bt((size_t)nrhs * N);
+    for (int64_t i = 0; i < N; i++)
+        for (int64_t r = 0; r < nrhs; r++) Bt[(size_t)r * N + i] = B[(size_t)i * nrhs + r];
+    GPT_TRY(launch_zero2d(st, RP, n128, dBt, n128));
+    GPT_HIP_CHECK(hipMemcpy2DAsync(dBt, (size_t)n128 * sizeof(double), Bt.data(), (size_t)N * sizeof(double),
+                                   (size_t)N * sizeof(double), (size_t)nrhs, hipMemcpyHostToDevice, st));
+    GPT_TRY(trsm_rlt(c, st, RP, n128, c->dA, c->NP, c->d_invd, dBt, n128));       // rows: (L^-1 b_r)^T
+    if (full)
+        for (int64_t r = 0; r < nrhs; r++) {
+            // the padded tail of each row is (numerically) zero except a ~1e-150 entry in the augmented
+            // column; clear it so the backward substitution sees an exact zero there
+            if (n128 > N) GPT_HIP_CHECK(hipMemsetAsync(dBt + r * n128 + N, 0, (size_t)(n128 - N) * sizeof(double), st));
+            GPT_TRY(launch_trsv_lt(st, n128, c->dA, c->NP, c->d_invd, dBt + r * n128));
+        }
+    GPT_HIP_CHECK(hipMemcpy2DAsync(Bt.data(), (size_t)N * sizeof(double), dBt, (size_t)n128 * sizeof(double),
+                                   (size_t)N * sizeof(double), (size_t)nrhs, hipMemcpyDeviceToHost, st));
+    GPT_HIP_CHECK(hipStreamSynchronize(st));
+    for (int64_t i = 0; i < N; i++)
+        for (int64_t r = 0; r < nrhs; r++) B[(size_t)i * nrhs + r] = Bt[(size_t)r * N + i];
+    return GPT_OK;
+}
+
+extern "C" int gpt_solve_L(gpt_ctx *c, double *B, int64_t nrhs) { return solve_common(c, B, nrhs, false); }
+extern "C" int gpt_cho_solve(gpt_ctx *c, double *B, int64_t nrhs) { return solve_common(c, B, nrhs, true); }
+
+// ------------------------------------------------------------------------------------------------
+// standalone dense entry points on host matrices
+// ------------------------------------------------------------------------------------------------
+extern "C" int gpt_potrf_host(gpt_ctx *c, double *A, int64_t N)
+{
+    CTX_ENTER(c);
+    if (!A || N <= 0) return GPT_E_ARG;
+    std::vector<double> y((size_t)N, 0.0);
+    double ll, ld;
+    int rc = gpt_fit_matrix(c, A, N, y.data(), &ll, &ld);
+    if (rc != GPT_OK) return rc;
+    return gpt_get_L(c, A);
+}
+
+extern "C" int gpt_gemm_nt_host(gpt_ctx *c, int64_t m, int64_t n, int64_t k, double alpha, const double *A,
+                                const double *B, double beta, double *C)
+{
+    CTX_ENTER(c);
+    if (m <= 0 || n <= 0 || k <= 0 || !A || !B || !C) return GPT_E_ARG;
+    const int64_t mp = round_up(m, 64), np = round_up(n, 64), kp = round_up(k, 64);
+    double *dA, *dB, *dC;
+    GPT_TRY(ensure(c, SLOT_KST, (size_t)mp * kp * sizeof(double), (void **)&dA));
+    GPT_TRY(ensure(c, SLOT_KSS, (size_t)np * kp * sizeof(double), (void **)&dB));
+    GPT_TRY(ensure(c, SLOT_RHS, (size_t)mp * np * sizeof(double), (void **)&dC));
+    hipStream_t st = c->stream;
+    GPT_TRY(launch_zero2d(st, mp, kp, dA, kp));
+    GPT_TRY(launch_zero2d(st, np, kp, dB, kp));
+    GPT_TRY(launch_zero2d(st, mp, np, dC, np));
+    GPT_HIP_CHECK(hipMemcpy2DAsync(dA, kp * sizeof(double), A, k * sizeof(double), k * sizeof(double), m, hipMemcpyHostToDevice, st));
+    GPT_HIP_CHECK(hipMemcpy2DAsync(dB, kp * sizeof(double), B, k * sizeof(double), k * sizeof(double), n, hipMemcpyHostToDevice, st));
+    GPT_HIP_CHECK(hipMemcpy2DAsync(dC, np * sizeof(double), C, n * sizeof(double), n * sizeof(double), m, hipMemcpyHostToDevice, st));
+    GPT_TRY(gemm_nt(c, st, mp, np, kp, alpha, dA, kp, dB, kp, beta, dC, np, 0));
+    GPT_HIP_CHECK(hipMemcpy2DAsync(C, n * sizeof(double), dC, np * sizeof(double), n * sizeof(double), m, hipMemcpyDeviceToHost, st));
+    GPT_HIP_CHECK(hipStreamSynchronize(st));
+    return GPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device API
+// ------------------------------------------------------------------------------------------------
+extern "C" int gpt_dev_kbuild(gpt_ctx *c, int kernel_id, const double *params_host, int nparams, const double *dXi,
+                              const int32_t *dni, int64_t M, const double *dXj, const int32_t *dnj, int64_t P, int D,
+                              int hyper_deriv, int symmetric, const int32_t *noise_n_host, int lower_only, int64_t i0,
+                              int64_t j0, const double *d_err_y, double noise_var, double diag_add, double *dK,
+                              int64_t ldk)
+{
+    CTX_ENTER(c);
+    KParams kp;
+    GPT_TRY(make_kparams(kernel_id, params_host, nparams, D, hyper_deriv, symmetric, noise_n_host, &kp));
+    return launch_kbuild(c->stream, kp, dXi, dni, M, dXj, dnj, P, lower_only, i0, j0, d_err_y, noise_var, diag_add,
+                         dK, ldk);
+}
+
+extern "C" int gpt_dev_gemm_nt(gpt_ctx *c, int64_t m, int64_t n, int64_t k, double alpha, const double *dA,
+                               int64_t lda, const double *dB, int64_t ldb, double beta, double *dC, int64_t ldc,
+                               int tri)
+{
+    CTX_ENTER(c);
+    return gemm_nt(c, c->stream, m, n, k, alpha, dA, lda, dB, ldb, beta, dC, ldc, tri);
+}
+
+extern "C" int gpt_dev_potrf_panel(gpt_ctx *c, int64_t m, int64_t nb, double *dA, int64_t lda, double *d_invd,
+                                   int32_t *d_info, int64_t info_base)
+{
+    CTX_ENTER(c);
+    if (nb <= 0 || nb % 128 || m < nb || m % 16) {
+        gpt_set_error("potrf_panel: need nb a multiple of 128 and m >= nb, m a multiple of 16");
+        return GPT_E_ARG;
+    }
+    return panel_rec(c, c->stream, dA, lda, m, nb, d_invd, d_info, info_base);
+}
+
+extern "C" int gpt_dev_potrf(gpt_ctx *c, int64_t n, double *dA, int64_t lda, double *d_invd, int32_t *d_info)
+{
+    CTX_ENTER(c);
+    return potrf_run(c, n, dA, lda, d_invd, d_info);
+}
+
+extern "C" int gpt_dev_trsm_rlt(gpt_ctx *c, int64_t m, int64_t n, const double *dL, int64_t ldl, const double *d_invd,
+                                double *dB, int64_t ldb)
+{
+    CTX_ENTER(c);
+    if (n <= 0 || n % 128 || m % 16) {
+        gpt_set_error("trsm_rlt: n must be a multiple of 128 and m a multiple of 16");
+        return GPT_E_ARG;
+    }
+    return trsm_rlt(c, c->stream, m, n, dL, ldl, d_invd, dB, ldb);
+}

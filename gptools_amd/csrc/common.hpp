@@ -1,0 +1,69 @@
+// common.hpp -- shared declarations for libgpt_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/gpt_hip.h"
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+#define GPT_WAVE 64
+
+void gpt_set_error(const char *fmt, ...);
+
+#define GPT_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            gpt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (e_ == hipErrorOutOfMemory) ? GPT_E_NOMEM : GPT_E_HIP;                \
+        }                                                                                \
+    } while (0)
+
+#define GPT_LAUNCH_CHECK()                                                               \
+    do {                                                                                 \
+        hipError_t e_ = hipGetLastError();                                               \
+        if (e_ != hipSuccess) {                                                          \
+            gpt_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return GPT_E_HIP;                                                            \
+        }                                                                                \
+    } while (0)
+
+// Kernel hyperparameters as passed by value to the device kernels.
+struct KParams {
+    int kernel_id;
+    int D;
+    int hyper_deriv;      // -1 = None
+    int symmetric;        // DiagonalNoiseKernel only fires for symmetric calls
+    double sigma;         // params[0]
+    double l[GPT_MAX_DIM];      // length scales (SE / M52)
+    double inv_l[GPT_MAX_DIM];  // 1 / l
+    double inv_var[GPT_MAX_DIM];// 1 / l^2
+    int noise_n[GPT_MAX_DIM];   // DiagonalNoiseKernel.n
+};
+
+// ---- launchers implemented in the .hip files (all asynchronous on `st`) -------------------
+int launch_kpairs(hipStream_t st, const KParams &kp, const double *dXi, const double *dXj,
+                  const int32_t *dni, const int32_t *dnj, int64_t M, double *dout);
+int launch_kbuild(hipStream_t st, const KParams &kp, const double *dXi, const int32_t *dni, int64_t M,
+                  const double *dXj, const int32_t *dnj, int64_t P, int lower_only, int64_t i0, int64_t j0,
+                  const double *d_err_y, double noise_var, double diag_add, double *dK, int64_t ldk);
+int launch_check_orders(hipStream_t st, const int32_t *dn, int64_t M, int D, int32_t *d_flag);
+int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A, int64_t lda,
+                   const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile);
+int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base);
+int launch_trsm_panel(hipStream_t st, int64_t m, const double *L, int64_t ldl, const double *invd,
+                      double *B, int64_t ldb);
+int launch_fill_pad(hipStream_t st, double *A, int64_t lda, int64_t n_valid, int64_t n_pad, const double *dy,
+                    double big);
+int launch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_t n, double *d_out2);
+int launch_extract_lower(hipStream_t st, const double *A, int64_t lda, int64_t n, double *out, int64_t ldo);
+int launch_trsv_lt(hipStream_t st, int64_t n, const double *L, int64_t ldl, const double *invd, double *x);
+int launch_gemv_n(hipStream_t st, int64_t m, int64_t n, const double *A, int64_t lda, const double *x, double *y);
+int launch_rowsumsq_sub(hipStream_t st, int64_t m, int64_t n, const double *V, int64_t ldv, const double *kdiag,
+                        double *var_out);
+int launch_add_noise_sym(hipStream_t st, const KParams &kp, const double *dX, const int32_t *dn, int64_t M,
+                         double *C, int64_t ldc);
+int launch_copy2d(hipStream_t st, int64_t rows, int64_t cols, const double *src, int64_t lds, double *dst, int64_t ldd);
+int launch_zero2d(hipStream_t st, int64_t rows, int64_t cols, double *dst, int64_t ldd);

@@ -1,0 +1,201 @@
+// kbuild.hip -- fused covariance-matrix builder K[i][j] = k(Xi[i], Xj[j], ni[i], nj[j]) for gfx950.
+//
+// Replaces GaussianProcess.compute_Kij (ref: gptools/gaussian_process.py:1535-1605): the reference
+// materialises four (M*P, D) tiled arrays (ref :1591-1594) and calls the kernel on the pair list;
+// here no tiling exists -- a workgroup owns a (ROWS x 256) tile of K, each lane keeps its column's
+// point Xj[j], nj[j] in registers, the tile's rows arrive through wave-uniform (scalar) loads, and
+// every store is a 512-byte contiguous wave store (HBM-write-bound: 8 bytes per pair).
+// Fused epilogue: the diagonal loading of ref :1447-1451 ((K + noise_var) + err_y^2) + diag_add.
+#include "kpair.hpp"
+
+#define KB_COLS 256
+#define KB_ROWS 32
+
+template <int KID, int D>
+__global__ __launch_bounds__(KB_COLS) void kbuild_kernel(
+    KParams kp, const double *__restrict__ Xi, const int32_t *__restrict__ ni, int64_t M,
+    const double *__restrict__ Xj, const int32_t *__restrict__ nj, int64_t P,
+    int lower_only, int64_t i0, int64_t j0, const double *__restrict__ err_y, double noise_var,
+    double diag_add, double *__restrict__ K, int64_t ldk)
+{
+    const int64_t rbase = (int64_t)blockIdx.y * KB_ROWS;
+    const int64_t cbase = (int64_t)blockIdx.x * KB_COLS;
+    if (lower_only && (cbase + j0 > rbase + KB_ROWS - 1 + i0)) return;     // tile strictly above the diagonal
+    const int64_t j = cbase + threadIdx.x;
+    const bool active = j < P;
+    const int64_t jc = active ? j : (P - 1);
+    double xj[D];
+    int njr[D];
+    int njsum = 0;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        xj[d] = Xj[jc * D + d];
+        njr[d] = nj[jc * D + d];
+        njsum |= njr[d];
+    }
+    const int64_t rend = (rbase + KB_ROWS < M) ? rbase + KB_ROWS : M;
+    for (int64_t i = rbase; i < rend; i++) {
+        double xi[D];
+        int nir[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {          // wave-uniform addresses -> scalar loads
+            xi[d] = Xi[i * D + d];
+            nir[d] = ni[i * D + d];
+        }
+        double v = any_pair<KID, D>(kp, xi, xj, nir, njr);
+        if (err_y != nullptr && (i + i0 == j + j0)) {
+            const double e = err_y[i + i0];
+            v = ((v + noise_var) + e * e) + diag_add;
+        }
+        if (active) K[i * ldk + j] = v;
+    }
+}
+
+template <int KID, int D>
+__global__ __launch_bounds__(256) void kpairs_kernel(KParams kp, const double *__restrict__ Xi,
+                                                     const double *__restrict__ Xj,
+                                                     const int32_t *__restrict__ ni,
+                                                     const int32_t *__restrict__ nj, int64_t M,
+                                                     double *__restrict__ out)
+{
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    double xi[D], xj[D];
+    int nir[D], njr[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        xi[d] = Xi[m * D + d];
+        xj[d] = Xj[m * D + d];
+        nir[d] = ni[m * D + d];
+        njr[d] = nj[m * D + d];
+    }
+    out[m] = any_pair<KID, D>(kp, xi, xj, nir, njr);
+}
+
+// C[a][b] += noise_k(X[a], X[b], n[a], n[b]) for the symmetric predict(noise=True) term
+// (ref: gptools/gaussian_process.py:985-986, gptools/kernel/noise.py:103-104).
+template <int D>
+__global__ __launch_bounds__(256) void add_noise_sym_kernel(KParams kp, const double *__restrict__ X,
+                                                            const int32_t *__restrict__ n, int64_t M,
+                                                            double *__restrict__ C, int64_t ldc)
+{
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t a = blockIdx.y;
+    if (b >= M) return;
+    double xa[D], xb[D];
+    int na[D], nb[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        xa[d] = X[a * D + d];
+        xb[d] = X[b * D + d];
+        na[d] = n[a * D + d];
+        nb[d] = n[b * D + d];
+    }
+    C[a * ldc + b] += noise_pair<D>(kp, xa, xb, na, nb);
+}
+
+template <int KID>
+static int kbuild_dispatch_d(hipStream_t st, const KParams &kp, const double *dXi, const int32_t *dni, int64_t M,
+                             const double *dXj, const int32_t *dnj, int64_t P, int lower_only, int64_t i0,
+                             int64_t j0, const double *d_err_y, double noise_var, double diag_add, double *dK,
+                             int64_t ldk)
+{
+    dim3 grid((unsigned)((P + KB_COLS - 1) / KB_COLS), (unsigned)((M + KB_ROWS - 1) / KB_ROWS));
+    dim3 block(KB_COLS);
+#define KB_CASE(DD)                                                                                     \
+    case DD:                                                                                            \
+        hipLaunchKernelGGL((kbuild_kernel<KID, DD>), grid, block, 0, st, kp, dXi, dni, M, dXj, dnj, P,   \
+                           lower_only, i0, j0, d_err_y, noise_var, diag_add, dK, ldk);                  \
+        break;
+    switch (kp.D) {
+        KB_CASE(1) KB_CASE(2) KB_CASE(3) KB_CASE(4) KB_CASE(5) KB_CASE(6) KB_CASE(7) KB_CASE(8)
+        KB_CASE(9) KB_CASE(10) KB_CASE(11) KB_CASE(12) KB_CASE(13) KB_CASE(14) KB_CASE(15) KB_CASE(16)
+    default:
+        gpt_set_error("kbuild: unsupported num_dim %d (max %d)", kp.D, GPT_MAX_DIM);
+        return GPT_E_ARG;
+    }
+#undef KB_CASE
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
+int launch_kbuild(hipStream_t st, const KParams &kp, const double *dXi, const int32_t *dni, int64_t M,
+                  const double *dXj, const int32_t *dnj, int64_t P, int lower_only, int64_t i0, int64_t j0,
+                  const double *d_err_y, double noise_var, double diag_add, double *dK, int64_t ldk)
+{
+    if (M <= 0 || P <= 0) return GPT_OK;
+    switch (kp.kernel_id) {
+    case GPT_KERNEL_SE:
+        return kbuild_dispatch_d<GPT_KERNEL_SE>(st, kp, dXi, dni, M, dXj, dnj, P, lower_only, i0, j0, d_err_y,
+                                                noise_var, diag_add, dK, ldk);
+    case GPT_KERNEL_M52:
+        return kbuild_dispatch_d<GPT_KERNEL_M52>(st, kp, dXi, dni, M, dXj, dnj, P, lower_only, i0, j0, d_err_y,
+                                                 noise_var, diag_add, dK, ldk);
+    case GPT_KERNEL_DIAGNOISE:
+        return kbuild_dispatch_d<GPT_KERNEL_DIAGNOISE>(st, kp, dXi, dni, M, dXj, dnj, P, lower_only, i0, j0,
+                                                       d_err_y, noise_var, diag_add, dK, ldk);
+    case GPT_KERNEL_ZERO:
+        return kbuild_dispatch_d<GPT_KERNEL_ZERO>(st, kp, dXi, dni, M, dXj, dnj, P, lower_only, i0, j0, d_err_y,
+                                                  noise_var, diag_add, dK, ldk);
+    default:
+        gpt_set_error("kbuild: unknown kernel_id %d", kp.kernel_id);
+        return GPT_E_ARG;
+    }
+}
+
+template <int KID>
+static int kpairs_dispatch_d(hipStream_t st, const KParams &kp, const double *dXi, const double *dXj,
+                             const int32_t *dni, const int32_t *dnj, int64_t M, double *dout)
+{
+    dim3 grid((unsigned)((M + 255) / 256)), block(256);
+#define KP_CASE(DD)                                                                                   \
+    case DD:                                                                                          \
+        hipLaunchKernelGGL((kpairs_kernel<KID, DD>), grid, block, 0, st, kp, dXi, dXj, dni, dnj, M, dout); \
+        break;
+    switch (kp.D) {
+        KP_CASE(1) KP_CASE(2) KP_CASE(3) KP_CASE(4) KP_CASE(5) KP_CASE(6) KP_CASE(7) KP_CASE(8)
+        KP_CASE(9) KP_CASE(10) KP_CASE(11) KP_CASE(12) KP_CASE(13) KP_CASE(14) KP_CASE(15) KP_CASE(16)
+    default:
+        gpt_set_error("kpairs: unsupported num_dim %d (max %d)", kp.D, GPT_MAX_DIM);
+        return GPT_E_ARG;
+    }
+#undef KP_CASE
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
+int launch_kpairs(hipStream_t st, const KParams &kp, const double *dXi, const double *dXj,
+                  const int32_t *dni, const int32_t *dnj, int64_t M, double *dout)
+{
+    if (M <= 0) return GPT_OK;
+    switch (kp.kernel_id) {
+    case GPT_KERNEL_SE: return kpairs_dispatch_d<GPT_KERNEL_SE>(st, kp, dXi, dXj, dni, dnj, M, dout);
+    case GPT_KERNEL_M52: return kpairs_dispatch_d<GPT_KERNEL_M52>(st, kp, dXi, dXj, dni, dnj, M, dout);
+    case GPT_KERNEL_DIAGNOISE: return kpairs_dispatch_d<GPT_KERNEL_DIAGNOISE>(st, kp, dXi, dXj, dni, dnj, M, dout);
+    case GPT_KERNEL_ZERO: return kpairs_dispatch_d<GPT_KERNEL_ZERO>(st, kp, dXi, dXj, dni, dnj, M, dout);
+    default:
+        gpt_set_error("kpairs: unknown kernel_id %d", kp.kernel_id);
+        return GPT_E_ARG;
+    }
+}
+
+int launch_add_noise_sym(hipStream_t st, const KParams &kp, const double *dX, const int32_t *dn, int64_t M,
+                         double *C, int64_t ldc)
+{
+    if (M <= 0) return GPT_OK;
+    dim3 grid((unsigned)((M + 255) / 256), (unsigned)M), block(256);
+#define AN_CASE(DD)                                                                                  \
+    case DD:                                                                                         \
+        hipLaunchKernelGGL((add_noise_sym_kernel<DD>), grid, block, 0, st, kp, dX, dn, M, C, ldc);   \
+        break;
+    switch (kp.D) {
+        AN_CASE(1) AN_CASE(2) AN_CASE(3) AN_CASE(4) AN_CASE(5) AN_CASE(6) AN_CASE(7) AN_CASE(8)
+        AN_CASE(9) AN_CASE(10) AN_CASE(11) AN_CASE(12) AN_CASE(13) AN_CASE(14) AN_CASE(15) AN_CASE(16)
+    default:
+        gpt_set_error("add_noise: unsupported num_dim %d", kp.D);
+        return GPT_E_ARG;
+    }
+#undef AN_CASE
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}

@@ -1,0 +1,255 @@
+// solve.hip -- memory-bound helpers around the factorisation (gfx950): padding / augmentation of
+// K_tot, log-determinant and quadratic-form reductions, triangular read-back, the backward
+// substitution for alpha, GEMV and the predictive-variance row reduction.
+//
+// ref: gptools/gaussian_process.py:1462-1467 (alpha, ll), :971 (mean = Kstar^T alpha),
+//      :987,1006 (cov diagonal / std).
+#include "common.hpp"
+
+// Rows [n_valid, n_pad) of the padded matrix: zero, unit diagonal.  If dy != NULL row n_valid
+// carries y^T (the "augmented row": after the factorisation it holds z^T = (L^-1 y)^T) and its
+// diagonal entry is `big`, so the pivot there stays positive whatever z.z is.
+__global__ void fill_pad_kernel(double *__restrict__ A, int64_t lda, int64_t n_valid, int64_t n_pad,
+                                const double *__restrict__ dy, double big)
+{
+    const int64_t row = n_valid + blockIdx.y;
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_pad || col >= n_pad) return;
+    double v = 0.0;
+    if (row == n_valid && dy != nullptr) {
+        if (col < n_valid) v = dy[col];
+        else if (col == row) v = big;
+    } else if (col == row) {
+        v = 1.0;
+    }
+    A[row * lda + col] = v;
+}
+
+int launch_fill_pad(hipStream_t st, double *A, int64_t lda, int64_t n_valid, int64_t n_pad, const double *dy,
+                    double big)
+{
+    if (n_pad <= n_valid) return GPT_OK;
+    dim3 grid((unsigned)((n_pad + 255) / 256), (unsigned)(n_pad - n_valid));
+    hipLaunchKernelGGL(fill_pad_kernel, grid, dim3(256), 0, st, A, lda, n_valid, n_pad, dy, big);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
+// out[0] = sum_{i<n} log A[i][i] ; out[1] = sum_{c<n} A[n][c]^2 (the augmented row z)
+__global__ __launch_bounds__(1024) void logdet_dot_kernel(const double *__restrict__ A, int64_t lda, int64_t n,
+                                                          int has_z, double *__restrict__ out)
+{
+    __shared__ double s0[16], s1[16];
+    double a = 0.0, b = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        a += log(A[i * lda + i]);
+        if (has_z) {
+            const double z = A[n * lda + i];
+            b = fma(z, z, b);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off);
+        b += __shfl_down(b, off);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        s0[wave] = a;
+        s1[wave] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ta = 0.0, tb = 0.0;
+        for (int w = 0; w < 16; w++) {
+            ta += s0[w];
+            tb += s1[w];
+        }
+        out[0] = ta;
+        out[1] = tb;
+    }
+}
+
+int launch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_t n, double *d_out2)
+{
+    hipLaunchKernelGGL(logdet_dot_kernel, dim3(1), dim3(1024), 0, st, A, lda, n, 1, d_out2);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
+__global__ void extract_lower_kernel(const double *__restrict__ A, int64_t lda, int64_t n,
+                                     double *__restrict__ out, int64_t ldo)
+{
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= n) return;
+    for (int64_t row = blockIdx.y; row < n; row += gridDim.y)
+        out[row * ldo + col] = (col <= row) ? A[row * lda + col] : 0.0;
+}
+
+int launch_extract_lower(hipStream_t st, const double *A, int64_t lda, int64_t n, double *out, int64_t ldo)
+{
+    if (n <= 0) return GPT_OK;
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)(n < 16384 ? n : 16384));
+    hipLaunchKernelGGL(extract_lower_kernel, grid, dim3(256), 0, st, A, lda, n, out, ldo);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
+__global__ void copy2d_kernel(int64_t rows, int64_t cols, const double *__restrict__ src, int64_t lds,
+                              double *__restrict__ dst, int64_t ldd)
+{
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= cols) return;
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) dst[row * ldd + col] = src[row * lds + col];
+}
+
+int launch_copy2d(hipStream_t st, int64_t rows, int64_t cols, const double *src, int64_t lds, double *dst, int64_t ldd)
+{
+    if (rows <= 0 || cols <= 0) return GPT_OK;
+    dim3 grid((unsigned)((cols + 255) / 256), (unsigned)(rows < 16384 ? rows : 16384));
+    hipLaunchKernelGGL(copy2d_kernel, grid, dim3(256), 0, st, rows, cols, src, lds, dst, ldd);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
+__global__ void zero2d_kernel(int64_t rows, int64_t cols, double *__restrict__ dst, int64_t ldd)
+{
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= cols) return;
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) dst[row * ldd + col] = 0.0;
+}
+
+int launch_zero2d(hipStream_t st, int64_t rows, int64_t cols, double *dst, int64_t ldd)
+{
+    if (rows <= 0 || cols <= 0) return GPT_OK;
+    dim3 grid((unsigned)((cols + 255) / 256), (unsigned)(rows < 16384 ? rows : 16384));
+    hipLaunchKernelGGL(zero2d_kernel, grid, dim3(256), 0, st, rows, cols, dst, ldd);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
+// ---- backward substitution  L^T x = z  (x overwrites z), n a multiple of 128 ----------------
+// Right-looking over 128-wide blocks, last block first:
+//   (1) trsv_lt_diag_kernel: one wave solves L_bb^T x_b = w_b (two entries per lane, the matrix
+//       row arrives from LDS, the pivot is broadcast with v_readlane; 1/L_ii comes from invd);
+//   (2) trsv_lt_update_kernel: w[0 : b*128) -= L[b-block rows, 0 : b*128)^T x_b, one column per
+//       lane, rows of L read as contiguous coalesced segments.
+__global__ __launch_bounds__(64) void trsv_lt_diag_kernel(const double *__restrict__ Lbb, int64_t ldl,
+                                                          const double *__restrict__ invd, double *__restrict__ x)
+{
+    extern __shared__ __attribute__((aligned(16))) double tsm[];
+    double (*S)[129] = reinterpret_cast<double (*)[129]>(tsm);
+    double *rdiag = tsm + 128 * 129;
+    const int lane = threadIdx.x;
+    for (int idx = lane; idx < 128 * 128; idx += 64) {
+        const int r = idx >> 7, c = idx & 127;
+        S[r][c] = Lbb[(int64_t)r * ldl + c];
+    }
+    for (int i = lane; i < 128; i += 64) rdiag[i] = invd[(i >> 4) * 256 + (i & 15) * 17];
+    double w0 = x[lane], w1 = x[lane + 64];
+    __syncthreads();
+    for (int j = 127; j >= 0; j--) {
+        const double src = (j >= 64) ? w1 : w0;
+        const int sl = j & 63;
+        const int lo = __builtin_amdgcn_readlane(__double2loint(src), sl);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(src), sl);
+        const double xj = __hiloint2double(hi, lo) * rdiag[j];
+        if (j >= 64) {
+            if (lane == sl) w1 = xj;
+            if (lane + 64 < j) w1 = fma(-S[j][lane + 64], xj, w1);
+            w0 = fma(-S[j][lane], xj, w0);
+        } else {
+            if (lane == sl) w0 = xj;
+            if (lane < j) w0 = fma(-S[j][lane], xj, w0);
+        }
+    }
+    x[lane] = w0;
+    x[lane + 64] = w1;
+}
+
+__global__ __launch_bounds__(256) void trsv_lt_update_kernel(int64_t ncols, const double *__restrict__ Lrow,
+                                                             int64_t ldl, const double *__restrict__ xb,
+                                                             double *__restrict__ w)
+{
+    __shared__ double xs[128];
+    if (threadIdx.x < 128) xs[threadIdx.x] = xb[threadIdx.x];
+    __syncthreads();
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= ncols) return;
+    double acc = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < 128; r++) acc = fma(Lrow[(int64_t)r * ldl + col], xs[r], acc);
+    w[col] -= acc;
+}
+
+int launch_trsv_lt(hipStream_t st, int64_t n, const double *L, int64_t ldl, const double *invd, double *x)
+{
+    if (n % 128) {
+        gpt_set_error("trsv_lt: n must be a multiple of 128");
+        return GPT_E_ARG;
+    }
+    static bool attr_set = false;
+    const size_t shmem = (size_t)(128 * 129 + 128) * sizeof(double);
+    if (!attr_set) {
+        GPT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(trsv_lt_diag_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        attr_set = true;
+    }
+    for (int64_t b = n / 128 - 1; b >= 0; b--) {
+        const double *Lbb = L + (b * 128) * ldl + b * 128;
+        hipLaunchKernelGGL(trsv_lt_diag_kernel, dim3(1), dim3(64), shmem, st, Lbb, ldl, invd + (b * 8) * 256, x + b * 128);
+        if (b > 0) {
+            const int64_t ncols = b * 128;
+            hipLaunchKernelGGL(trsv_lt_update_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, st, ncols,
+                               L + (b * 128) * ldl, ldl, x + b * 128, x);
+        }
+    }
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
+// y (m) = A (m x n, row-major) * x (n): one wave per row
+__global__ __launch_bounds__(256) void gemv_n_kernel(int64_t m, int64_t n, const double *__restrict__ A, int64_t lda,
+                                                     const double *__restrict__ x, double *__restrict__ y)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m) return;
+    double acc = 0.0;
+    for (int64_t c = lane; c < n; c += 64) acc = fma(A[row * lda + c], x[c], acc);
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (lane == 0) y[row] = acc;
+}
+
+int launch_gemv_n(hipStream_t st, int64_t m, int64_t n, const double *A, int64_t lda, const double *x, double *y)
+{
+    if (m <= 0) return GPT_OK;
+    hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, m, n, A, lda, x, y);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
+// var[i] = kdiag[i] - sum_c V[i][c]^2  (diagonal of Kss - V V^T without forming the M x M product)
+__global__ __launch_bounds__(256) void rowsumsq_sub_kernel(int64_t m, int64_t n, const double *__restrict__ V,
+                                                           int64_t ldv, const double *__restrict__ kdiag,
+                                                           double *__restrict__ var_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m) return;
+    double acc = 0.0;
+    for (int64_t c = lane; c < n; c += 64) {
+        const double v = V[row * ldv + c];
+        acc = fma(v, v, acc);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (lane == 0) var_out[row] = kdiag[row] - acc;
+}
+
+int launch_rowsumsq_sub(hipStream_t st, int64_t m, int64_t n, const double *V, int64_t ldv, const double *kdiag,
+                        double *var_out)
+{
+    if (m <= 0) return GPT_OK;
+    hipLaunchKernelGGL(rowsumsq_sub_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, m, n, V, ldv, kdiag, var_out);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}

@@ -1,0 +1,193 @@
+/*
+ * gpt_hip.h -- C ABI of libgpt_hip.so: the MI355X (gfx950) implementation of gptools'
+ * covariance-build + Cholesky log-marginal-likelihood hot path.
+ *
+ * Plain C, no torch / numpy types: pointers, sizes and scalars only.  Matrices are row-major
+ * (C order, like the numpy arrays the reference passes around).  Every entry point returns an
+ * int status:
+ *      0            success
+ *     >0            LAPACK convention: the leading minor of that order is not positive
+ *                   definite (the Python layer raises numpy.linalg.LinAlgError, which
+ *                   GaussianProcess.update_hyperparameters turns into +inf exactly like
+ *                   gaussian_process.py:1391-1406)
+ *     <0            GPT_E_* below
+ * gpt_last_error() returns a thread-local human-readable message for the last failure.
+ *
+ * Citations "ref: file:line" are into the reference tree (markchil/gptools).
+ *
+ * There are two layers:
+ *   (1) context API, host pointers in / host scalars out, device state stays resident in HBM
+ *       between calls -- this is what a ctypes/cffi binding inside gptools would call;
+ *   (2) device API (gpt_dev_*), raw device pointers + the context's stream -- used by callers
+ *       that own device memory themselves (the one-process-per-GPU block-cyclic Cholesky in
+ *       gptools_amd/dist.py passes torch.Tensor.data_ptr() values).
+ */
+#ifndef GPT_HIP_H_
+#define GPT_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPT_OK 0
+#define GPT_E_ARG (-1)      /* bad argument / shape                       -> ValueError           */
+#define GPT_E_VALUE (-2)    /* Matern52 derivative order > 1              -> ValueError  (ref: kernel/matern.py:545-546) */
+#define GPT_E_NOTIMPL (-3)  /* unsupported hyper_deriv                     -> NotImplementedError (ref: kernel/matern.py:543-544) */
+#define GPT_E_HIP (-4)      /* HIP runtime error                          -> RuntimeError         */
+#define GPT_E_NOMEM (-5)    /* device allocation failed                   -> MemoryError          */
+#define GPT_E_STATE (-6)    /* call out of order (e.g. predict before fit) -> RuntimeError         */
+
+/* kernel_id values (ref: kernel/squared_exponential.py:31, kernel/matern.py:468,
+ * kernel/noise.py:27, kernel/noise.py:112) */
+#define GPT_KERNEL_SE 0
+#define GPT_KERNEL_M52 1
+#define GPT_KERNEL_DIAGNOISE 2
+#define GPT_KERNEL_ZERO 3
+
+#define GPT_MAX_DIM 16      /* largest supported num_dim */
+
+typedef struct gpt_ctx gpt_ctx;
+
+int gpt_version(void);
+const char *gpt_last_error(void);
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* One context = one GPU + one main HIP stream (+ an internal high-priority panel stream used for
+ * look-ahead).  stream == NULL: the library creates its own non-blocking stream; otherwise the
+ * caller's hipStream_t is used for all work (pass torch.cuda.current_stream().cuda_stream). */
+int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out);
+int gpt_ctx_destroy(gpt_ctx *ctx);
+/* Options: "nb_outer" (outer block width, multiple of 128), "lookahead" (0/1), "graph" (0/1:
+ * replay the factorisation from a captured hipGraph), "timing" (0/1: record per-phase HIP
+ * events), "tile" (0 auto, 64, 128: force the GEMM macro-tile). */
+int gpt_ctx_set_option(gpt_ctx *ctx, const char *key, int64_t value);
+int gpt_ctx_synchronize(gpt_ctx *ctx);
+void *gpt_ctx_stream(gpt_ctx *ctx);
+
+/* ---- Kernel.__call__ ---------------------------------------------------------------------- */
+/* Replaces  Kernel.__call__(Xi, Xj, ni, nj, hyper_deriv=None, symmetric=False) -> (M,) float64
+ *   ref: kernel/core.py:220-257 (contract), kernel/squared_exponential.py:82-174,
+ *        kernel/matern.py:512-555 -> kernel/_matern.pyx:14-32 -> kernel/src/matern.c:165-186
+ *        (`double matern52(const double*, const double*, const int32_t*, const int32_t*, int32_t,
+ *          const double*)`, kernel/include/matern.h:24-26), kernel/noise.py:76-110,123-152.
+ * Element-wise pair list: row m of the four (M, D) inputs gives out[m].  params = the kernel's
+ * full parameter vector ([sigma_f, l_1..l_D] for SE / Matern52, [sigma_n] for the noise kernels).
+ * hyper_deriv = -1 for None.  noise_n: DiagonalNoiseKernel.n (D ints) or NULL (zeros).
+ * All pointers are host pointers. */
+int gpt_kpairs(gpt_ctx *ctx, int kernel_id, const double *params, int nparams,
+               const double *Xi, const double *Xj, const int32_t *ni, const int32_t *nj,
+               int64_t M, int D, int hyper_deriv, int symmetric, const int32_t *noise_n,
+               double *out);
+
+/* ---- GaussianProcess.compute_Kij ---------------------------------------------------------- */
+/* Replaces  GaussianProcess.compute_Kij(Xi, Xj, ni, nj, noise, hyper_deriv, k) -> (M, P)
+ *   ref: gaussian_process.py:1535-1605.  Xj == NULL means Xj = Xi, nj = ni, symmetric = True
+ *   (ref :1580-1585).  The (M*P, D) tiled temporaries of ref :1591-1594 are never formed: one
+ *   fused kernel evaluates pair (i, j) from X rows held in registers/LDS and writes K[i*P + j].
+ * K_out: host (M, P) row-major. */
+int gpt_kbuild(gpt_ctx *ctx, int kernel_id, const double *params, int nparams,
+               const double *Xi, const int32_t *ni, int64_t M,
+               const double *Xj, const int32_t *nj, int64_t P, int D,
+               int hyper_deriv, const int32_t *noise_n, double *K_out);
+
+/* ---- GaussianProcess.add_data (device residency) ------------------------------------------ */
+/* Uploads the training inputs the later calls use (ref: gaussian_process.py:376-503 defines the
+ * host layout: X (N, D) float64, n (N, D) int).  Invalidates any factorisation. */
+int gpt_set_data(gpt_ctx *ctx, const double *X, const int32_t *n, int64_t N, int D);
+
+/* ---- GaussianProcess.compute_K_L_alpha_ll ------------------------------------------------- */
+/* Replaces the T-free body of GaussianProcess.compute_K_L_alpha_ll   ref: gaussian_process.py:1428-1467
+ *   K_tot = K + noise_var*I + diag(err_y^2) + diag_add*I          (ref :1431-1451; diag_add = diag_factor*eps)
+ *   L     = cholesky(K_tot, lower)                                (ref :1452, LAPACK dpotrf)
+ *   z     = L^-1 y  ;  ll_data = -1/2 z.z - sum(log L_ii) - N/2 log(2 pi)    (ref :1462-1467)
+ * y is the mean-subtracted target (ref :1455-1461); the log-prior (ref :1469) is added by the
+ * caller.  K_tot / L stay resident in HBM; alpha (ref :1462) is computed on demand by
+ * gpt_get_alpha.  err_y: (N,) host.  Only `params` need change between calls (MAP loop). */
+int gpt_fit(gpt_ctx *ctx, int kernel_id, const double *params, int nparams, double noise_var,
+            const double *y, const double *err_y, double diag_add,
+            double *ll_data_out, double *logdet_half_out);
+
+/* Same as gpt_fit but for an explicit, caller-assembled symmetric K_tot (host, (N, N) row-major;
+ * only the lower triangle is read): used for the `T` (linear transform) branch,
+ * ref: gaussian_process.py:1443-1446, where K_tot = T (K + noise_K) T^T + ... is (N_y, N_y). */
+int gpt_fit_matrix(gpt_ctx *ctx, const double *K_tot, int64_t N, const double *y,
+                   double *ll_data_out, double *logdet_half_out);
+
+/* State read-back (host outputs).  L: (N, N) lower, strict upper zero like scipy.linalg.cholesky
+ * (ref: gaussian_process.py:1452).  alpha: (N,) = K_tot^-1 y (ref :1462). */
+int gpt_get_L(gpt_ctx *ctx, double *L_out);
+int gpt_get_alpha(gpt_ctx *ctx, double *alpha_out);
+
+/* ---- GaussianProcess.predict (non-MCMC branch) -------------------------------------------- */
+/* Replaces  ref: gaussian_process.py:965-1006 for the T-free, untransformed case:
+ *   Kstar = K(X, Xstar) ; mean = Kstar^T alpha ; v = L^-1 Kstar ; cov = K(Xstar,Xstar) - v^T v ;
+ *   std = sqrt(diag(cov)).
+ * want: 0 = mean only, 1 = mean + std, 2 = mean + cov (M, M) (+ std if std_out != NULL).
+ * noise_params != NULL adds the DiagonalNoiseKernel term to K(Xstar, Xstar) (ref :985-986,
+ * kernel/noise.py:103-104; the X-vs-Xstar term of ref :967-968 is identically zero because that
+ * call is not `symmetric`, kernel/noise.py:109-110).
+ * Uses the kernel / params of the last gpt_fit. */
+int gpt_predict(gpt_ctx *ctx, const double *Xstar, const int32_t *nstar, int64_t M, int want,
+                const double *noise_params, const int32_t *noise_n,
+                double *mean_out, double *std_out, double *cov_out);
+
+/* Generic right-hand sides against the resident factor (host in/out, row-major):
+ *   gpt_solve_L   : B (N, nrhs) <- L^-1 B          (ref: gaussian_process.py:983 solve_triangular)
+ *   gpt_cho_solve : B (N, nrhs) <- K_tot^-1 B      (ref: gaussian_process.py:1462,1487,1503 cho_solve) */
+int gpt_solve_L(gpt_ctx *ctx, double *B, int64_t nrhs);
+int gpt_cho_solve(gpt_ctx *ctx, double *B, int64_t nrhs);
+
+/* Per-phase timings of the last gpt_fit in milliseconds (HIP events on the context's stream):
+ * out[0]=upload, [1]=kbuild, [2]=potrf, [3]=ll tail, [4]=total; returns the count written. */
+int gpt_last_timings(gpt_ctx *ctx, double *out_ms, int n);
+
+/* Standalone dense kernels on host matrices (used by parity tests and the roofline bench). */
+int gpt_potrf_host(gpt_ctx *ctx, double *A, int64_t N);                 /* in place, lower */
+int gpt_gemm_nt_host(gpt_ctx *ctx, int64_t m, int64_t n, int64_t k, double alpha, const double *A,
+                     const double *B, double beta, double *C);          /* C = beta C + alpha A B^T */
+
+/* ---- device API --------------------------------------------------------------------------- */
+/* All pointers below are DEVICE pointers unless marked host; work is enqueued on the context's
+ * stream and NOT synchronised.  Leading dimensions are in elements.  Block sizes: every m, n, k
+ * passed to the dense routines must be a multiple of 64 (callers pad). */
+
+/* Fused covariance builder on device data.  Writes the (M, P) block K[i][j], i in [0,M), j in
+ * [0,P) of k(Xi[i], Xj[j], ni[i], nj[j]) to dK (row stride ldk).  lower_only != 0: only tiles
+ * that intersect {i + i0 >= j + j0} are written (i0, j0 = global offsets of the block).  If
+ * d_err_y != NULL, entries with i + i0 == j + j0 get ((k + noise_var) + err_y[i+i0]^2) + diag_add. */
+int gpt_dev_kbuild(gpt_ctx *ctx, int kernel_id, const double *params_host, int nparams,
+                   const double *dXi, const int32_t *dni, int64_t M,
+                   const double *dXj, const int32_t *dnj, int64_t P, int D,
+                   int hyper_deriv, int symmetric, const int32_t *noise_n_host,
+                   int lower_only, int64_t i0, int64_t j0,
+                   const double *d_err_y, double noise_var, double diag_add,
+                   double *dK, int64_t ldk);
+
+/* C (m x n) = beta*C + alpha * A (m x k) * B (n x k)^T.  tri != 0: C's origin lies on the global
+ * diagonal and only 64-aligned tiles with col_tile <= row_tile are computed (SYRK-style). */
+int gpt_dev_gemm_nt(gpt_ctx *ctx, int64_t m, int64_t n, int64_t k, double alpha,
+                    const double *dA, int64_t lda, const double *dB, int64_t ldb,
+                    double beta, double *dC, int64_t ldc, int tri);
+
+/* Factor one block column ("panel"): A is (m x nb), its top nb x nb block is the diagonal block.
+ * On exit the top block holds L_kk (lower) and the rows below hold A21 * L_kk^-T.  d_invd:
+ * workspace/outputs, (nb/16) blocks of 16x16 doubles = inverses of L's 16x16 diagonal blocks.
+ * d_info: int32 on device, set to info_base + j + 1 at the first non-positive pivot (never
+ * cleared here). */
+int gpt_dev_potrf_panel(gpt_ctx *ctx, int64_t m, int64_t nb, double *dA, int64_t lda,
+                        double *d_invd, int32_t *d_info, int64_t info_base);
+
+/* Whole lower Cholesky of the n x n matrix dA in place (blocked right-looking, look-ahead).
+ * d_invd: (n/16)*256 doubles. */
+int gpt_dev_potrf(gpt_ctx *ctx, int64_t n, double *dA, int64_t lda, double *d_invd, int32_t *d_info);
+
+/* B (m x n) <- B * L^-T with L (n x n) lower, d_invd from the factorisation of L. */
+int gpt_dev_trsm_rlt(gpt_ctx *ctx, int64_t m, int64_t n, const double *dL, int64_t ldl,
+                     const double *d_invd, double *dB, int64_t ldb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPT_HIP_H_ */

@@ -1,0 +1,473 @@
+#!/usr/bin/env python
+"""Generate the golden input/output fixtures (``tests/golden/*.npz``).
+
+Container-only: imports the *reference* gptools from /root/reference through
+``ref_harness`` and records its outputs on seeded inputs.  The fixtures are data
+(inputs + expected outputs); neither this script nor the harness copies
+reference source.  Re-run with ``python tests/golden/gen_golden.py``.
+
+Fixture groups follow SURVEY.md section 8(c):
+  G1 pair-level ``Kernel.__call__``            (kernel/squared_exponential.py:82-174, kernel/matern.py:512-555)
+  G2 Gram matrices ``compute_Kij``             (gaussian_process.py:1535-1605)
+  G3 fit ``compute_K_L_alpha_ll``              (gaussian_process.py:1418-1522)
+  G4 ``predict``                               (gaussian_process.py:913-1034)
+  G5 ``update_hyperparameters`` sweep          (gaussian_process.py:1332-1416)
+  G6 demo known-answer (config 1)              (demo/demo.py:133-253)
+  G7 tests/test_matern.py scenario, seeded     (tests/test_matern.py:4-31)
+"""
+import os
+import pickle
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness  # noqa: E402
+
+gptools = ref_harness.import_reference()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote %-28s %8.1f KiB" % (name + ".npz", os.path.getsize(path) / 1024.0))
+
+
+def se_kernel(d, params):
+    return gptools.SquaredExponentialKernel(
+        num_dim=d, initial_params=list(params), param_bounds=[(0.0, 1e3)] * (d + 1))
+
+
+def m52_kernel(d, params):
+    return gptools.Matern52Kernel(
+        num_dim=d, initial_params=list(params), param_bounds=[(0.0, 1e3)] * (d + 1))
+
+
+# ----------------------------------------------------------------------------
+# G1: pair-level
+# ----------------------------------------------------------------------------
+def gen_g1():
+    rs = np.random.RandomState(101)
+    out = {}
+    for d in (1, 2, 3, 4):
+        M = 240
+        Xi = rs.rand(M, d)
+        Xj = rs.rand(M, d)
+        # tau == 0 rows and duplicate points
+        Xj[:20] = Xi[:20]
+        Xj[20:30, 0] = Xi[20:30, 0]
+        ni = rs.randint(0, 3, size=(M, d))
+        nj = rs.randint(0, 3, size=(M, d))
+        ni[40:60] = 0                       # one-sided
+        nj[60:80] = 0
+        ni[80:100] = 0
+        nj[80:100] = 0                      # plain rows inside a derivative call
+        params = np.concatenate(([1.7], 0.25 + 0.5 * rs.rand(d)))
+        k = se_kernel(d, params)
+        out["se_d%d_Xi" % d] = Xi
+        out["se_d%d_Xj" % d] = Xj
+        out["se_d%d_ni" % d] = ni.astype(np.int32)
+        out["se_d%d_nj" % d] = nj.astype(np.int32)
+        out["se_d%d_params" % d] = params
+        out["se_d%d_k" % d] = k(Xi, Xj, ni, nj)
+        for hd in range(0, d + 1):
+            with np.errstate(all="ignore"):
+                out["se_d%d_hd%d" % (d, hd)] = k(Xi, Xj, ni, nj, hyper_deriv=hd)
+        # the "no derivatives anywhere" fast path (squared_exponential.py:110-113)
+        z = np.zeros_like(ni)
+        out["se_d%d_k0" % d] = k(Xi, Xj, z, z)
+        for hd in range(0, d + 1):
+            out["se_d%d_k0_hd%d" % (d, hd)] = k(Xi, Xj, z, z, hyper_deriv=hd)
+        # high orders (up to 4 per side => combined order 8)
+        nih = rs.randint(0, 5, size=(M, d))
+        njh = rs.randint(0, 5, size=(M, d))
+        out["se_d%d_nih" % d] = nih.astype(np.int32)
+        out["se_d%d_njh" % d] = njh.astype(np.int32)
+        out["se_d%d_kh" % d] = k(Xi, Xj, nih, njh)
+
+        # Matern 5/2: all four branch classes x (r == 0 | r > 0) x (a == b | a != b)
+        mi = np.zeros((M, d), dtype=np.int32)
+        mj = np.zeros((M, d), dtype=np.int32)
+        cls = rs.randint(0, 4, size=M)
+        cls[:20] = np.arange(20) % 4        # r == 0 rows cover every class
+        for m in range(M):
+            if cls[m] in (1, 3):
+                mi[m, rs.randint(0, d)] = 1
+            if cls[m] in (2, 3):
+                mj[m, rs.randint(0, d)] = 1
+        if d > 1:
+            mi[100:110] = 0
+            mj[100:110] = 0
+            mi[100:110, 0] = 1
+            mj[100:110, 0] = 1             # a == b
+            mi[110:120] = 0
+            mj[110:120] = 0
+            mi[110:120, 0] = 1
+            mj[110:120, 1] = 1             # a != b
+            mi[4:8] = 0
+            mj[4:8] = 0
+            mi[4:6, 0] = 1
+            mj[4:6, 0] = 1                 # r == 0, a == b
+            mi[6:8, 0] = 1
+            mj[6:8, 1] = 1                 # r == 0, a != b
+        km = m52_kernel(d, params)
+        out["m52_d%d_ni" % d] = mi
+        out["m52_d%d_nj" % d] = mj
+        out["m52_d%d_k" % d] = km(Xi, Xj, mi, mj)
+    save("g1_pairs", **out)
+
+
+# ----------------------------------------------------------------------------
+# G2: Gram matrices
+# ----------------------------------------------------------------------------
+def deriv_pattern(rs, N, d, frac=0.25, max_order=1):
+    """Rows [0, N-frac*N) value observations; the rest derivative observations."""
+    n = np.zeros((N, d), dtype=int)
+    n0 = int(N * (1.0 - frac))
+    for i in range(n0, N):
+        n[i, i % d] = 1 if max_order == 1 else rs.randint(1, max_order + 1)
+    return n
+
+
+def gen_g2():
+    rs = np.random.RandomState(202)
+    out = {}
+    for kname, mk, maxo in (("se", se_kernel, 2), ("m52", m52_kernel, 1)):
+        for d in (1, 2, 3):
+            N, P = 64, 40
+            X = rs.rand(N, d)
+            Xs = rs.rand(P, d)
+            X[5] = X[4]                      # duplicate training point
+            Xs[3] = X[7]                     # test point on a training point
+            n = deriv_pattern(rs, N, d, 0.25, maxo)
+            ns = deriv_pattern(rs, P, d, 0.5, maxo)
+            params = np.concatenate(([1.3], 0.2 + 0.4 * rs.rand(d)))
+            gp = gptools.GaussianProcess(mk(d, params))
+            key = "%s_d%d_" % (kname, d)
+            out[key + "X"] = X
+            out[key + "Xs"] = Xs
+            out[key + "n"] = n.astype(np.int32)
+            out[key + "ns"] = ns.astype(np.int32)
+            out[key + "params"] = params
+            out[key + "K"] = gp.compute_Kij(X, None, n, None)
+            out[key + "Ks"] = gp.compute_Kij(X, Xs, n, ns)
+            out[key + "Kss"] = gp.compute_Kij(Xs, None, ns, None)
+            z = np.zeros_like(n)
+            out[key + "K0"] = gp.compute_Kij(X, None, z, None)
+            if kname == "se":
+                for hd in range(0, d + 1):
+                    out[key + "K0_hd%d" % hd] = gp.compute_Kij(X, None, z, None, hyper_deriv=hd)
+                    with np.errstate(all="ignore"):
+                        out[key + "K_hd%d" % hd] = gp.compute_Kij(X, None, n, None, hyper_deriv=hd)
+    save("g2_gram", **out)
+
+
+# ----------------------------------------------------------------------------
+# G3 / G4: fit and predict
+# ----------------------------------------------------------------------------
+def synth(rs, N, d, n):
+    X = rs.rand(N, d)
+    s = X.sum(axis=1)
+    y = np.sin(s)
+    der = n.sum(axis=1) > 0
+    y[der] = np.cos(s[der])
+    y = y + 0.05 * rs.randn(N)
+    return X, y
+
+
+def record_fit(out, key, gp, with_L=True):
+    gp.compute_K_L_alpha_ll()
+    out[key + "ll"] = np.float64(gp.ll)
+    out[key + "prior"] = np.float64(gp.hyperprior(gp.params))
+    out[key + "logdet_half"] = np.float64(np.log(np.diag(gp.L)).sum())
+    out[key + "alpha"] = np.asarray(gp.alpha).ravel()
+    if with_L:
+        out[key + "L"] = np.asarray(gp.L)
+
+
+def gen_g3_g4():
+    rs = np.random.RandomState(303)
+    out3, out4 = {}, {}
+    cases = []
+    for kname, mk in (("se", se_kernel), ("m52", m52_kernel)):
+        for N, d in ((16, 1), (64, 2), (256, 3), (512, 2)):
+            cases.append((kname, mk, N, d))
+    for kname, mk, N, d in cases:
+        key = "%s_N%d_d%d_" % (kname, N, d)
+        n = deriv_pattern(rs, N, d, 0.25, 1)
+        X, y = synth(rs, N, d, n)
+        params = np.concatenate(([1.0], 0.3 * np.ones(d)))
+        err_y = 0.05 if N != 64 else 0.02 + 0.06 * rs.rand(N)   # scalar / heteroscedastic
+        gp = gptools.GaussianProcess(mk(d, params), X=X, y=y, err_y=err_y, n=n)
+        out3[key + "X"] = X
+        out3[key + "y"] = y
+        out3[key + "n"] = n.astype(np.int32)
+        out3[key + "err_y"] = np.asarray(gp.err_y)
+        out3[key + "params"] = params
+        record_fit(out3, key, gp, with_L=(N <= 256))
+
+        # predict at M = 32 incl. derivative rows
+        M = 32
+        Xs = rs.rand(M, d)
+        ns = deriv_pattern(rs, M, d, 0.5, 1)
+        mean, cov = gp.predict(Xs, n=ns, return_cov=True)
+        mean2, std = gp.predict(Xs, n=ns)
+        out4[key + "Xs"] = Xs
+        out4[key + "ns"] = ns.astype(np.int32)
+        out4[key + "mean"] = mean
+        out4[key + "cov"] = cov
+        out4[key + "std"] = std
+        # scalar n
+        m0, s0 = gp.predict(Xs, n=0)
+        out4[key + "mean_n0"] = m0
+        out4[key + "std_n0"] = s0
+        # output_transform
+        OT = rs.rand(5, M)
+        mo, co = gp.predict(Xs, n=ns, return_cov=True, output_transform=OT)
+        out4[key + "OT"] = OT
+        out4[key + "mean_ot"] = mo
+        out4[key + "cov_ot"] = co
+
+    # DiagonalNoiseKernel (+ predict noise=True)
+    for kname, mk in (("se", se_kernel), ("m52", m52_kernel)):
+        N, d = 64, 2
+        key = "%s_noise_" % kname
+        n = deriv_pattern(rs, N, d, 0.25, 1)
+        X, y = synth(rs, N, d, n)
+        params = np.array([1.1, 0.35, 0.25])
+        nk = gptools.DiagonalNoiseKernel(num_dim=d, initial_noise=0.07, noise_bound=(0.0, 5.0))
+        gp = gptools.GaussianProcess(mk(d, params), noise_k=nk, X=X, y=y, err_y=0.01, n=n)
+        out3[key + "X"] = X
+        out3[key + "y"] = y
+        out3[key + "n"] = n.astype(np.int32)
+        out3[key + "err_y"] = np.asarray(gp.err_y)
+        out3[key + "params"] = params
+        out3[key + "noise"] = np.float64(0.07)
+        record_fit(out3, key, gp)
+        M = 24
+        Xs = rs.rand(M, d)
+        Xs[2] = Xs[1]                        # duplicate test points (noise fires off-diagonal)
+        ns = np.zeros((M, d), dtype=int)
+        ns[M // 2:, 0] = 1
+        mean, cov = gp.predict(Xs, n=ns, noise=True, return_cov=True)
+        out4[key + "Xs"] = Xs
+        out4[key + "ns"] = ns.astype(np.int32)
+        out4[key + "mean"] = mean
+        out4[key + "cov"] = cov
+        mean_nn, cov_nn = gp.predict(Xs, n=ns, noise=False, return_cov=True)
+        out4[key + "cov_nonoise"] = cov_nn
+
+    # ConstantMeanFunction and T (linear transform) branch, SE
+    N, d = 48, 1
+    n = np.zeros((N, d), dtype=int)
+    X, y = synth(rs, N, d, n)
+    y = y + 2.5
+    params = np.array([0.9, 0.2])
+    mu = gptools.ConstantMeanFunction(initial_params=[2.4])
+    gp = gptools.GaussianProcess(se_kernel(d, params), mu=mu, X=X, y=y, err_y=0.05)
+    key = "se_mu_"
+    out3[key + "X"] = X
+    out3[key + "y"] = y
+    out3[key + "n"] = n.astype(np.int32)
+    out3[key + "err_y"] = np.asarray(gp.err_y)
+    out3[key + "params"] = params
+    out3[key + "mu"] = np.float64(2.4)
+    record_fit(out3, key, gp)
+    Xs = rs.rand(16, d)
+    ns = np.zeros((16, d), dtype=int)
+    ns[8:] = 1
+    mean, std = gp.predict(Xs, n=ns)
+    out4[key + "Xs"] = Xs
+    out4[key + "ns"] = ns.astype(np.int32)
+    out4[key + "mean"] = mean
+    out4[key + "std"] = std
+
+    # T: 12 transformed observations of 36 latent points + 10 plain points
+    d = 1
+    Xq = rs.rand(36, d)
+    T = rs.rand(12, 36) / 36.0
+    yT = T.dot(np.sin(3.0 * Xq[:, 0])) + 0.01 * rs.randn(12)
+    Xp = rs.rand(10, d)
+    yp = np.sin(3.0 * Xp[:, 0]) + 0.01 * rs.randn(10)
+    gp = gptools.GaussianProcess(se_kernel(d, np.array([1.2, 0.3])))
+    gp.add_data(Xp, yp, err_y=0.01)
+    gp.add_data(Xq, yT, err_y=0.01, T=T)
+    key = "se_T_"
+    out3[key + "Xp"] = Xp
+    out3[key + "yp"] = yp
+    out3[key + "Xq"] = Xq
+    out3[key + "yT"] = yT
+    out3[key + "T"] = T
+    out3[key + "params"] = np.array([1.2, 0.3])
+    out3[key + "Tfull"] = np.asarray(gp.T)
+    record_fit(out3, key, gp)
+    Xs = rs.rand(16, d)
+    mean, std = gp.predict(Xs)
+    out4[key + "Xs"] = Xs
+    out4[key + "mean"] = mean
+    out4[key + "std"] = std
+
+    # analytic hyper-derivative of ll (use_hyper_deriv=True), SE with noise kernel
+    N, d = 40, 2
+    n = np.zeros((N, d), dtype=int)
+    X, y = synth(rs, N, d, n)
+    nk = gptools.DiagonalNoiseKernel(num_dim=d, initial_noise=0.1, noise_bound=(0.0, 5.0))
+    gp = gptools.GaussianProcess(se_kernel(d, [1.0, 0.3, 0.4]), noise_k=nk, X=X, y=y, err_y=0.02,
+                                 use_hyper_deriv=True)
+    key = "se_hd_"
+    gp.compute_K_L_alpha_ll()
+    out3[key + "X"] = X
+    out3[key + "y"] = y
+    out3[key + "params"] = np.array([1.0, 0.3, 0.4])
+    out3[key + "noise"] = np.float64(0.1)
+    out3[key + "ll"] = np.float64(gp.ll)
+    out3[key + "ll_deriv"] = np.asarray(gp.ll_deriv)
+
+    save("g3_fit", **out3)
+    save("g4_predict", **out4)
+
+
+# ----------------------------------------------------------------------------
+# G5: update_hyperparameters sweep
+# ----------------------------------------------------------------------------
+def gen_g5():
+    rs = np.random.RandomState(505)
+    out = {}
+    N, d = 96, 2
+    n = deriv_pattern(rs, N, d, 0.25, 1)
+    X, y = synth(rs, N, d, n)
+    for kname, cls in (("se", gptools.SquaredExponentialKernel), ("m52", gptools.Matern52Kernel)):
+        k = cls(num_dim=d, initial_params=[1.0, 0.3, 0.3], param_bounds=[(1e-3, 10.0)] * 3)
+        gp = gptools.GaussianProcess(k, X=X, y=y, err_y=0.05, n=n)
+        thetas = [
+            [1.0, 0.3, 0.3], [0.5, 0.2, 0.6], [2.0, 0.8, 0.1], [0.1, 0.05, 0.05],
+            [5.0, 3.0, 3.0], [1.5, 0.31, 0.29], [0.9, 1.0, 1.0], [3.0, 0.15, 0.45],
+            [11.0, 0.3, 0.3],    # out of bounds -> +inf (gaussian_process.py:1387-1389)
+            [1.0, -0.1, 0.3],    # out of bounds -> +inf
+            [1.0, 0.3, 1e-4],    # below the lower bound -> +inf
+        ]
+        vals = [gp.update_hyperparameters(np.asarray(t, dtype=float)) for t in thetas]
+        out[kname + "_thetas"] = np.asarray(thetas)
+        out[kname + "_negll"] = np.asarray(vals, dtype=float)
+    out["X"] = X
+    out["y"] = y
+    out["n"] = n.astype(np.int32)
+    out["err_y"] = np.float64(0.05)
+    # non positive-definite: duplicated points, noiseless, diag_factor = 0 -> LinAlgError -> +inf
+    Xd = np.vstack((X[:8], X[:8]))
+    yd = np.concatenate((y[:8], y[:8]))
+    nd = np.zeros((16, d), dtype=int)
+    k = gptools.SquaredExponentialKernel(num_dim=d, initial_params=[1.0, 0.3, 0.3],
+                                         param_bounds=[(1e-3, 10.0)] * 3)
+    gp = gptools.GaussianProcess(k, X=Xd, y=yd, err_y=0.0, n=nd, diag_factor=0.0)
+    out["nonpd_X"] = Xd
+    out["nonpd_y"] = yd
+    out["nonpd_negll"] = np.float64(gp.update_hyperparameters(np.array([1.0, 0.3, 0.3])))
+    save("g5_update", **out)
+
+
+# ----------------------------------------------------------------------------
+# G6: demo (config 1)
+# ----------------------------------------------------------------------------
+def gen_g6():
+    out = {}
+    with open(os.path.join(ref_harness.REF_ROOT, "demo", "sample_data_core.pkl"), "rb") as f:
+        core = pickle.load(f, encoding="latin1")
+    with open(os.path.join(ref_harness.REF_ROOT, "demo", "sample_data_edge.pkl"), "rb") as f:
+        edge = pickle.load(f, encoding="latin1")
+    for nm, dat in (("core", core), ("edge", edge)):
+        for kk in ("X", "y", "err_y"):
+            out["%s_%s" % (nm, kk)] = np.asarray(dat[kk], dtype=float)
+
+    def make_gp():
+        hp = gptools.UniformJointPrior(0, 20) * gptools.GammaJointPriorAlt(1, 0.7)
+        gp = gptools.GaussianProcess(gptools.SquaredExponentialKernel(hyperprior=hp))
+        gp.add_data(core["X"], core["y"], err_y=core["err_y"])
+        gp.add_data(0, 0, n=1)
+        return gp
+
+    gp = make_gp()
+    demo_params = np.array([1.8849006111246833, 0.97760159723344708])   # demo/demo.py:191
+    out["demo_params"] = demo_params
+    out["negll_demo"] = np.float64(gp.update_hyperparameters(demo_params))
+    out["ll_demo"] = np.float64(gp.ll)
+    out["prior_demo"] = np.float64(gp.hyperprior(gp.params))
+    out["alpha_demo"] = np.asarray(gp.alpha).ravel()
+    out["L_demo"] = np.asarray(gp.L)
+    Xs = np.linspace(0, 1.1, 400)
+    out["X_star"] = Xs
+    y_star, err_y_star = gp.predict(Xs)
+    out["y_star"] = y_star
+    out["err_y_star"] = err_y_star
+    g_star, err_g_star = gp.predict(Xs, n=1)
+    out["grad_y_star"] = g_star
+    out["err_grad_y_star"] = err_g_star
+    full = gp.predict(np.concatenate((Xs, Xs)),
+                      n=np.concatenate((np.zeros_like(Xs), np.ones_like(Xs))), full_output=True)
+    out["full_mean"] = full["mean"]
+    out["full_std"] = full["std"]
+    out["full_cov_diag"] = np.diag(full["cov"]).copy()
+    out["full_cov_rows"] = full["cov"][[0, 199, 400, 799], :].copy()
+
+    # MAP estimate, deterministic (no random starts): L-BFGS-B and SLSQP from a fixed start
+    for method in ("SLSQP", "L-BFGS-B"):
+        gp = make_gp()
+        gp.update_hyperparameters(np.array([1.0, 1.0]))
+        res, nres = gp.optimize_hyperparameters(method=method, random_starts=0, num_proc=0)
+        out["map_%s_x" % method.replace("-", "")] = np.asarray(res.x)
+        out["map_%s_fun" % method.replace("-", "")] = np.float64(res.fun)
+
+    # with a fitted DiagonalNoiseKernel (demo/demo.py:126-128,158-159,192)
+    hp = gptools.UniformJointPrior(0, 20) * gptools.GammaJointPriorAlt(1, 0.7)
+    k_noise = gptools.DiagonalNoiseKernel(noise_bound=[0, 5])
+    gpn = gptools.GaussianProcess(gptools.SquaredExponentialKernel(hyperprior=hp), noise_k=k_noise)
+    gpn.add_data(core["X"], core["y"])
+    gpn.add_data(0, 0, n=1)
+    pn = np.array([1.7095365754195335, 1.222639837707701, 0.12181881916114756])   # demo/demo.py:192
+    out["demo_noise_params"] = pn
+    out["negll_demo_noise"] = np.float64(gpn.update_hyperparameters(pn))
+    yn, en = gpn.predict(Xs)
+    out["y_star_noise"] = yn
+    out["err_y_star_noise"] = en
+    save("g6_demo", **out)
+
+
+# ----------------------------------------------------------------------------
+# G7: tests/test_matern.py scenario with a seeded length-scale draw
+# ----------------------------------------------------------------------------
+def gen_g7():
+    f_X = np.random.RandomState(0).randn(5, 2)
+    f_y = f_X[:, 0] ** 2 + f_X[:, 1] ** 2
+    g_y_0 = 2 * f_X[:, 0]
+    g_y_1 = 2 * f_X[:, 1]
+    length_scales = np.random.RandomState(7).lognormal(size=2).tolist()
+    K1 = gptools.MaternKernelArb(num_dim=2, initial_params=[10, 5.0 / 2.0] + length_scales)
+    K2 = gptools.Matern52Kernel(num_dim=2, initial_params=[10] + length_scales)
+    gp1 = gptools.GaussianProcess(K1)
+    gp2 = gptools.GaussianProcess(K2)
+    gp1.add_data(f_X, f_y)
+    gp1.add_data(f_X, g_y_0, n=np.vstack((np.ones(len(f_X)), np.zeros(len(f_X)))).T)
+    gp1.add_data(f_X, g_y_1, n=np.vstack((np.zeros(len(f_X)), np.ones(len(f_X)))).T)
+    k1 = gp1.compute_Kij(gp1.X, None, gp1.n, None)
+    k2 = gp2.compute_Kij(gp1.X, None, gp1.n, None)
+    np.testing.assert_array_almost_equal(k1, k2, decimal=8)
+    save("g7_test_matern", X=np.asarray(gp1.X), n=np.asarray(gp1.n, dtype=np.int32),
+         y=np.asarray(gp1.y), length_scales=np.asarray(length_scales),
+         K_arb=np.asarray(k1, dtype=float), K_m52=np.asarray(k2, dtype=float))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g34", "g5", "g6", "g7"]
+    if "g1" in which:
+        gen_g1()
+    if "g2" in which:
+        gen_g2()
+    if "g34" in which:
+        gen_g3_g4()
+    if "g5" in which:
+        gen_g5()
+    if "g6" in which:
+        gen_g6()
+    if "g7" in which:
+        gen_g7()
