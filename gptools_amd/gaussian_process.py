@@ -1,0 +1,621 @@
+"""GaussianProcess: the reference's GP API with the covariance build + Cholesky + LML + predict
+hot path running on an MI355X through the C ABI of ``libgpt_hip.so``.
+
+ref: gptools/gaussian_process.py:56-503 (class, add_data), :623-783 (optimize_hyperparameters),
+:785-1034 (predict), :1332-1416 (update_hyperparameters), :1418-1522 (compute_K_L_alpha_ll),
+:1535-1605 (compute_Kij), :2443-2486 (_OptimizeHyperparametersEval).
+
+What runs where
+  * GPU (include/gpt_hip.h): ``K(X, X', n, n')`` (fused, never tiled), ``K_tot`` assembly, blocked
+    Cholesky, ``z = L^-1 y`` (as an extra row of the factorisation), log-determinant, ``alpha``,
+    and predict's ``K*^T alpha``, ``K*^T L^-T`` and ``K** - v^T v``.
+  * Host Python: argument checking, hyperparameter bookkeeping, the O(num_params) log-prior, the
+    mean function, ``T`` / ``output_transform`` products and scipy.optimize driving the MAP loop.
+There is no CPU fallback for the hot path: without the HIP library every computation raises.
+
+State attributes follow the reference: ``X n y err_y T K noise_K L alpha ll ll_deriv
+K_up_to_date``.  ``K``, ``noise_K``, ``L`` and ``alpha`` are fetched lazily from the device the
+first time they are read after a fit, so the MAP loop moves only ``params`` and a scalar.
+"""
+import sys
+import traceback
+import warnings
+
+import numpy as np
+import scipy.linalg
+import scipy.optimize
+
+from . import _lib
+from .error_handling import GPArgumentError, GPImpossibleParamsError
+from .kernel import Kernel, ZeroKernel, DiagonalNoiseKernel
+from .utils import CombinedBounds
+
+__all__ = ["GaussianProcess"]
+
+_NATIVE_FIT = (_lib.KERNEL_SE, _lib.KERNEL_M52)
+
+
+def _combine(a, b, c=None):
+    out = CombinedBounds(a, b)
+    return CombinedBounds(out, c) if c is not None else out
+
+
+class GaussianProcess(object):
+    """Gaussian process regression with derivative observations and predictions.
+
+    Parameters are those of ref: gptools/gaussian_process.py:196-238: ``k``, ``noise_k``, ``X``,
+    ``y``, ``err_y``, ``n``, ``T``, ``diag_factor``, ``mu``, ``use_hyper_deriv``, ``verbose``;
+    ``device`` (extra) selects the GPU.
+    """
+
+    def __init__(self, k, noise_k=None, X=None, y=None, err_y=0, n=0, T=None, diag_factor=1e2, mu=None,
+                 use_hyper_deriv=False, verbose=False, device=0):
+        if not isinstance(k, Kernel):
+            raise TypeError("Argument k must be an instance of Kernel when constructing GaussianProcess!")
+        if noise_k is None:
+            noise_k = ZeroKernel(k.num_dim)
+        elif not isinstance(noise_k, Kernel):
+            raise TypeError("Keyword noise_k must be an instance of Kernel when constructing GaussianProcess!")
+        self.mu = mu
+        self.diag_factor = diag_factor
+        self.k = k
+        self.noise_k = noise_k
+        self.use_hyper_deriv = use_hyper_deriv
+        self.verbose = verbose
+        self.device = device
+        self.y = np.array([], dtype=float)
+        self.X = None
+        self.err_y = np.array([], dtype=float)
+        self.n = None
+        self.T = None
+        self.ll = None
+        self.ll_deriv = None
+        self._reset_device_state()
+        if X is not None:
+            if y is None:
+                raise GPArgumentError("Must pass both X and y when constructing GaussianProcess!")
+            self.add_data(X, y, err_y=err_y, n=n, T=T)
+        elif y is not None:
+            raise GPArgumentError("Must pass both X and y when constructing GaussianProcess!")
+        else:
+            self.K_up_to_date = False
+
+    # ---- device plumbing -------------------------------------------------------------------
+    def _reset_device_state(self):
+        self._ctx_obj = None
+        self._data_on_device = False
+        self._cache = {}
+        self._fit_mode = None
+
+    @property
+    def _ctx(self):
+        """Per-instance context (owns the resident factorisation); created on first use."""
+        if self._ctx_obj is None:
+            self._ctx_obj = _lib.Context(self.device)
+        return self._ctx_obj
+
+    def __getstate__(self):
+        # The reference keeps the GP picklable for its process pools (gaussian_process.py:1701-1703);
+        # device handles never cross a pickle: they are re-created lazily in the new process.
+        st = dict(self.__dict__)
+        st["_ctx_obj"] = None
+        st["_data_on_device"] = False
+        st["_cache"] = {}
+        st["_fit_mode"] = None
+        st["K_up_to_date"] = False
+        return st
+
+    # ---- hyperparameter views (ref: gptools/gaussian_process.py:246-374) ---------------------
+    @property
+    def hyperprior(self):
+        hp = self.k.hyperprior * self.noise_k.hyperprior
+        if self.mu is not None:
+            hp = hp * self.mu.hyperprior
+        return hp
+
+    @property
+    def num_dim(self):
+        return self.k.num_dim
+
+    def _parts(self):
+        return [self.k, self.noise_k] + ([self.mu] if self.mu is not None else [])
+
+    def _view(self, attr):
+        return _combine(*[getattr(p, attr) for p in self._parts()])
+
+    def _scatter(self, attr, value, count_attr):
+        pos = 0
+        for p in self._parts():
+            cnt = getattr(p, count_attr)
+            setattr(p, attr, value[pos:pos + cnt])
+            pos += cnt
+
+    @property
+    def fixed_params(self):
+        return self._view("fixed_params")
+
+    @fixed_params.setter
+    def fixed_params(self, value):
+        self._scatter("fixed_params", np.asarray(value, dtype=bool), "num_params")
+
+    @property
+    def params(self):
+        return self._view("params")
+
+    @params.setter
+    def params(self, value):
+        self.K_up_to_date = False
+        self._scatter("params", np.asarray(value, dtype=float), "num_params")
+
+    @property
+    def param_bounds(self):
+        return self.hyperprior.bounds
+
+    @param_bounds.setter
+    def param_bounds(self, value):
+        self.hyperprior.bounds = value
+
+    @property
+    def param_names(self):
+        return self._view("param_names")
+
+    @param_names.setter
+    def param_names(self, value):
+        self._scatter("param_names", value, "num_params")
+
+    @property
+    def free_params(self):
+        return self._view("free_params")
+
+    @free_params.setter
+    def free_params(self, value):
+        self.K_up_to_date = False
+        self._scatter("free_params", np.asarray(value, dtype=float), "num_free_params")
+
+    @property
+    def free_param_bounds(self):
+        return self._view("free_param_bounds")
+
+    @free_param_bounds.setter
+    def free_param_bounds(self, value):
+        self._scatter("free_param_bounds", np.asarray(value, dtype=float), "num_free_params")
+
+    @property
+    def free_param_names(self):
+        return self._view("free_param_names")
+
+    @free_param_names.setter
+    def free_param_names(self, value):
+        self.K_up_to_date = False
+        self._scatter("free_param_names", np.asarray(value, dtype=str), "num_free_params")
+
+    # ---- data ingest (ref: gptools/gaussian_process.py:376-503) ------------------------------
+    def add_data(self, X, y, err_y=0, n=0, T=None):
+        """Append observations.  ``X`` (M, D), ``y`` (M,), ``err_y`` scalar or (M,) standard
+        deviations, ``n`` scalar or (M, D) derivative orders, ``T`` optional (M, N) transform."""
+        y = np.atleast_1d(np.asarray(y, dtype=float))
+        if y.ndim != 1:
+            raise ValueError("Training targets y must have only one dimension with length greater than one! "
+                             "Shape of y given is {}".format(y.shape))
+        try:
+            iter(err_y)
+        except TypeError:
+            err_y = err_y * np.ones_like(y, dtype=float)
+        else:
+            err_y = np.asarray(err_y, dtype=float)
+            if err_y.shape != y.shape:
+                raise ValueError("When using array-like err_y, shape must match shape of y! Shape of err_y given is "
+                                 "{}, shape of y given is {}.".format(err_y.shape, y.shape))
+        if (err_y < 0).any():
+            raise ValueError("All elements of err_y must be non-negative!")
+        X = np.atleast_2d(np.asarray(X, dtype=float))
+        if self.num_dim == 1 and X.shape[0] == 1:
+            X = X.T
+        if T is None and X.shape != (len(y), self.num_dim):
+            raise ValueError("Shape of training inputs must be (len(y), k.num_dim)! X given has shape {}, shape of "
+                             "y is {} and num_dim={:d}.".format(X.shape, y.shape, self.num_dim))
+        try:
+            iter(n)
+        except TypeError:
+            n = n * np.ones_like(X, dtype=int)
+        else:
+            n = np.atleast_2d(np.asarray(n, dtype=int))
+            if self.num_dim == 1 and n.shape[1] != 1:
+                n = n.T
+            if n.shape != X.shape:
+                raise ValueError("When using array-like n, shape must be (len(y), k.num_dim)! Shape of n given is "
+                                 "{}, shape of y given is {} and num_dim={:d}.".format(n.shape, y.shape, self.num_dim))
+        if (n < 0).any():
+            raise ValueError("All elements of n must be non-negative integers!")
+        if T is None and self.T is not None:
+            T = np.eye(len(y))
+        if T is not None:
+            T = np.atleast_2d(np.asarray(T, dtype=float))
+            if T.ndim != 2:
+                raise ValueError("T must have exactly 2 dimensions!")
+            if T.shape[0] != len(y):
+                raise ValueError("T must have as many rows are there are elements in y!")
+            if T.shape[1] != X.shape[0]:
+                raise ValueError("There must be as many columns in T as there are rows in X!")
+            if self.T is None and self.X is not None:
+                self.T = np.eye(len(self.y))
+            self.T = T if self.T is None else scipy.linalg.block_diag(self.T, T)
+        self.X = X if self.X is None else np.vstack((self.X, X))
+        self.y = np.append(self.y, y)
+        self.err_y = np.append(self.err_y, err_y)
+        self.n = n if self.n is None else np.vstack((self.n, n))
+        self.K_up_to_date = False
+        self._data_on_device = False
+
+    # ---- covariance matrices (ref: gptools/gaussian_process.py:1535-1605) --------------------
+    def compute_Kij(self, Xi, Xj, ni, nj, noise=False, hyper_deriv=None, k=None):
+        """Covariance matrix between ``Xi`` (M, D) and ``Xj`` (P, D) -> (M, P); ``Xj=None`` gives the
+        symmetric ``K(Xi, Xi)``.  Native kernels use the fused GPU builder (``gpt_kbuild``); other
+        ``Kernel`` subclasses receive the row-major pair list like the reference."""
+        if k is None:
+            k = self.noise_k if noise else self.k
+        Xi = np.atleast_2d(np.asarray(Xi, dtype=float))
+        ni = np.atleast_2d(np.asarray(ni, dtype=int))
+        kid = getattr(k, "_gpt_kernel_id", None)
+        if kid is not None and type(k).__call__ in (Kernel.__call__, _M52_CALL, _ZERO_CALL):
+            if kid == _lib.KERNEL_M52 and hyper_deriv is not None:
+                raise NotImplementedError("Hyperparameter derivatives have not been implemented!")
+            Xj_ = None if Xj is None else np.atleast_2d(np.asarray(Xj, dtype=float))
+            nj_ = None if Xj is None else np.atleast_2d(np.asarray(nj, dtype=int))
+            return self._ctx.kbuild(kid, k.params, Xi, ni, Xj_, nj_, hyper_deriv=hyper_deriv,
+                                    noise_n=getattr(k, "n", None))
+        symmetric = Xj is None
+        if symmetric:
+            Xj, nj = Xi, ni
+        Xj = np.atleast_2d(np.asarray(Xj, dtype=float))
+        nj = np.atleast_2d(np.asarray(nj, dtype=int))
+        M, P = Xi.shape[0], Xj.shape[0]
+        Kij = k(np.repeat(Xi, P, axis=0), np.tile(Xj, (M, 1)), np.repeat(ni, P, axis=0), np.tile(nj, (M, 1)),
+                hyper_deriv=hyper_deriv, symmetric=symmetric)
+        return np.reshape(Kij, (M, -1))
+
+    # ---- lazily materialised state ------------------------------------------------------------
+    def _cached(self, key, fn):
+        if key not in self._cache:
+            self._cache[key] = fn()
+        return self._cache[key]
+
+    @property
+    def K(self):
+        """Noise-free training covariance (ref attribute ``K``, gaussian_process.py:1431)."""
+        self.compute_K_L_alpha_ll()
+        return self._cached("K", lambda: self.compute_Kij(self.X, None, self.n, None))
+
+    @property
+    def noise_K(self):
+        """Noise part of the training covariance (ref: gaussian_process.py:1434-1439)."""
+        self.compute_K_L_alpha_ll()
+        return self._cached("noise_K", self._noise_K)
+
+    def _noise_K(self):
+        N = self.X.shape[0]
+        if isinstance(self.noise_k, ZeroKernel):
+            return np.zeros((N, N))
+        if isinstance(self.noise_k, DiagonalNoiseKernel):
+            return self.noise_k.params[0] ** 2.0 * np.eye(N)
+        return self.compute_Kij(self.X, None, self.n, None, noise=True)
+
+    @property
+    def L(self):
+        """Lower Cholesky factor of ``K_tot`` (ref: gaussian_process.py:1452)."""
+        self.compute_K_L_alpha_ll()
+        return self._cached("L", lambda: self._ctx.get_L(len(self.y)))
+
+    @property
+    def alpha(self):
+        """``K_tot^-1 (y - T mu)`` as an (N_y, 1) column (ref: gaussian_process.py:1462)."""
+        self.compute_K_L_alpha_ll()
+        return self._cached("alpha", lambda: self._ctx.get_alpha(len(self.y)).reshape(-1, 1))
+
+    # ---- the fit (ref: gptools/gaussian_process.py:1418-1522) --------------------------------
+    def _y_alph(self):
+        if self.mu is None:
+            return self.y
+        mu_alph = self.mu(self.X, self.n)
+        if self.T is not None:
+            mu_alph = self.T.dot(mu_alph)
+        return self.y - mu_alph
+
+    def _fast_fit_possible(self):
+        return (self.T is None and getattr(self.k, "_gpt_kernel_id", None) in _NATIVE_FIT and
+                type(self.k).__call__ in (Kernel.__call__, _M52_CALL) and
+                isinstance(self.noise_k, (ZeroKernel, DiagonalNoiseKernel)))
+
+    def compute_K_L_alpha_ll(self):
+        """Build ``K_tot``, factor it and evaluate the log-posterior ``ll`` on the GPU (no-op while
+        ``K_up_to_date``).  Raises ``numpy.linalg.LinAlgError`` if ``K_tot`` is not positive
+        definite, like ``scipy.linalg.cholesky`` in the reference."""
+        if self.K_up_to_date:
+            return
+        if self.X is None:
+            raise GPArgumentError("No data have been added to the GaussianProcess!")
+        self._cache = {}
+        y_alph = self._y_alph()
+        diag_add = self.diag_factor * sys.float_info.epsilon
+        ctx = self._ctx
+        if self._fast_fit_possible():
+            if not self._data_on_device:
+                ctx.set_data(self.X, self.n)
+                self._data_on_device = True
+            if isinstance(self.noise_k, ZeroKernel):
+                noise_var = 0.0
+            else:
+                noise_var = self.noise_k.params[0] ** 2.0
+            ll_data, _ = ctx.fit(self.k._gpt_kernel_id, self.k.params, noise_var, y_alph, self.err_y, diag_add)
+            self._fit_mode = "kernel"
+        else:
+            # T (linear transform) or a Python-defined kernel: K is still built by the GPU builder
+            # where the kernel is native, the small T products are host GEMMs, the factorisation and
+            # solves run on the GPU (gpt_fit_matrix).
+            K = self.compute_Kij(self.X, None, self.n, None)
+            self._cache["K"] = K
+            noise_K = self._noise_K()
+            self._cache["noise_K"] = noise_K
+            KnK = K + noise_K
+            if self.T is not None:
+                KnK = self.T.dot(KnK).dot(self.T.T)
+            K_tot = KnK + np.diag(self.err_y ** 2.0) + diag_add * np.eye(len(self.y))
+            ll_data, _ = ctx.fit_matrix(K_tot, y_alph)
+            self._data_on_device = False
+            self._fit_mode = "matrix"
+        self.ll = ll_data + self.hyperprior(self.params)          # log-posterior (ref :1469)
+        if self.use_hyper_deriv:
+            self._compute_ll_deriv()
+        self.K_up_to_date = True
+
+    def _compute_ll_deriv(self):
+        """Gradient of the log-posterior with respect to the free hyperparameters
+        (ref: gptools/gaussian_process.py:1471-1520): 1/2 (alpha^T dK alpha - tr(K_tot^-1 dK))."""
+        warnings.warn("Use of hyperparameter derivatives is experimental!")
+        ctx = self._ctx
+        Ny = len(self.y)
+        alpha = ctx.get_alpha(Ny)
+        self._cache["alpha"] = alpha.reshape(-1, 1)
+
+        def term(dK):
+            if self.T is not None:
+                dK = self.T.dot(dK).dot(self.T.T)
+            W = ctx.solve_L(dK)                     # L^-1 dK
+            W2 = ctx.solve_L(np.ascontiguousarray(W.T))    # L^-1 (L^-1 dK)^T -> trace equals tr(K^-1 dK)
+            return 0.5 * (alpha.dot(dK.dot(alpha)) - np.trace(W2))
+
+        ll_deriv = np.zeros(len(self.free_params))
+        if isinstance(self.noise_k, ZeroKernel):
+            knk = self.k
+        elif isinstance(self.noise_k, DiagonalNoiseKernel):
+            knk = self.k
+            if not self.noise_k.fixed_params[0]:
+                ll_deriv[len(self.k.free_params)] = term(2.0 * self.noise_k.params[0] * np.eye(Ny))
+        else:
+            knk = self.k + self.noise_k
+        free_idx = np.arange(0, len(knk.params), dtype=int)[~np.asarray(knk.fixed_params, dtype=bool)]
+        for i, pi in enumerate(free_idx):
+            ll_deriv[i] = term(self.compute_Kij(self.X, None, self.n, None, k=knk, hyper_deriv=int(pi)))
+        if self.mu is not None:
+            free_idx = np.arange(0, len(self.mu.params), dtype=int)[~self.mu.fixed_params]
+            for i, pi in enumerate(free_idx):
+                dmu = self.mu(self.X, self.n, hyper_deriv=int(pi))
+                if self.T is not None:
+                    dmu = self.T.dot(dmu)
+                ll_deriv[i + len(knk.free_params)] = dmu.dot(alpha)
+        free_idx = np.arange(0, len(self.params), dtype=int)[~np.asarray(self.fixed_params[:], dtype=bool)]
+        for i, pi in enumerate(free_idx):
+            ll_deriv[i] += self.hyperprior(self.params[:], hyper_deriv=int(pi))
+        self.ll_deriv = ll_deriv
+
+    # ---- hyperparameter update (ref: gptools/gaussian_process.py:1332-1416) -------------------
+    def update_hyperparameters(self, new_params, hyper_deriv_handling="default", exit_on_bounds=True,
+                               inf_on_error=True):
+        """Set the free hyperparameters and refit; returns ``-ll`` (and ``-ll_deriv``).  Impossible
+        parameters and linear-algebra failures give ``+inf`` when ``inf_on_error``."""
+        use_hyper_deriv = self.use_hyper_deriv
+        if hyper_deriv_handling == "value":
+            self.use_hyper_deriv = False
+        elif hyper_deriv_handling == "deriv":
+            self.use_hyper_deriv = True
+        new_params = np.asarray(new_params, dtype=float)
+        nk, nn = len(self.k.free_params), len(self.noise_k.free_params)
+        self.k.set_hyperparams(new_params[:nk])
+        self.noise_k.set_hyperparams(new_params[nk:nk + nn])
+        if self.mu is not None:
+            self.mu.set_hyperparams(new_params[nk + nn:])
+        self.K_up_to_date = False
+        try:
+            if exit_on_bounds and np.isinf(self.hyperprior(self.params)):
+                raise GPImpossibleParamsError("Impossible values for params!")
+            self.compute_K_L_alpha_ll()
+        except Exception as e:
+            self.use_hyper_deriv = use_hyper_deriv
+            if not inf_on_error:
+                raise e
+            if not isinstance(e, GPImpossibleParamsError) and self.verbose:
+                warnings.warn("Unhandled exception when updating GP! Exception was:\n{:s}\nState of params is: "
+                              "{:s}".format(traceback.format_exc(), str(self.free_params[:])))
+            if use_hyper_deriv and hyper_deriv_handling == "default":
+                return (np.inf, np.zeros(len(self.free_params)))
+            if hyper_deriv_handling == "deriv":
+                return np.zeros(len(self.free_params))
+            return np.inf
+        self.use_hyper_deriv = use_hyper_deriv
+        if use_hyper_deriv and hyper_deriv_handling == "default":
+            return (-1.0 * self.ll, -1.0 * self.ll_deriv)
+        if hyper_deriv_handling == "deriv":
+            return -1.0 * self.ll_deriv
+        return -1.0 * self.ll
+
+    # ---- MAP estimate (ref: gptools/gaussian_process.py:623-783, :2443-2486) ------------------
+    def optimize_hyperparameters(self, method="SLSQP", opt_kwargs={}, verbose=False, random_starts=None,
+                                 num_proc=None, max_tries=1):
+        """Maximise the log-posterior with ``scipy.optimize.minimize`` from ``random_starts`` draws
+        of the hyperprior (0: start from the current values).  Every objective evaluation is one GPU
+        fit.  ``num_proc`` is accepted for compatibility; starts run one after another because a
+        HIP context must not be shared across forked workers."""
+        opt_kwargs = dict(opt_kwargs or {})
+        if "method" in opt_kwargs:
+            method = opt_kwargs["method"]
+        else:
+            opt_kwargs["method"] = method
+        if num_proc is None:
+            num_proc = 1
+        param_ranges = np.array(self.free_param_bounds[:], dtype=float)
+        lo, hi = param_ranges[:, 0], param_ranges[:, 1]
+        lo[np.isnan(lo) | np.isinf(lo)] = -1e16
+        hi[np.isnan(hi) | np.isinf(hi)] = 1e16
+        free_mask = ~np.asarray(self.fixed_params[:], dtype=bool)
+
+        def draw():
+            return np.atleast_2d(self.hyperprior.random_draw(size=random_starts).T)[:, free_mask]
+
+        if random_starts == 0:
+            param_samples = [np.array(self.free_params[:], dtype=float)]
+        else:
+            if random_starts is None:
+                random_starts = max(num_proc, 1)
+            param_samples = draw()
+        opt_kwargs.setdefault("bounds", param_ranges)
+        if self.use_hyper_deriv:
+            opt_kwargs["jac"] = True
+
+        def run(samp):
+            try:
+                return scipy.optimize.minimize(self.update_hyperparameters, samp, **opt_kwargs)
+            except Exception:
+                if self.verbose:
+                    warnings.warn("Minimizer failed, skipping sample. Error is: {:s}. State of params is: "
+                                  "{:s}".format(traceback.format_exc(), str(self.free_params[:])), RuntimeWarning)
+                return None
+
+        trial, res_min, res = 0, None, []
+        while trial < max_tries and res_min is None:
+            if trial >= 1 and random_starts != 0:
+                param_samples = draw()
+            trial += 1
+            res = [r for r in (run(s) for s in param_samples) if r is not None]
+            finite = [r for r in res if np.isfinite(r.fun)]
+            res_min = min(finite, key=lambda r: r.fun) if finite else None
+        if res_min is None:
+            raise ValueError("Optimizer failed to find a valid solution. Try changing the parameter bounds, "
+                             "picking a new initial guess or increasing the number of random starts.")
+        self.update_hyperparameters(res_min.x)
+        if verbose:
+            print("Got {:d} completed starts, optimal result is:".format(len(res)))
+            print(res_min)
+            print("\nLL\t{:.3g}".format(-1 * res_min.fun))
+            for v, l in zip(res_min.x, self.free_param_names[:]):
+                print("{:s}\t{:.3g}".format(str(l).replace("\\", ""), v))
+        if not res_min.success:
+            warnings.warn("Optimizer {:s} reports failure, selected hyperparameters are likely NOT optimal. Status: "
+                          "{:d}, Message: '{:s}'. Try adjusting bounds, initial guesses or the number of random "
+                          "starts used.".format(method, res_min.status, str(res_min.message)), RuntimeWarning)
+        bounds = np.asarray(self.free_param_bounds[:], dtype=float)
+        if (res_min.x <= 1.001 * bounds[:, 0]).any() or (res_min.x >= 0.999 * bounds[:, 1]).any():
+            warnings.warn("Optimizer appears to have hit/exceeded the bounds. Bounds are:\n{:s}\n, solution is:\n"
+                          "{:s}. Try adjusting bounds, initial guesses or the number of random starts "
+                          "used.".format(str(bounds), str(res_min.x)))
+        return (res_min, len(res))
+
+    # ---- prediction (ref: gptools/gaussian_process.py:785-1034) ------------------------------
+    def predict(self, Xstar, n=0, noise=False, return_std=True, return_cov=False, full_output=False,
+                return_samples=False, num_samples=1, samp_kwargs={}, return_mean_func=False, use_MCMC=False,
+                full_MC=False, rejection_func=None, ddof=1, output_transform=None, **kwargs):
+        """Predictive mean (and std / covariance) at ``Xstar`` (M, D) for derivative orders ``n``.
+
+        Returns ``mean``, ``(mean, std)``, ``(mean, cov)`` or the ``full_output`` dict exactly like the
+        reference's non-MCMC branch.  Sampling / MCMC options are outside the accelerated path."""
+        if use_MCMC or return_samples or full_MC:
+            raise NotImplementedError("MCMC marginalisation and posterior sampling are outside the accelerated "
+                                      "hot path (SURVEY.md section 8).")
+        Xstar = np.atleast_2d(np.asarray(Xstar, dtype=float))
+        if self.num_dim == 1 and Xstar.shape[0] == 1:
+            Xstar = Xstar.T
+        if Xstar.shape[1] != self.num_dim:
+            raise ValueError("Second dimension of Xstar must be equal to self.num_dim! Shape of Xstar given is "
+                             "{:s}, num_dim is {:d}.".format(str(Xstar.shape), self.num_dim))
+        if output_transform is not None:
+            output_transform = np.atleast_2d(np.asarray(output_transform, dtype=float))
+            if output_transform.ndim != 2:
+                raise ValueError("output_transform must have exactly 2 dimensions! Shape of output_transform given "
+                                 "is {:s}.".format(str(output_transform.shape)))
+            if output_transform.shape[1] != Xstar.shape[0]:
+                raise ValueError("output_transform must have the same number of columns the number of rows in "
+                                 "Xstar! Shape of output_transform given is {:s}, shape of Xstar is "
+                                 "{:s}.".format(str(output_transform.shape), str(Xstar.shape)))
+        try:
+            iter(n)
+        except TypeError:
+            n = n * np.ones(Xstar.shape, dtype=int)
+        else:
+            n = np.atleast_2d(np.asarray(n, dtype=int))
+            if self.num_dim == 1 and n.shape[0] == 1:
+                n = n.T
+            if n.shape != Xstar.shape:
+                raise ValueError("When using array-like n, shape must match shape of Xstar! Shape of n given is "
+                                 "{:s}, shape of Xstar given is {:s}.".format(str(n.shape), str(Xstar.shape)))
+        if (n < 0).any():
+            raise ValueError("All elements of n must be non-negative integers!")
+
+        self.compute_K_L_alpha_ll()
+        need_cov = return_cov or full_output or (output_transform is not None and (return_std or return_cov))
+        need_std = return_std or need_cov
+        if self._fit_mode == "kernel":
+            want = 2 if need_cov else (1 if need_std else 0)
+            noise_params = noise_n = None
+            if noise and isinstance(self.noise_k, DiagonalNoiseKernel) and not isinstance(self.noise_k, ZeroKernel):
+                noise_params, noise_n = self.noise_k.params, self.noise_k.n
+            mean, std, covariance = self._ctx.predict(Xstar, n, want, noise_params, noise_n)
+        else:
+            mean, std, covariance = self._predict_general(Xstar, n, noise, need_std)
+        mean_func = None
+        if self.mu is not None:
+            mean_func = self.mu(Xstar, n)
+            mean = mean + mean_func
+        if output_transform is not None:
+            mean = output_transform.dot(mean)
+            if mean_func is not None:
+                mean_func = output_transform.dot(mean_func)
+            if covariance is not None:
+                covariance = output_transform.dot(covariance.dot(output_transform.T))
+                std = np.sqrt(np.diagonal(covariance))
+        if not need_std:
+            return mean
+        if full_output:
+            out = {"mean": mean, "std": std, "cov": covariance}
+            if return_mean_func and mean_func is not None:
+                out["mean_func"] = mean_func
+                out["cov_func"] = np.zeros((len(mean_func), len(mean_func)), dtype=float)
+                out["std_func"] = np.zeros_like(mean_func)
+                out["mean_without_func"] = mean - mean_func
+                out["cov_without_func"] = covariance
+                out["std_without_func"] = std
+            return out
+        if return_cov:
+            return (mean, covariance)
+        return (mean, std)
+
+    def _predict_general(self, Xstar, n, noise, need_std):
+        """predict for fits that went through ``gpt_fit_matrix`` (``T`` present or a Python kernel):
+        covariance blocks from ``compute_Kij``, triangular solves on the GPU."""
+        Kstar = self.compute_Kij(self.X, Xstar, self.n, n)
+        if noise:
+            Kstar = Kstar + self.compute_Kij(self.X, Xstar, self.n, n, noise=True)
+        if self.T is not None:
+            Kstar = self.T.dot(Kstar)
+        mean = Kstar.T.dot(self.alpha).ravel()
+        if not need_std:
+            return mean, None, None
+        v = self._ctx.solve_L(Kstar)
+        Kss = self.compute_Kij(Xstar, None, n, None)
+        if noise:
+            Kss = Kss + self.compute_Kij(Xstar, None, n, None, noise=True)
+        covariance = Kss - v.T.dot(v)
+        return mean, np.sqrt(np.diagonal(covariance)), covariance
+
+
+from .kernel.matern import Matern52Kernel as _M52       # noqa: E402
+_M52_CALL = _M52.__call__
+_ZERO_CALL = ZeroKernel.__call__

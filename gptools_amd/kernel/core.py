@@ -1,0 +1,243 @@
+"""Kernel plugin base class: hyperparameter storage + the ``__call__`` pair-list contract.
+
+ref: gptools/kernel/core.py:44-421 (Kernel), :424-584 (BinaryKernel / SumKernel).
+
+Covariance kernels are evaluated element-wise on a pair list: row m of the four (M, D) inputs
+``Xi, Xj, ni, nj`` gives covariance m (ref: gptools/kernel/core.py:220-257).  Kernels that carry a
+``_gpt_kernel_id`` are evaluated by the HIP library (``gpt_kpairs`` for the pair list,
+``gpt_kbuild`` / ``gpt_fit`` for whole matrices, see include/gpt_hip.h); user subclasses written
+in Python keep working through the same interface (``GaussianProcess.compute_Kij`` then feeds them
+the tiled pair list exactly like ref: gptools/gaussian_process.py:1591-1603).
+"""
+import warnings
+
+import numpy as np
+
+from ..error_handling import GPArgumentError
+from ..utils import UniformJointPrior, IndependentJointPrior, MaskedBounds
+from .. import _lib
+
+__all__ = ["Kernel", "BinaryKernel", "SumKernel"]
+
+
+class Kernel(object):
+    """Covariance kernel base class (not meant to be instantiated directly).
+
+    Parameters follow ref: gptools/kernel/core.py:136-210: ``num_dim``, ``num_params``,
+    ``initial_params``, ``fixed_params``, ``param_bounds``, ``param_names``, ``enforce_bounds``,
+    ``hyperprior``.  Length scales of stationary kernels are the last ``num_dim`` parameters.
+    """
+
+    _gpt_kernel_id = None     # set by the kernels the HIP library implements natively
+
+    def __init__(self, num_dim=1, num_params=0, initial_params=None, fixed_params=None, param_bounds=None,
+                 param_names=None, enforce_bounds=False, hyperprior=None):
+        if not isinstance(num_params, (int, np.integer)) or num_params < 0:
+            raise ValueError("num_params must be an integer >= 0!")
+        self.num_params = int(num_params)
+        if param_names is None:
+            param_names = [""] * self.num_params
+        elif len(param_names) != self.num_params:
+            raise ValueError("param_names must be a list of length num_params!")
+        self.param_names = np.asarray(param_names, dtype=str)
+        if not isinstance(num_dim, (int, np.integer)) or num_dim < 1:
+            raise ValueError("num_dim must be an integer > 0!")
+        self.num_dim = int(num_dim)
+        self.enforce_bounds = enforce_bounds
+
+        if initial_params is None:
+            if fixed_params is not None:
+                raise GPArgumentError("Must pass explicit parameter values if fixing parameters!")
+            initial_params = np.ones(self.num_params, dtype=float)
+            fixed_params = np.zeros(self.num_params, dtype=bool)
+        else:
+            if len(initial_params) != self.num_params:
+                raise ValueError("Length of initial_params must be equal to num_params!")
+            if fixed_params is None:
+                fixed_params = np.zeros(self.num_params, dtype=bool)
+            elif len(fixed_params) != self.num_params:
+                raise ValueError("Length of fixed_params must be equal to num_params!")
+        self.fixed_params = np.asarray(fixed_params, dtype=bool)
+
+        if param_bounds is None and hyperprior is None:
+            if (~self.fixed_params).any():
+                warnings.warn("Neither param_bounds nor hyperprior were specified when creating the kernel, "
+                              "defaults may not be appropriate for your data.")
+            param_bounds = self.num_params * [(0.0, 1e16)]
+        elif param_bounds is not None and len(param_bounds) != self.num_params:
+            raise ValueError("Length of param_bounds must be equal to num_params!")
+
+        if hyperprior is None:
+            hyperprior = UniformJointPrior(param_bounds)
+        elif not callable(hyperprior) or isinstance(hyperprior, (list, tuple)):
+            if len(hyperprior) != self.num_params:
+                raise ValueError("If hyperprior is a list its length must be equal to num_params!")
+            hyperprior = IndependentJointPrior(hyperprior)
+        self.params = np.array(initial_params, dtype=float)
+        self.hyperprior = hyperprior
+
+    # ---- bounds / free-parameter views (ref: gptools/kernel/core.py:212-352) ----
+    @property
+    def param_bounds(self):
+        return self.hyperprior.bounds
+
+    @param_bounds.setter
+    def param_bounds(self, value):
+        self.hyperprior.bounds = value
+
+    @property
+    def num_free_params(self):
+        return int(np.sum(~self.fixed_params))
+
+    @property
+    def free_param_idxs(self):
+        return np.arange(0, self.num_params)[~self.fixed_params]
+
+    @property
+    def free_params(self):
+        return MaskedBounds(self.params, self.free_param_idxs)
+
+    @free_params.setter
+    def free_params(self, value):
+        self.params[self.free_param_idxs] = np.asarray(value, dtype=float)
+
+    @property
+    def free_param_bounds(self):
+        return MaskedBounds(self.hyperprior.bounds, self.free_param_idxs)
+
+    @free_param_bounds.setter
+    def free_param_bounds(self, value):
+        for i, v in zip(self.free_param_idxs, value):
+            self.hyperprior.bounds[i] = v
+
+    @property
+    def free_param_names(self):
+        return MaskedBounds(self.param_names, self.free_param_idxs)
+
+    @free_param_names.setter
+    def free_param_names(self, value):
+        self.param_names = np.asarray(self.param_names, dtype=str)
+        self.param_names[~self.fixed_params] = value
+
+    def set_hyperparams(self, new_params):
+        """Set the free hyperparameters, clamping to the bounds if ``enforce_bounds``
+        (ref: gptools/kernel/core.py:259-287)."""
+        new_params = np.array(new_params, dtype=float)
+        if len(new_params) != len(self.free_params):
+            raise ValueError("Length of new_params must be {:d}!".format(len(self.free_params)))
+        if self.enforce_bounds:
+            for idx, (p, b) in enumerate(zip(new_params, self.free_param_bounds)):
+                if b[0] is not None and p < b[0]:
+                    new_params[idx] = b[0]
+                elif b[1] is not None and p > b[1]:
+                    new_params[idx] = b[1]
+        self.params[~self.fixed_params] = new_params
+
+    # ---- evaluation ----
+    def __call__(self, Xi, Xj, ni, nj, hyper_deriv=None, symmetric=False):
+        """Covariances of the M pairs ``(Xi[m], Xj[m])`` with derivative orders ``(ni[m], nj[m])``.
+
+        Native kernels run ``gpt_kpairs`` on the GPU; the base class itself is abstract
+        (ref: gptools/kernel/core.py:254-257).
+        """
+        if self._gpt_kernel_id is None:
+            raise NotImplementedError("This is an abstract method -- please use one of the implementing subclasses!")
+        return _lib.default_context().kpairs(
+            self._gpt_kernel_id, self.params, np.atleast_2d(Xi), np.atleast_2d(Xj), np.atleast_2d(ni),
+            np.atleast_2d(nj), hyper_deriv=hyper_deriv, symmetric=symmetric, noise_n=getattr(self, "n", None))
+
+    def _compute_r2l2(self, tau, return_l=False):
+        """Anisotropic ``sum_d tau_d^2 / l_d^2`` with the 0/0 -> 0 rule; a host helper for Python
+        plugin kernels (ref: gptools/kernel/core.py:384-421)."""
+        tau = np.asarray(tau, dtype=float)
+        l_mat = np.tile(self.params[-self.num_dim:], (tau.shape[0], 1))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tau_over_l = tau / l_mat
+        tau_over_l[(tau == 0) & (l_mat == 0)] = 0.0
+        r2l2 = np.sum(tau_over_l ** 2, axis=1)
+        return (r2l2, l_mat) if return_l else r2l2
+
+    def __add__(self, other):
+        return SumKernel(self, other)
+
+    def __mul__(self, other):
+        raise NotImplementedError("ProductKernel is outside the accelerated hot path (SURVEY.md section 8f).")
+
+
+class BinaryKernel(Kernel):
+    """Two kernels combined; parameters are the concatenation ``k1.params, k2.params``
+    (ref: gptools/kernel/core.py:424-546)."""
+
+    def __init__(self, k1, k2):
+        if not isinstance(k1, Kernel) or not isinstance(k2, Kernel):
+            raise TypeError("Both arguments to BinaryKernel must be instances of type Kernel!")
+        if k1.num_dim != k2.num_dim:
+            raise ValueError("Only kernels having the same number of dimensions can be summed!")
+        self.k1 = k1
+        self.k2 = k2
+        self._enforce_bounds = k1.enforce_bounds or k2.enforce_bounds
+        self.num_dim = k1.num_dim
+        self.num_params = k1.num_params + k2.num_params
+        self.param_names = np.concatenate((np.asarray(k1.param_names, dtype=str), np.asarray(k2.param_names, dtype=str)))
+        self.hyperprior = k1.hyperprior * k2.hyperprior
+
+    @property
+    def enforce_bounds(self):
+        return self._enforce_bounds
+
+    @enforce_bounds.setter
+    def enforce_bounds(self, v):
+        self._enforce_bounds = v
+        self.k1.enforce_bounds = v
+        self.k2.enforce_bounds = v
+
+    @property
+    def fixed_params(self):
+        return np.concatenate((self.k1.fixed_params, self.k2.fixed_params))
+
+    @fixed_params.setter
+    def fixed_params(self, v):
+        self.k1.fixed_params = np.asarray(v[:self.k1.num_params], dtype=bool)
+        self.k2.fixed_params = np.asarray(v[self.k1.num_params:], dtype=bool)
+
+    @property
+    def params(self):
+        return np.concatenate((self.k1.params, self.k2.params))
+
+    @params.setter
+    def params(self, v):
+        self.k1.params = np.asarray(v[:self.k1.num_params], dtype=float)
+        self.k2.params = np.asarray(v[self.k1.num_params:], dtype=float)
+
+    @property
+    def free_params(self):
+        return np.concatenate((self.k1.free_params[:], self.k2.free_params[:]))
+
+    @property
+    def free_param_bounds(self):
+        return list(self.k1.free_param_bounds[:]) + list(self.k2.free_param_bounds[:])
+
+    @property
+    def free_param_names(self):
+        return np.concatenate((self.k1.free_param_names[:], self.k2.free_param_names[:]))
+
+    def set_hyperparams(self, new_params):
+        new_params = np.asarray(new_params, dtype=float)
+        if len(new_params) != len(self.free_params):
+            raise ValueError("Length of new_params must be {:d}!".format(len(self.free_params)))
+        n1 = self.k1.num_free_params
+        self.k1.set_hyperparams(new_params[:n1])
+        self.k2.set_hyperparams(new_params[n1:])
+
+
+class SumKernel(BinaryKernel):
+    """``k1 + k2``: each term is evaluated by its own (GPU) kernel and the results are added
+    (ref: gptools/kernel/core.py:549-584)."""
+
+    def __call__(self, Xi, Xj, ni, nj, hyper_deriv=None, symmetric=False):
+        if hyper_deriv is None:
+            return (self.k1(Xi, Xj, ni, nj, symmetric=symmetric) +
+                    self.k2(Xi, Xj, ni, nj, symmetric=symmetric))
+        if hyper_deriv < self.k1.num_params:
+            return self.k1(Xi, Xj, ni, nj, hyper_deriv=hyper_deriv, symmetric=symmetric)
+        return self.k2(Xi, Xj, ni, nj, hyper_deriv=hyper_deriv - self.k1.num_params, symmetric=symmetric)

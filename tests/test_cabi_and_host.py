@@ -1,0 +1,175 @@
+"""CPU suite, part 2: the C-ABI library loads and exports every symbol include/gpt_hip.h declares
+(no compute without a GPU), the product path fails loudly without a device, and the host logic
+(data ingest, hyperparameter views, priors, pickling) behaves like the reference."""
+import os
+import pickle
+import re
+import warnings
+
+import numpy as np
+import pytest
+import scipy.stats
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="module")
+def g():
+    warnings.simplefilter("ignore")
+    import gptools_amd
+    return gptools_amd
+
+
+def test_library_exports_every_declared_symbol():
+    from gptools_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "gpt_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gpt_[A-Za-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.gpt_version() >= 100
+
+
+def test_no_cpu_fallback_in_product_package():
+    """The shipped package must not import or execute the oracle."""
+    pkg = os.path.join(ROOT, "gptools_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), os.path.join(dirpath, f)
+
+
+@pytest.mark.skipif(_have_gpu(), reason="checks the no-GPU failure mode")
+def test_hot_path_fails_loudly_without_gpu(g):
+    from gptools_amd import _lib
+    k = g.SquaredExponentialKernel(num_dim=1, initial_params=[1.0, 0.3], param_bounds=[(0, 10)] * 2)
+    gp = g.GaussianProcess(k, X=np.linspace(0, 1, 8), y=np.zeros(8), err_y=0.1)
+    with pytest.raises(_lib.GPTBackendError):
+        gp.compute_K_L_alpha_ll()
+    with pytest.raises(_lib.GPTBackendError):
+        k(np.zeros((2, 1)), np.zeros((2, 1)), np.zeros((2, 1), int), np.zeros((2, 1), int))
+    # update_hyperparameters swallows every exception into +inf like the reference (gaussian_process.py:1391-1406)
+    assert gp.update_hyperparameters([1.0, 0.3]) == np.inf
+
+
+def test_add_data_validation_and_layout(g):
+    k = g.SquaredExponentialKernel(num_dim=2, initial_params=[1, 1, 1], param_bounds=[(0, 10)] * 3)
+    gp = g.GaussianProcess(k)
+    gp.add_data(np.zeros((4, 2)), np.arange(4.0), err_y=0.1)
+    gp.add_data(np.ones((3, 2)), np.arange(3.0), err_y=[0.1, 0.2, 0.3], n=[[1, 0], [0, 1], [0, 0]])
+    assert gp.X.shape == (7, 2) and gp.n.shape == (7, 2) and gp.y.shape == (7,)
+    assert gp.n.dtype.kind == "i" and gp.n[4].tolist() == [1, 0]
+    np.testing.assert_allclose(gp.err_y, [0.1] * 4 + [0.1, 0.2, 0.3])
+    assert gp.K_up_to_date is False
+    with pytest.raises(ValueError):
+        gp.add_data(np.zeros((2, 3)), np.zeros(2))
+    with pytest.raises(ValueError):
+        gp.add_data(np.zeros((2, 2)), np.zeros(2), err_y=-1.0)
+    with pytest.raises(ValueError):
+        gp.add_data(np.zeros((2, 2)), np.zeros(2), n=-1)
+    with pytest.raises(ValueError):
+        gp.add_data(np.zeros((2, 2)), np.zeros(2), err_y=[0.1, 0.1, 0.1])
+    with pytest.raises(ValueError):
+        gp.add_data(np.zeros((2, 2)), np.zeros((2, 2)))
+    # 1-D convenience: a (1, M) X is transposed (gaussian_process.py:439-440)
+    k1 = g.SquaredExponentialKernel(num_dim=1, initial_params=[1, 1], param_bounds=[(0, 10)] * 2)
+    gp1 = g.GaussianProcess(k1)
+    gp1.add_data(np.linspace(0, 1, 5), np.zeros(5))
+    gp1.add_data(0, 0, n=1)
+    assert gp1.X.shape == (6, 1) and gp1.n[-1, 0] == 1
+    # T handling: block-diagonal growth with identity for earlier untransformed data (gaussian_process.py:470-491)
+    gp1.add_data(np.linspace(0, 1, 4), [1.0, 2.0], T=np.ones((2, 4)) / 4)
+    assert gp1.T.shape == (8, 10)
+    np.testing.assert_array_equal(gp1.T[:6, :6], np.eye(6))
+    with pytest.raises(g.GPArgumentError):
+        g.GaussianProcess(k1, X=np.zeros(3))
+    with pytest.raises(TypeError):
+        g.GaussianProcess("not a kernel")
+
+
+def test_hyperparameter_views_and_bounds(g):
+    k = g.SquaredExponentialKernel(num_dim=2, initial_params=[1.0, 2.0, 3.0], fixed_params=[False, True, False],
+                                   param_bounds=[(0, 10), (0, 20), (0, 30)], enforce_bounds=True)
+    nk = g.DiagonalNoiseKernel(num_dim=2, initial_noise=0.5, noise_bound=(0, 5))
+    mu = g.ConstantMeanFunction(initial_params=[0.3])
+    gp = g.GaussianProcess(k, noise_k=nk, mu=mu)
+    assert gp.params[:] == [1.0, 2.0, 3.0, 0.5, 0.3]
+    assert list(gp.free_params[:]) == [1.0, 3.0, 0.5, 0.3]
+    assert [tuple(b) for b in gp.free_param_bounds[:]] == [(0, 10), (0, 30), (0, 5), (-1e3, 1e3)]
+    assert list(~gp.fixed_params) == [True, False, True, True, True]
+    k.set_hyperparams([50.0, -1.0])          # clamped by enforce_bounds (kernel/core.py:271-280)
+    assert list(k.params) == [10.0, 2.0, 0.0]
+    with pytest.raises(ValueError):
+        k.set_hyperparams([1.0])
+    gp.free_params = [4.0, 5.0, 0.6, 0.7]
+    assert gp.params[:] == [4.0, 2.0, 5.0, 0.6, 0.7]
+    gp.params[0] = 7.0                        # CombinedBounds writes through (utils.py:163-171)
+    assert k.params[0] == 7.0
+    with pytest.raises(g.GPArgumentError):
+        g.SquaredExponentialKernel(num_dim=1, fixed_params=[True, True])
+    with pytest.raises(ValueError):
+        g.SquaredExponentialKernel(num_dim=0)
+    assert g.SquaredExponentialKernel(num_dim=3, param_bounds=[(0, 1)] * 4).param_names.tolist() == \
+        ["\\sigma_f", "l_1", "l_2", "l_3"]
+    s = k + g.Matern52Kernel(num_dim=2, initial_params=[1, 1, 1], param_bounds=[(0, 1)] * 3)
+    assert s.num_params == 6 and len(s.free_params) == 5
+
+
+def test_priors_match_reference_formulas(g):
+    hp = g.UniformJointPrior(0, 20) * g.GammaJointPriorAlt(1, 0.7)       # demo/demo.py:111
+    th = [1.8849006111246833, 0.97760159723344708]
+    b = (1 + np.sqrt(1 + 4 * 0.49)) / (2 * 0.49)
+    a = 1 + b
+    want = -np.log(20.0) + scipy.stats.gamma.logpdf(th[1], a, loc=0, scale=1.0 / b)
+    assert abs(hp(th) - want) < 1e-13
+    assert hp([21.0, 1.0]) == -np.inf
+    assert hp(th, hyper_deriv=0) == 0.0
+    assert abs(hp(th, hyper_deriv=1) - ((a - 1) / th[1] - b)) < 1e-13
+    u = g.UniformJointPrior([(0, 2), (1, 3)])
+    assert abs(u([1, 2]) - (-2 * np.log(2.0))) < 1e-15 and u([3, 2]) == -np.inf
+    assert g.UniformJointPrior([0, 1], ub=[2, 3]).bounds == [(0, 2), (1, 3)]
+    draws = hp.random_draw(size=7)
+    assert draws.shape == (2, 7) and (draws[0] >= 0).all() and (draws[0] <= 20).all()
+    nrm = g.NormalJointPrior([0.0], [2.0])
+    assert abs(nrm([1.0]) - scipy.stats.norm.logpdf(1.0, 0, 2)) < 1e-14
+    assert abs(nrm([1.0], hyper_deriv=0) - (-0.25)) < 1e-14
+
+
+def test_demo_fixture_prior_value(g, golden):
+    g6 = golden("g6_demo")
+    gp = g.GaussianProcess(g.SquaredExponentialKernel(
+        hyperprior=g.UniformJointPrior(0, 20) * g.GammaJointPriorAlt(1, 0.7)))
+    gp.k.params[:] = g6["demo_params"]
+    assert abs(gp.hyperprior(gp.params) - float(g6["prior_demo"])) < 1e-12
+
+
+def test_mean_functions(g):
+    mu = g.ConstantMeanFunction(initial_params=[2.5])
+    X = np.random.RandomState(0).rand(6, 2)
+    n = np.array([[0, 0], [1, 0], [0, 0], [0, 1], [0, 0], [2, 0]])
+    np.testing.assert_array_equal(mu(X, n), [2.5, 0, 2.5, 0, 2.5, 0])
+    np.testing.assert_array_equal(mu(X, n, hyper_deriv=0), [1, 0, 1, 0, 1, 0])
+    lin = g.LinearMeanFunction(num_dim=2, initial_params=[2.0, -1.0, 0.5])
+    np.testing.assert_allclose(lin(X, n), np.where(n.sum(1) == 0, 2 * X[:, 0] - X[:, 1] + 0.5,
+                                                   np.where(n[:, 0] == 1, 2.0, np.where(n[:, 1] == 1, -1.0, 0.0))))
+
+
+def test_gp_pickles_without_device_state(g):
+    k = g.Matern52Kernel(num_dim=2, initial_params=[1, 0.5, 0.5], param_bounds=[(0, 10)] * 3)
+    gp = g.GaussianProcess(k, X=np.random.rand(5, 2), y=np.random.rand(5), err_y=0.1)
+    gp2 = pickle.loads(pickle.dumps(gp))
+    assert gp2._ctx_obj is None and gp2.K_up_to_date is False
+    np.testing.assert_array_equal(gp2.X, gp.X)
+    assert gp2.k.params.tolist() == gp.k.params.tolist()

@@ -1,0 +1,460 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI (gptools_amd._lib -> libgpt_hip.so) and
+through the reference-shaped GaussianProcess / Kernel API, against
+  (1) the committed golden vectors generated from the reference (tests/golden/*.npz),
+  (2) the CPU oracle (oracle/) on seeded inputs at sizes it finishes in seconds,
+  (3) size-independent properties at BASELINE.json's full sizes.
+Tolerances (fp64): K entries 1e-12 relative (+1e-13 of the matrix scale); log|K| 1e-10; LML 1e-8
+relative (north_star), tightened to 1e-9 on the fixtures; predictive mean/variance 1e-6 of sigma_f^2.
+"""
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+KERNELS = ("se", "m52")
+KID = {"se": 0, "m52": 1}
+EPS = sys.float_info.epsilon
+
+
+@pytest.fixture(scope="module")
+def g():
+    warnings.simplefilter("ignore")
+    import gptools_amd
+    return gptools_amd
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from gptools_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def make_kernel(g, kern, d, params, **kw):
+    cls = g.SquaredExponentialKernel if kern == "se" else g.Matern52Kernel
+    kw.setdefault("param_bounds", [(0.0, 1e3)] * (d + 1))
+    return cls(num_dim=d, initial_params=list(params), **kw)
+
+
+# ---------------------------------------------------------------- G1: Kernel.__call__ ---------
+@pytest.mark.parametrize("d", [1, 2, 3, 4])
+def test_g1_kernel_call_se(g, golden, d):
+    G = golden("g1_pairs")
+    p = G["se_d%d_params" % d]
+    Xi, Xj, ni, nj = (G["se_d%d_%s" % (d, s)] for s in ("Xi", "Xj", "ni", "nj"))
+    k = make_kernel(g, "se", d, p)
+    assert_close(k(Xi, Xj, ni, nj), G["se_d%d_k" % d], rtol=1e-12, msg="k")
+    assert_close(k(Xi, Xj, 0 * ni, 0 * nj), G["se_d%d_k0" % d], rtol=1e-12, msg="k0")
+    assert_close(k(Xi, Xj, G["se_d%d_nih" % d], G["se_d%d_njh" % d]), G["se_d%d_kh" % d], rtol=1e-10, msg="orders<=8")
+    for hd in range(d + 1):
+        assert_close(k(Xi, Xj, ni, nj, hyper_deriv=hd), G["se_d%d_hd%d" % (d, hd)], rtol=1e-9, msg="hd %d" % hd)
+        assert_close(k(Xi, Xj, 0 * ni, 0 * nj, hyper_deriv=hd), G["se_d%d_k0_hd%d" % (d, hd)], rtol=1e-12)
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4])
+def test_g1_kernel_call_m52(g, golden, oracle, d):
+    G = golden("g1_pairs")
+    p = G["se_d%d_params" % d]
+    Xi, Xj = G["se_d%d_Xi" % d], G["se_d%d_Xj" % d]
+    ni, nj = G["m52_d%d_ni" % d], G["m52_d%d_nj" % d]
+    k = make_kernel(g, "m52", d, p)
+    got = k(Xi, Xj, ni, nj)
+    assert_close(got, G["m52_d%d_k" % d], rtol=1e-12, msg="vs golden")
+    if oracle.have_ref():      # the reference's own C code, compiled into oracle/_ref
+        assert_close(got, p[0] ** 2 * oracle.ref_matern52(Xi, Xj, ni, nj, p[1:] ** 2), rtol=1e-12, msg="vs _ref")
+    # exact r == 0 limits (matern.c:83-84,100-101,123-127)
+    z = np.zeros((4, d))
+    e0 = np.zeros((4, d), int)
+    e0[:, 0] = 1
+    assert np.array_equal(k(z, z, 0 * e0, 0 * e0), np.full(4, p[0] ** 2))
+    assert np.array_equal(k(z, z, e0, 0 * e0), np.zeros(4))
+    np.testing.assert_allclose(k(z, z, e0, e0), np.full(4, p[0] ** 2 * (5.0 / 3.0) / p[1] ** 2), rtol=1e-15)
+
+
+def test_kernel_error_contract(g):
+    k = make_kernel(g, "m52", 2, [1, 1, 1])
+    X = np.zeros((3, 2))
+    n0 = np.zeros((3, 2), int)
+    n2 = n0.copy()
+    n2[1, 0] = 2
+    n11 = n0.copy()
+    n11[2] = 1
+    with pytest.raises(ValueError):
+        k(X, X, n2, n0)
+    with pytest.raises(ValueError):
+        k(X, X, n0, n11)
+    with pytest.raises(NotImplementedError):
+        k(X, X, n0, n0, hyper_deriv=0)
+    with pytest.raises(ValueError):
+        k(X, X[:2], n0, n0)
+    with pytest.raises(NotImplementedError):
+        g.Kernel(num_dim=1, num_params=0)(X, X, n0, n0)
+    nk = g.DiagonalNoiseKernel(num_dim=2, initial_noise=0.3, noise_bound=(0, 1))
+    Xr = np.random.RandomState(0).rand(3, 2)
+    np.testing.assert_array_equal(nk(Xr, Xr, n0, n0, symmetric=True), [0.09, 0.09, 0.09])
+    np.testing.assert_array_equal(nk(Xr, Xr, n0, n0, symmetric=False), [0, 0, 0])
+    np.testing.assert_array_equal(nk(Xr, Xr, n0, n11, symmetric=True), [0.09, 0.09, 0])
+    np.testing.assert_allclose(nk(Xr, Xr, n0, n0, hyper_deriv=0, symmetric=True), [0.6] * 3)
+    assert g.ZeroKernel(2)(Xr, Xr, n0, n0).tolist() == [0, 0, 0]
+
+
+def test_kernel_call_ragged_and_empty(g, oracle):
+    rs = np.random.RandomState(5)
+    for kern in KERNELS:
+        for M in (1, 63, 64, 65, 257, 1000):
+            d = 3
+            Xi, Xj = rs.rand(M, d), rs.rand(M, d)
+            ni = (rs.rand(M, d) < 0.1).astype(int)
+            ni[ni.sum(1) > 1] = 0
+            nj = np.roll(ni, 1, axis=0)
+            p = [1.2, 0.3, 0.5, 0.7]
+            assert_close(make_kernel(g, kern, d, p)(Xi, Xj, ni, nj), oracle.kpairs(kern, p, Xi, Xj, ni, nj), rtol=1e-12)
+    k = make_kernel(g, "se", 2, [1, 1, 1])
+    assert k(np.zeros((0, 2)), np.zeros((0, 2)), np.zeros((0, 2), int), np.zeros((0, 2), int)).shape == (0,)
+
+
+# ---------------------------------------------------------------- G2: compute_Kij -------------
+@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_g2_compute_Kij(g, golden, kern, d):
+    G = golden("g2_gram")
+    key = "%s_d%d_" % (kern, d)
+    p, X, Xs, n, ns = (G[key + s] for s in ("params", "X", "Xs", "n", "ns"))
+    gp = g.GaussianProcess(make_kernel(g, kern, d, p))
+    assert_close(gp.compute_Kij(X, None, n, None), G[key + "K"], rtol=1e-12, msg="K")
+    assert_close(gp.compute_Kij(X, Xs, n, ns), G[key + "Ks"], rtol=1e-12, msg="Ks")
+    assert_close(gp.compute_Kij(Xs, None, ns, None), G[key + "Kss"], rtol=1e-12, msg="Kss")
+    if kern == "se":
+        for hd in range(d + 1):
+            assert_close(gp.compute_Kij(X, None, n, None, hyper_deriv=hd), G[key + "K_hd%d" % hd], rtol=1e-9)
+            assert_close(gp.compute_Kij(X, None, 0 * n, None, hyper_deriv=hd), G[key + "K0_hd%d" % hd], rtol=1e-12)
+    else:
+        with pytest.raises(NotImplementedError):
+            gp.compute_Kij(X, None, n, None, hyper_deriv=0)
+
+
+def test_g7_reference_test_matern(g, golden):
+    """The reference's only unit test (tests/test_matern.py:4-31), seeded: 8 decimals vs mpmath."""
+    G = golden("g7_test_matern")
+    gp = g.GaussianProcess(make_kernel(g, "m52", 2, [10.0] + list(G["length_scales"])))
+    K = gp.compute_Kij(G["X"], None, G["n"], None)
+    np.testing.assert_array_almost_equal(K, G["K_arb"], decimal=8)
+    assert_close(K, G["K_m52"], rtol=1e-12)
+
+
+def test_python_plugin_kernel_still_works(g):
+    """A user Kernel subclass written in Python goes through the pair-list path of compute_Kij."""
+    class Lin(g.Kernel):
+        def __call__(self, Xi, Xj, ni, nj, hyper_deriv=None, symmetric=False):
+            return self.params[0] ** 2 * (Xi * Xj).sum(axis=1) + (1.0 if symmetric else 0.0)
+    gp = g.GaussianProcess(Lin(num_dim=2, num_params=1, initial_params=[2.0], param_bounds=[(0, 10)]))
+    X = np.random.RandomState(1).rand(5, 2)
+    n = np.zeros((5, 2), int)
+    np.testing.assert_allclose(gp.compute_Kij(X, None, n, None), 4.0 * X.dot(X.T) + 1.0)
+    np.testing.assert_allclose(gp.compute_Kij(X, X[:3], n, n[:3]), 4.0 * X.dot(X[:3].T))
+    gp.add_data(X, np.arange(5.0), err_y=0.3)
+    gp.compute_K_L_alpha_ll()
+    Kt = 4.0 * X.dot(X.T) + 1.0 + 0.09 * np.eye(5) + 1e2 * EPS * np.eye(5)
+    np.testing.assert_allclose(gp.L, np.linalg.cholesky(Kt), rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(gp.alpha.ravel(), np.linalg.solve(Kt, np.arange(5.0)), rtol=1e-10)
+
+
+# ---------------------------------------------------------------- G3/G4: fit + predict --------
+FIT_CASES = [(k, N, d) for k in KERNELS for (N, d) in ((16, 1), (64, 2), (256, 3), (512, 2))]
+
+
+@pytest.mark.parametrize("kern,N,d", FIT_CASES)
+def test_g3_fit_g4_predict(g, golden, kern, N, d):
+    G3, G4 = golden("g3_fit"), golden("g4_predict")
+    key = "%s_N%d_d%d_" % (kern, N, d)
+    p, X, y, n, err = (G3[key + s] for s in ("params", "X", "y", "n", "err_y"))
+    gp = g.GaussianProcess(make_kernel(g, kern, d, p), X=X, y=y, err_y=err, n=n)
+    gp.compute_K_L_alpha_ll()
+    assert gp.K_up_to_date
+    assert abs(gp.ll - G3[key + "ll"]) <= 1e-9 * abs(G3[key + "ll"])
+    assert abs(np.log(np.diag(gp.L)).sum() - G3[key + "logdet_half"]) <= 1e-10 * abs(G3[key + "logdet_half"]) + 1e-10
+    assert gp.alpha.shape == (N, 1)
+    assert_close(gp.alpha.ravel(), G3[key + "alpha"], rtol=1e-6, atol_scale=1e-7, msg="alpha")
+    if key + "L" in G3:
+        assert_close(gp.L, G3[key + "L"], rtol=1e-7, atol_scale=1e-11, msg="L")
+        assert np.array_equal(np.triu(gp.L, 1), np.zeros_like(gp.L))
+    sf2 = p[0] ** 2
+    Xs, ns = G4[key + "Xs"], G4[key + "ns"]
+    mean, std = gp.predict(Xs, n=ns)
+    np.testing.assert_allclose(mean, G4[key + "mean"], rtol=0, atol=1e-6 * sf2)
+    np.testing.assert_allclose(std ** 2, G4[key + "std"] ** 2, rtol=0, atol=1e-6 * sf2)
+    mean2, cov = gp.predict(Xs, n=ns, return_cov=True)
+    np.testing.assert_allclose(cov, G4[key + "cov"], rtol=0, atol=1e-6 * sf2)
+    np.testing.assert_allclose(mean2, mean, rtol=0, atol=1e-12)
+    m0, s0 = gp.predict(Xs, n=0)
+    np.testing.assert_allclose(m0, G4[key + "mean_n0"], rtol=0, atol=1e-6 * sf2)
+    np.testing.assert_allclose(s0 ** 2, G4[key + "std_n0"] ** 2, rtol=0, atol=1e-6 * sf2)
+    mo, co = gp.predict(Xs, n=ns, return_cov=True, output_transform=G4[key + "OT"])
+    np.testing.assert_allclose(mo, G4[key + "mean_ot"], rtol=0, atol=1e-5 * sf2)
+    np.testing.assert_allclose(co, G4[key + "cov_ot"], rtol=0, atol=1e-4 * sf2)
+    assert np.array_equal(gp.predict(Xs, n=ns, return_std=False), mean)
+    full = gp.predict(Xs, n=ns, full_output=True)
+    assert set(full) == {"mean", "std", "cov"}
+    # reading K after the fit gives the noise-free covariance, noise_K the zeros of ZeroKernel
+    assert_close(gp.K, gp.compute_Kij(X, None, n, None), rtol=0, atol_scale=0)
+    assert not gp.noise_K.any()
+
+
+@pytest.mark.parametrize("kern", KERNELS)
+def test_g3_noise_kernel_and_predict_noise(g, golden, kern):
+    G3, G4 = golden("g3_fit"), golden("g4_predict")
+    key = "%s_noise_" % kern
+    p, X, y, n, err = (G3[key + s] for s in ("params", "X", "y", "n", "err_y"))
+    nk = g.DiagonalNoiseKernel(num_dim=2, initial_noise=float(G3[key + "noise"]), noise_bound=(0.0, 5.0))
+    gp = g.GaussianProcess(make_kernel(g, kern, 2, p), noise_k=nk, X=X, y=y, err_y=err, n=n)
+    gp.compute_K_L_alpha_ll()
+    assert abs(gp.ll - G3[key + "ll"]) <= 1e-9 * abs(G3[key + "ll"])
+    assert_close(gp.L, G3[key + "L"], rtol=1e-8, atol_scale=1e-12)
+    np.testing.assert_allclose(gp.noise_K, float(G3[key + "noise"]) ** 2 * np.eye(len(y)))
+    Xs, ns = G4[key + "Xs"], G4[key + "ns"]
+    mean, cov = gp.predict(Xs, n=ns, noise=True, return_cov=True)
+    np.testing.assert_allclose(mean, G4[key + "mean"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(cov, G4[key + "cov"], rtol=0, atol=1e-7)
+    _, cov0 = gp.predict(Xs, n=ns, noise=False, return_cov=True)
+    np.testing.assert_allclose(cov0, G4[key + "cov_nonoise"], rtol=0, atol=1e-7)
+    _, std = gp.predict(Xs, n=ns, noise=True)
+    np.testing.assert_allclose(std ** 2, np.diag(G4[key + "cov"]), rtol=0, atol=1e-7)
+
+
+def test_g3_mean_function_and_T(g, golden):
+    G3, G4 = golden("g3_fit"), golden("g4_predict")
+    key = "se_mu_"
+    mu = g.ConstantMeanFunction(initial_params=[float(G3[key + "mu"])])
+    gp = g.GaussianProcess(make_kernel(g, "se", 1, G3[key + "params"]), mu=mu, X=G3[key + "X"], y=G3[key + "y"],
+                           err_y=G3[key + "err_y"])
+    gp.compute_K_L_alpha_ll()
+    assert abs(gp.ll - G3[key + "ll"]) <= 1e-9 * abs(G3[key + "ll"])
+    mean, std = gp.predict(G4[key + "Xs"], n=G4[key + "ns"])
+    np.testing.assert_allclose(mean, G4[key + "mean"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(std ** 2, G4[key + "std"] ** 2, rtol=0, atol=1e-7)
+    key = "se_T_"
+    gp = g.GaussianProcess(make_kernel(g, "se", 1, G3[key + "params"]))
+    gp.add_data(G3[key + "Xp"], G3[key + "yp"], err_y=0.01)
+    gp.add_data(G3[key + "Xq"], G3[key + "yT"], err_y=0.01, T=G3[key + "T"])
+    np.testing.assert_array_equal(gp.T, G3[key + "Tfull"])
+    gp.compute_K_L_alpha_ll()
+    assert abs(gp.ll - G3[key + "ll"]) <= 1e-9 * abs(G3[key + "ll"])
+    assert_close(gp.L, G3[key + "L"], rtol=1e-7, atol_scale=1e-11)
+    assert_close(gp.alpha.ravel(), G3[key + "alpha"], rtol=1e-6, atol_scale=1e-8)
+    mean, std = gp.predict(G4[key + "Xs"])
+    np.testing.assert_allclose(mean, G4[key + "mean"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(std ** 2, G4[key + "std"] ** 2, rtol=0, atol=1e-7)
+
+
+def test_g3_analytic_ll_gradient(g, golden):
+    G3 = golden("g3_fit")
+    key = "se_hd_"
+    nk = g.DiagonalNoiseKernel(num_dim=2, initial_noise=float(G3[key + "noise"]), noise_bound=(0.0, 5.0))
+    gp = g.GaussianProcess(make_kernel(g, "se", 2, G3[key + "params"]), noise_k=nk, X=G3[key + "X"], y=G3[key + "y"],
+                           err_y=0.02, use_hyper_deriv=True)
+    val, grad = gp.update_hyperparameters(list(G3[key + "params"]) + [float(G3[key + "noise"])])
+    assert abs(-val - G3[key + "ll"]) <= 1e-9 * abs(G3[key + "ll"])
+    assert_close(-grad, G3[key + "ll_deriv"], rtol=1e-7, atol_scale=1e-9)
+
+
+# ---------------------------------------------------------------- G5: update_hyperparameters --
+@pytest.mark.parametrize("kern", KERNELS)
+def test_g5_update_hyperparameters_sweep(g, golden, kern):
+    G = golden("g5_update")
+    cls = g.SquaredExponentialKernel if kern == "se" else g.Matern52Kernel
+    k = cls(num_dim=2, initial_params=[1.0, 0.3, 0.3], param_bounds=[(1e-3, 10.0)] * 3)
+    gp = g.GaussianProcess(k, X=G["X"], y=G["y"], err_y=float(G["err_y"]), n=G["n"])
+    for theta, want in zip(G[kern + "_thetas"], G[kern + "_negll"]):
+        got = gp.update_hyperparameters(theta)
+        if np.isinf(want):
+            assert got == np.inf
+        else:
+            assert abs(got - want) <= 1e-8 * abs(want), (theta, got, want)
+
+
+def test_g5_not_positive_definite(g, golden):
+    G = golden("g5_update")
+    k = g.SquaredExponentialKernel(num_dim=2, initial_params=[1.0, 0.3, 0.3], param_bounds=[(1e-3, 10.0)] * 3)
+    gp = g.GaussianProcess(k, X=G["nonpd_X"], y=G["nonpd_y"], err_y=0.0, diag_factor=0.0)
+    assert np.isinf(G["nonpd_negll"]) and gp.update_hyperparameters([1.0, 0.3, 0.3]) == np.inf
+    gp.K_up_to_date = False
+    with pytest.raises(np.linalg.LinAlgError):        # propagates when called directly
+        gp.compute_K_L_alpha_ll()
+    with pytest.raises(np.linalg.LinAlgError):
+        gp.update_hyperparameters([1.0, 0.3, 0.3], inf_on_error=False)
+
+
+# ---------------------------------------------------------------- G6: demo (config 1) ---------
+def _demo_gp(g, G):
+    hp = g.UniformJointPrior(0, 20) * g.GammaJointPriorAlt(1, 0.7)
+    gp = g.GaussianProcess(g.SquaredExponentialKernel(hyperprior=hp))
+    gp.add_data(G["core_X"], G["core_y"], err_y=G["core_err_y"])
+    gp.add_data(0, 0, n=1)
+    return gp
+
+
+def test_g6_demo_known_answer_and_predictions(g, golden):
+    G = golden("g6_demo")
+    gp = _demo_gp(g, G)
+    negll = gp.update_hyperparameters(G["demo_params"])
+    assert abs(negll - 38.7782559807733) < 1e-8            # demo/demo.py:191 (probed in SURVEY.md section 4)
+    assert abs(negll - float(G["negll_demo"])) < 1e-8
+    assert_close(gp.alpha.ravel(), G["alpha_demo"], rtol=1e-8, atol_scale=1e-10)
+    assert_close(gp.L, G["L_demo"], rtol=1e-9, atol_scale=1e-12)
+    Xs = G["X_star"]
+    y_star, err_y_star = gp.predict(Xs)
+    np.testing.assert_allclose(y_star, G["y_star"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(err_y_star ** 2, G["err_y_star"] ** 2, rtol=0, atol=1e-8)
+    gy, egy = gp.predict(Xs, n=1)
+    np.testing.assert_allclose(gy, G["grad_y_star"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(egy ** 2, G["err_grad_y_star"] ** 2, rtol=0, atol=1e-7)
+    out = gp.predict(np.concatenate((Xs, Xs)), n=np.concatenate((np.zeros_like(Xs), np.ones_like(Xs))),
+                     full_output=True)
+    np.testing.assert_allclose(out["mean"], G["full_mean"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(np.diag(out["cov"]), G["full_cov_diag"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(out["cov"][[0, 199, 400, 799], :], G["full_cov_rows"], rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("method", ["SLSQP", "L-BFGS-B"])
+def test_g6_demo_map_estimate(g, golden, method):
+    G = golden("g6_demo")
+    gp = _demo_gp(g, G)
+    gp.update_hyperparameters(np.array([1.0, 1.0]))
+    res, nres = gp.optimize_hyperparameters(method=method, random_starts=0, num_proc=0)
+    tag = method.replace("-", "")
+    assert nres == 1
+    assert abs(res.fun - float(G["map_%s_fun" % tag])) < 1e-6
+    np.testing.assert_allclose(res.x, G["map_%s_x" % tag], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(gp.params[:], [1.8849006111246833, 0.97760159723344708, 0.0], rtol=0, atol=1e-3)
+
+
+def test_g6_demo_fitted_noise(g, golden):
+    G = golden("g6_demo")
+    hp = g.UniformJointPrior(0, 20) * g.GammaJointPriorAlt(1, 0.7)
+    gpn = g.GaussianProcess(g.SquaredExponentialKernel(hyperprior=hp),
+                            noise_k=g.DiagonalNoiseKernel(noise_bound=[0, 5]))
+    gpn.add_data(G["core_X"], G["core_y"])
+    gpn.add_data(0, 0, n=1)
+    assert abs(gpn.update_hyperparameters(G["demo_noise_params"]) - float(G["negll_demo_noise"])) < 1e-9
+    y, e = gpn.predict(G["X_star"])
+    np.testing.assert_allclose(y, G["y_star_noise"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(e ** 2, G["err_y_star_noise"] ** 2, rtol=0, atol=1e-9)
+
+
+# ---------------------------------------------------------------- oracle parity, seeded -------
+def c3_inputs(N, d, seed=1234):
+    """SURVEY.md section 8(d) synthetic inputs, C3 pattern: last quarter first-derivative rows."""
+    rs = np.random.RandomState(seed)
+    X = rs.rand(N, d)
+    s = X.sum(1)
+    n = np.zeros((N, d), dtype=int)
+    y = np.sin(s)
+    for i in range(3 * N // 4, N):
+        n[i, i % d] = 1
+        y[i] = np.cos(s[i])
+    return X, n, y + 0.05 * rs.randn(N)
+
+
+@pytest.mark.parametrize("kern,N,d,deriv", [("se", 1000, 2, False), ("m52", 1300, 3, True), ("se", 2049, 4, True),
+                                            ("m52", 127, 1, True), ("se", 128, 2, False), ("m52", 129, 2, True)])
+def test_fit_matches_oracle(ctx, oracle, kern, N, d, deriv):
+    X, n, y = c3_inputs(N, d)
+    if not deriv:
+        n[:] = 0
+    p = np.concatenate(([1.0], 0.3 * np.ones(d)))
+    err = 0.05 * np.ones(N)
+    ref = oracle.fit(kern, p, X, n, y, err, chol="scipy")
+    ctx.set_data(X, n)
+    for opts in ({"lookahead": 0, "nb_outer": 128}, {"lookahead": 1, "nb_outer": 256}, {"lookahead": 1, "nb_outer": 512},
+                 {"lookahead": 1, "nb_outer": 256, "graph": 1}):
+        for k_, v_ in dict({"graph": 0}, **opts).items():
+            ctx.set_option(k_, v_)
+        ll, ld = ctx.fit(KID[kern], p, 0.0, y, err, 1e2 * EPS)
+        assert abs(ll - ref["ll_data"]) <= 1e-8 * abs(ref["ll_data"]), opts
+        assert abs(ld - ref["logdet_half"]) <= 1e-10 * abs(ref["logdet_half"]), opts
+    ctx.set_option("graph", 0)
+    assert_close(ctx.get_L(N), ref["L"], rtol=1e-6, atol_scale=1e-10)
+    Xs = np.random.RandomState(7).rand(64, d)
+    ns = np.zeros((64, d), int)
+    ns[32:, 0] = 1
+    mr, sr, cr = oracle.predict(kern, p, X, n, ref["L"], ref["alpha"], Xs, ns)
+    m, s, c = ctx.predict(Xs, ns, 2)
+    np.testing.assert_allclose(m, mr, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(c, cr, rtol=0, atol=1e-6)
+
+
+def test_dense_kernels_against_numpy(ctx):
+    rs = np.random.RandomState(11)
+    for (m, n, k) in ((64, 64, 64), (200, 130, 70), (640, 384, 256), (1024, 1024, 512)):
+        A, B, C0 = rs.randn(m, k), rs.randn(n, k), rs.randn(m, n)
+        for tile in (64, 128):
+            ctx.set_option("tile", tile)
+            got = ctx.gemm_nt_host(-1.0, A, B, 1.0, C0)
+            np.testing.assert_allclose(got, C0 - A.dot(B.T), rtol=0, atol=1e-11 * k)
+            got = ctx.gemm_nt_host(2.0, A, B, 0.0, C0)
+            np.testing.assert_allclose(got, 2.0 * A.dot(B.T), rtol=0, atol=1e-11 * k)
+    ctx.set_option("tile", 0)
+    for N in (1, 17, 128, 129, 640, 1500):
+        A = rs.randn(N, N)
+        A = A.dot(A.T) + N * np.eye(N)
+        L = ctx.potrf_host(A)
+        np.testing.assert_allclose(L, np.linalg.cholesky(A), rtol=1e-11, atol=1e-11)
+        B = rs.randn(N, 5)
+        ctx.fit_matrix(A, np.zeros(N))
+        np.testing.assert_allclose(ctx.solve_L(B), np.linalg.solve(np.linalg.cholesky(A), B), rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(ctx.cho_solve(B), np.linalg.solve(A, B), rtol=1e-9, atol=1e-11)
+    with pytest.raises(np.linalg.LinAlgError) as ei:
+        ctx.potrf_host(np.array([[4.0, 2.0, 0], [2.0, 1.0, 0], [0, 0, 1.0]]))
+    assert "2-th leading minor" in str(ei.value)
+
+
+# ---------------------------------------------------------------- full BASELINE sizes ---------
+@pytest.mark.parametrize("cfg", ["C2", "C3"])
+def test_full_size_properties(ctx, oracle, cfg):
+    """BASELINE configs[1] (SE, N=4096, d=2) and configs[2] (Matern52 + derivative rows, N=8192, d=3):
+    (a) LML and log|K| vs the CPU path (oracle K-build + LAPACK Cholesky) within 1e-8 relative;
+    (b) reconstruction: (L L^T) x == K_tot x for random x (matrix-free, through gpt_kbuild row blocks);
+    (c) K_tot alpha == y; (d) same answer with and without look-ahead / graph replay."""
+    if cfg == "C2":
+        kern, N, d = "se", 4096, 2
+        X, n, y = c3_inputs(N, d)
+        n[:] = 0
+    else:
+        kern, N, d = "m52", 8192, 3
+        X, n, y = c3_inputs(N, d)
+    p = np.concatenate(([1.0], 0.3 * np.ones(d)))
+    err = 0.05 * np.ones(N)
+    ctx.set_data(X, n)
+    res = []
+    for opts in ({"lookahead": 1, "graph": 0}, {"lookahead": 0, "graph": 0}, {"lookahead": 1, "graph": 1}):
+        for k_, v_ in opts.items():
+            ctx.set_option(k_, v_)
+        res.append(ctx.fit(KID[kern], p, 0.0, y, err, 1e2 * EPS))
+    ctx.set_option("graph", 0)
+    for r in res[1:]:
+        assert abs(r[0] - res[0][0]) <= 1e-11 * abs(res[0][0]) and abs(r[1] - res[0][1]) <= 1e-12 * abs(res[0][1])
+    ll, ld = res[-1]
+    ref = oracle.fit(kern, p, X, n, y, err, chol="scipy")
+    assert abs(ll - ref["ll_data"]) <= 1e-8 * abs(ref["ll_data"])
+    assert abs(ld - ref["logdet_half"]) <= 1e-8 * abs(ref["logdet_half"])
+    L = ctx.get_L(N)
+    alpha = ctx.get_alpha(N)
+    assert np.array_equal(np.triu(L, 1)[:64, :64], np.zeros((64, 64)))
+    Kt = ctx.kbuild(KID[kern], p, X, n)
+    Kt[np.arange(N), np.arange(N)] += err ** 2 + 1e2 * EPS
+    np.testing.assert_allclose(Kt, Kt.T, rtol=0, atol=1e-13)           # symmetry of the builder
+    x = np.random.RandomState(3).randn(N, 4)
+    np.testing.assert_allclose(L.dot(L.T.dot(x)), Kt.dot(x), rtol=0, atol=1e-9 * np.abs(Kt.dot(x)).max())
+    np.testing.assert_allclose(Kt.dot(alpha), y, rtol=0, atol=1e-7)
+    assert_close(alpha, ref["alpha"], rtol=1e-5, atol_scale=1e-7)
+    Xs = np.random.RandomState(64).rand(64, d)
+    ns = np.zeros((64, d), int)
+    mr, sr, _ = oracle.predict(kern, p, X, n, ref["L"], ref["alpha"], Xs, ns, want_cov=False)
+    m, s, _ = ctx.predict(Xs, ns, 1)
+    np.testing.assert_allclose(m, mr, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(s ** 2, sr ** 2, rtol=0, atol=1e-6)

@@ -1,0 +1,171 @@
+"""CPU suite, part 1: the oracle (oracle/gpt_oracle.c) against the golden vectors generated from
+the imported reference (tests/golden/gen_golden.py), against the reference's own C source compiled
+into oracle/_ref, and against scipy for the third-party pieces it restates."""
+import sys
+
+import numpy as np
+import pytest
+import scipy.linalg
+import scipy.special
+
+from conftest import assert_close
+
+KERNELS = ("se", "m52")
+
+
+def test_hermite_restatement_matches_scipy_bitwise(oracle):
+    rs = np.random.RandomState(0)
+    for n in range(0, 14):
+        x = np.concatenate((rs.randn(300) * 2.0, [0.0, -0.0, 1.0, -1.0, 1e-300, 37.5]))
+        got = np.array([oracle.eval_hermite(n, v) for v in x])
+        assert np.array_equal(got, scipy.special.eval_hermite(n, x)), "order %d" % n
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4])
+def test_g1_pairs_se(oracle, golden, d):
+    g = golden("g1_pairs")
+    p = g["se_d%d_params" % d]
+    Xi, Xj, ni, nj = (g["se_d%d_%s" % (d, s)] for s in ("Xi", "Xj", "ni", "nj"))
+    assert_close(oracle.kpairs("se", p, Xi, Xj, ni, nj), g["se_d%d_k" % d], msg="k")
+    assert_close(oracle.kpairs("se", p, Xi, Xj, 0 * ni, 0 * nj), g["se_d%d_k0" % d], msg="k0")
+    assert_close(oracle.kpairs("se", p, Xi, Xj, g["se_d%d_nih" % d], g["se_d%d_njh" % d]), g["se_d%d_kh" % d],
+                 rtol=1e-11, msg="high orders")
+    for hd in range(d + 1):
+        with np.errstate(all="ignore"):
+            got = oracle.kpairs("se", p, Xi, Xj, ni, nj, hyper_deriv=hd)
+        assert_close(got, g["se_d%d_hd%d" % (d, hd)], rtol=1e-10, msg="hd %d" % hd)
+        assert_close(oracle.kpairs("se", p, Xi, Xj, 0 * ni, 0 * nj, hyper_deriv=hd), g["se_d%d_k0_hd%d" % (d, hd)],
+                     msg="k0 hd %d" % hd)
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4])
+def test_g1_pairs_m52_bit_exact_and_ref(oracle, golden, d):
+    g = golden("g1_pairs")
+    p = g["se_d%d_params" % d]
+    Xi, Xj = g["se_d%d_Xi" % d], g["se_d%d_Xj" % d]
+    ni, nj = g["m52_d%d_ni" % d], g["m52_d%d_nj" % d]
+    want = g["m52_d%d_k" % d]
+    # same C arithmetic as kernel/src/matern.c -> bit-exact
+    assert np.array_equal(oracle.kpairs("m52", p, Xi, Xj, ni, nj), want)
+    if oracle.have_ref():
+        assert np.array_equal(p[0] ** 2 * oracle.ref_matern52(Xi, Xj, ni, nj, p[1:] ** 2), want)
+
+
+def test_m52_error_contract(oracle):
+    X = np.zeros((2, 2))
+    n2 = np.array([[2, 0], [0, 0]])
+    with pytest.raises(ValueError):
+        oracle.kpairs("m52", [1, 1, 1], X, X, n2, 0 * n2)
+    with pytest.raises(ValueError):
+        oracle.kpairs("m52", [1, 1, 1], X, X, 0 * n2, np.array([[1, 1], [0, 0]]))
+    with pytest.raises(NotImplementedError):
+        oracle.kpairs("m52", [1, 1, 1], X, X, 0 * n2, 0 * n2, hyper_deriv=0)
+
+
+@pytest.mark.parametrize("kern", KERNELS)
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_g2_gram(oracle, golden, kern, d):
+    g = golden("g2_gram")
+    key = "%s_d%d_" % (kern, d)
+    p, X, Xs, n, ns = (g[key + s] for s in ("params", "X", "Xs", "n", "ns"))
+    assert_close(oracle.kbuild(kern, p, X, n), g[key + "K"], msg="K")
+    assert_close(oracle.kbuild(kern, p, X, n, Xs, ns), g[key + "Ks"], msg="Ks")
+    assert_close(oracle.kbuild(kern, p, Xs, ns), g[key + "Kss"], msg="Kss")
+    assert_close(oracle.kbuild(kern, p, X, 0 * n), g[key + "K0"], msg="K0")
+    if kern == "se":
+        for hd in range(d + 1):
+            assert_close(oracle.kbuild(kern, p, X, 0 * n, hyper_deriv=hd), g[key + "K0_hd%d" % hd], msg="K0 hd")
+            with np.errstate(all="ignore"):
+                got = oracle.kbuild(kern, p, X, n, hyper_deriv=hd)
+            assert_close(got, g[key + "K_hd%d" % hd], rtol=1e-10, msg="K hd")
+
+
+FIT_CASES = [(k, N, d) for k in KERNELS for (N, d) in ((16, 1), (64, 2), (256, 3), (512, 2))]
+
+
+@pytest.mark.parametrize("kern,N,d", FIT_CASES)
+def test_g3_fit_and_g4_predict(oracle, golden, kern, N, d):
+    g3, g4 = golden("g3_fit"), golden("g4_predict")
+    key = "%s_N%d_d%d_" % (kern, N, d)
+    p, X, y, n, err = (g3[key + s] for s in ("params", "X", "y", "n", "err_y"))
+    for chol in ("c", "scipy"):
+        f = oracle.fit(kern, p, X, n, y, err, chol=chol)
+        ll = f["ll_data"] + float(g3[key + "prior"])
+        # K_tot condition numbers reach ~1e6 here: fp64 rounding differences between Cholesky variants are
+        # amplified accordingly, hence 1e-9 on ll / alpha while log|K| and L stay at 1e-11.
+        assert abs(ll - g3[key + "ll"]) <= 1e-9 * abs(g3[key + "ll"]), chol
+        assert abs(f["logdet_half"] - g3[key + "logdet_half"]) <= 1e-11 * abs(g3[key + "logdet_half"]) + 1e-11
+        assert_close(f["alpha"], g3[key + "alpha"], rtol=1e-7, atol_scale=1e-8, msg="alpha " + chol)
+        if key + "L" in g3:
+            assert_close(f["L"], g3[key + "L"], rtol=1e-8, atol_scale=1e-11, msg="L " + chol)
+    Xs, ns = g4[key + "Xs"], g4[key + "ns"]
+    mean, std, cov = oracle.predict(kern, p, X, n, f["L"], f["alpha"], Xs, ns)
+    assert_close(mean, g4[key + "mean"], rtol=1e-7, atol_scale=1e-8, msg="mean")
+    assert_close(cov, g4[key + "cov"], rtol=1e-6, atol_scale=1e-9, msg="cov")
+    assert_close(std, g4[key + "std"], rtol=1e-6, atol_scale=1e-8, msg="std")
+
+
+@pytest.mark.parametrize("kern", KERNELS)
+def test_g3_noise_kernel(oracle, golden, kern):
+    g3, g4 = golden("g3_fit"), golden("g4_predict")
+    key = "%s_noise_" % kern
+    p, X, y, n, err = (g3[key + s] for s in ("params", "X", "y", "n", "err_y"))
+    sn = float(g3[key + "noise"])
+    f = oracle.fit(kern, p, X, n, y, err, noise_var=sn ** 2.0)
+    assert abs(f["ll_data"] + float(g3[key + "prior"]) - g3[key + "ll"]) <= 1e-10 * abs(g3[key + "ll"])
+    assert_close(f["L"], g3[key + "L"], rtol=1e-9, atol_scale=1e-12)
+    Xs, ns = g4[key + "Xs"], g4[key + "ns"]
+    mean, std, cov = oracle.predict(kern, p, X, n, f["L"], f["alpha"], Xs, ns, noise_params=[sn], noise_n=[0, 0])
+    assert_close(mean, g4[key + "mean"], rtol=1e-8, atol_scale=1e-10)
+    assert_close(cov, g4[key + "cov"], rtol=1e-8, atol_scale=1e-10)
+    _, _, cov0 = oracle.predict(kern, p, X, n, f["L"], f["alpha"], Xs, ns)
+    assert_close(cov0, g4[key + "cov_nonoise"], rtol=1e-8, atol_scale=1e-10)
+    assert abs((cov - cov0)[1, 2] - sn ** 2.0) < 1e-12   # duplicate test points: noise fires off-diagonal too
+
+
+def test_cholesky_restatement_vs_lapack(oracle):
+    rs = np.random.RandomState(3)
+    for N in (1, 7, 64, 300):
+        A = rs.randn(N, N)
+        A = A.dot(A.T) + N * np.eye(N)
+        L = oracle.potrf_lower(A)
+        Lr = scipy.linalg.cholesky(A, lower=True)
+        assert_close(L, Lr, rtol=1e-12, atol_scale=1e-14)
+        B = rs.randn(N, 3)
+        assert_close(oracle.solve_lower(L, B), scipy.linalg.solve_triangular(Lr, B, lower=True), rtol=1e-10)
+        assert_close(oracle.solve_lower(L, B, trans=True), scipy.linalg.solve_triangular(Lr, B, lower=True, trans="T"),
+                     rtol=1e-10)
+    with pytest.raises(np.linalg.LinAlgError):
+        oracle.potrf_lower(np.array([[1.0, 2.0], [2.0, 1.0]]))
+
+
+def test_g6_demo_known_answer(oracle, golden):
+    """demo/demo.py:190-192: ll at the published MAP parameters, predictions on the 400-point grid."""
+    g = golden("g6_demo")
+    X = np.concatenate((g["core_X"], [0.0]))[:, None]
+    y = np.concatenate((g["core_y"], [0.0]))
+    err = np.concatenate((g["core_err_y"], [0.0]))
+    n = np.zeros((len(y), 1), dtype=int)
+    n[-1, 0] = 1
+    f = oracle.fit("se", g["demo_params"], X, n, y, err)
+    assert abs(f["ll_data"] + float(g["prior_demo"]) - (-38.7782559807733)) < 1e-9
+    assert_close(f["alpha"], g["alpha_demo"], rtol=1e-9, atol_scale=1e-11)
+    Xs = g["X_star"][:, None]
+    m, s, _ = oracle.predict("se", g["demo_params"], X, n, f["L"], f["alpha"], Xs, np.zeros((400, 1), int))
+    assert_close(m, g["y_star"], rtol=1e-9, atol_scale=1e-11)
+    # std is compared through the variance: where a noiseless constraint pins the curve the variance is a
+    # ~1e-14 cancellation residue and sqrt() turns its rounding into ~1e-8 absolute differences.
+    assert_close(s ** 2, g["err_y_star"] ** 2, rtol=1e-7, atol_scale=1e-9)
+    m1, s1, _ = oracle.predict("se", g["demo_params"], X, n, f["L"], f["alpha"], Xs, np.ones((400, 1), int))
+    assert_close(m1, g["grad_y_star"], rtol=1e-9, atol_scale=1e-11)
+    assert_close(s1 ** 2, g["err_grad_y_star"] ** 2, rtol=1e-7, atol_scale=1e-9)
+
+
+def test_g7_reference_test_matern(oracle, golden):
+    """tests/test_matern.py:4-31 with a seeded length-scale draw: Matern52 vs the mpmath MaternKernelArb
+    Gram matrix to 8 decimals (the reference's own tolerance), and bit-exact vs the C extension."""
+    g = golden("g7_test_matern")
+    p = np.concatenate(([10.0], g["length_scales"]))
+    K = oracle.kbuild("m52", p, g["X"], g["n"])
+    np.testing.assert_array_almost_equal(K, g["K_arb"], decimal=8)
+    assert np.array_equal(K, g["K_m52"])
