@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the covariance-build + Cholesky log-marginal-likelihood hot path on MI355X.
+
+Metric (BASELINE.json): "K-build+Cholesky GFLOP/s (% fp64 MFMA peak) and LML evals/sec, N=8192".
+A *step* is one LML evaluation on a fixed synthetic data set: fused K-build (with the diagonal
+loading) + blocked Cholesky + z = L^-1 y + log-determinant + the ll scalar -- what
+GaussianProcess.update_hyperparameters costs per call (ref: gptools/gaussian_process.py:1418-1469).
+X, n are resident in HBM before the timed region; per step only the hyperparameters (and the 2 x 64 KB
+y / err_y vectors) cross the boundary.
+
+  python bench.py --gpus 1 --steps K --warmup W          # 1 GPU: config C3 (Matern52, N=8192, d=3, derivative rows)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+                                                          # N>1: config C4 (SE, N=32768, d=4) block-cyclic panel
+                                                          # Cholesky partitioned over the N ranks, RCCL broadcasts
+value  = algorithmic flops of the steps / wall time, in GFLOP/s, with the LAPACK potrf+potrs count
+         (N^3/3 + N^2/2 + N/6 + 2 N^2) -- K-build time is in the denominator but adds no flops.
+roofline  : the trailing-update SYRK/GEMM kernel (fp64 MFMA bound), achieved = sum of algorithmic flops of the
+            large GEMM launches / sum of their HIP-event durations, measured in the timed steps.
+cpu_baseline : the oracle's fused K-build (OpenMP) + scipy.linalg.cholesky / cho_solve on the host cores
+            (rank 0, N=1 only), a reported baseline and the parity reference for ll.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X fp64 matrix peak (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz); measured 77.8
+METRIC = "K-build+Cholesky GFLOP/s (% fp64 MFMA peak) and LML evals/sec, N=8192"
+
+WORKLOADS = {
+    # name: (kernel, N, d, derivative rows)                        BASELINE.json configs[i]
+    "c2": ("se", 4096, 2, False),      # configs[1]
+    "c3": ("m52", 8192, 3, True),      # configs[2]  <- the metric's N=8192 configuration
+    "c5": ("se", 16384, 2, False),     # configs[4] (one objective evaluation of the MAP loop)
+    "c4": ("se", 32768, 4, False),     # configs[3]
+}
+KID = {"se": 0, "m52": 1}
+
+
+def synth(kernel, N, d, deriv):
+    """Deterministic inputs of SURVEY.md section 8(d)."""
+    rs = np.random.RandomState(1234)
+    X = rs.rand(N, d)
+    s = X.sum(axis=1)
+    y = np.sin(s)
+    n = np.zeros((N, d), dtype=np.int32)
+    if deriv:
+        for i in range(3 * N // 4, N):
+            n[i, i % d] = 1
+            y[i] = np.cos(s[i])
+    y = y + 0.05 * rs.randn(N)
+    params = np.concatenate(([1.0], 0.3 * np.ones(d)))
+    return X, n, y, 0.05 * np.ones(N), params
+
+
+def flops_fit(N):
+    return N ** 3 / 3.0 + N ** 2 / 2.0 + N / 6.0 + 2.0 * N ** 2
+
+
+def cpu_baseline(kernel, X, n, y, err, params, budget_s=20.0):
+    """Oracle K-build (all host cores, OpenMP) + LAPACK Cholesky / solve through scipy, like the reference's
+    scipy.linalg.cholesky + cho_solve (gaussian_process.py:1452,1462)."""
+    from oracle import oracle as O
+    cores = len(os.sched_getaffinity(0))
+    N = X.shape[0]
+    t_all, reps, res = 0.0, 0, None
+    while reps < 1 or (t_all + t_all / reps < budget_s and reps < 5):
+        t0 = time.perf_counter()
+        res = O.fit(kernel, params, X, n, y, err, chol="scipy")
+        t_all += time.perf_counter() - t0
+        reps += 1
+    t = t_all / reps
+    return res, {
+        "value": flops_fit(N) / t * 1e-9, "unit": "GFLOP/s", "cores": cores, "kind": "port",
+        "sample": "%d full LML evaluation(s) of the same workload (N=%d): oracle fused K-build (C, OpenMP) + "
+                  "scipy.linalg.cholesky + cho_solve; %.2f s per evaluation" % (reps, N, t),
+        "lml_evals_per_s": 1.0 / t,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--nb", type=int, default=0, help="outer block width (0 = default)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from gptools_amd import _lib
+    wl = args.workload or ("c3" if world == 1 else "c4")
+    kernel, N, d, deriv = WORKLOADS[wl]
+    X, n, y, err, params = synth(kernel, N, d, deriv)
+    diag_add = 1e2 * sys.float_info.epsilon
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    roof = None
+    extra = {}
+    if world == 1:
+        ctx = _lib.Context(local_rank)
+        if args.nb:
+            ctx.set_option("nb_outer", args.nb)
+        ctx.set_option("timing", 1)
+        ctx.set_data(X, n)
+
+        def step():
+            return ctx.fit(KID[kernel], params, 0.0, y, err, diag_add)
+        for _ in range(args.warmup):
+            ll, ld = step()
+        ctx.set_option("profile_gemm", 1)
+        ctx.gemm_profile_read()
+        barrier()
+        t0 = time.perf_counter()
+        tk = tp = 0.0
+        for _ in range(args.steps):
+            ll, ld = step()
+            tm = ctx.last_timings()
+            tk += tm["kbuild"]
+            tp += tm["potrf"]
+        barrier()
+        elapsed = time.perf_counter() - t0
+        gflops_alg, gms, gcount = ctx.gemm_profile_read()
+        ctx.set_option("profile_gemm", 0)
+        if gcount:
+            ach = gflops_alg / (gms * 1e-3) * 1e-12
+            roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<128,128> (trailing SYRK/GEMM update)",
+                    "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                    "traffic": None, "launches_per_step": gcount / args.steps,
+                    "avg_launch_us": gms * 1e3 / gcount, "flops_per_launch": gflops_alg / gcount}
+        extra["kbuild_ms"] = tk / args.steps
+        extra["potrf_ms"] = tp / args.steps
+        extra["kbuild_GBps_written"] = (8.0 * N * (N + 1) / 2.0) / (tk / args.steps * 1e-3) * 1e-9
+        parallelism = "1 GPU, look-ahead on a second HIP stream"
+    else:
+        from gptools_amd.dist import DistributedLML
+        plan = DistributedLML(X, n, nb=args.nb or 512, device=local_rank)
+
+        def step():
+            return plan.fit(KID[kernel], params, y, err)
+        for _ in range(args.warmup):
+            ll, ld = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ll, ld = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        parallelism = "1-D block-cyclic block columns (nb=%d) over %d ranks, RCCL panel broadcast" % (plan.nb, world)
+
+    if rank == 0:
+        per_step = elapsed / args.steps
+        value = flops_fit(N) / per_step * 1e-9
+        out = {
+            "metric": METRIC, "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": per_step * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %s kernel, N=%d, d=%d%s, err_y=0.05, sigma_f=1, l=0.3 (BASELINE.json configs)"
+                                   % (wl.upper(), {"se": "SquaredExponential", "m52": "Matern52"}[kernel], N, d,
+                                      ", last quarter of rows first-derivative observations" if deriv else ""),
+                       "N": N, "d": d, "parallelism": parallelism},
+            "lml_evals_per_s": 1.0 / per_step,
+            "pct_fp64_mfma_peak": 100.0 * value * 1e-3 / (FP64_MFMA_PEAK_TFLOPS * world),
+            "ll_data": ll, "logdet_half": ld,
+        }
+        out.update(extra)
+        if roof is not None:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu:
+            ref, cb = cpu_baseline(kernel, X, n, y, err, params)
+            out["cpu_baseline"] = cb
+            out["parity"] = {"ll_rel_err_vs_cpu": abs(ll - ref["ll_data"]) / abs(ref["ll_data"]),
+                             "logdet_rel_err_vs_cpu": abs(ld - ref["logdet_half"]) / abs(ref["logdet_half"]),
+                             "tolerance": 1e-8}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

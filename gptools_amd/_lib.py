@@ -43,6 +43,7 @@ SIGNATURES = {
     "gpt_solve_L": (C.c_int, [_vp, _dp, _i64]),
     "gpt_cho_solve": (C.c_int, [_vp, _dp, _i64]),
     "gpt_last_timings": (C.c_int, [_vp, _dp, C.c_int]),
+    "gpt_gemm_profile_read": (C.c_int, [_vp, _dp]),
     "gpt_potrf_host": (C.c_int, [_vp, _dp, _i64]),
     "gpt_gemm_nt_host": (C.c_int, [_vp, _i64, _i64, _i64, C.c_double, _dp, _dp, C.c_double, _dp]),
     "gpt_dev_kbuild": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _vp, _i64, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int,
@@ -252,6 +253,12 @@ class Context(object):
         out = np.zeros(5)
         self._lib.gpt_last_timings(self.handle, dptr(out), 5)
         return dict(upload=out[0], kbuild=out[1], potrf=out[2], tail=out[3], total=out[4])
+
+    def gemm_profile_read(self):
+        """(algorithmic flops, summed launch ms, launches) of the profiled GEMM launches since the last read."""
+        out = np.zeros(3)
+        check(self._lib.gpt_gemm_profile_read(self.handle, dptr(out)))
+        return float(out[0]), float(out[1]), int(out[2])
 
     def potrf_host(self, A):
         L = np.array(A, dtype=np.float64, order="C")

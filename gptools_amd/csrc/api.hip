@@ -70,6 +70,11 @@ struct gpt_ctx {
     bool factored = false, alpha_valid = false, have_kernel = false;
     KParams kp;
     double timings[5] = {0, 0, 0, 0, 0};
+    // per-launch HIP-event timing of the dominant (large) GEMM/SYRK launches, for the roofline line
+    int prof_gemm = 0;
+    struct GemmProf { hipEvent_t e0, e1; double flops; };
+    std::vector<GemmProf> gprof;
+    size_t gprof_used = 0;
     // graph cache for the factorisation
     hipGraphExec_t gexec = nullptr;
     int64_t g_n = 0, g_nb = 0;
@@ -174,7 +179,26 @@ static int check_m52_orders(const int32_t *n, int64_t M, int D)
 static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A,
                    int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri)
 {
-    return launch_gemm_nt(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, c->tile);
+    // algorithmic flop count: 2k per computed element of C (lower trapezoid when tri)
+    const double elems = tri ? 0.5 * (double)n * (double)(n + 1) + (double)(m - n) * (double)n : (double)m * (double)n;
+    const double flops = 2.0 * (double)k * elems;
+    const bool prof = c->prof_gemm && flops >= 1.0e9;
+    gpt_ctx::GemmProf *gp = nullptr;
+    if (prof) {
+        if (c->gprof_used == c->gprof.size()) {
+            gpt_ctx::GemmProf g;
+            GPT_HIP_CHECK(hipEventCreate(&g.e0));
+            GPT_HIP_CHECK(hipEventCreate(&g.e1));
+            g.flops = 0;
+            c->gprof.push_back(g);
+        }
+        gp = &c->gprof[c->gprof_used++];
+        gp->flops = flops;
+        GPT_HIP_CHECK(hipEventRecord(gp->e0, st));
+    }
+    int rc = launch_gemm_nt(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, c->tile);
+    if (prof) GPT_HIP_CHECK(hipEventRecord(gp->e1, st));
+    return rc;
 }
 
 // Factor the block column Ap (m x w, diag block on top): recursive halving down to 128 columns.
@@ -348,6 +372,7 @@ extern "C" int gpt_ctx_destroy(gpt_ctx *c)
     for (auto &b : c->slots)
         if (b.p) hipFree(b.p);
     for (auto e : c->events) hipEventDestroy(e);
+    for (auto &g : c->gprof) { hipEventDestroy(g.e0); hipEventDestroy(g.e1); }
     for (int i = 0; i < 5; i++)
         if (c->tev[i]) hipEventDestroy(c->tev[i]);
     if (c->d_info) hipFree(c->d_info);
@@ -372,6 +397,7 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     } else if (!strcmp(key, "lookahead")) c->lookahead = value ? 1 : 0;
     else if (!strcmp(key, "graph")) c->use_graph = value ? 1 : 0;
     else if (!strcmp(key, "timing")) c->timing = value ? 1 : 0;
+    else if (!strcmp(key, "profile_gemm")) c->prof_gemm = value ? 1 : 0;
     else if (!strcmp(key, "tile")) {
         if (value != 0 && value != 64 && value != 128) {
             gpt_set_error("tile must be 0, 64 or 128");
@@ -618,6 +644,26 @@ extern "C" int gpt_last_timings(gpt_ctx *c, double *out_ms, int n)
     const int cnt = n < 5 ? n : 5;
     for (int i = 0; i < cnt; i++) out_ms[i] = c->timings[i];
     return cnt;
+}
+
+extern "C" int gpt_gemm_profile_read(gpt_ctx *c, double *out3)
+{
+    CTX_ENTER(c);
+    if (!out3) return GPT_E_ARG;
+    GPT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    GPT_HIP_CHECK(hipStreamSynchronize(c->panel_stream));
+    double flops = 0, ms = 0;
+    for (size_t i = 0; i < c->gprof_used; i++) {
+        float t = 0;
+        GPT_HIP_CHECK(hipEventElapsedTime(&t, c->gprof[i].e0, c->gprof[i].e1));
+        ms += t;
+        flops += c->gprof[i].flops;
+    }
+    out3[0] = flops;
+    out3[1] = ms;
+    out3[2] = (double)c->gprof_used;
+    c->gprof_used = 0;
+    return GPT_OK;
 }
 
 #define NEED_FACTOR(c)                                                        \

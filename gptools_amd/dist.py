@@ -1,0 +1,232 @@
+"""One-process-per-GPU block-cyclic panel Cholesky for the log-marginal-likelihood at large N.
+
+The reference has no distributed code at all (its only parallelism is a process
+pool over independent hyperparameter samples); what must match is the *result* of
+``GaussianProcess.compute_K_L_alpha_ll`` (ref: gptools/gaussian_process.py:1418-1469): ``ll`` and
+``sum(log diag L)``.  Design:
+
+  * 1-D block-cyclic distribution of block columns: block column J (``nb`` wide) lives on rank
+    ``J % world`` as columns ``[lj*nb, (lj+1)*nb)`` of that rank's local (NP x nloc*nb) row-major
+    matrix, full height.  Every rank holds X, n, y (a few hundred KB) and builds its own block
+    columns of K_tot with the fused K-builder: K never crosses xGMI.
+  * Right-looking factorisation: the owner factors panel k (diagonal block + TRSM of the rows below,
+    ``gpt_dev_potrf_panel``) in a contiguous (m x nb) buffer and broadcasts it (RCCL over xGMI via
+    ``torch.distributed.broadcast``); every rank applies it to its local trailing block columns
+    with the fp64-MFMA SYRK/GEMM (``gpt_dev_gemm_nt``).  Look-ahead: the owner of panel k+1 updates
+    and factors that block column first and starts its broadcast asynchronously, before anyone
+    finishes applying panel k, so the transfer and the latency-bound panel hide behind the updates.
+  * ``z = L^-1 y`` rides along as the augmented row N of the matrix, so the only
+    other collective is one all-reduce of three scalars (log-det part, z.z part, info).
+
+All dense work goes through a small ``ops`` object.  The product implementation is
+:class:`HipPanelOps` (C ABI of libgpt_hip.so on CUDA tensors; raises without a GPU).  The
+multi-process CPU tests inject a numpy implementation from ``tests/`` to exercise the
+partitioning / communication logic under the ``gloo`` backend.
+"""
+import math
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+__all__ = ["HipPanelOps", "DistributedLML"]
+
+BIG_PIVOT = 1e300
+
+
+class HipPanelOps(object):
+    """Dense local operations on CUDA tensors through the device API of include/gpt_hip.h."""
+
+    def __init__(self, device):
+        if not torch.cuda.is_available():
+            raise _lib.GPTBackendError("HipPanelOps needs a GPU (gptools_amd has no CPU fallback)")
+        self.device = torch.device("cuda", device) if not isinstance(device, torch.device) else device
+        torch.cuda.set_device(self.device)
+        # A dedicated torch stream shared with the library: torch's tensor ops, the RCCL collectives and the
+        # HIP kernels launched through the C ABI are then ordered on one queue (the legacy default stream has
+        # handle 0, which the library would replace by a private, unordered stream).
+        self.stream = torch.cuda.Stream(self.device)
+        self.ctx = _lib.Context(self.device.index, stream=self.stream.cuda_stream)
+        self.lib = _lib.load()
+        self.ctx.set_option("lookahead", 0)
+
+    def stream_ctx(self):
+        return torch.cuda.stream(self.stream)
+
+    def kbuild_block(self, kernel_id, params, X, n, r0, r1, c0, c1, err_y, noise_var, diag_add, out, ld):
+        """out[(i - r0) * ld + (j - c0)] = K_tot[i][j] for i in [r0, r1), j in [c0, c1) (global indices)."""
+        params = _lib.f64(params)
+        D = X.shape[1]
+        esz_d, esz_i = 8, 4
+        _lib.check(self.lib.gpt_dev_kbuild(
+            self.ctx.handle, int(kernel_id), _lib.dptr(params), len(params),
+            X.data_ptr() + r0 * D * esz_d, n.data_ptr() + r0 * D * esz_i, r1 - r0,
+            X.data_ptr() + c0 * D * esz_d, n.data_ptr() + c0 * D * esz_i, c1 - c0, D,
+            -1, 1, None, 1, r0, c0, err_y.data_ptr(), float(noise_var), float(diag_add), out, ld))
+
+    def potrf_panel(self, m, nb, A, lda, invd, info, info_base):
+        _lib.check(self.lib.gpt_dev_potrf_panel(self.ctx.handle, m, nb, A, lda, invd.data_ptr(), info.data_ptr(),
+                                                info_base))
+
+    def gemm_nt(self, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri):
+        _lib.check(self.lib.gpt_dev_gemm_nt(self.ctx.handle, m, n, k, float(alpha), A, lda, B, ldb, float(beta),
+                                            C, ldc, int(tri)))
+
+
+def _ptr(t, row, col):
+    """Address of element (row, col) of a 2-D row-major tensor."""
+    return t.data_ptr() + (row * t.stride(0) + col) * t.element_size()
+
+
+class DistributedLML(object):
+    """Evaluate the LML data term of a GP whose K_tot is partitioned over the ranks of ``group``.
+
+    ``X`` (N, D) float64 and ``n`` (N, D) integer derivative orders are replicated on every rank.
+    ``fit(kernel_id, params, y, err_y, ...)`` returns ``(ll_data, logdet_half)`` on every rank and
+    raises ``numpy.linalg.LinAlgError`` if K_tot is not positive definite.
+    """
+
+    def __init__(self, X, n, nb=512, group=None, ops=None, device=None, lookahead=True):
+        if nb <= 0 or nb % 128:
+            raise ValueError("nb must be a positive multiple of 128")
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if ops is None:
+            ops = HipPanelOps(0 if device is None else device)
+        self.ops = ops
+        self.device = getattr(ops, "device", torch.device("cpu"))
+        self.lookahead = bool(lookahead) and self.world > 1
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        n = np.ascontiguousarray(n, dtype=np.int32)
+        self.N, self.D = X.shape
+        self.nb = nb
+        self.NP = (self.N + 1 + nb - 1) // nb * nb
+        self.nblk = self.NP // nb
+        self.my_blocks = [J for J in range(self.nblk) if J % self.world == self.rank]
+        self.nloc = len(self.my_blocks)
+        dev = self.device
+        self.X = torch.from_numpy(X).to(dev)
+        self.n = torch.from_numpy(n).to(dev)
+        self.A = torch.empty((self.NP, max(self.nloc, 1) * nb), dtype=torch.float64, device=dev)
+        self.P = [torch.empty((self.NP, nb), dtype=torch.float64, device=dev) for _ in range(2)]
+        self.invd = torch.empty(((nb // 16) * 256,), dtype=torch.float64, device=dev)
+        self.info = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.y = torch.empty((self.NP,), dtype=torch.float64, device=dev)
+        self.err = torch.zeros((self.NP,), dtype=torch.float64, device=dev)
+        self.timings = {}
+
+    # ------------------------------------------------------------------------------------------
+    def _assemble(self, kernel_id, params, noise_var, diag_add):
+        """Each rank builds its block columns of K_tot (lower part) plus the padding / augmented row."""
+        N, nb, A = self.N, self.nb, self.A
+        ld = A.stride(0)
+        if self.NP > N:
+            A[N:, :].zero_()
+        for lj, J in enumerate(self.my_blocks):
+            c0, c1 = J * nb, min((J + 1) * nb, N)
+            if c0 < N:
+                self.ops.kbuild_block(kernel_id, params, self.X, self.n, c0, N, c0, c1, self.err, noise_var, diag_add,
+                                      _ptr(A, c0, lj * nb), ld)
+                A[N, lj * nb: lj * nb + (c1 - c0)] = self.y[c0:c1]        # augmented row: y^T
+            # unit diagonal on the padding, a huge pivot under the augmented row
+            p0 = max(c0, N)
+            if p0 < (J + 1) * nb:
+                idx = torch.arange(p0, (J + 1) * nb, device=A.device)
+                A[idx, lj * nb + (idx - c0)] = 1.0
+                if c0 <= N < (J + 1) * nb:
+                    A[N, lj * nb + (N - c0)] = BIG_PIVOT
+
+    def _bcast(self, buf, src, async_op=False):
+        if self.world == 1:
+            return None
+        gsrc = dist.get_global_rank(self.group, src) if self.group is not None else src
+        return dist.broadcast(buf, src=gsrc, group=self.group, async_op=async_op)
+
+    def _factor_panel(self, k, buf):
+        """Owner side: copy block column k into the contiguous panel buffer, factor it there, write L back."""
+        nb, A = self.nb, self.A
+        lk = k // self.world
+        m = self.NP - k * nb
+        view = A[k * nb:, lk * nb:(lk + 1) * nb]
+        buf[:m].copy_(view)
+        self.ops.potrf_panel(m, nb, buf.data_ptr(), nb, self.invd, self.info, k * nb)
+        view.copy_(buf[:m])
+
+    def _update_block(self, k, J, buf):
+        """A[J*nb:, block J] -= P_k[rows of J..] * P_k[rows of block J]^T  (lower trapezoid)."""
+        nb, A = self.nb, self.A
+        lj = J // self.world
+        mJ = self.NP - J * nb
+        off = (J - k) * nb
+        self.ops.gemm_nt(mJ, nb, nb, -1.0, _ptr(buf, off, 0), nb, _ptr(buf, off, 0), nb, 1.0,
+                         _ptr(A, J * nb, lj * nb), A.stride(0), 1)
+
+    def fit(self, kernel_id, params, y, err_y, noise_var=0.0, diag_factor=1e2):
+        import contextlib
+        sc = self.ops.stream_ctx() if hasattr(self.ops, "stream_ctx") else contextlib.nullcontext()
+        with sc:
+            return self._fit(kernel_id, params, y, err_y, noise_var, diag_factor)
+
+    def _fit(self, kernel_id, params, y, err_y, noise_var, diag_factor):
+        N, nb, NP, world, rank = self.N, self.nb, self.NP, self.world, self.rank
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        err_y = np.array(np.broadcast_to(err_y, (N,)), dtype=np.float64)
+        self.y[:N] = torch.from_numpy(y).to(self.device)
+        self.err[:N] = torch.from_numpy(err_y).to(self.device)
+        self.info.zero_()
+        self._assemble(kernel_id, params, noise_var, diag_factor * sys.float_info.epsilon)
+
+        nblk = self.nblk
+        pending = None
+        if rank == 0 % world:
+            self._factor_panel(0, self.P[0])
+        pending = self._bcast(self.P[0][:NP], 0, async_op=True)
+        for k in range(nblk):
+            buf = self.P[k % 2]
+            if pending is not None:
+                pending.wait()
+                pending = None
+            nxt = k + 1
+            mine = [J for J in self.my_blocks if J > k]
+            if nxt < nblk:
+                own_next = (nxt % world == rank)
+                nbuf = self.P[nxt % 2]
+                if self.lookahead:
+                    if own_next:
+                        self._update_block(k, nxt, buf)
+                        self._factor_panel(nxt, nbuf)
+                        mine = [J for J in mine if J != nxt]
+                    pending = self._bcast(nbuf[:NP - nxt * nb], nxt % world, async_op=True)
+            for J in mine:
+                self._update_block(k, J, buf)
+            if nxt < nblk and not self.lookahead:
+                if nxt % world == rank:
+                    self._factor_panel(nxt, self.P[nxt % 2])
+                pending = self._bcast(self.P[nxt % 2][:NP - nxt * nb], nxt % world, async_op=True)
+
+        # ---- scalars: sum(log L_ii) over i < N, z.z from the augmented row, info ----
+        red = torch.zeros((3,), dtype=torch.float64, device=self.device)
+        for lj, J in enumerate(self.my_blocks):
+            c0, c1 = J * nb, min((J + 1) * nb, N)
+            if c0 >= N:
+                continue
+            blk = self.A[c0:c1, lj * nb: lj * nb + (c1 - c0)]
+            red[0] += torch.log(torch.diagonal(blk)).sum()
+            z = self.A[N, lj * nb: lj * nb + (c1 - c0)]
+            red[1] += (z * z).sum()
+        red[2] = self.info.to(torch.float64)[0]
+        if world > 1:
+            # info: non-zero on the owner of the failing panel only; max picks it up
+            info_t = red[2:3].clone()
+            dist.all_reduce(red[:2], op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(info_t, op=dist.ReduceOp.MAX, group=self.group)
+            red[2] = info_t[0]
+        logdet_half, zz, info = (float(v) for v in red.cpu())
+        if info != 0 and info <= N:
+            raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % int(info))
+        ll_data = -0.5 * zz - logdet_half - 0.5 * N * math.log(2.0 * math.pi)
+        return ll_data, logdet_half

@@ -61,7 +61,8 @@ int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out);
 int gpt_ctx_destroy(gpt_ctx *ctx);
 /* Options: "nb_outer" (outer block width, multiple of 128), "lookahead" (0/1), "graph" (0/1:
  * replay the factorisation from a captured hipGraph), "timing" (0/1: record per-phase HIP
- * events), "tile" (0 auto, 64, 128: force the GEMM macro-tile). */
+ * events), "profile_gemm" (0/1: HIP-event timing of each large GEMM launch, see
+ * gpt_gemm_profile_read), "tile" (0 auto, 64, 128: force the GEMM macro-tile). */
 int gpt_ctx_set_option(gpt_ctx *ctx, const char *key, int64_t value);
 int gpt_ctx_synchronize(gpt_ctx *ctx);
 void *gpt_ctx_stream(gpt_ctx *ctx);
@@ -142,6 +143,12 @@ int gpt_cho_solve(gpt_ctx *ctx, double *B, int64_t nrhs);
 /* Per-phase timings of the last gpt_fit in milliseconds (HIP events on the context's stream):
  * out[0]=upload, [1]=kbuild, [2]=potrf, [3]=ll tail, [4]=total; returns the count written. */
 int gpt_last_timings(gpt_ctx *ctx, double *out_ms, int n);
+
+/* With option "profile_gemm" = 1 every large (>= 1 GFLOP) trailing-update GEMM/SYRK launch is bracketed
+ * by HIP events on the stream it runs on.  Reads and resets the accumulators:
+ * out3[0] = algorithmic flops (2k per computed element of C, lower trapezoid for SYRK-style launches),
+ * out3[1] = summed launch durations in ms, out3[2] = number of launches. */
+int gpt_gemm_profile_read(gpt_ctx *ctx, double *out3);
 
 /* Standalone dense kernels on host matrices (used by parity tests and the roofline bench). */
 int gpt_potrf_host(gpt_ctx *ctx, double *A, int64_t N);                 /* in place, lower */

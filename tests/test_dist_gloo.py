@@ -1,0 +1,144 @@
+"""CPU suite, part 3: the N>1 path (gptools_amd/dist.py) under torch.distributed/gloo with world_size 2 and 3.
+
+The partitioning, look-ahead ordering, panel broadcast and the scalar all-reduce are the product code;
+the dense local operations are injected here as numpy/scipy stand-ins (test infrastructure: the product
+ops class, HipPanelOps, refuses to run without a GPU)."""
+import ctypes
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _view(ptr, rows, cols, ld):
+    base = np.ctypeslib.as_array((ctypes.c_double * (max(rows - 1, 0) * ld + cols)).from_address(ptr))
+    return np.lib.stride_tricks.as_strided(base, shape=(rows, cols), strides=(ld * 8, 8))
+
+
+class NumpyPanelOps(object):
+    """Same interface as gptools_amd.dist.HipPanelOps, on CPU tensors, built from the oracle + scipy."""
+    device = torch.device("cpu")
+
+    def __init__(self):
+        from oracle import oracle as O
+        self.O = O
+
+    def kbuild_block(self, kernel_id, params, X, n, r0, r1, c0, c1, err_y, noise_var, diag_add, out, ld):
+        Xn, nn = X.numpy(), n.numpy()
+        K = self.O.kbuild(kernel_id, params, Xn[r0:r1], nn[r0:r1], Xn[c0:c1], nn[c0:c1])
+        e = err_y.numpy()
+        for j in range(c0, c1):
+            if r0 <= j < r1:
+                K[j - r0, j - c0] = ((K[j - r0, j - c0] + noise_var) + e[j] ** 2) + diag_add
+        _view(out, r1 - r0, c1 - c0, ld)[:, :] = K
+
+    def potrf_panel(self, m, nb, A, lda, invd, info, info_base):
+        import scipy.linalg
+        P = _view(A, m, nb, lda)
+        try:
+            L = scipy.linalg.cholesky(np.tril(P[:nb]) + np.tril(P[:nb], -1).T, lower=True)
+        except np.linalg.LinAlgError as e:
+            if int(info[0]) == 0:
+                info[0] = info_base + 1
+            return
+        P[:nb] = L
+        if m > nb:
+            P[nb:] = scipy.linalg.solve_triangular(L, P[nb:].T, lower=True).T
+
+    def gemm_nt(self, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri):
+        Av, Bv, Cv = _view(A, m, k, lda).copy(), _view(B, n, k, ldb).copy(), _view(C, m, n, ldc)
+        Cv[:, :] = beta * Cv + alpha * Av.dot(Bv.T)
+
+
+def _inputs(N, d, seed=4):
+    rs = np.random.RandomState(seed)
+    X = rs.rand(N, d)
+    n = np.zeros((N, d), dtype=np.int32)
+    for i in range(3 * N // 4, N):
+        n[i, i % d] = 1
+    y = np.sin(X.sum(1)) + 0.05 * rs.randn(N)
+    return X, n, y
+
+
+def _worker(rank, world, port, N, d, nb, kernel_id, lookahead, bad, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gptools_amd.dist import DistributedLML
+        X, n, y = _inputs(N, d)
+        if bad:
+            X[1] = X[0]
+            n[:] = 0
+        plan = DistributedLML(X, n, nb=nb, ops=NumpyPanelOps(), lookahead=lookahead)
+        p = np.concatenate(([1.0], 0.3 * np.ones(d)))
+        try:
+            res = plan.fit(kernel_id, p, y, 0.0 if bad else 0.05, diag_factor=0.0 if bad else 1e2)
+        except np.linalg.LinAlgError as e:
+            res = ("LinAlgError", str(e))
+        # second evaluation with other hyperparameters reuses the buffers (MAP-loop usage)
+        res2 = None if bad else plan.fit(kernel_id, 1.1 * p, y, 0.05)
+        q.put((rank, res, res2, plan.my_blocks))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(world, N, d, nb, kernel_id, lookahead, bad=False):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, d, nb, kernel_id, lookahead, bad, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(out)
+
+
+@pytest.mark.parametrize("world,N,d,nb,kid,lookahead", [
+    (2, 700, 3, 128, 1, True),      # Matern52 with derivative rows, 6 block columns over 2 ranks
+    (2, 700, 3, 128, 1, False),
+    (3, 500, 2, 128, 0, True),      # SE, uneven block ownership (5 block columns over 3 ranks)
+    (2, 100, 2, 256, 0, True),      # fewer block columns than ranks -> an idle rank must still take part
+])
+def test_distributed_fit_matches_single_process_oracle(world, N, d, nb, kid, lookahead):
+    from oracle import oracle as O
+    out = _run(world, N, d, nb, kid, lookahead)
+    X, n, y = _inputs(N, d)
+    p = np.concatenate(([1.0], 0.3 * np.ones(d)))
+    ref = O.fit(kid, p, X, n, y, 0.05 * np.ones(N))
+    ref2 = O.fit(kid, 1.1 * p, X, n, y, 0.05 * np.ones(N))
+    owned = []
+    for rank, res, res2, blocks in out:
+        assert abs(res[0] - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"]), (rank, res, ref["ll_data"])
+        assert abs(res[1] - ref["logdet_half"]) <= 1e-10 * abs(ref["logdet_half"])
+        assert abs(res2[0] - ref2["ll_data"]) <= 1e-9 * abs(ref2["ll_data"])
+        owned += blocks
+    assert sorted(owned) == list(range((N + 1 + nb - 1) // nb))     # block-cyclic cover, no overlap
+    assert len({r[1] for r in out}) == 1                            # every rank reports the same numbers
+
+
+def test_distributed_not_positive_definite_raises_on_every_rank():
+    out = _run(2, 300, 2, 128, 0, True, bad=True)
+    for rank, res, _, _ in out:
+        assert res[0] == "LinAlgError" and "not positive definite" in res[1]

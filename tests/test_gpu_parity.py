@@ -458,3 +458,20 @@ def test_full_size_properties(ctx, oracle, cfg):
     m, s, _ = ctx.predict(Xs, ns, 1)
     np.testing.assert_allclose(m, mr, rtol=0, atol=1e-6)
     np.testing.assert_allclose(s ** 2, sr ** 2, rtol=0, atol=1e-6)
+
+
+def test_distributed_plan_on_one_gpu(ctx, oracle):
+    """gptools_amd.dist with the product ops (HipPanelOps, device API of the C ABI) and world_size 1:
+    same ll / log|K| as the single-context path and the oracle."""
+    from gptools_amd.dist import DistributedLML
+    X, n, y = c3_inputs(1500, 3)
+    p = np.array([1.0, 0.3, 0.3, 0.3])
+    err = 0.05 * np.ones(1500)
+    ref = oracle.fit("m52", p, X, n, y, err, chol="scipy")
+    for nb in (128, 256, 512):
+        plan = DistributedLML(X, n, nb=nb, device=0)
+        ll, ld = plan.fit(1, p, y, err)
+        assert abs(ll - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"]), nb
+        assert abs(ld - ref["logdet_half"]) <= 1e-10 * abs(ref["logdet_half"]), nb
+        ll2, _ = plan.fit(1, p, y, err)
+        assert ll2 == ll
