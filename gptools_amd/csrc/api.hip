@@ -6,6 +6,7 @@
 // and GaussianProcess.predict (ref: gptools/gaussian_process.py:965-1006) sequencing.
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include <vector>
@@ -49,7 +50,7 @@ struct gpt_ctx {
     std::vector<hipEvent_t> events;       // sync-only events (look-ahead fork/join)
     hipEvent_t tev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     // options
-    int64_t nb_outer = 256;
+    int64_t nb_outer = 512;
     int lookahead = 1;
     int use_graph = 0;
     int timing = 0;
@@ -334,7 +335,22 @@ extern "C" int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out)
     if (stream) {
         c->stream = (hipStream_t)stream;
     } else {
-        GPT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        // The context's own main stream is created with a CU mask that leaves a few CUs to the (unmasked,
+        // high-priority) panel stream: the 128x128 diagonal-block kernel needs ~133 KB of LDS and would otherwise
+        // never find a CU while a trailing update occupies the chip, which defeats the look-ahead.
+        int reserve = 32;
+        if (const char *e = getenv("GPT_RESERVE_CUS")) reserve = atoi(e);
+        hipDeviceProp_t prop;
+        GPT_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+        const int ncu = prop.multiProcessorCount;
+        bool masked = false;
+        if (reserve > 0 && reserve < ncu) {
+            std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+            for (int i = reserve; i < ncu; i++) mask[i / 32] |= (1u << (i % 32));
+            masked = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+            if (!masked) (void)hipGetLastError();
+        }
+        if (!masked) GPT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
     GPT_HIP_CHECK(hipStreamCreateWithPriority(&c->panel_stream, hipStreamNonBlocking, hi));
@@ -399,7 +415,7 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "timing")) c->timing = value ? 1 : 0;
     else if (!strcmp(key, "profile_gemm")) c->prof_gemm = value ? 1 : 0;
     else if (!strcmp(key, "tile")) {
-        if (value != 0 && value != 64 && value != 128) {
+        if (value != 0 && value != 64 && value != 128 && value != 129) {
             gpt_set_error("tile must be 0, 64 or 128");
             return GPT_E_ARG;
         }

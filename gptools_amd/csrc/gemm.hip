@@ -7,17 +7,26 @@
 //
 // Design (CDNA4):
 //   * v_mfma_f64_16x16x4_f64 (64 cycles/SIMD, 2048 flop): a wave owns a (BM/2 x BN/2) sub-tile as
-//     RM x RN accumulator fragments held in AGPR/VGPRs for the whole k loop.
-//   * LDS tile layout [k/4][row][4]: the fragment read "row = lane&15, k = lane>>4" of one
-//     16-row block is 512 contiguous bytes -> conflict-free ds_read_b64; staging writes are
-//     ds_write_b128.
-//   * global -> register -> LDS staging in full 128-byte row segments, double-buffered so the
-//     loads of k-tile t+1 are in flight during the MFMAs of k-tile t (one barrier per k-tile).
-//   * XCD-aware bijective remap of the linear workgroup id so that each XCD's L2 sees a
-//     contiguous run of tiles (shared A row-panels); `tri` enumerates only the lower tiles.
+//     RM x RN accumulator fragments that stay in registers for the whole k loop.
+//   * Operand k-tiles (BK = 16 doubles = one 128-byte line per row) go HBM/L2 -> LDS with
+//     global_load_lds_dwordx4 (LDS-DMA, no VGPR staging, no ds_write); double-buffered, one barrier
+//     per k-tile.  The LDS image is row-major [row][16] with the eight 16-byte chunks of a row XOR-
+//     swizzled by ((row >> 1) & 7): the DMA destination stays lane-linear (the swizzle is applied to
+//     the per-lane SOURCE address) and both the DMA writes and the ds_read_b128 fragment reads are
+//     bank-conflict free.
+//   * One ds_read_b128 gives a lane two consecutive k values; the sum over k is order independent, so
+//     MFMA step 2t+u of a k-tile contracts k = 8t + 2*(lane>>4) + u for A and B alike.
+//   * The accumulators start from (beta/alpha)*C: the C tile is fetched in the prologue next to the
+//     first operand tiles, the epilogue only stores.
+//   * Large updates use a persistent variant: one workgroup per CU walks a static, XCD-aware tile list and
+//     pipelines ACROSS tiles (next tile's C and first k-tile are fetched under the current MFMAs).
+//   * `tri` enumerates only the lower tiles of a SYRK-style update.
 #include "common.hpp"
 
 #define GM_BK 16
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
 
 __device__ __forceinline__ int64_t xcd_remap(int64_t pid, int64_t nwg)
 {
@@ -27,132 +36,288 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t pid, int64_t nwg)
     return base + local;
 }
 
+__device__ __forceinline__ void tile_decode(int64_t id, int tri, int64_t ntn, int64_t *ti, int64_t *tj)
+{
+    if (tri) {
+        const int64_t ntri = ntn * (ntn + 1) / 2;
+        if (id < ntri) {
+            int64_t t = (int64_t)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
+            while (t * (t + 1) / 2 > id) t--;
+            while ((t + 1) * (t + 2) / 2 <= id) t++;
+            *ti = t;
+            *tj = id - t * (t + 1) / 2;
+        } else {
+            const int64_t r = id - ntri;
+            *ti = ntn + r / ntn;
+            *tj = r % ntn;
+        }
+    } else {
+        *ti = id / ntn;
+        *tj = id % ntn;
+    }
+}
+
+// Per-lane source pointers of the LDS-DMA that stages an R-row operand tile: wave-instruction q covers rows
+// [8q, 8q+8) of the tile, lane -> (row = 8q + lane/8, physical 16-byte chunk p = lane%8) and fetches the
+// logical chunk p ^ ((row >> 1) & 7) of that row.  Each wave issues R/32 of the R/8 instructions.
+template <int R>
+__device__ __forceinline__ void stage_ptrs(const double *M, int64_t ld, int64_t r0, int64_t lim, int wave, int lane,
+                                           const double *(&src)[R / 32])
+{
+#pragma unroll
+    for (int qq = 0; qq < R / 32; qq++) {
+        const int q = wave * (R / 32) + qq;
+        const int row = q * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int64_t gr = r0 + row;
+        if (gr >= lim) gr = lim - 1;
+        src[qq] = M + gr * ld + c * 2;
+    }
+}
+
+// LDS-DMA issue through inline asm: hipcc drains every builtin LDS-DMA with s_waitcnt vmcnt(0) before the next
+// ds_read, which would expose the full memory latency in every k-tile; an asm statement is invisible to that
+// bookkeeping, so the DMA stays in flight under the MFMAs and is drained by the explicit dma_wait() in front of
+// the barrier that publishes the buffer (cdna_hip_programming.md section 5.7: M0 is written and restored inside
+// the same statement).
+__device__ __forceinline__ void glds16(const double *gsrc, unsigned lds_byte_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_byte_addr)
+                 : "memory");
+}
+
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+
+template <int R>
+__device__ __forceinline__ void stage_issue(const double *const (&src)[R / 32], int64_t koff, unsigned tile_lds, int wave)
+{
+#pragma unroll
+    for (int qq = 0; qq < R / 32; qq++) {
+        const int q = wave * (R / 32) + qq;
+        glds16(src[qq] + koff, tile_lds + (unsigned)(q * 8 * GM_BK * sizeof(double)));
+    }
+}
+
+// One k-tile of MFMAs for a wave: RM x RN fragments, A rows start at arow0, B rows at brow0 (tile-local).
+template <int RM, int RN>
+__device__ __forceinline__ void mma_ktile(const double *tA, const double *tB, int arow0, int brow0, int fr, int fk,
+                                          f64x4 (&acc)[RM][RN])
+{
+    const int sw = (fr >> 1) & 7;
+#pragma unroll
+    for (int t = 0; t < GM_BK / 8; t++) {
+        const int p = ((fk + 4 * t) ^ sw) * 2;
+        f64x2 af[RM], bf[RN];
+#pragma unroll
+        for (int i = 0; i < RM; i++) af[i] = *reinterpret_cast<const f64x2 *>(tA + (arow0 + i * 16 + fr) * GM_BK + p);
+#pragma unroll
+        for (int j = 0; j < RN; j++) bf[j] = *reinterpret_cast<const f64x2 *>(tB + (brow0 + j * 16 + fr) * GM_BK + p);
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int i = 0; i < RM; i++)
+#pragma unroll
+                for (int j = 0; j < RN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][u], bf[j][u], acc[i][j], 0, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One output tile per workgroup (used with 64x64 tiles for small / latency-bound updates).
+// ------------------------------------------------------------------------------------------------
 template <int BM, int BN, int WPS>
 __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     int64_t m, int64_t n, int64_t k, double alpha, const double *__restrict__ A, int64_t lda,
     const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
     int tri, int64_t ntm, int64_t ntn, int64_t nwg)
 {
-    constexpr int WM = BM / 2, WN = BN / 2;          // wave sub-tile
-    constexpr int RM = WM / 16, RN = WN / 16;        // MFMA fragment repeats
-    constexpr int EPA = BM / 16, EPB = BN / 16;      // doubles staged per thread per k-tile
-    constexpr int TPRA = GM_BK / EPA, TPRB = GM_BK / EPB;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int RM = WM / 16, RN = WN / 16;
+    __shared__ __attribute__((aligned(16))) double sA[2][BM * GM_BK];
+    __shared__ __attribute__((aligned(16))) double sB[2][BN * GM_BK];
 
-    __shared__ __attribute__((aligned(16))) double sA[2][GM_BK / 4][BM][4];
-    __shared__ __attribute__((aligned(16))) double sB[2][GM_BK / 4][BN][4];
-
-    // ---- tile coordinates ----
-    const int64_t id = xcd_remap(blockIdx.x, nwg);
     int64_t ti, tj;
-    if (tri) {
-        const int64_t ntri = ntn * (ntn + 1) / 2;
-        if (id < ntri) {
-            ti = (int64_t)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
-            while (ti * (ti + 1) / 2 > id) ti--;
-            while ((ti + 1) * (ti + 2) / 2 <= id) ti++;
-            tj = id - ti * (ti + 1) / 2;
-        } else {
-            const int64_t r = id - ntri;
-            ti = ntn + r / ntn;
-            tj = r % ntn;
-        }
-    } else {
-        ti = id / ntn;
-        tj = id % ntn;
-    }
+    tile_decode(xcd_remap(blockIdx.x, nwg), tri, ntn, &ti, &tj);
     const int64_t row0 = ti * BM, col0 = tj * BN;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fk = lane >> 4;
 
-    // ---- staging assignment ----
-    const int a_row = tid / TPRA, a_seg = tid % TPRA;
-    const int b_row = tid / TPRB, b_seg = tid % TPRB;
-    int64_t ga_row = row0 + a_row;
-    if (ga_row >= m) ga_row = m - 1;
-    int64_t gb_row = col0 + b_row;
-    if (gb_row >= n) gb_row = n - 1;
-    const double *pa = A + ga_row * lda + a_seg * EPA;
-    const double *pb = B + gb_row * ldb + b_seg * EPB;
+    const double *srcA[BM / 32], *srcB[BN / 32];
+    stage_ptrs<BM>(A, lda, row0, m, wave, lane, srcA);
+    stage_ptrs<BN>(B, ldb, col0, n, wave, lane, srcB);
+    const unsigned ldsA = lds_addr(&sA[0][0]), ldsB = lds_addr(&sB[0][0]);
+    constexpr unsigned ABYTES = BM * GM_BK * sizeof(double), BBYTES = BN * GM_BK * sizeof(double);
+    stage_issue<BM>(srcA, 0, ldsA, wave);
+    stage_issue<BN>(srcB, 0, ldsB, wave);
 
-    f64x2 ra[EPA / 2], rb[EPB / 2];
     f64x4 acc[RM][RN];
+    const double cs = (beta != 0.0) ? beta / alpha : 0.0;
 #pragma unroll
     for (int i = 0; i < RM; i++)
-#pragma unroll
-        for (int j = 0; j < RN; j++) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
-
-    const int64_t nk = k / GM_BK;
-
-#define GM_LOAD(kt)                                                                        \
-    do {                                                                                   \
-        _Pragma("unroll") for (int q = 0; q < EPA / 2; q++)                                \
-            ra[q] = *reinterpret_cast<const f64x2 *>(pa + (int64_t)(kt) * GM_BK + 2 * q);  \
-        _Pragma("unroll") for (int q = 0; q < EPB / 2; q++)                                \
-            rb[q] = *reinterpret_cast<const f64x2 *>(pb + (int64_t)(kt) * GM_BK + 2 * q);  \
-    } while (0)
-
-#define GM_STORE(buf)                                                                                   \
-    do {                                                                                                \
-        _Pragma("unroll") for (int q = 0; q < EPA / 2; q++) {                                           \
-            const int kk = a_seg * EPA + 2 * q;                                                         \
-            *reinterpret_cast<f64x2 *>(&sA[buf][kk >> 2][a_row][kk & 3]) = ra[q];                       \
-        }                                                                                               \
-        _Pragma("unroll") for (int q = 0; q < EPB / 2; q++) {                                           \
-            const int kk = b_seg * EPB + 2 * q;                                                         \
-            *reinterpret_cast<f64x2 *>(&sB[buf][kk >> 2][b_row][kk & 3]) = rb[q];                       \
-        }                                                                                               \
-    } while (0)
-
-    GM_LOAD(0);
-    GM_STORE(0);
-    __syncthreads();
-
-    const int fr = lane & 15, fk = lane >> 4;
-    for (int64_t kt = 0; kt < nk; kt++) {
-        const int cur = (int)(kt & 1);
-        if (kt + 1 < nk) GM_LOAD(kt + 1);
-#pragma unroll
-        for (int g = 0; g < GM_BK / 4; g++) {
-            double af[RM], bf[RN];
-#pragma unroll
-            for (int i = 0; i < RM; i++) af[i] = sA[cur][g][wm * WM + i * 16 + fr][fk];
-#pragma unroll
-            for (int j = 0; j < RN; j++) bf[j] = sB[cur][g][wn * WN + j * 16 + fr][fk];
-#pragma unroll
-            for (int i = 0; i < RM; i++)
-#pragma unroll
-                for (int j = 0; j < RN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            GM_STORE(cur ^ 1);
-            __syncthreads();
-        }
-    }
-#undef GM_LOAD
-#undef GM_STORE
-
-    // ---- epilogue: C = beta*C + alpha*acc  (fragment: col = lane&15, row = (lane>>4) + 4*r) ----
-#pragma unroll
-    for (int i = 0; i < RM; i++) {
 #pragma unroll
         for (int j = 0; j < RN; j++) {
             const int64_t col = col0 + wn * WN + j * 16 + fr;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int64_t row = row0 + wm * WM + i * 16 + fk + 4 * r;
-                if (row < m && col < n) {
-                    double *pc = C + row * ldc + col;
-                    double v = alpha * acc[i][j][r];
-                    if (beta != 0.0) v = fma(beta, *pc, v);
-                    *pc = v;
-                }
+                acc[i][j][r] = (beta != 0.0 && row < m && col < n) ? cs * C[row * ldc + col] : 0.0;
             }
         }
+    dma_wait();
+    __syncthreads();
+
+    const int64_t nk = k / GM_BK;
+    for (int64_t kt = 0; kt < nk; kt++) {
+        const int cur = (int)(kt & 1);
+        if (kt + 1 < nk) {
+            stage_issue<BM>(srcA, (kt + 1) * GM_BK, ldsA + (cur ^ 1) * ABYTES, wave);
+            stage_issue<BN>(srcB, (kt + 1) * GM_BK, ldsB + (cur ^ 1) * BBYTES, wave);
+        }
+        mma_ktile<RM, RN>(sA[cur], sB[cur], wm * WM, wn * WN, fr, fk, acc);
+        dma_wait();
+        __syncthreads();
     }
+
+#pragma unroll
+    for (int i = 0; i < RM; i++)
+#pragma unroll
+        for (int j = 0; j < RN; j++) {
+            const int64_t col = col0 + wn * WN + j * 16 + fr;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int64_t row = row0 + wm * WM + i * 16 + fk + 4 * r;
+                if (row < m && col < n) C[row * ldc + col] = alpha * acc[i][j][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent 128x128 variant: one workgroup per CU, static XCD-aware tile list, cross-tile pipelining.
+// 128 accumulator + 128 next-C registers per lane (one wave per SIMD).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void gemm_nt_persist_kernel(
+    int64_t m, int64_t n, int64_t k, double alpha, const double *__restrict__ A, int64_t lda,
+    const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
+    int tri, int64_t ntn, int64_t ntiles)
+{
+    constexpr int BM = 128, BN = 128, WM = 64, WN = 64, RM = 4, RN = 4;
+    __shared__ __attribute__((aligned(16))) double sA[2][BM * GM_BK];
+    __shared__ __attribute__((aligned(16))) double sB[2][BN * GM_BK];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int64_t G = gridDim.x;
+    // block b runs on XCD b % 8: give each XCD a contiguous run of G/8 tiles per sweep (shared A row-panels)
+    const int64_t slot = (G % 8 == 0) ? (int64_t)(blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+    const int64_t nk = k / GM_BK;
+    const double cs = (beta != 0.0) ? beta / alpha : 0.0;
+
+    int64_t lid = slot;
+    if (lid >= ntiles) return;
+    int64_t ti, tj;
+    tile_decode(lid, tri, ntn, &ti, &tj);
+    int64_t row0 = ti * BM, col0 = tj * BN;
+
+    const double *srcA[4], *srcB[4], *nsrcA[4], *nsrcB[4];
+    stage_ptrs<BM>(A, lda, row0, m, wave, lane, srcA);
+    stage_ptrs<BN>(B, ldb, col0, n, wave, lane, srcB);
+    const unsigned ldsA = lds_addr(&sA[0][0]), ldsB = lds_addr(&sB[0][0]);
+    constexpr unsigned TBYTES = 128 * GM_BK * sizeof(double);
+    stage_issue<BM>(srcA, 0, ldsA, wave);
+    stage_issue<BN>(srcB, 0, ldsB, wave);
+
+    f64x4 acc[RM][RN], cn[RM][RN];
+#define GP_LOADC(DST, R0, C0, SCALE)                                                              \
+    do {                                                                                          \
+        const bool full_ = (beta != 0.0) && ((R0) + BM <= m) && ((C0) + BN <= n);                 \
+        const double *cb_ = C + ((R0) + wm * WM + fk) * ldc + (C0) + wn * WN + fr;                \
+        if (full_) {                                                                              \
+            _Pragma("unroll") for (int i = 0; i < RM; i++)                                        \
+            _Pragma("unroll") for (int j = 0; j < RN; j++)                                        \
+            _Pragma("unroll") for (int r = 0; r < 4; r++)                                         \
+                DST[i][j][r] = (SCALE) * cb_[(i * 16 + 4 * r) * ldc + j * 16];                    \
+        } else {                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < RM; i++)                                        \
+            _Pragma("unroll") for (int j = 0; j < RN; j++) {                                      \
+                const int64_t col = (C0) + wn * WN + j * 16 + fr;                                 \
+                _Pragma("unroll") for (int r = 0; r < 4; r++) {                                   \
+                    const int64_t row = (R0) + wm * WM + i * 16 + fk + 4 * r;                     \
+                    DST[i][j][r] = (beta != 0.0 && row < m && col < n) ? (SCALE) * C[row * ldc + col] : 0.0; \
+                }                                                                                 \
+            }                                                                                     \
+        }                                                                                         \
+    } while (0)
+    GP_LOADC(acc, row0, col0, cs);
+    dma_wait();
+    __syncthreads();
+    int cur = 0;
+    const int64_t ctrig = (nk >= 4) ? nk - 4 : 0;
+
+    for (;;) {
+        const int64_t nlid = lid + G;
+        const bool has_next = nlid < ntiles;
+        int64_t nrow0 = 0, ncol0 = 0;
+        if (has_next) {
+            int64_t nti, ntj;
+            tile_decode(nlid, tri, ntn, &nti, &ntj);
+            nrow0 = nti * BM;
+            ncol0 = ntj * BN;
+            stage_ptrs<BM>(A, lda, nrow0, m, wave, lane, nsrcA);
+            stage_ptrs<BN>(B, ldb, ncol0, n, wave, lane, nsrcB);
+        }
+        for (int64_t kt = 0; kt < nk; kt++) {
+            if (kt + 1 < nk) {
+                stage_issue<BM>(srcA, (kt + 1) * GM_BK, ldsA + (cur ^ 1) * TBYTES, wave);
+                stage_issue<BN>(srcB, (kt + 1) * GM_BK, ldsB + (cur ^ 1) * TBYTES, wave);
+            } else if (has_next) {
+                stage_issue<BM>(nsrcA, 0, ldsA + (cur ^ 1) * TBYTES, wave);
+                stage_issue<BN>(nsrcB, 0, ldsB + (cur ^ 1) * TBYTES, wave);
+            }
+            if (has_next && kt == ctrig) GP_LOADC(cn, nrow0, ncol0, 1.0);
+            mma_ktile<RM, RN>(sA[cur], sB[cur], wm * WM, wn * WN, fr, fk, acc);
+            dma_wait();
+            __syncthreads();
+            cur ^= 1;
+        }
+        // results of this tile: fire-and-forget stores
+#pragma unroll
+        for (int i = 0; i < RM; i++)
+#pragma unroll
+            for (int j = 0; j < RN; j++) {
+                const int64_t col = col0 + wn * WN + j * 16 + fr;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int64_t row = row0 + wm * WM + i * 16 + fk + 4 * r;
+                    if (row < m && col < n) C[row * ldc + col] = alpha * acc[i][j][r];
+                }
+            }
+        if (!has_next) break;
+#pragma unroll
+        for (int i = 0; i < RM; i++)
+#pragma unroll
+            for (int j = 0; j < RN; j++) acc[i][j] = cs * cn[i][j];
+        lid = nlid;
+        row0 = nrow0;
+        col0 = ncol0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            srcA[q] = nsrcA[q];
+            srcB[q] = nsrcB[q];
+        }
+    }
+#undef GP_LOADC
 }
 
 template <int BM, int BN, int WPS>
@@ -160,18 +325,31 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
                          int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri)
 {
     const int64_t ntm = (m + BM - 1) / BM, ntn = (n + BN - 1) / BN;
-    int64_t nwg;
-    if (tri) {
-        if (ntm < ntn) {
-            gpt_set_error("gemm_nt: tri requires m >= n");
-            return GPT_E_ARG;
-        }
-        nwg = ntn * (ntn + 1) / 2 + (ntm - ntn) * ntn;
-    } else {
-        nwg = ntm * ntn;
-    }
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS>), dim3((unsigned)nwg), dim3(256), 0, st, m, n, k, alpha, A,
+    const int64_t nwg = tri ? ntn * (ntn + 1) / 2 + (ntm - ntn) * ntn : ntm * ntn;
+    // 1 KiB of unused dynamic LDS caps the 64x64 kernel (32 KiB static) at four workgroups per CU, which keeps
+    // 28 KiB of LDS and a quarter of the register file free on every CU for the high-priority panel stream.
+    const size_t dyn = (BM == 64) ? 1024 : 0;
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS>), dim3((unsigned)nwg), dim3(256), dyn, st, m, n, k, alpha, A,
                        lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
+static int gemm_launch_persist(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A,
+                               int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri)
+{
+    const int64_t ntm = (m + 127) / 128, ntn = (n + 127) / 128;
+    const int64_t ntiles = tri ? ntn * (ntn + 1) / 2 + (ntm - ntn) * ntn : ntm * ntn;
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GPT_E_HIP;
+        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int64_t G = ntiles < ncu ? ntiles : ncu;
+    hipLaunchKernelGGL(gemm_nt_persist_kernel, dim3((unsigned)G), dim3(256), 0, st, m, n, k, alpha, A, lda, B, ldb, beta,
+                       C, ldc, tri, ntn, ntiles);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
@@ -180,6 +358,10 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
                    const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile)
 {
     if (m <= 0 || n <= 0) return GPT_OK;
+    if (alpha == 0.0) {
+        gpt_set_error("gemm_nt: alpha must be non-zero");
+        return GPT_E_ARG;
+    }
     if (k <= 0 || (k % GM_BK) != 0 || (lda & 1) || (ldb & 1)) {
         gpt_set_error("gemm_nt: k must be a positive multiple of %d and lda/ldb even (k=%lld)", GM_BK, (long long)k);
         return GPT_E_ARG;
@@ -188,12 +370,13 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
         gpt_set_error("gemm_nt: A and B must be 16-byte aligned");
         return GPT_E_ARG;
     }
-    int tile = force_tile;
-    if (tile == 0) {
-        // 128x128 macro-tiles once they alone can fill the 256 CUs, else 64x64 to spread the work
-        const int64_t t128 = ((m + 127) / 128) * ((n + 127) / 128) / (tri ? 2 : 1);
-        tile = (t128 >= 192) ? 128 : 64;
+    if (tri && m < n) {
+        gpt_set_error("gemm_nt: tri requires m >= n");
+        return GPT_E_ARG;
     }
-    if (tile == 128) return gemm_launch_t<128, 128, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri);
+    int tile = force_tile;
+    if (tile == 0) tile = 64;   // measured on MI355X: 64x64 tiles at 4-5 workgroups per CU beat the 128x128 variants
+    if (tile == 129) return gemm_launch_t<128, 128, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri);
+    if (tile == 128) return gemm_launch_persist(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri);
     return gemm_launch_t<64, 64, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri);
 }

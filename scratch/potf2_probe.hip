@@ -1,21 +1,9 @@
-// potrf.hip -- leaf kernels of the blocked right-looking Cholesky for gfx950 (fp64).
-//
-// Replaces LAPACK dpotrf as reached by scipy.linalg.cholesky(K_tot, lower=True)
-// (ref: gptools/gaussian_process.py:1452).  The host-side blocking (outer block columns, recursive
-// panel, look-ahead on a second stream) lives in api.hip; this file holds
-//   potf2_diag_kernel  : one workgroup factors a 128x128 diagonal block entirely inside LDS,
-//                        16-column inner blocks; inner TRSM/SYRK on v_mfma_f64_16x16x4_f64; the
-//                        16x16 pivot blocks are factored by one wave with one matrix row per lane
-//                        and v_readlane broadcasts (no barriers inside a pivot block); also emits
-//                        the inverses of the 16x16 diagonal blocks of L ("invd").
-//   trsm_panel_kernel  : X * L_kk^T = B for the rows below a diagonal block; one wave per 16
-//                        rows, blocked forward substitution, every multiply on MFMA; the
-//                        accumulator -> operand re-layout goes through a private LDS strip.
-// MFMA f64 16x16x4 layouts (cdna_hip_programming.md section 3, verified by scratch/mfma_probe.hip):
-//   A operand: lane l holds A[i = l & 15][k = l >> 4];  B operand: lane l holds B[k = l >> 4][j = l & 15];
-//   C/D: lane l, register r holds D[row = (l >> 4) + 4 r][col = l & 15].
-#include "common.hpp"
-
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <cmath>
+#include "../gptools_amd/csrc/common.hpp"
+void gpt_set_error(const char*, ...) {}
 #define PD_NB 128
 #define PD_PITCH 130          // LDS row pitch (doubles): 16 rows x (lane>>4) fragment reads are conflict-free
 #define PD_TP 18              // pitch of the 16x16 inverse scratch
@@ -79,6 +67,7 @@ __device__ __forceinline__ void pivot_col(double (&a)[16], double (&x)[16], doub
 // Factor the 16x16 pivot block jb of S with one wave: lane (l & 15) keeps ROW l of the block in a[0..15] and, at
 // the same time, COLUMN l of inv(L_jj) in x[0..15]; both recurrences consume the same broadcast L[c][j], so the
 // inverse costs one extra FMA per broadcast.  Writes L_jj back to S, inv(L_jj) to T (LDS) and invd_out (global).
+__device__ long long *g_dbg2;
 __device__ __forceinline__ void pivot_block_16(double (*S)[PD_PITCH], double (*T)[PD_TP], int jb, int lane,
                                                double *invd_out, int32_t *info, int64_t info_col0)
 {
@@ -89,9 +78,9 @@ __device__ __forceinline__ void pivot_block_16(double (*S)[PD_PITCH], double (*T
         a[c] = S[jb * 16 + row][jb * 16 + c];
         x[c] = (c == row) ? 1.0 : 0.0;
     }
+    long long ta = __builtin_readcyclecounter();
     int bad = 0;
-    __builtin_amdgcn_sched_barrier(0);      // measured: letting hipcc mix the block loads / stores into the column
-    double d = bcast_lane(a[0], 0);         // chain costs ~35% of the pivot time
+    double d = bcast_lane(a[0], 0);
     pivot_col<0>(a, x, d, bad);
     pivot_col<1>(a, x, d, bad);
     pivot_col<2>(a, x, d, bad);
@@ -109,7 +98,7 @@ __device__ __forceinline__ void pivot_block_16(double (*S)[PD_PITCH], double (*T
     pivot_col<14>(a, x, d, bad);
     pivot_col<15>(a, x, d, bad);
     asm volatile("" : "+v"(a[15]), "+v"(x[15]));
-    __builtin_amdgcn_sched_barrier(0);
+    long long tb = __builtin_readcyclecounter();
     if (bad != 0 && lane == 0) atomicCAS(info, 0, (int32_t)(info_col0 + jb * 16 + bad));
     if (lane < 16) {
 #pragma unroll
@@ -119,6 +108,8 @@ __device__ __forceinline__ void pivot_block_16(double (*S)[PD_PITCH], double (*T
             invd_out[jb * 256 + c * 16 + row] = x[c];
         }
     }
+    long long tc = __builtin_readcyclecounter();
+    if (lane == 0) { g_dbg2[jb * 2] = tb - ta; g_dbg2[jb * 2 + 1] = tc - tb; }
 }
 
 #define PD_THREADS 512
@@ -126,7 +117,7 @@ __device__ __forceinline__ void pivot_block_16(double (*S)[PD_PITCH], double (*T
 
 __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restrict__ A, int64_t lda,
                                                                 double *__restrict__ invd, int32_t *info,
-                                                                int64_t info_col0)
+                                                                int64_t info_col0, long long *dbg)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double (*S)[PD_PITCH] = reinterpret_cast<double (*)[PD_PITCH]>(smem);
@@ -136,6 +127,8 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restri
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fk = lane >> 4;
 
+    for (int pass = 0; pass < 3; pass++) {
+    __syncthreads();
     {   // whole 128 x 128 block -> LDS, all 16 loads of a thread in flight together (one 1-KiB row per wave-instruction)
         constexpr int NLD = PD_NB * PD_NB / 2 / PD_THREADS;
         f64x2 v[NLD];
@@ -204,8 +197,12 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restri
             for (int r = 0; r < 4; r++) S[ti * 16 + fk + 4 * r][tj * 16 + fr] = acc[r];
             if (wave == 0) break;
         }
+        long long tq0 = __builtin_readcyclecounter();
         if (wave == 0) pivot_block_16(S, T, jb + 1, lane, invd, info, info_col0);
+        long long tq1 = __builtin_readcyclecounter();
+        if (tid == 0) dbg[pass * 8 + jb] = tq1 - tq0;
         __syncthreads();
+    }
     }
 
     {   // lower triangle back to global; pairs that straddle the diagonal keep the caller's upper entry
@@ -223,107 +220,24 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restri
     }
 }
 
-int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base)
-{
-    static bool attr_set = false;
+
+int main() {
+    const int n = 128; std::vector<double> A(n * n);
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) A[i * n + j] = (i == j ? n : 0) + 0.5 * cos(i * 0.37 + j * 0.11) * cos(j * 0.37 + i * 0.11);
+    double *dA, *dinv; int *dinfo; long long *ddbg;
+    hipMalloc(&dA, n * n * 8); hipMalloc(&dinv, 8 * 256 * 8); hipMalloc(&dinfo, 4); hipMalloc(&ddbg, 64 * 8);
+    hipMemset(dinfo, 0, 4);
+    long long *d2; hipMalloc(&d2, 64 * 8); hipMemcpyToSymbol(HIP_SYMBOL(g_dbg2), &d2, sizeof(d2));
     const size_t shmem = (size_t)(PD_NB * PD_PITCH + 16 * PD_TP) * sizeof(double);
-    if (!attr_set) {
-        GPT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(potf2_diag_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        attr_set = true;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(potf2_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    long long h[64];
+    for (int rep = 0; rep < 2; rep++) {
+        hipMemcpy(dA, A.data(), n * n * 8, hipMemcpyHostToDevice);
+        hipLaunchKernelGGL(potf2_diag_kernel, dim3(1), dim3(PD_THREADS), shmem, 0, dA, (int64_t)n, dinv, dinfo, (int64_t)0, ddbg);
+        hipDeviceSynchronize();
+        hipMemcpy(h, ddbg, sizeof(h), hipMemcpyDeviceToHost);
+        long long h2[16]; hipMemcpy(h2, d2, sizeof(h2), hipMemcpyDeviceToHost); printf("inner (columns, stores):"); for (int j = 0; j < 8; j++) printf(" (%lld,%lld)", h2[2*j], h2[2*j+1]); printf("\n");
+        for (int p = 0; p < 3; p++) { printf("launch %d pass %d pivot durations:", rep, p); for (int j = 0; j < 7; j++) printf(" %lld", h[p * 8 + j]); printf("\n"); }
     }
-    hipLaunchKernelGGL(potf2_diag_kernel, dim3(1), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base);
-    GPT_LAUNCH_CHECK();
-    return GPT_OK;
-}
-
-// ---- panel TRSM: B (m x 128) <- B * L^-T, L = 128x128 lower, invd = inverses of its 16x16 diagonal blocks ----
-// One wave per 16 rows, blocked forward substitution X_j = (B_j - sum_{c<j} X_c L_jc^T) inv(L_jj)^T with every
-// product on MFMA.  The 28 strictly-lower 16x16 blocks of L are packed once per workgroup into LDS in B-operand
-// lane order (a fragment read is 512 contiguous bytes); the B tiles, the inv(L_jj) fragments and the A-operand
-// form of the finished X_c blocks live in registers; the accumulator -> A-operand re-layout goes through a
-// 16x16 per-wave LDS scratch.
-#define TP_WAVES 4
-#define TP_SP 18
-__global__ __launch_bounds__(64 * TP_WAVES, 2) void trsm_panel_kernel(int64_t m, const double *__restrict__ L,
-                                                                      int64_t ldl, const double *__restrict__ invd,
-                                                                      double *__restrict__ B, int64_t ldb)
-{
-    __shared__ __attribute__((aligned(16))) double Lp[28][4][64];
-    __shared__ __attribute__((aligned(16))) double Sc[TP_WAVES][16][TP_SP];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 15, fk = lane >> 4;
-    constexpr int NB16 = PD_NB / 16;
-
-    // pack L's strictly-lower blocks: block (j, c), c < j, index j(j-1)/2 + c; element (jj, k) -> [k/4][jj + 16 (k%4)]
-    {
-        const int r = tid >> 4, cc = tid & 15;
-        double v[28];
-#pragma unroll
-        for (int j = 1; j < NB16; j++)
-#pragma unroll
-            for (int c = 0; c < j; c++) v[j * (j - 1) / 2 + c] = L[(int64_t)(j * 16 + r) * ldl + c * 16 + cc];
-#pragma unroll
-        for (int b = 0; b < 28; b++) Lp[b][cc >> 2][r + 16 * (cc & 3)] = v[b];
-    }
-    const int64_t row0 = ((int64_t)blockIdx.x * TP_WAVES + wave) * 16;
-    const bool active = row0 < m;
-    f64x4 bt[NB16];
-    double dv[NB16][4], xa[NB16][4];
-    if (active) {
-#pragma unroll
-        for (int j = 0; j < NB16; j++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) bt[j][r] = B[(row0 + fk + 4 * r) * ldb + j * 16 + fr];
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) dv[j][kk] = invd[j * 256 + fr * 16 + fk + 4 * kk];
-        }
-    }
-    __syncthreads();
-    if (!active) return;
-    double (*X)[TP_SP] = Sc[wave];
-#pragma unroll
-    for (int j = 0; j < NB16; j++) {
-        f64x4 acc = bt[j];
-#pragma unroll
-        for (int c = 0; c < j; c++) {
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[c][kk], Lp[j * (j - 1) / 2 + c][kk][lane], acc, 0, 0, 0);
-        }
-        // accumulator (C layout) -> A operand through the per-wave scratch
-#pragma unroll
-        for (int r = 0; r < 4; r++) X[fk + 4 * r][fr] = acc[r];
-        double av[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) av[kk] = X[fr][fk + 4 * kk];
-        f64x4 res = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) res = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], dv[j][kk], res, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            B[(row0 + fk + 4 * r) * ldb + j * 16 + fr] = res[r];
-            X[fk + 4 * r][fr] = res[r];
-        }
-        if (j + 1 < NB16) {
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) xa[j][kk] = -X[fr][fk + 4 * kk];
-        }
-    }
-}
-
-int launch_trsm_panel(hipStream_t st, int64_t m, const double *L, int64_t ldl, const double *invd, double *B,
-                      int64_t ldb)
-{
-    if (m <= 0) return GPT_OK;
-    if (m % 16) {
-        gpt_set_error("trsm_panel: m must be a multiple of 16 (m=%lld)", (long long)m);
-        return GPT_E_ARG;
-    }
-    const int64_t nwave = m / 16;
-    const unsigned grid = (unsigned)((nwave + TP_WAVES - 1) / TP_WAVES);
-    hipLaunchKernelGGL(trsm_panel_kernel, dim3(grid), dim3(64 * TP_WAVES), 0, st, m, L, ldl, invd, B, ldb);
-    GPT_LAUNCH_CHECK();
-    return GPT_OK;
+    return 0;
 }
