@@ -153,9 +153,13 @@ def main():
         ctx.set_option("profile_gemm", 0)
         if gcount:
             ach = gflops_alg / (gms * 1e-3) * 1e-12
-            roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<128,128> (trailing SYRK/GEMM update)",
+            traffic = None        # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+            tj = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")   # FETCH doubled per the gfx950 note), committed
+            if wl == "c3" and os.path.exists(tj):
+                traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+            roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<64,64> (trailing SYRK/GEMM updates >= 1 GFLOP)",
                     "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
-                    "traffic": None, "launches_per_step": gcount / args.steps,
+                    "traffic": traffic, "traffic_unit": "bytes/launch", "launches_per_step": gcount / args.steps,
                     "avg_launch_us": gms * 1e3 / gcount, "flops_per_launch": gflops_alg / gcount}
         extra["kbuild_ms"] = tk / args.steps
         extra["potrf_ms"] = tp / args.steps

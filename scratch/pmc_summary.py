@@ -1,0 +1,41 @@
+"""Summarise the rocprofv3 CSV outputs of scratch/prof_all.sh into profiles/ (per round)."""
+import csv, collections, re, sys, json
+src, out = sys.argv[1], sys.argv[2]
+def short(n): return re.sub(r'\(.*', '', n).replace('void ', '')
+lines = []
+# kernel stats
+rows = list(csv.DictReader(open(src + '/trace/t_kernel_stats.csv')))
+lines.append("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu   (C3: Matern52, N=8192, d=3)")
+lines.append("%-44s %7s %14s %12s %10s %10s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "%"))
+for r in rows:
+    lines.append("%-44s %7s %14s %12.0f %10s %10s %7s" % (short(r['Name'])[:44], r['Calls'], r['TotalDurationNs'], float(r['AverageNs']), r['MinNs'], r['MaxNs'], r['Percentage']))
+bench = [l for l in open(src + '/trace.log') if l.startswith('{')]
+if bench: lines.append("\n# bench.py line of the traced run:\n" + bench[-1].strip())
+def agg(path):
+    rows = list(csv.DictReader(open(path)))
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter(); seen = set()
+    for r in rows:
+        k = short(r['Kernel_Name']); acc[k][r['Counter_Name']] += float(r['Counter_Value'])
+        if (r['Dispatch_Id'], k) not in seen:
+            seen.add((r['Dispatch_Id'], k)); cnt[k] += 1
+            acc[k]['_dur_ns_' + path.split('/')[-2]] += float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+    return acc, cnt
+lines.append("\n# PMC passes (separate runs, rocprofv3 --kernel-trace --pmc <...> -- python3 bench.py --steps 2 --warmup 1 --no-cpu; 3 LML evaluations each)")
+res = {}
+for name in ('pmc_fetch', 'pmc_write', 'pmc_sq'):
+    acc, cnt = agg(src + '/' + name + '/t_counter_collection.csv')
+    for k in acc:
+        res.setdefault(k, {'dispatches': cnt[k]}).update(acc[k])
+for k, v in sorted(res.items(), key=lambda kv: -kv[1].get('SQ_BUSY_CYCLES', 0)):
+    d = v['dispatches']
+    s = "%-28s disp %4d" % (k[:28], d)
+    if 'FETCH_SIZE' in v: s += "  FETCH_SIZE %.4g KB (x2 gfx950 correction -> %.4g GB)" % (v['FETCH_SIZE'], 2 * v['FETCH_SIZE'] * 1024 / 1e9)
+    if 'WRITE_SIZE' in v: s += "  WRITE_SIZE %.4g KB (%.4g GB)" % (v['WRITE_SIZE'], v['WRITE_SIZE'] * 1024 / 1e9)
+    if v.get('_dur_ns_pmc_sq') and 'SQ_VALU_MFMA_BUSY_CYCLES' in v:
+        s += "  MFMA-busy %.1f%% (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x 2.4 GHz x kernel time in that pass))" % (
+            100 * v['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * 2.4 * v['_dur_ns_pmc_sq']))
+    if v.get('SQ_LDS_IDX_ACTIVE'): s += "  LDS conflict cycles %.1f%%" % (100 * v.get('SQ_LDS_BANK_CONFLICT', 0) / v['SQ_LDS_IDX_ACTIVE'])
+    if 'SQ_INSTS_VALU_MFMA_MOPS_F64' in v: s += "  MFMA f64 flops %.4g" % (v['SQ_INSTS_VALU_MFMA_MOPS_F64'] * 512)
+    lines.append(s)
+open(out, 'w').write("\n".join(lines) + "\n")
+print("\n".join(lines))
