@@ -55,6 +55,7 @@ struct gpt_ctx {
     int use_graph = 0;
     int timing = 0;
     int tile = 0;
+    int gemm_pad = 1024;
     // resident training inputs
     int64_t N = 0;
     int D = 0;
@@ -63,7 +64,7 @@ struct gpt_ctx {
     // factorisation state
     int64_t NP = 0;            // padded order (multiple of 128, > N)
     double *dA = nullptr;      // NP x NP, row-major, lower triangle meaningful
-    double *d_invd = nullptr;  // (NP/16) x 16 x 16
+    double *d_invd = nullptr;  // (NP/128) x GPT_WS_BLOCK packed workspace (see common.hpp)
     int32_t *d_info = nullptr;
     double *d_y = nullptr, *d_erry = nullptr, *d_scal = nullptr, *d_alpha = nullptr;
     double *h_scal = nullptr;  // pinned
@@ -197,7 +198,9 @@ static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, 
         gp->flops = flops;
         GPT_HIP_CHECK(hipEventRecord(gp->e0, st));
     }
-    int rc = launch_gemm_nt(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, c->tile);
+    // trailing updates on the main stream leave room on every CU for the panel stream (see gemm.hip)
+    const int lds_pad = (st == c->stream && c->lookahead) ? c->gemm_pad : 0;
+    int rc = launch_gemm_nt(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, c->tile, lds_pad);
     if (prof) GPT_HIP_CHECK(hipEventRecord(gp->e1, st));
     return rc;
 }
@@ -213,7 +216,7 @@ static int panel_rec(gpt_ctx *c, hipStream_t st, double *Ap, int64_t lda, int64_
     const int64_t h = (w / 256) * 128 > 0 ? (w / 256) * 128 : 128;
     GPT_TRY(panel_rec(c, st, Ap, lda, m, h, invd, info, base));
     GPT_TRY(gemm_nt(c, st, m - h, w - h, h, -1.0, Ap + h * lda, lda, Ap + h * lda, lda, 1.0, Ap + h * lda + h, lda, 1));
-    return panel_rec(c, st, Ap + h * lda + h, lda, m - h, w - h, invd + (h / 16) * 256, info, base + h);
+    return panel_rec(c, st, Ap + h * lda + h, lda, m - h, w - h, invd + (h / 128) * GPT_WS_BLOCK, info, base + h);
 }
 
 static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *invd, int32_t *info)
@@ -229,7 +232,7 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
     if (!la) {
         for (int64_t k = 0; k < nblk; k++) {
             const int64_t c0 = k * nbo, w = (n - c0 < nbo) ? n - c0 : nbo, m = n - c0;
-            GPT_TRY(panel_rec(c, S, A + c0 * lda + c0, lda, m, w, invd + (c0 / 16) * 256, info, c0));
+            GPT_TRY(panel_rec(c, S, A + c0 * lda + c0, lda, m, w, invd + (c0 / 128) * GPT_WS_BLOCK, info, c0));
             const int64_t r0 = c0 + w;
             if (r0 < n)
                 GPT_TRY(gemm_nt(c, S, n - r0, n - r0, w, -1.0, A + r0 * lda + c0, lda, A + r0 * lda + c0, lda, 1.0,
@@ -267,7 +270,7 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
                             A + r0 * lda + r0, lda, 1));
         hipEvent_t e_upd = get_event(c, 2 + 2 * k + 1);
         GPT_HIP_CHECK(hipEventRecord(e_upd, S));
-        GPT_TRY(panel_rec(c, P, A + n0 * lda + n0, lda, n - n0, w1, invd + (n0 / 16) * 256, info, n0));
+        GPT_TRY(panel_rec(c, P, A + n0 * lda + n0, lda, n - n0, w1, invd + (n0 / 128) * GPT_WS_BLOCK, info, n0));
         e_panel = get_event(c, 2 + 2 * (k + 1));
         GPT_HIP_CHECK(hipEventRecord(e_panel, P));
     }
@@ -311,7 +314,7 @@ static int trsm_rlt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, const doub
     const int64_t h = (n / 256) * 128 > 0 ? (n / 256) * 128 : 128;
     GPT_TRY(trsm_rlt(c, st, m, h, L, ldl, invd, B, ldb));
     GPT_TRY(gemm_nt(c, st, m, n - h, h, -1.0, B, ldb, L + h * ldl, ldl, 1.0, B + h, ldb, 0));
-    return trsm_rlt(c, st, m, n - h, L + h * ldl + h, ldl, invd + (h / 16) * 256, B + h, ldb);
+    return trsm_rlt(c, st, m, n - h, L + h * ldl + h, ldl, invd + (h / 128) * GPT_WS_BLOCK, B + h, ldb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -414,6 +417,7 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "graph")) c->use_graph = value ? 1 : 0;
     else if (!strcmp(key, "timing")) c->timing = value ? 1 : 0;
     else if (!strcmp(key, "profile_gemm")) c->prof_gemm = value ? 1 : 0;
+    else if (!strcmp(key, "gemm_pad")) c->gemm_pad = (int)value;
     else if (!strcmp(key, "tile")) {
         if (value != 0 && value != 64 && value != 128 && value != 129) {
             gpt_set_error("tile must be 0, 64 or 128");
@@ -553,7 +557,7 @@ static int ensure_factor_storage(gpt_ctx *c, int64_t N)
     GPT_HIP_CHECK(hipStreamSynchronize(c->stream));
     free_factor(c);
     GPT_HIP_CHECK(hipMalloc(&c->dA, (size_t)NP * NP * sizeof(double)));
-    GPT_HIP_CHECK(hipMalloc(&c->d_invd, (size_t)(NP / 16) * 256 * sizeof(double)));
+    GPT_HIP_CHECK(hipMalloc(&c->d_invd, (size_t)(NP / 128) * GPT_WS_BLOCK * sizeof(double)));
     GPT_HIP_CHECK(hipMalloc(&c->d_y, (size_t)NP * sizeof(double)));
     GPT_HIP_CHECK(hipMalloc(&c->d_erry, (size_t)NP * sizeof(double)));
     GPT_HIP_CHECK(hipMalloc(&c->d_alpha, (size_t)NP * sizeof(double)));

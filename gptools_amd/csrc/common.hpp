@@ -9,6 +9,13 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 #define GPT_WAVE 64
+// Per 128-column diagonal block the factorisation leaves a packed workspace ("ws") of GPT_WS_BLOCK doubles:
+//   [0, 2048)     inverses of the eight 16x16 diagonal blocks of L_kk,
+//   [2048, 9216)  the 28 strictly-lower 16x16 blocks of L_kk (block (j, c), c < j, at index j(j-1)/2 + c),
+// every 16x16 block stored in MFMA B-operand lane order: element (r, c) at [c / 4][r + 16 * (c % 4)], so that a
+// fragment is 512 contiguous bytes for the panel TRSM.
+#define GPT_WS_BLOCK 9216
+#define GPT_WS_LOFF 2048
 
 void gpt_set_error(const char *fmt, ...);
 
@@ -51,7 +58,7 @@ int launch_kbuild(hipStream_t st, const KParams &kp, const double *dXi, const in
                   const double *d_err_y, double noise_var, double diag_add, double *dK, int64_t ldk);
 int launch_check_orders(hipStream_t st, const int32_t *dn, int64_t M, int D, int32_t *d_flag);
 int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A, int64_t lda,
-                   const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile);
+                   const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile, int lds_pad);
 int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base);
 int launch_trsm_panel(hipStream_t st, int64_t m, const double *L, int64_t ldl, const double *invd,
                       double *B, int64_t ldb);

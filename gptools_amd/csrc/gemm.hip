@@ -24,6 +24,7 @@
 #include "common.hpp"
 
 #define GM_BK 16
+#define GPT_TRY_RC(expr) do { int rc_ = (expr); if (rc_ != GPT_OK) return rc_; } while (0)
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -137,15 +138,24 @@ template <int BM, int BN, int WPS>
 __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     int64_t m, int64_t n, int64_t k, double alpha, const double *__restrict__ A, int64_t lda,
     const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
-    int tri, int64_t ntm, int64_t ntn, int64_t nwg)
+    int tri, int64_t ntm, int64_t ntn, int64_t nwg, const int2 *__restrict__ order)
 {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int RM = WM / 16, RN = WN / 16;
     __shared__ __attribute__((aligned(16))) double sA[2][BM * GM_BK];
     __shared__ __attribute__((aligned(16))) double sB[2][BN * GM_BK];
 
+    // tile of this workgroup: from the host-built, XCD-aware order table (see tile_order()) or, without one, the
+    // closed-form enumeration
     int64_t ti, tj;
-    tile_decode(xcd_remap(blockIdx.x, nwg), tri, ntn, &ti, &tj);
+    if (order != nullptr) {
+        const int2 t = order[blockIdx.x];
+        if (t.x < 0) return;
+        ti = t.x;
+        tj = t.y;
+    } else {
+        tile_decode(xcd_remap(blockIdx.x, nwg), tri, ntn, &ti, &tj);
+    }
     const int64_t row0 = ti * BM, col0 = tj * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -320,17 +330,91 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_persist_kernel(
 #undef GP_LOADC
 }
 
+// ---- XCD-aware tile order ------------------------------------------------------------------------------------
+// Workgroup b runs on XCD b % 8 and the workgroups of one XCD start in the order of b / 8.  The table gives XCD x
+// the supertiles x, x+8, x+16, ... of the (lower part of the) tile grid, a supertile being an SG x SG square of
+// tiles walked row by row: the ~100 workgroups resident on an XCD at any time then share SG A-panels and SG
+// B-panels through that XCD's L2 instead of each streaming its own B panel (measured before: 337 MB of HBM/MALL
+// traffic per launch against ~130 MB algorithmic).  Tables are built once per (ntm, ntn, tri) and cached on the
+// device; slots past an XCD's list hold (-1, -1).
+#include <mutex>
+#include <vector>
+struct TileOrder {
+    int64_t ntm, ntn;
+    int tri, dev;
+    int2 *d_tab;
+    int64_t grid;
+};
+static std::vector<TileOrder> g_orders;
+static std::mutex g_orders_mu;
+
+static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64_t *grid)
+{
+    constexpr int SG = 8;
+    int dev = 0;
+    GPT_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_orders_mu);
+    for (const auto &o : g_orders)
+        if (o.ntm == ntm && o.ntn == ntn && o.tri == tri && o.dev == dev) {
+            *tab = o.d_tab;
+            *grid = o.grid;
+            return GPT_OK;
+        }
+    std::vector<std::vector<int2>> per(8);
+    const int64_t sm = (ntm + SG - 1) / SG, sn = (ntn + SG - 1) / SG;
+    int64_t sidx = 0;
+    for (int64_t si = 0; si < sm; si++)
+        for (int64_t sj = 0; sj < sn; sj++) {
+            if (tri && sj > si) continue;
+            std::vector<int2> &dst = per[sidx % 8];
+            bool any = false;
+            for (int64_t i = si * SG; i < (si + 1) * SG && i < ntm; i++)
+                for (int64_t j = sj * SG; j < (sj + 1) * SG && j < ntn; j++) {
+                    if (tri && j > i) continue;
+                    dst.push_back(make_int2((int)i, (int)j));
+                    any = true;
+                }
+            if (any) sidx++;
+        }
+    size_t mx = 0;
+    for (auto &v : per) mx = v.size() > mx ? v.size() : mx;
+    std::vector<int2> flat(mx * 8, make_int2(-1, -1));
+    for (int x = 0; x < 8; x++)
+        for (size_t l = 0; l < per[x].size(); l++) flat[l * 8 + x] = per[x][l];
+    TileOrder o;
+    o.ntm = ntm;
+    o.ntn = ntn;
+    o.tri = tri;
+    o.dev = dev;
+    o.grid = (int64_t)flat.size();
+    o.d_tab = nullptr;
+    GPT_HIP_CHECK(hipMalloc(&o.d_tab, flat.size() * sizeof(int2)));
+    GPT_HIP_CHECK(hipMemcpy(o.d_tab, flat.data(), flat.size() * sizeof(int2), hipMemcpyHostToDevice));
+    g_orders.push_back(o);
+    *tab = o.d_tab;
+    *grid = o.grid;
+    return GPT_OK;
+}
+
 template <int BM, int BN, int WPS>
 static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A,
-                         int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri)
+                         int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri,
+                         int lds_pad)
 {
     const int64_t ntm = (m + BM - 1) / BM, ntn = (n + BN - 1) / BN;
-    const int64_t nwg = tri ? ntn * (ntn + 1) / 2 + (ntm - ntn) * ntn : ntm * ntn;
-    // 1 KiB of unused dynamic LDS caps the 64x64 kernel (32 KiB static) at four workgroups per CU, which keeps
-    // 28 KiB of LDS and a quarter of the register file free on every CU for the high-priority panel stream.
-    const size_t dyn = (BM == 64) ? 1024 : 0;
+    int64_t nwg = tri ? ntn * (ntn + 1) / 2 + (ntm - ntn) * ntn : ntm * ntn;
+    const int2 *order = nullptr;
+    if (nwg >= 512) {                      // large launches only: small ones live in L2 anyway
+        int64_t grid = 0;
+        GPT_TRY_RC(tile_order(ntm, ntn, tri, &order, &grid));
+        nwg = grid;
+    }
+    // lds_pad bytes of unused dynamic LDS cap the residency of the 64x64 kernel (32 KiB static): the trailing
+    // update on the main stream asks for 8 KiB -> three workgroups per CU, leaving 40 KiB of LDS and over 40 % of the
+    // register file on every CU to the high-priority panel stream (whose own GEMMs and TRSMs need 32 / 9 KiB).
+    const size_t dyn = (BM == 64) ? (size_t)lds_pad : 0;
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS>), dim3((unsigned)nwg), dim3(256), dyn, st, m, n, k, alpha, A,
-                       lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg);
+                       lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
@@ -355,7 +439,7 @@ static int gemm_launch_persist(hipStream_t st, int64_t m, int64_t n, int64_t k, 
 }
 
 int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A, int64_t lda,
-                   const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile)
+                   const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile, int lds_pad)
 {
     if (m <= 0 || n <= 0) return GPT_OK;
     if (alpha == 0.0) {
@@ -376,7 +460,7 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
     }
     int tile = force_tile;
     if (tile == 0) tile = 64;   // measured on MI355X: 64x64 tiles at 4-5 workgroups per CU beat the 128x128 variants
-    if (tile == 129) return gemm_launch_t<128, 128, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri);
+    if (tile == 129) return gemm_launch_t<128, 128, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0);
     if (tile == 128) return gemm_launch_persist(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri);
-    return gemm_launch_t<64, 64, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri);
+    return gemm_launch_t<64, 64, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, lds_pad);
 }

@@ -31,49 +31,59 @@ __device__ __forceinline__ double bcast_lane(double v, int srclane)
 // the same size as the Cholesky's own.  The pivot chain of the factorisation is instruction-issue bound on a single
 // wave, so the IEEE sqrt + divide sequences (~60 instructions) are replaced by 5; the diagonal entry sqrt(d) is
 // simply d * (1/sqrt(d)).  Checked against scipy/LAPACK factors in tests/test_gpu_parity.py.
-__device__ __forceinline__ double rsqrt_nr(double d)
-{
-    const double y0 = __builtin_amdgcn_rsq(d);
-    const double t = d * y0, h = 0.5 * y0;
-    const double u = fma(-t, y0, 1.0);
-    return fma(h, u, y0);
-}
-
-template <int J>
-struct PivotUpd {
-    template <int C>
-    static __device__ __forceinline__ void run(double (&a)[16], double (&x)[16])
+// The five steps are kept separate (struct RsqPipe) so that pivot_col can issue them one at a time BETWEEN the
+// broadcast/FMA groups of the previous column: the wave issues in order, and a dependent chain placed in one piece
+// would stall it for its whole latency.
+struct RsqPipe {
+    double d, y0, t, h, u, inv;
+    __device__ __forceinline__ void step(int k)
     {
-        const double l = bcast_lane(a[J], C);            // L[c][j], wave-uniform (SGPR pair)
-        a[C] = fma(-a[J], l, a[C]);
-        x[C] = fma(-l, x[J], x[C]);
-        // keep each {2 x v_readlane, 2 x v_fma} group together: left alone, hipcc hoists all 15 broadcasts of a column
-        // ahead of the FMAs, runs out of SGPRs and spills every multiplier with v_writelane/s_nop, which doubles
-        // the instruction count of this issue-bound chain.
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (C + 1 < 16) run<C + 1>(a, x);
+        if (k == 0) y0 = __builtin_amdgcn_rsq(d);
+        else if (k == 1) { t = d * y0; h = 0.5 * y0; }
+        else if (k == 2) u = fma(-t, y0, 1.0);
+        else if (k == 3) inv = fma(h, u, y0);
     }
 };
 
-// One column of the pivot block.  d is the (wave-uniform) pivot; the NEXT pivot is formed in the uniform domain as
-// a[j+1][j+1] - (a[j+1][j] * inv)^2 from two scalar broadcasts that do not wait for this column's updates, so the
-// rsqrt of column j+1 overlaps the rank-1 update of column j.
-template <int J>
-__device__ __forceinline__ void pivot_col(double (&a)[16], double (&x)[16], double &d, int &bad)
+// One column J of the pivot block; on entry rp.inv = 1/sqrt(pivot J).  The NEXT pivot is formed in the uniform
+// domain as a[J+1][J+1] - l^2 with l = L[J+1][J] (two scalar broadcasts), and its rsqrt pipeline is advanced one
+// step per broadcast/FMA group of this column.  Each group {2 x v_readlane, 2 x v_fma} is fenced with
+// sched_barrier: left alone, hipcc hoists all broadcasts of a column ahead of the FMAs, runs out of SGPRs and
+// spills every multiplier with v_writelane/s_nop, which doubled the instruction count of this issue-bound chain.
+template <int J, int C>
+__device__ __forceinline__ void pivot_group(double (&a)[16], double (&x)[16], RsqPipe &np)
 {
-    if (!(d > 0.0)) {                                     // not positive definite (LAPACK info = j + 1)
-        if (bad == 0) bad = J + 1;
-        d = 1.0;
+    if constexpr (C < 16) {
+        const double l = bcast_lane(a[J], C);            // L[c][j], wave-uniform (SGPR pair)
+        a[C] = fma(-a[J], l, a[C]);
+        x[C] = fma(-l, x[J], x[C]);
+        np.step(C - J - 1);                                // C = J+1 carries step 0 (v_rsq), ... J+4 the last
+        __builtin_amdgcn_sched_barrier(0);
+        pivot_group<J, C + 1>(a, x, np);
     }
-    const double inv = rsqrt_nr(d);
-    if constexpr (J + 1 < 16) {
-        const double p = bcast_lane(a[J], J + 1), q = bcast_lane(a[J + 1], J + 1);
-        const double pl = p * inv;
-        d = fma(-pl, pl, q);
-    }
+}
+
+template <int J>
+__device__ __forceinline__ void pivot_col(double (&a)[16], double (&x)[16], RsqPipe &rp, int &bad)
+{
+    const double inv = rp.inv;
     a[J] *= inv;                                          // lane J: d * inv = sqrt(d)
     x[J] *= inv;
-    if constexpr (J + 1 < 16) PivotUpd<J>::template run<J + 1>(a, x);
+    if constexpr (J + 1 < 16) {
+        RsqPipe np;
+        const double l = bcast_lane(a[J], J + 1), q = bcast_lane(a[J + 1], J + 1);
+        double dn = fma(-l, l, q);
+        if (!(dn > 0.0)) {                                // not positive definite (LAPACK info = j + 2)
+            if (bad == 0) bad = J + 2;
+            dn = 1.0;
+        }
+        np.d = dn;
+        __builtin_amdgcn_sched_barrier(0);
+        pivot_group<J, J + 1>(a, x, np);
+#pragma unroll
+        for (int k = 15 - J; k < 4; k++) np.step(k);      // columns with fewer than four groups finish the pipeline here
+        rp = np;
+    }
 }
 
 // Factor the 16x16 pivot block jb of S with one wave: lane (l & 15) keeps ROW l of the block in a[0..15] and, at
@@ -91,23 +101,32 @@ __device__ __forceinline__ void pivot_block_16(double (*S)[PD_PITCH], double (*T
     }
     int bad = 0;
     __builtin_amdgcn_sched_barrier(0);      // measured: letting hipcc mix the block loads / stores into the column
-    double d = bcast_lane(a[0], 0);         // chain costs ~35% of the pivot time
-    pivot_col<0>(a, x, d, bad);
-    pivot_col<1>(a, x, d, bad);
-    pivot_col<2>(a, x, d, bad);
-    pivot_col<3>(a, x, d, bad);
-    pivot_col<4>(a, x, d, bad);
-    pivot_col<5>(a, x, d, bad);
-    pivot_col<6>(a, x, d, bad);
-    pivot_col<7>(a, x, d, bad);
-    pivot_col<8>(a, x, d, bad);
-    pivot_col<9>(a, x, d, bad);
-    pivot_col<10>(a, x, d, bad);
-    pivot_col<11>(a, x, d, bad);
-    pivot_col<12>(a, x, d, bad);
-    pivot_col<13>(a, x, d, bad);
-    pivot_col<14>(a, x, d, bad);
-    pivot_col<15>(a, x, d, bad);
+    RsqPipe rp;                             // chain costs ~35% of the pivot time
+    rp.d = bcast_lane(a[0], 0);
+    if (!(rp.d > 0.0)) {
+        bad = 1;
+        rp.d = 1.0;
+    }
+    rp.step(0);
+    rp.step(1);
+    rp.step(2);
+    rp.step(3);
+    pivot_col<0>(a, x, rp, bad);
+    pivot_col<1>(a, x, rp, bad);
+    pivot_col<2>(a, x, rp, bad);
+    pivot_col<3>(a, x, rp, bad);
+    pivot_col<4>(a, x, rp, bad);
+    pivot_col<5>(a, x, rp, bad);
+    pivot_col<6>(a, x, rp, bad);
+    pivot_col<7>(a, x, rp, bad);
+    pivot_col<8>(a, x, rp, bad);
+    pivot_col<9>(a, x, rp, bad);
+    pivot_col<10>(a, x, rp, bad);
+    pivot_col<11>(a, x, rp, bad);
+    pivot_col<12>(a, x, rp, bad);
+    pivot_col<13>(a, x, rp, bad);
+    pivot_col<14>(a, x, rp, bad);
+    pivot_col<15>(a, x, rp, bad);
     asm volatile("" : "+v"(a[15]), "+v"(x[15]));
     __builtin_amdgcn_sched_barrier(0);
     if (bad != 0 && lane == 0) atomicCAS(info, 0, (int32_t)(info_col0 + jb * 16 + bad));
@@ -116,7 +135,7 @@ __device__ __forceinline__ void pivot_block_16(double (*S)[PD_PITCH], double (*T
         for (int c = 0; c < 16; c++) {
             if (c <= row) S[jb * 16 + row][jb * 16 + c] = a[c];
             T[c][row] = x[c];
-            invd_out[jb * 256 + c * 16 + row] = x[c];
+            invd_out[jb * 256 + (row >> 2) * 64 + c + 16 * (row & 3)] = x[c];     // packed element (c, row)
         }
     }
 }
@@ -208,6 +227,19 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restri
         __syncthreads();
     }
 
+    {   // the 28 strictly-lower 16x16 blocks of L in B-operand lane order for the panel TRSM (coalesced stores)
+        double *lp = invd + GPT_WS_LOFF;
+#pragma unroll
+        for (int q = 0; q < 28 * 256 / PD_THREADS; q++) {
+            const int idx = tid + q * PD_THREADS;
+            const int b = idx >> 8, kk = (idx >> 6) & 3, l = idx & 63;
+            int j = (int)((sqrtf(8.0f * (float)b + 1.0f) + 1.0f) * 0.5f);
+            while (j * (j - 1) / 2 > b) j--;
+            while ((j + 1) * j / 2 <= b) j++;
+            const int c = b - j * (j - 1) / 2;
+            lp[idx] = S[j * 16 + (l & 15)][c * 16 + (l >> 4) + 4 * kk];
+        }
+    }
     {   // lower triangle back to global; pairs that straddle the diagonal keep the caller's upper entry
         constexpr int NLD = PD_NB * PD_NB / 2 / PD_THREADS;
 #pragma unroll
@@ -237,12 +269,14 @@ int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int3
     return GPT_OK;
 }
 
-// ---- panel TRSM: B (m x 128) <- B * L^-T, L = 128x128 lower, invd = inverses of its 16x16 diagonal blocks ----
+// ---- panel TRSM: B (m x 128) <- B * L^-T, L = 128x128 lower, invd = the block's packed workspace (common.hpp) ----
 // One wave per 16 rows, blocked forward substitution X_j = (B_j - sum_{c<j} X_c L_jc^T) inv(L_jj)^T with every
-// product on MFMA.  The 28 strictly-lower 16x16 blocks of L are packed once per workgroup into LDS in B-operand
-// lane order (a fragment read is 512 contiguous bytes); the B tiles, the inv(L_jj) fragments and the A-operand
-// form of the finished X_c blocks live in registers; the accumulator -> A-operand re-layout goes through a
-// 16x16 per-wave LDS scratch.
+// product on MFMA.  The 28 strictly-lower 16x16 blocks of L arrive already packed in B-operand lane order (written
+// by potf2_diag_kernel) and are copied once per workgroup into LDS with coalesced 16-byte loads (a fragment read is
+// 512 contiguous bytes); the B tiles, the packed inv(L_jj) fragments and the A-operand form of the finished X_c
+// blocks live in registers; the accumulator -> A-operand re-layout goes through a 16x16 per-wave LDS scratch.
+// (A variant that streams the L fragments from global memory needs only 9 KB of LDS but measured 12.6 us against
+// 10.8 us for this one, and did not improve the overlap with a concurrent trailing update.)
 #define TP_WAVES 4
 #define TP_SP 18
 __global__ __launch_bounds__(64 * TP_WAVES, 2) void trsm_panel_kernel(int64_t m, const double *__restrict__ L,
@@ -255,18 +289,15 @@ __global__ __launch_bounds__(64 * TP_WAVES, 2) void trsm_panel_kernel(int64_t m,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fk = lane >> 4;
     constexpr int NB16 = PD_NB / 16;
+    (void)L;
+    (void)ldl;
 
-    // pack L's strictly-lower blocks: block (j, c), c < j, index j(j-1)/2 + c; element (jj, k) -> [k/4][jj + 16 (k%4)]
-    {
-        const int r = tid >> 4, cc = tid & 15;
-        double v[28];
+    // Prologue: all loads are issued before the first wait.
+    const double *lpk = invd + GPT_WS_LOFF;
+    constexpr int NPK = 28 * 256 / 2 / (64 * TP_WAVES);      // 16-byte chunks per thread
+    f64x2 v[NPK];
 #pragma unroll
-        for (int j = 1; j < NB16; j++)
-#pragma unroll
-            for (int c = 0; c < j; c++) v[j * (j - 1) / 2 + c] = L[(int64_t)(j * 16 + r) * ldl + c * 16 + cc];
-#pragma unroll
-        for (int b = 0; b < 28; b++) Lp[b][cc >> 2][r + 16 * (cc & 3)] = v[b];
-    }
+    for (int q = 0; q < NPK; q++) v[q] = *reinterpret_cast<const f64x2 *>(lpk + 2 * (tid + q * 64 * TP_WAVES));
     const int64_t row0 = ((int64_t)blockIdx.x * TP_WAVES + wave) * 16;
     const bool active = row0 < m;
     f64x4 bt[NB16];
@@ -277,8 +308,13 @@ __global__ __launch_bounds__(64 * TP_WAVES, 2) void trsm_panel_kernel(int64_t m,
 #pragma unroll
             for (int r = 0; r < 4; r++) bt[j][r] = B[(row0 + fk + 4 * r) * ldb + j * 16 + fr];
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) dv[j][kk] = invd[j * 256 + fr * 16 + fk + 4 * kk];
+            for (int kk = 0; kk < 4; kk++) dv[j][kk] = invd[j * 256 + kk * 64 + lane];
         }
+    }
+    {
+        double *lflat = &Lp[0][0][0];
+#pragma unroll
+        for (int q = 0; q < NPK; q++) *reinterpret_cast<f64x2 *>(lflat + 2 * (tid + q * 64 * TP_WAVES)) = v[q];
     }
     __syncthreads();
     if (!active) return;

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64) void trsv_lt_diag_kernel(const double *__restri
         const int r = idx >> 7, c = idx & 127;
         S[r][c] = Lbb[(int64_t)r * ldl + c];
     }
-    for (int i = lane; i < 128; i += 64) rdiag[i] = invd[(i >> 4) * 256 + (i & 15) * 17];
+    for (int i = lane; i < 128; i += 64) rdiag[i] = invd[(i >> 4) * 256 + ((i & 15) >> 2) * 64 + (i & 15) + 16 * (i & 3)];   // packed (r, r) of block i/16
     double w0 = x[lane], w1 = x[lane + 64];
     __syncthreads();
     for (int j = 127; j >= 0; j--) {
@@ -196,7 +196,7 @@ int launch_trsv_lt(hipStream_t st, int64_t n, const double *L, int64_t ldl, cons
     }
     for (int64_t b = n / 128 - 1; b >= 0; b--) {
         const double *Lbb = L + (b * 128) * ldl + b * 128;
-        hipLaunchKernelGGL(trsv_lt_diag_kernel, dim3(1), dim3(64), shmem, st, Lbb, ldl, invd + (b * 8) * 256, x + b * 128);
+        hipLaunchKernelGGL(trsv_lt_diag_kernel, dim3(1), dim3(64), shmem, st, Lbb, ldl, invd + b * GPT_WS_BLOCK, x + b * 128);
         if (b > 0) {
             const int64_t ncols = b * 128;
             hipLaunchKernelGGL(trsv_lt_update_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, st, ncols,

@@ -113,7 +113,7 @@ class DistributedLML(object):
         self.n = torch.from_numpy(n).to(dev)
         self.A = torch.empty((self.NP, max(self.nloc, 1) * nb), dtype=torch.float64, device=dev)
         self.P = [torch.empty((self.NP, nb), dtype=torch.float64, device=dev) for _ in range(2)]
-        self.invd = torch.empty(((nb // 16) * 256,), dtype=torch.float64, device=dev)
+        self.invd = torch.empty(((nb // 128) * 9216,), dtype=torch.float64, device=dev)     # GPT_WS_BLOCK per 128 columns
         self.info = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.y = torch.empty((self.NP,), dtype=torch.float64, device=dev)
         self.err = torch.zeros((self.NP,), dtype=torch.float64, device=dev)

@@ -47,6 +47,7 @@ extern "C" {
 #define GPT_KERNEL_ZERO 3
 
 #define GPT_MAX_DIM 16      /* largest supported num_dim */
+#define GPT_WS_BLOCK 9216    /* doubles of factorisation workspace per 128 columns (d_invd arguments) */
 
 typedef struct gpt_ctx gpt_ctx;
 
@@ -180,14 +181,15 @@ int gpt_dev_gemm_nt(gpt_ctx *ctx, int64_t m, int64_t n, int64_t k, double alpha,
 
 /* Factor one block column ("panel"): A is (m x nb), its top nb x nb block is the diagonal block.
  * On exit the top block holds L_kk (lower) and the rows below hold A21 * L_kk^-T.  d_invd:
- * workspace/outputs, (nb/16) blocks of 16x16 doubles = inverses of L's 16x16 diagonal blocks.
+ * workspace/output of GPT_WS_BLOCK (= 9216) doubles per 128 columns: the inverses of L's 16x16 diagonal
+ * blocks and L's strictly-lower 16x16 blocks, packed in MFMA operand order for the panel TRSM.
  * d_info: int32 on device, set to info_base + j + 1 at the first non-positive pivot (never
  * cleared here). */
 int gpt_dev_potrf_panel(gpt_ctx *ctx, int64_t m, int64_t nb, double *dA, int64_t lda,
                         double *d_invd, int32_t *d_info, int64_t info_base);
 
 /* Whole lower Cholesky of the n x n matrix dA in place (blocked right-looking, look-ahead).
- * d_invd: (n/16)*256 doubles. */
+ * d_invd: (n/128)*GPT_WS_BLOCK doubles. */
 int gpt_dev_potrf(gpt_ctx *ctx, int64_t n, double *dA, int64_t lda, double *d_invd, int32_t *d_info);
 
 /* B (m x n) <- B * L^-T with L (n x n) lower, d_invd from the factorisation of L. */
