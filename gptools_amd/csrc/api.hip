@@ -419,7 +419,7 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "profile_gemm")) c->prof_gemm = value ? 1 : 0;
     else if (!strcmp(key, "gemm_pad")) c->gemm_pad = (int)value;
     else if (!strcmp(key, "tile")) {
-        if (value != 0 && value != 64 && value != 128 && value != 129) {
+        if (value != 0 && value != 64 && value != 65 && value != 128 && value != 129) {
             gpt_set_error("tile must be 0, 64 or 128");
             return GPT_E_ARG;
         }

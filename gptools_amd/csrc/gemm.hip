@@ -134,7 +134,7 @@ __device__ __forceinline__ void mma_ktile(const double *tA, const double *tB, in
 // ------------------------------------------------------------------------------------------------
 // One output tile per workgroup (used with 64x64 tiles for small / latency-bound updates).
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WPS>
+template <int BM, int BN, int WPS, int NSTAGE>
 __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     int64_t m, int64_t n, int64_t k, double alpha, const double *__restrict__ A, int64_t lda,
     const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
@@ -142,8 +142,11 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
 {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int RM = WM / 16, RN = WN / 16;
-    __shared__ __attribute__((aligned(16))) double sA[2][BM * GM_BK];
-    __shared__ __attribute__((aligned(16))) double sB[2][BN * GM_BK];
+    // NSTAGE LDS buffers per operand: 2 for the large launches (four workgroups per CU hide the DMA latency for each
+    // other), 4 for the small, latency-bound launches of the panel (one workgroup per CU: the DMA of k-tile t+3 is
+    // in flight while k-tile t is multiplied, drained with a COUNTED s_waitcnt vmcnt).
+    __shared__ __attribute__((aligned(16))) double sA[NSTAGE][BM * GM_BK];
+    __shared__ __attribute__((aligned(16))) double sB[NSTAGE][BN * GM_BK];
 
     // tile of this workgroup: from the host-built, XCD-aware order table (see tile_order()) or, without one, the
     // closed-form enumeration
@@ -167,8 +170,15 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     stage_ptrs<BN>(B, ldb, col0, n, wave, lane, srcB);
     const unsigned ldsA = lds_addr(&sA[0][0]), ldsB = lds_addr(&sB[0][0]);
     constexpr unsigned ABYTES = BM * GM_BK * sizeof(double), BBYTES = BN * GM_BK * sizeof(double);
-    stage_issue<BM>(srcA, 0, ldsA, wave);
-    stage_issue<BN>(srcB, 0, ldsB, wave);
+    const int64_t nk = k / GM_BK;
+    constexpr int PRE = NSTAGE - 1;                         // k-tiles requested ahead of the one being multiplied
+    constexpr int PERSTAGE = BM / 32 + BN / 32;             // DMA instructions per wave per k-tile
+#pragma unroll
+    for (int t = 0; t < PRE; t++)
+        if (t < nk) {
+            stage_issue<BM>(srcA, (int64_t)t * GM_BK, ldsA + t * ABYTES, wave);
+            stage_issue<BN>(srcB, (int64_t)t * GM_BK, ldsB + t * BBYTES, wave);
+        }
 
     f64x4 acc[RM][RN];
     const double cs = (beta != 0.0) ? beta / alpha : 0.0;
@@ -183,18 +193,23 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
                 acc[i][j][r] = (beta != 0.0 && row < m && col < n) ? cs * C[row * ldc + col] : 0.0;
             }
         }
-    dma_wait();
+    // k-tile 0 must have landed (the C loads above are older than nothing newer than the DMAs -> full drain is
+    // correct here; in the loop the wait is counted)
+    if (NSTAGE == 2 || nk < PRE) dma_wait();
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PRE - 1) * PERSTAGE) : "memory");
     __syncthreads();
 
-    const int64_t nk = k / GM_BK;
     for (int64_t kt = 0; kt < nk; kt++) {
-        const int cur = (int)(kt & 1);
-        if (kt + 1 < nk) {
-            stage_issue<BM>(srcA, (kt + 1) * GM_BK, ldsA + (cur ^ 1) * ABYTES, wave);
-            stage_issue<BN>(srcB, (kt + 1) * GM_BK, ldsB + (cur ^ 1) * BBYTES, wave);
+        const int cur = (int)(kt % NSTAGE);
+        if (kt + PRE < nk) {
+            const int nxt = (int)((kt + PRE) % NSTAGE);
+            stage_issue<BM>(srcA, (kt + PRE) * GM_BK, ldsA + nxt * ABYTES, wave);
+            stage_issue<BN>(srcB, (kt + PRE) * GM_BK, ldsB + nxt * BBYTES, wave);
         }
         mma_ktile<RM, RN>(sA[cur], sB[cur], wm * WM, wn * WN, fr, fk, acc);
-        dma_wait();
+        // k-tile kt+1 must be complete before the barrier; up to PRE-1 younger k-tiles may stay in flight
+        if (NSTAGE == 2 || kt + PRE >= nk) dma_wait();
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PRE - 1) * PERSTAGE) : "memory");
         __syncthreads();
     }
 
@@ -396,7 +411,7 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
     return GPT_OK;
 }
 
-template <int BM, int BN, int WPS>
+template <int BM, int BN, int WPS, int NSTAGE>
 static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A,
                          int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri,
                          int lds_pad)
@@ -413,8 +428,8 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
     // update on the main stream asks for 8 KiB -> three workgroups per CU, leaving 40 KiB of LDS and over 40 % of the
     // register file on every CU to the high-priority panel stream (whose own GEMMs and TRSMs need 32 / 9 KiB).
     const size_t dyn = (BM == 64) ? (size_t)lds_pad : 0;
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS>), dim3((unsigned)nwg), dim3(256), dyn, st, m, n, k, alpha, A,
-                       lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg), dim3(256), dyn, st, m, n, k, alpha,
+                       A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
@@ -460,7 +475,11 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
     }
     int tile = force_tile;
     if (tile == 0) tile = 64;   // measured on MI355X: 64x64 tiles at 4-5 workgroups per CU beat the 128x128 variants
-    if (tile == 129) return gemm_launch_t<128, 128, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0);
+    if (tile == 129) return gemm_launch_t<128, 128, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0);
     if (tile == 128) return gemm_launch_persist(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri);
-    return gemm_launch_t<64, 64, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, lds_pad);
+    // A 4-stage variant (gemm_launch_t<64, 64, 1, 4>, DMA three k-tiles ahead, counted vmcnt) was measured on the
+    // small panel updates (8064x128x128: 12 us either way): they are bound by launch + prologue latency, not by the
+    // DMA wait, so everything uses the 2-stage kernel.
+    if (force_tile == 65) return gemm_launch_t<64, 64, 1, 4>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0);
+    return gemm_launch_t<64, 64, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, lds_pad);
 }

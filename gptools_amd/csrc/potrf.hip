@@ -88,15 +88,18 @@ __device__ __forceinline__ void pivot_col(double (&a)[16], double (&x)[16], RsqP
 
 // Factor the 16x16 pivot block jb of S with one wave: lane (l & 15) keeps ROW l of the block in a[0..15] and, at
 // the same time, COLUMN l of inv(L_jj) in x[0..15]; both recurrences consume the same broadcast L[c][j], so the
-// inverse costs one extra FMA per broadcast.  Writes L_jj back to S, inv(L_jj) to T (LDS) and invd_out (global).
+// inverse costs one extra FMA per broadcast.  Writes L_jj back to S and inv(L_jj) to T (LDS; one buffer per pivot
+// block, copied to the global workspace by the storing wave).  FROM_GLOBAL: the rows come straight from global
+// memory (first block: the pivot starts while the other waves are still staging the 128x128 block into LDS).
+template <bool FROM_GLOBAL>
 __device__ __forceinline__ void pivot_block_16(double (*S)[PD_PITCH], double (*T)[PD_TP], int jb, int lane,
-                                               double *invd_out, int32_t *info, int64_t info_col0)
+                                               const double *Ag, int64_t lda, int32_t *info, int64_t info_col0)
 {
     const int row = lane & 15;
     double a[16], x[16];
 #pragma unroll
     for (int c = 0; c < 16; c++) {
-        a[c] = S[jb * 16 + row][jb * 16 + c];
+        a[c] = FROM_GLOBAL ? Ag[(int64_t)row * lda + c] : S[jb * 16 + row][jb * 16 + c];
         x[c] = (c == row) ? 1.0 : 0.0;
     }
     int bad = 0;
@@ -135,7 +138,6 @@ __device__ __forceinline__ void pivot_block_16(double (*S)[PD_PITCH], double (*T
         for (int c = 0; c < 16; c++) {
             if (c <= row) S[jb * 16 + row][jb * 16 + c] = a[c];
             T[c][row] = x[c];
-            invd_out[jb * 256 + (row >> 2) * 64 + c + 16 * (row & 3)] = x[c];     // packed element (c, row)
         }
     }
 }
@@ -149,35 +151,38 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restri
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double (*S)[PD_PITCH] = reinterpret_cast<double (*)[PD_PITCH]>(smem);
-    double (*T)[PD_TP] = reinterpret_cast<double (*)[PD_TP]>(smem + PD_NB * PD_PITCH);
+    typedef double TBuf[16][PD_TP];
+    TBuf *T = reinterpret_cast<TBuf *>(smem + PD_NB * PD_PITCH);      // T[jb]: inv(L_jb,jb), one buffer per pivot block
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fk = lane >> 4;
+    constexpr int NB16 = PD_NB / 16;
 
-    {   // whole 128 x 128 block -> LDS, all 16 loads of a thread in flight together (one 1-KiB row per wave-instruction)
-        constexpr int NLD = PD_NB * PD_NB / 2 / PD_THREADS;
-        f64x2 v[NLD];
+    // ---- stage the block into LDS (waves 1..7) while wave 0 already factors the first pivot block from global ----
+    if (wave == 0) {
+        pivot_block_16<true>(S, T[0], 0, lane, A, lda, info, info_col0);
+    } else {
+        constexpr int NCH = PD_NB * PD_NB / 2;                  // 16-byte chunks
+        constexpr int PER = (NCH + (PD_THREADS - 64) - 1) / (PD_THREADS - 64);
+        f64x2 v[PER];
 #pragma unroll
-        for (int q = 0; q < NLD; q++) {
-            const int idx = tid + q * PD_THREADS;
+        for (int q = 0; q < PER; q++) {
+            const int idx = (tid - 64) + q * (PD_THREADS - 64);
             const int r = idx / (PD_NB / 2), c2 = (idx % (PD_NB / 2)) * 2;
-            v[q] = *reinterpret_cast<const f64x2 *>(A + (int64_t)r * lda + c2);
+            if (idx < NCH) v[q] = *reinterpret_cast<const f64x2 *>(A + (int64_t)r * lda + c2);
         }
 #pragma unroll
-        for (int q = 0; q < NLD; q++) {
-            const int idx = tid + q * PD_THREADS;
+        for (int q = 0; q < PER; q++) {
+            const int idx = (tid - 64) + q * (PD_THREADS - 64);
             const int r = idx / (PD_NB / 2), c2 = (idx % (PD_NB / 2)) * 2;
-            *reinterpret_cast<f64x2 *>(&S[r][c2]) = v[q];
+            if (idx < NCH && !(r < 16 && c2 < 16)) *reinterpret_cast<f64x2 *>(&S[r][c2]) = v[q];   // tile (0,0) is wave 0's
         }
     }
     __syncthreads();
-    if (wave == 0) pivot_block_16(S, T, 0, lane, invd, info, info_col0);
-    __syncthreads();
 
-    constexpr int NB16 = PD_NB / 16;
     for (int jb = 0; jb < NB16; jb++) {
-        // (b) strip solve: X_ti = B_ti * inv(L_jj)^T for the 16-row tiles below the pivot block
+        // (b) strip solve: X_ti = B_ti * inv(L_jj)^T for the 16-row tiles below the pivot block (waves 0..6)
         {
             const int ti = jb + 1 + wave;
             if (ti < NB16) {
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restri
 #pragma unroll
                 for (int kk = 0; kk < 4; kk++) {
                     av[kk] = S[ti * 16 + fr][jb * 16 + fk + 4 * kk];
-                    bv[kk] = T[fr][fk + 4 * kk];
+                    bv[kk] = T[jb][fr][fk + 4 * kk];
                 }
 #pragma unroll
                 for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
@@ -195,70 +200,57 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restri
             }
         }
         __syncthreads();
-        if (jb + 1 >= NB16) break;
-        // (c) trailing update inside the block: S_titj -= X_ti X_tj^T, jb < tj <= ti.
-        //     Wave 0 takes the next pivot tile first and factors it while the other waves do the rest.
-        const int rem = NB16 - 1 - jb;
-        const int ntile = rem * (rem + 1) / 2;
-        const int first = (wave == 0) ? 0 : wave;
-        const int step = (wave == 0) ? ntile : (PD_WAVES - 1);
-        for (int t = first; t < ntile; t += step) {
-            int a_ = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-            while (a_ * (a_ + 1) / 2 > t) a_--;
-            while ((a_ + 1) * (a_ + 2) / 2 <= t) a_++;
-            const int b_ = t - a_ * (a_ + 1) / 2;
-            const int ti = jb + 1 + a_, tj = jb + 1 + b_;
-            f64x4 acc;
-#pragma unroll
-            for (int r = 0; r < 4; r++) acc[r] = S[ti * 16 + fk + 4 * r][tj * 16 + fr];
-            double av[4], bv[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                av[kk] = -S[ti * 16 + fr][jb * 16 + fk + 4 * kk];
-                bv[kk] = S[tj * 16 + fr][jb * 16 + fk + 4 * kk];
+        // (c) wave 0: next pivot tile update + pivot; waves 1..6: the other trailing tiles; wave 7: column block jb of L
+        //     (now final) goes to global memory, row-major and packed, together with inv(L_jj).
+        if (wave == PD_WAVES - 1) {
+            for (int r4 = jb * 16 + fk; r4 < PD_NB; r4 += 4) {                  // rows jb*16.., 16 columns each
+                const int c = jb * 16 + fr;
+                if (c <= r4) A[(int64_t)r4 * lda + c] = S[r4][c];
             }
+            double *ip = invd + jb * 256, *lp = invd + GPT_WS_LOFF;
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
+            for (int kk = 0; kk < 4; kk++) ip[kk * 64 + lane] = T[jb][fr][fk + 4 * kk];     // packed element (fr, fk + 4kk)
+            for (int j = jb + 1; j < NB16; j++) {                               // packed blocks (j, jb)
+                const int b = j * (j - 1) / 2 + jb;
 #pragma unroll
-            for (int r = 0; r < 4; r++) S[ti * 16 + fk + 4 * r][tj * 16 + fr] = acc[r];
-            if (wave == 0) break;
+                for (int kk = 0; kk < 4; kk++) lp[b * 256 + kk * 64 + lane] = S[j * 16 + fr][jb * 16 + fk + 4 * kk];
+            }
+        } else if (jb + 1 < NB16) {
+            const int rem = NB16 - 1 - jb;
+            const int ntile = rem * (rem + 1) / 2;
+            const int first = (wave == 0) ? 0 : wave;
+            const int step = (wave == 0) ? ntile : (PD_WAVES - 2);
+            for (int t = first; t < ntile; t += step) {
+                int a_ = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                while (a_ * (a_ + 1) / 2 > t) a_--;
+                while ((a_ + 1) * (a_ + 2) / 2 <= t) a_++;
+                const int b_ = t - a_ * (a_ + 1) / 2;
+                const int ti = jb + 1 + a_, tj = jb + 1 + b_;
+                f64x4 acc;
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[r] = S[ti * 16 + fk + 4 * r][tj * 16 + fr];
+                double av[4], bv[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    av[kk] = -S[ti * 16 + fr][jb * 16 + fk + 4 * kk];
+                    bv[kk] = S[tj * 16 + fr][jb * 16 + fk + 4 * kk];
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) S[ti * 16 + fk + 4 * r][tj * 16 + fr] = acc[r];
+                if (wave == 0) break;
+            }
+            if (wave == 0) pivot_block_16<false>(S, T[jb + 1], jb + 1, lane, nullptr, 0, info, info_col0);
         }
-        if (wave == 0) pivot_block_16(S, T, jb + 1, lane, invd, info, info_col0);
         __syncthreads();
-    }
-
-    {   // the 28 strictly-lower 16x16 blocks of L in B-operand lane order for the panel TRSM (coalesced stores)
-        double *lp = invd + GPT_WS_LOFF;
-#pragma unroll
-        for (int q = 0; q < 28 * 256 / PD_THREADS; q++) {
-            const int idx = tid + q * PD_THREADS;
-            const int b = idx >> 8, kk = (idx >> 6) & 3, l = idx & 63;
-            int j = (int)((sqrtf(8.0f * (float)b + 1.0f) + 1.0f) * 0.5f);
-            while (j * (j - 1) / 2 > b) j--;
-            while ((j + 1) * j / 2 <= b) j++;
-            const int c = b - j * (j - 1) / 2;
-            lp[idx] = S[j * 16 + (l & 15)][c * 16 + (l >> 4) + 4 * kk];
-        }
-    }
-    {   // lower triangle back to global; pairs that straddle the diagonal keep the caller's upper entry
-        constexpr int NLD = PD_NB * PD_NB / 2 / PD_THREADS;
-#pragma unroll
-        for (int q = 0; q < NLD; q++) {
-            const int idx = tid + q * PD_THREADS;
-            const int r = idx / (PD_NB / 2), c2 = (idx % (PD_NB / 2)) * 2;
-            if (c2 + 1 <= r) {
-                *reinterpret_cast<f64x2 *>(A + (int64_t)r * lda + c2) = *reinterpret_cast<const f64x2 *>(&S[r][c2]);
-            } else if (c2 == r) {
-                A[(int64_t)r * lda + c2] = S[r][c2];
-            }
-        }
     }
 }
 
 int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base)
 {
     static bool attr_set = false;
-    const size_t shmem = (size_t)(PD_NB * PD_PITCH + 16 * PD_TP) * sizeof(double);
+    const size_t shmem = (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
     if (!attr_set) {
         GPT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(potf2_diag_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
