@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--nb", type=int, default=0, help="outer block width (0 = default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--dist", action="store_true", help="use the block-cyclic DistributedLML path even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -126,7 +127,7 @@ def main():
 
     roof = None
     extra = {}
-    if world == 1:
+    if world == 1 and not args.dist:
         ctx = _lib.Context(local_rank)
         if args.nb:
             ctx.set_option("nb_outer", args.nb)
@@ -179,9 +180,10 @@ def main():
             ll, ld = step()
         barrier()
         elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
         parallelism = "1-D block-cyclic block columns (nb=%d) over %d ranks, RCCL panel broadcast" % (plan.nb, world)
 
     if rank == 0:
@@ -202,7 +204,7 @@ def main():
         out.update(extra)
         if roof is not None:
             out["roofline"] = roof
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and not args.dist:
             ref, cb = cpu_baseline(kernel, X, n, y, err, params)
             out["cpu_baseline"] = cb
             out["parity"] = {"ll_rel_err_vs_cpu": abs(ll - ref["ll_data"]) / abs(ref["ll_data"]),

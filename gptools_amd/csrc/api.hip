@@ -56,6 +56,7 @@ struct gpt_ctx {
     int timing = 0;
     int tile = 0;
     int gemm_pad = 1024;
+    hipEvent_t panel_hook = nullptr;   // awaited by the panel stream after the first 128-leaf of a block column
     // resident training inputs
     int64_t N = 0;
     int D = 0;
@@ -211,7 +212,12 @@ static int panel_rec(gpt_ctx *c, hipStream_t st, double *Ap, int64_t lda, int64_
 {
     if (w == 128) {
         GPT_TRY(launch_potf2_diag(st, Ap, lda, invd, info, base));
-        return launch_trsm_panel(st, m - 128, Ap, lda, invd, Ap + 128 * lda, lda);
+        GPT_TRY(launch_trsm_panel(st, m - 128, Ap, lda, invd, Ap + 128 * lda, lda));
+        if (c->panel_hook) {            // the other columns of this block column are brought up to date elsewhere
+            GPT_HIP_CHECK(hipStreamWaitEvent(st, c->panel_hook, 0));
+            c->panel_hook = nullptr;
+        }
+        return GPT_OK;
     }
     const int64_t h = (w / 256) * 128 > 0 ? (w / 256) * 128 : 128;
     GPT_TRY(panel_rec(c, st, Ap, lda, m, h, invd, info, base));
@@ -256,22 +262,32 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
         const int64_t n0 = c0 + w;                                   // first column of block k+1
         const int64_t w1 = (n - n0 < nbo) ? n - n0 : nbo;
         const int64_t r0 = n0 + w1;                                   // first column after block k+1
-        // P: bring block column k+1 up to date with panel k, then factor it
-        if (k > 0) {
-            hipEvent_t e_upd_prev = get_event(c, 2 + 2 * (k - 1) + 1);
-            GPT_HIP_CHECK(hipStreamWaitEvent(P, e_upd_prev, 0));
-        }
-        GPT_TRY(gemm_nt(c, P, n - n0, w1, w, -1.0, A + n0 * lda + c0, lda, A + n0 * lda + c0, lda, 1.0,
+        const int64_t wf = (w1 < 128) ? w1 : 128;                     // columns the panel needs before its first leaf
+        // P: only the first 128 columns of block column k+1 are brought up to date on the critical path ...
+        if (k > 0) GPT_HIP_CHECK(hipStreamWaitEvent(P, get_event(c, 3 + 3 * (k - 1)), 0));
+        GPT_TRY(gemm_nt(c, P, n - n0, wf, w, -1.0, A + n0 * lda + c0, lda, A + n0 * lda + c0, lda, 1.0,
                         A + n0 * lda + n0, lda, 1));
-        // S: apply panel k to everything right of block k+1
+        // ... S does its other columns (while P factors the first diagonal block), then everything to the right
         GPT_HIP_CHECK(hipStreamWaitEvent(S, e_panel, 0));
+        c->panel_hook = nullptr;
+        if (w1 > wf) {
+            const int64_t n1 = n0 + wf;
+            GPT_TRY(gemm_nt(c, S, n - n1, w1 - wf, w, -1.0, A + n1 * lda + c0, lda, A + n1 * lda + c0, lda, 1.0,
+                            A + n1 * lda + n1, lda, 1));
+            hipEvent_t e_cu = get_event(c, 4 + 3 * k);
+            GPT_HIP_CHECK(hipEventRecord(e_cu, S));
+            c->panel_hook = e_cu;
+        }
         if (r0 < n)
             GPT_TRY(gemm_nt(c, S, n - r0, n - r0, w, -1.0, A + r0 * lda + c0, lda, A + r0 * lda + c0, lda, 1.0,
                             A + r0 * lda + r0, lda, 1));
-        hipEvent_t e_upd = get_event(c, 2 + 2 * k + 1);
-        GPT_HIP_CHECK(hipEventRecord(e_upd, S));
+        GPT_HIP_CHECK(hipEventRecord(get_event(c, 3 + 3 * k), S));
         GPT_TRY(panel_rec(c, P, A + n0 * lda + n0, lda, n - n0, w1, invd + (n0 / 128) * GPT_WS_BLOCK, info, n0));
-        e_panel = get_event(c, 2 + 2 * (k + 1));
+        if (c->panel_hook) {                                          // (block column of a single leaf: nothing waited)
+            GPT_HIP_CHECK(hipStreamWaitEvent(P, c->panel_hook, 0));
+            c->panel_hook = nullptr;
+        }
+        e_panel = get_event(c, 2 + 3 * (k + 1));
         GPT_HIP_CHECK(hipEventRecord(e_panel, P));
     }
     GPT_HIP_CHECK(hipStreamWaitEvent(S, e_panel, 0));

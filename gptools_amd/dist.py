@@ -99,7 +99,11 @@ class DistributedLML(object):
             ops = HipPanelOps(0 if device is None else device)
         self.ops = ops
         self.device = getattr(ops, "device", torch.device("cpu"))
-        self.lookahead = bool(lookahead) and self.world > 1
+        # GPT_DIST_FORCE_COLLECTIVES=1 issues the (self-)broadcasts and all-reduces even with a single rank, so the
+        # RCCL call pattern can be exercised on a 1-GPU box (tests/test_gpu_parity.py).
+        import os
+        self.force_collectives = bool(int(os.environ.get("GPT_DIST_FORCE_COLLECTIVES", "0"))) and dist.is_initialized()
+        self.lookahead = bool(lookahead) and (self.world > 1 or self.force_collectives)
         X = np.ascontiguousarray(X, dtype=np.float64)
         n = np.ascontiguousarray(n, dtype=np.int32)
         self.N, self.D = X.shape
@@ -141,7 +145,7 @@ class DistributedLML(object):
                     A[N, lj * nb + (N - c0)] = BIG_PIVOT
 
     def _bcast(self, buf, src, async_op=False):
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return None
         gsrc = dist.get_global_rank(self.group, src) if self.group is not None else src
         return dist.broadcast(buf, src=gsrc, group=self.group, async_op=async_op)
@@ -219,7 +223,7 @@ class DistributedLML(object):
             z = self.A[N, lj * nb: lj * nb + (c1 - c0)]
             red[1] += (z * z).sum()
         red[2] = self.info.to(torch.float64)[0]
-        if world > 1:
+        if world > 1 or self.force_collectives:
             # info: non-zero on the owner of the failing panel only; max picks it up
             info_t = red[2:3].clone()
             dist.all_reduce(red[:2], op=dist.ReduceOp.SUM, group=self.group)

@@ -475,3 +475,34 @@ def test_distributed_plan_on_one_gpu(ctx, oracle):
         assert abs(ld - ref["logdet_half"]) <= 1e-10 * abs(ref["logdet_half"]), nb
         ll2, _ = plan.fit(1, p, y, err)
         assert ll2 == ll
+
+
+def test_distributed_plan_rccl_single_rank(oracle):
+    """The RCCL call pattern of gptools_amd.dist (async panel broadcasts on the ops stream, scalar all-reduces)
+    on the one GPU that is available: a 1-rank nccl process group with the collectives forced on."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, numpy as np, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29517', GPT_DIST_FORCE_COLLECTIVES='1')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "from gptools_amd.dist import DistributedLML\n"
+        "from test_gpu_parity import c3_inputs\n"
+        "X, n, y = c3_inputs(1500, 3)\n"
+        "plan = DistributedLML(X, n, nb=256, device=0)\n"
+        "assert plan.force_collectives and plan.lookahead\n"
+        "print('RESULT', *plan.fit(1, np.array([1.0, 0.3, 0.3, 0.3]), y, 0.05 * np.ones(1500)))\n"
+        "print('RESULT2', *plan.fit(1, np.array([1.0, 0.3, 0.3, 0.3]), y, 0.05 * np.ones(1500)))\n"
+        "dist.destroy_process_group()\n" % ((os.path.dirname(os.path.dirname(os.path.abspath(__file__))),) * 2))
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    vals = [l.split()[1:] for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    X, n, y = c3_inputs(1500, 3)
+    ref = oracle.fit("m52", np.array([1.0, 0.3, 0.3, 0.3]), X, n, y, 0.05 * np.ones(1500), chol="scipy")
+    for v in vals:
+        assert abs(float(v[0]) - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"])
+        assert abs(float(v[1]) - ref["logdet_half"]) <= 1e-10 * abs(ref["logdet_half"])
+    assert len(vals) == 2
