@@ -82,6 +82,12 @@ def load():
                 raise GPTBackendError(
                     "%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                     "(gptools_amd has no CPU fallback)" % LIB_PATH)
+            try:
+                # torch wheels bundle their own libamdhip64; it has to be the first HIP runtime in the process,
+                # otherwise torch.cuda (streams, RCCL in gptools_amd.dist) stays unavailable afterwards
+                import torch  # noqa: F401
+            except ImportError:
+                pass
             lib = C.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)          # AttributeError if the export is missing

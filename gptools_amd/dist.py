@@ -150,24 +150,44 @@ class DistributedLML(object):
         gsrc = dist.get_global_rank(self.group, src) if self.group is not None else src
         return dist.broadcast(buf, src=gsrc, group=self.group, async_op=async_op)
 
-    def _factor_panel(self, k, buf):
-        """Owner side: copy block column k into the contiguous panel buffer, factor it there, write L back."""
-        nb, A = self.nb, self.A
+    def _stage_panel(self, k, buf):
+        """Owner side: copy block column k (every update before panel k-1 applied) into the contiguous panel
+        buffer.  Issued *before* waiting for panel k-1 so the strided copy is off the critical chain."""
+        nb = self.nb
         lk = k // self.world
-        m = self.NP - k * nb
-        view = A[k * nb:, lk * nb:(lk + 1) * nb]
-        buf[:m].copy_(view)
-        self.ops.potrf_panel(m, nb, buf.data_ptr(), nb, self.invd, self.info, k * nb)
-        view.copy_(buf[:m])
+        buf[:self.NP - k * nb].copy_(self.A[k * nb:, lk * nb:(lk + 1) * nb])
 
-    def _update_block(self, k, J, buf):
-        """A[J*nb:, block J] -= P_k[rows of J..] * P_k[rows of block J]^T  (lower trapezoid)."""
+    def _factor_staged(self, k, buf):
+        """Owner side: factor the staged panel in place in the broadcast buffer.  L is never copied back: the
+        local matrix is only a work area, the scalars the LML needs are accumulated here from the panel."""
+        nb, N = self.nb, self.N
+        m = self.NP - k * nb
+        self.ops.potrf_panel(m, nb, buf.data_ptr(), nb, self.invd, self.info, k * nb)
+        self._factored.append((k, buf))
+
+    def _accumulate_scalars(self):
+        """sum(log L_ii) over i < N and z.z (augmented row N) from the panels this rank factored since the
+        last call; runs after the broadcast of the panel has been enqueued."""
+        nb, N = self.nb, self.N
+        for k, buf in self._factored:
+            w = min(nb, N - k * nb)
+            if w <= 0:
+                continue
+            self.red[0] += torch.log(torch.diagonal(buf[:w, :w])).sum()
+            z = buf[N - k * nb, :w]
+            self.red[1] += (z * z).sum()
+        self._factored = []
+
+    def _update_block(self, k, J, buf, C=None, ldc=None):
+        """A[J*nb:, block J] -= P_k[rows of J..] * P_k[rows of block J]^T  (lower trapezoid); with ``C`` given the
+        target is a staged panel buffer instead of the local matrix."""
         nb, A = self.nb, self.A
         lj = J // self.world
         mJ = self.NP - J * nb
         off = (J - k) * nb
-        self.ops.gemm_nt(mJ, nb, nb, -1.0, _ptr(buf, off, 0), nb, _ptr(buf, off, 0), nb, 1.0,
-                         _ptr(A, J * nb, lj * nb), A.stride(0), 1)
+        if C is None:
+            C, ldc = _ptr(A, J * nb, lj * nb), A.stride(0)
+        self.ops.gemm_nt(mJ, nb, nb, -1.0, _ptr(buf, off, 0), nb, _ptr(buf, off, 0), nb, 1.0, C, ldc, 1)
 
     def fit(self, kernel_id, params, y, err_y, noise_var=0.0, diag_factor=1e2):
         import contextlib
@@ -185,43 +205,42 @@ class DistributedLML(object):
         self._assemble(kernel_id, params, noise_var, diag_factor * sys.float_info.epsilon)
 
         nblk = self.nblk
+        self.red = red = torch.zeros((3,), dtype=torch.float64, device=self.device)
+        self._factored = []
         pending = None
         if rank == 0 % world:
-            self._factor_panel(0, self.P[0])
+            self._stage_panel(0, self.P[0])
+            self._factor_staged(0, self.P[0])
         pending = self._bcast(self.P[0][:NP], 0, async_op=True)
+        self._accumulate_scalars()
         for k in range(nblk):
             buf = self.P[k % 2]
+            nxt = k + 1
+            nbuf = self.P[nxt % 2]
+            own_next = nxt < nblk and nxt % world == rank
+            if own_next and self.lookahead:
+                self._stage_panel(nxt, nbuf)          # before the wait: overlaps the tail of broadcast k
             if pending is not None:
                 pending.wait()
                 pending = None
-            nxt = k + 1
             mine = [J for J in self.my_blocks if J > k]
-            if nxt < nblk:
-                own_next = (nxt % world == rank)
-                nbuf = self.P[nxt % 2]
-                if self.lookahead:
-                    if own_next:
-                        self._update_block(k, nxt, buf)
-                        self._factor_panel(nxt, nbuf)
-                        mine = [J for J in mine if J != nxt]
-                    pending = self._bcast(nbuf[:NP - nxt * nb], nxt % world, async_op=True)
+            if nxt < nblk and self.lookahead:
+                if own_next:
+                    self._update_block(k, nxt, buf, nbuf.data_ptr(), nb)
+                    self._factor_staged(nxt, nbuf)
+                    mine = [J for J in mine if J != nxt]
+                pending = self._bcast(nbuf[:NP - nxt * nb], nxt % world, async_op=True)
+                self._accumulate_scalars()
             for J in mine:
                 self._update_block(k, J, buf)
             if nxt < nblk and not self.lookahead:
-                if nxt % world == rank:
-                    self._factor_panel(nxt, self.P[nxt % 2])
-                pending = self._bcast(self.P[nxt % 2][:NP - nxt * nb], nxt % world, async_op=True)
+                if own_next:
+                    self._stage_panel(nxt, nbuf)
+                    self._factor_staged(nxt, nbuf)
+                pending = self._bcast(nbuf[:NP - nxt * nb], nxt % world, async_op=True)
+                self._accumulate_scalars()
 
         # ---- scalars: sum(log L_ii) over i < N, z.z from the augmented row, info ----
-        red = torch.zeros((3,), dtype=torch.float64, device=self.device)
-        for lj, J in enumerate(self.my_blocks):
-            c0, c1 = J * nb, min((J + 1) * nb, N)
-            if c0 >= N:
-                continue
-            blk = self.A[c0:c1, lj * nb: lj * nb + (c1 - c0)]
-            red[0] += torch.log(torch.diagonal(blk)).sum()
-            z = self.A[N, lj * nb: lj * nb + (c1 - c0)]
-            red[1] += (z * z).sum()
         red[2] = self.info.to(torch.float64)[0]
         if world > 1 or self.force_collectives:
             # info: non-zero on the owner of the failing panel only; max picks it up
