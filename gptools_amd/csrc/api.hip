@@ -56,7 +56,7 @@ struct gpt_ctx {
     int timing = 0;
     int tile = 0;
     int gemm_pad = 1024;
-    hipEvent_t panel_hook = nullptr;   // awaited by the panel stream after the first 128-leaf of a block column
+    hipEvent_t head_event = nullptr;   // set by gpt_fit: the first nb_outer+128 columns of K_tot are built (panel 0 may start)
     // resident training inputs
     int64_t N = 0;
     int D = 0;
@@ -212,17 +212,39 @@ static int panel_rec(gpt_ctx *c, hipStream_t st, double *Ap, int64_t lda, int64_
 {
     if (w == 128) {
         GPT_TRY(launch_potf2_diag(st, Ap, lda, invd, info, base));
-        GPT_TRY(launch_trsm_panel(st, m - 128, Ap, lda, invd, Ap + 128 * lda, lda));
-        if (c->panel_hook) {            // the other columns of this block column are brought up to date elsewhere
-            GPT_HIP_CHECK(hipStreamWaitEvent(st, c->panel_hook, 0));
-            c->panel_hook = nullptr;
-        }
-        return GPT_OK;
+        return launch_trsm_panel(st, m - 128, Ap, lda, invd, Ap + 128 * lda, lda);
     }
     const int64_t h = (w / 256) * 128 > 0 ? (w / 256) * 128 : 128;
     GPT_TRY(panel_rec(c, st, Ap, lda, m, h, invd, info, base));
     GPT_TRY(gemm_nt(c, st, m - h, w - h, h, -1.0, Ap + h * lda, lda, Ap + h * lda, lda, 1.0, Ap + h * lda + h, lda, 1));
     return panel_rec(c, st, Ap + h * lda + h, lda, m - h, w - h, invd + (h / 128) * GPT_WS_BLOCK, info, base + h);
+}
+
+// Look-ahead panel: block column [c0, c0+w) of the n x n matrix, right-looking in 128-column leaves.  Every leaf's
+// rank-128 update also reaches the GPT_PANEL_EXT columns that follow the block column, so when the panel is done the
+// first leaf of the NEXT block column is already up to date with respect to this one and its pivot chain can start
+// without waiting for anybody.  `wait_ev` (the other stream's update of the columns this panel reads beyond its first
+// leaf) is waited for before the first update; `done_ev` is recorded once L of the block column is final.
+#define GPT_PANEL_EXT 128
+static int panel_ext(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64_t n, int64_t c0, int64_t w,
+                     double *invd, int32_t *info, hipEvent_t wait_ev, hipEvent_t done_ev)
+{
+    const int64_t cend = (c0 + w + GPT_PANEL_EXT < n) ? c0 + w + GPT_PANEL_EXT : n;
+    for (int64_t lc = c0; lc < c0 + w; lc += 128) {
+        double *Ad = A + lc * lda + lc;
+        double *ws = invd + (lc / 128) * GPT_WS_BLOCK;
+        const int64_t r1 = lc + 128;
+        GPT_TRY(launch_potf2_diag(st, Ad, lda, ws, info, lc));
+        const bool last = (r1 == c0 + w) && done_ev;
+        // (a stop event on the launch is not recorded by stream capture: under a graph use a plain record)
+        GPT_TRY(launch_trsm_panel(st, n - r1, Ad, lda, ws, Ad + 128 * lda, lda, (last && !c->use_graph) ? done_ev : nullptr));
+        if (last && c->use_graph) GPT_HIP_CHECK(hipEventRecord(done_ev, st));
+        if (lc == c0 && wait_ev) GPT_HIP_CHECK(hipStreamWaitEvent(st, wait_ev, 0));
+        if (cend > r1)
+            GPT_TRY(gemm_nt(c, st, n - r1, cend - r1, 128, -1.0, A + r1 * lda + lc, lda, A + r1 * lda + lc, lda, 1.0,
+                            A + r1 * lda + r1, lda, 1));
+    }
+    return GPT_OK;
 }
 
 static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *invd, int32_t *info)
@@ -235,6 +257,8 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
     const int64_t nblk = (n + nbo - 1) / nbo;
     hipStream_t S = c->stream, P = c->panel_stream;
     const bool la = c->lookahead && nblk > 1;
+    hipEvent_t head = c->head_event;
+    c->head_event = nullptr;
     if (!la) {
         for (int64_t k = 0; k < nblk; k++) {
             const int64_t c0 = k * nbo, w = (n - c0 < nbo) ? n - c0 : nbo, m = n - c0;
@@ -246,51 +270,41 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
         }
         return GPT_OK;
     }
-    // ---- look-ahead: panel k+1 is factored on P while S applies panel k to the rest ----
-    hipEvent_t e_start = get_event(c, 0);
-    if (!e_start) return GPT_E_HIP;
-    GPT_HIP_CHECK(hipEventRecord(e_start, S));
-    GPT_HIP_CHECK(hipStreamWaitEvent(P, e_start, 0));
-    {
-        const int64_t w = (n < nbo) ? n : nbo;
-        GPT_TRY(panel_rec(c, P, A, lda, n, w, invd, info, 0));
+    // ---- look-ahead.  P (high priority, reserved CUs) runs the latency-bound chain: the panels, each extended by
+    // GPT_PANEL_EXT columns (panel_ext).  S applies panel k (rank nbo) to everything right of column
+    // u0 = c0 + nbo + EXT in two launches: the nbo columns panel k+1 is going to touch first ("urgent", event e_cu),
+    // then the rest.  P never waits for a large update: its only dependency is e_cu(k) before the first update of
+    // panel k+1, and S has the whole first pivot block + TRSM of that panel to get there.
+    if (!head) {
+        head = get_event(c, 0);
+        if (!head) return GPT_E_HIP;
+        GPT_HIP_CHECK(hipEventRecord(head, S));
     }
-    hipEvent_t e_panel = get_event(c, 1);
-    GPT_HIP_CHECK(hipEventRecord(e_panel, P));
-    for (int64_t k = 0; k + 1 < nblk; k++) {
-        const int64_t c0 = k * nbo, w = nbo;
-        const int64_t n0 = c0 + w;                                   // first column of block k+1
-        const int64_t w1 = (n - n0 < nbo) ? n - n0 : nbo;
-        const int64_t r0 = n0 + w1;                                   // first column after block k+1
-        const int64_t wf = (w1 < 128) ? w1 : 128;                     // columns the panel needs before its first leaf
-        // P: only the first 128 columns of block column k+1 are brought up to date on the critical path ...
-        if (k > 0) GPT_HIP_CHECK(hipStreamWaitEvent(P, get_event(c, 3 + 3 * (k - 1)), 0));
-        GPT_TRY(gemm_nt(c, P, n - n0, wf, w, -1.0, A + n0 * lda + c0, lda, A + n0 * lda + c0, lda, 1.0,
-                        A + n0 * lda + n0, lda, 1));
-        // ... S does its other columns (while P factors the first diagonal block), then everything to the right
-        GPT_HIP_CHECK(hipStreamWaitEvent(S, e_panel, 0));
-        c->panel_hook = nullptr;
-        if (w1 > wf) {
-            const int64_t n1 = n0 + wf;
-            GPT_TRY(gemm_nt(c, S, n - n1, w1 - wf, w, -1.0, A + n1 * lda + c0, lda, A + n1 * lda + c0, lda, 1.0,
-                            A + n1 * lda + n1, lda, 1));
-            hipEvent_t e_cu = get_event(c, 4 + 3 * k);
+    GPT_HIP_CHECK(hipStreamWaitEvent(P, head, 0));
+    hipEvent_t e_cu_prev = nullptr;
+    for (int64_t k = 0; k < nblk; k++) {
+        const int64_t c0 = k * nbo, w = (n - c0 < nbo) ? n - c0 : nbo;
+        hipEvent_t e_panel = get_event(c, 2 + 2 * k), e_cu = get_event(c, 3 + 2 * k);
+        if (!e_panel || !e_cu) return GPT_E_HIP;
+        GPT_TRY(panel_ext(c, P, A, lda, n, c0, w, invd, info, e_cu_prev, e_panel));
+        e_cu_prev = nullptr;
+        const int64_t u0 = c0 + w + GPT_PANEL_EXT;
+        if (u0 < n) {
+            const int64_t u1 = (u0 + nbo < n) ? u0 + nbo : n;
+            GPT_HIP_CHECK(hipStreamWaitEvent(S, e_panel, 0));
+            GPT_TRY(gemm_nt(c, S, n - u0, u1 - u0, w, -1.0, A + u0 * lda + c0, lda, A + u0 * lda + c0, lda, 1.0,
+                            A + u0 * lda + u0, lda, 1));
             GPT_HIP_CHECK(hipEventRecord(e_cu, S));
-            c->panel_hook = e_cu;
+            e_cu_prev = e_cu;
+            if (u1 < n)
+                GPT_TRY(gemm_nt(c, S, n - u1, n - u1, w, -1.0, A + u1 * lda + c0, lda, A + u1 * lda + c0, lda, 1.0,
+                                A + u1 * lda + u1, lda, 1));
         }
-        if (r0 < n)
-            GPT_TRY(gemm_nt(c, S, n - r0, n - r0, w, -1.0, A + r0 * lda + c0, lda, A + r0 * lda + c0, lda, 1.0,
-                            A + r0 * lda + r0, lda, 1));
-        GPT_HIP_CHECK(hipEventRecord(get_event(c, 3 + 3 * k), S));
-        GPT_TRY(panel_rec(c, P, A + n0 * lda + n0, lda, n - n0, w1, invd + (n0 / 128) * GPT_WS_BLOCK, info, n0));
-        if (c->panel_hook) {                                          // (block column of a single leaf: nothing waited)
-            GPT_HIP_CHECK(hipStreamWaitEvent(P, c->panel_hook, 0));
-            c->panel_hook = nullptr;
-        }
-        e_panel = get_event(c, 2 + 3 * (k + 1));
-        GPT_HIP_CHECK(hipEventRecord(e_panel, P));
     }
-    GPT_HIP_CHECK(hipStreamWaitEvent(S, e_panel, 0));
+    hipEvent_t e_end = get_event(c, 1);
+    if (!e_end) return GPT_E_HIP;
+    GPT_HIP_CHECK(hipEventRecord(e_end, P));
+    GPT_HIP_CHECK(hipStreamWaitEvent(S, e_end, 0));
     return GPT_OK;
 }
 
@@ -372,6 +386,15 @@ extern "C" int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out)
         if (!masked) GPT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
+    if (const char *e = getenv("GPT_PANEL_CUS")) {        // experiment: confine the panel stream to the first CUs
+        const int pc = atoi(e);
+        hipDeviceProp_t prop;
+        GPT_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+        const int ncu = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+        for (int i = 0; i < pc && i < ncu; i++) mask[i / 32] |= (1u << (i % 32));
+        GPT_HIP_CHECK(hipExtStreamCreateWithCUMask(&c->panel_stream, (uint32_t)mask.size(), mask.data()));
+    } else
     GPT_HIP_CHECK(hipStreamCreateWithPriority(&c->panel_stream, hipStreamNonBlocking, hi));
     for (int i = 0; i < 5; i++) GPT_HIP_CHECK(hipEventCreate(&c->tev[i]));
     GPT_HIP_CHECK(hipMalloc(&c->d_info, sizeof(int32_t)));
@@ -582,12 +605,14 @@ static int ensure_factor_storage(gpt_ctx *c, int64_t N)
 }
 
 // Factor the (already assembled, lower) N x N matrix in dA, with y in d_y; produce ll terms.
-static int factor_and_ll(gpt_ctx *c, int64_t N, double *ll_data_out, double *logdet_half_out)
+static int factor_and_ll(gpt_ctx *c, int64_t N, double *ll_data_out, double *logdet_half_out, bool padded = false)
 {
     hipStream_t st = c->stream;
     const int64_t NP = c->NP;
-    GPT_HIP_CHECK(hipMemsetAsync(c->d_info, 0, sizeof(int32_t), st));
-    GPT_TRY(launch_fill_pad(st, c->dA, NP, N, NP, c->d_y, 1e300));
+    if (!padded) {
+        GPT_HIP_CHECK(hipMemsetAsync(c->d_info, 0, sizeof(int32_t), st));
+        GPT_TRY(launch_fill_pad(st, c->dA, NP, N, NP, c->d_y, 1e300));
+    }
     if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[2], st));
     GPT_TRY(potrf_run(c, NP, c->dA, NP, c->d_invd, c->d_info));
     if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[3], st));
@@ -647,11 +672,26 @@ extern "C" int gpt_fit(gpt_ctx *c, int kernel_id, const double *params, int npar
     GPT_HIP_CHECK(hipMemcpyAsync(c->d_y, y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, st));
     GPT_HIP_CHECK(hipMemcpyAsync(c->d_erry, err_y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, st));
     if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[1], st));
-    GPT_TRY(launch_kbuild(st, kp, c->dX, c->dn, N, c->dX, c->dn, N, 1, 0, 0, c->d_erry, noise_var, diag_add, c->dA,
-                          c->NP));
+    // The columns the first panel touches are built first so that its pivot chain overlaps the rest of the build.
+    const int64_t NP = c->NP;
+    GPT_HIP_CHECK(hipMemsetAsync(c->d_info, 0, sizeof(int32_t), st));
+    GPT_TRY(launch_fill_pad(st, c->dA, NP, N, NP, c->d_y, 1e300));
+    int64_t head = round_up(c->nb_outer + GPT_PANEL_EXT, 256);
+    hipEvent_t e_head = nullptr;
+    if (c->lookahead && !c->use_graph && head < N && (e_head = get_event(c, 0)) != nullptr) {
+        GPT_TRY(launch_kbuild(st, kp, c->dX, c->dn, N, c->dX, c->dn, head, 1, 0, 0, c->d_erry, noise_var, diag_add,
+                              c->dA, NP));
+        GPT_HIP_CHECK(hipEventRecord(e_head, st));
+        GPT_TRY(launch_kbuild(st, kp, c->dX, c->dn, N, c->dX + head * c->D, c->dn + head * c->D, N - head, 1, 0, head,
+                              c->d_erry, noise_var, diag_add, c->dA + head, NP));
+    } else {
+        GPT_TRY(launch_kbuild(st, kp, c->dX, c->dn, N, c->dX, c->dn, N, 1, 0, 0, c->d_erry, noise_var, diag_add, c->dA,
+                              NP));
+    }
     c->kp = kp;
     c->have_kernel = true;
-    return factor_and_ll(c, N, ll_data_out, logdet_half_out);
+    c->head_event = e_head;
+    return factor_and_ll(c, N, ll_data_out, logdet_half_out, true);
 }
 
 extern "C" int gpt_fit_matrix(gpt_ctx *c, const double *K_tot, int64_t N, const double *y, double *ll_data_out,

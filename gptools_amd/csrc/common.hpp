@@ -1,6 +1,7 @@
 // common.hpp -- shared declarations for libgpt_hip.so (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/gpt_hip.h"
@@ -61,7 +62,7 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
                    const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile, int lds_pad);
 int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base);
 int launch_trsm_panel(hipStream_t st, int64_t m, const double *L, int64_t ldl, const double *invd,
-                      double *B, int64_t ldb);
+                      double *B, int64_t ldb, hipEvent_t done = nullptr);
 int launch_fill_pad(hipStream_t st, double *A, int64_t lda, int64_t n_valid, int64_t n_pad, const double *dy,
                     double big);
 int launch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_t n, double *d_out2);

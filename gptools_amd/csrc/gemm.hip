@@ -404,7 +404,16 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
     o.grid = (int64_t)flat.size();
     o.d_tab = nullptr;
     GPT_HIP_CHECK(hipMalloc(&o.d_tab, flat.size() * sizeof(int2)));
-    GPT_HIP_CHECK(hipMemcpy(o.d_tab, flat.data(), flat.size() * sizeof(int2), hipMemcpyHostToDevice));
+    {   // upload on a private non-blocking stream: the caller may be inside a stream capture (hipGraph option), where
+        // a copy on the legacy stream would be an illegal dependency on the capturing stream
+        hipStream_t up = nullptr;
+        GPT_HIP_CHECK(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+        hipError_t e1 = hipMemcpyAsync(o.d_tab, flat.data(), flat.size() * sizeof(int2), hipMemcpyHostToDevice, up);
+        hipError_t e2 = hipStreamSynchronize(up);
+        hipStreamDestroy(up);
+        GPT_HIP_CHECK(e1);
+        GPT_HIP_CHECK(e2);
+    }
     g_orders.push_back(o);
     *tab = o.d_tab;
     *grid = o.grid;

@@ -342,16 +342,22 @@ __global__ __launch_bounds__(64 * TP_WAVES, 2) void trsm_panel_kernel(int64_t m,
 }
 
 int launch_trsm_panel(hipStream_t st, int64_t m, const double *L, int64_t ldl, const double *invd, double *B,
-                      int64_t ldb)
+                      int64_t ldb, hipEvent_t done)
 {
-    if (m <= 0) return GPT_OK;
+    if (m <= 0) {
+        if (done) GPT_HIP_CHECK(hipEventRecord(done, st));
+        return GPT_OK;
+    }
     if (m % 16) {
         gpt_set_error("trsm_panel: m must be a multiple of 16 (m=%lld)", (long long)m);
         return GPT_E_ARG;
     }
     const int64_t nwave = m / 16;
     const unsigned grid = (unsigned)((nwave + TP_WAVES - 1) / TP_WAVES);
-    hipLaunchKernelGGL(trsm_panel_kernel, dim3(grid), dim3(64 * TP_WAVES), 0, st, m, L, ldl, invd, B, ldb);
+    // `done` rides on the kernel's own completion signal (hipExtLaunchKernelGGL stop event): a separate
+    // hipEventRecord would put a barrier packet -- ~6 us of command-processor time -- on the panel chain
+    if (done) hipExtLaunchKernelGGL(trsm_panel_kernel, dim3(grid), dim3(64 * TP_WAVES), 0, st, nullptr, done, 0, m, L, ldl, invd, B, ldb);
+    else hipLaunchKernelGGL(trsm_panel_kernel, dim3(grid), dim3(64 * TP_WAVES), 0, st, m, L, ldl, invd, B, ldb);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }

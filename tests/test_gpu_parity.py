@@ -388,6 +388,29 @@ def test_fit_matches_oracle(ctx, oracle, kern, N, d, deriv):
     np.testing.assert_allclose(c, cr, rtol=0, atol=1e-6)
 
 
+def test_graph_capture_with_fresh_tile_tables(ctx):
+    """hipGraph option at a size whose trailing updates need XCD tile-order tables that do not exist yet: the
+    tables are uploaded while the stream is capturing.  Same ll as the eager schedule, twice (graph replay)."""
+    N, d = 4480, 2
+    X, n, y = c3_inputs(N, d)
+    n[:] = 0
+    p = np.array([1.0, 0.3, 0.3])
+    err = 0.05 * np.ones(N)
+    ctx.set_data(X, n)
+    try:
+        for k_, v_ in {"lookahead": 1, "nb_outer": 384, "graph": 1}.items():
+            ctx.set_option(k_, v_)
+        g1 = ctx.fit(0, p, 0.0, y, err, 1e2 * EPS)
+        g2 = ctx.fit(0, p, 0.0, y, err, 1e2 * EPS)
+        ctx.set_option("graph", 0)
+        e1 = ctx.fit(0, p, 0.0, y, err, 1e2 * EPS)
+    finally:
+        ctx.set_option("graph", 0)
+        ctx.set_option("nb_outer", 512)
+    assert g1 == g2
+    assert abs(g1[0] - e1[0]) <= 1e-11 * abs(e1[0]) and abs(g1[1] - e1[1]) <= 1e-12 * abs(e1[1])
+
+
 def test_dense_kernels_against_numpy(ctx):
     rs = np.random.RandomState(11)
     for (m, n, k) in ((64, 64, 64), (200, 130, 70), (640, 384, 256), (1024, 1024, 512)):
