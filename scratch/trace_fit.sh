@@ -1,9 +1,10 @@
 #!/bin/bash
+# usage: trace_fit.sh <workload> [opt=val ...]  -> gpurun_out/tl/timeline.txt
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/tl
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- python3 $R/scratch/fit_loop.py c3 6 > $OUT/trace.log 2>&1
-tail -3 $OUT/trace.log
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- python3 $R/scratch/fit_loop.py "$@" > $OUT/trace.log 2>&1
+tail -1 $OUT/trace.log
 python3 $R/scratch/timeline.py $OUT/trace 0 1e9 > $OUT/timeline.txt
 tail -1 $OUT/timeline.txt
