@@ -75,9 +75,10 @@ struct gpt_ctx {
     double timings[5] = {0, 0, 0, 0, 0};
     // per-launch HIP-event timing of the dominant (large) GEMM/SYRK launches, for the roofline line
     int prof_gemm = 0;
-    struct GemmProf { hipEvent_t e0, e1; double flops; };
+    struct GemmProf { hipEvent_t e0, e1, stop; double flops; };
     std::vector<GemmProf> gprof;
     size_t gprof_used = 0;
+    double prof_flops = 0, prof_ms = 0, prof_count = 0;
     // graph cache for the factorisation
     hipGraphExec_t gexec = nullptr;
     int64_t g_n = 0, g_nb = 0;
@@ -105,7 +106,7 @@ static hipEvent_t get_event(gpt_ctx *c, size_t idx)
 {
     while (c->events.size() <= idx) {
         hipEvent_t e = nullptr;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;      // (timing-capable: an edge can double as a GEMM stop event)
         c->events.push_back(e);
     }
     return c->events[idx];
@@ -180,7 +181,8 @@ static int check_m52_orders(const int32_t *n, int64_t M, int D)
 // Dense drivers on device data
 // ------------------------------------------------------------------------------------------------
 static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A,
-                   int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri)
+                   int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri,
+                   hipEvent_t done = nullptr)
 {
     // algorithmic flop count: 2k per computed element of C (lower trapezoid when tri)
     const double elems = tri ? 0.5 * (double)n * (double)(n + 1) + (double)(m - n) * (double)n : (double)m * (double)n;
@@ -193,16 +195,31 @@ static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, 
             GPT_HIP_CHECK(hipEventCreate(&g.e0));
             GPT_HIP_CHECK(hipEventCreate(&g.e1));
             g.flops = 0;
+            g.stop = g.e1;
             c->gprof.push_back(g);
         }
         gp = &c->gprof[c->gprof_used++];
         gp->flops = flops;
-        GPT_HIP_CHECK(hipEventRecord(gp->e0, st));
     }
     // trailing updates on the main stream leave room on every CU for the panel stream (see gemm.hip)
     const int lds_pad = (st == c->stream && c->lookahead) ? c->gemm_pad : 0;
-    int rc = launch_gemm_nt(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, c->tile, lds_pad);
-    if (prof) GPT_HIP_CHECK(hipEventRecord(gp->e1, st));
+    // `done` (a cross-stream edge) and the timing events ride on the dispatch packet itself where possible
+    // (hipExtLaunchKernelGGL): a separate hipEventRecord is a barrier packet, ~6 us of command-processor time
+    const bool ext = !c->use_graph && (c->tile == 0 || c->tile == 64);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ext) {
+        e0 = prof ? gp->e0 : nullptr;
+        e1 = done ? done : (prof ? gp->e1 : nullptr);
+        if (prof) gp->stop = e1;
+    } else if (prof) {
+        gp->stop = gp->e1;
+        GPT_HIP_CHECK(hipEventRecord(gp->e0, st));
+    }
+    int rc = launch_gemm_nt(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, c->tile, lds_pad, e0, e1);
+    if (!ext) {
+        if (prof) GPT_HIP_CHECK(hipEventRecord(gp->e1, st));
+        if (done) GPT_HIP_CHECK(hipEventRecord(done, st));
+    }
     return rc;
 }
 
@@ -293,8 +310,7 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
             const int64_t u1 = (u0 + nbo < n) ? u0 + nbo : n;
             GPT_HIP_CHECK(hipStreamWaitEvent(S, e_panel, 0));
             GPT_TRY(gemm_nt(c, S, n - u0, u1 - u0, w, -1.0, A + u0 * lda + c0, lda, A + u0 * lda + c0, lda, 1.0,
-                            A + u0 * lda + u0, lda, 1));
-            GPT_HIP_CHECK(hipEventRecord(e_cu, S));
+                            A + u0 * lda + u0, lda, 1, e_cu));
             e_cu_prev = e_cu;
             if (u1 < n)
                 GPT_TRY(gemm_nt(c, S, n - u1, n - u1, w, -1.0, A + u1 * lda + c0, lda, A + u1 * lda + c0, lda, 1.0,
@@ -605,6 +621,8 @@ static int ensure_factor_storage(gpt_ctx *c, int64_t N)
 }
 
 // Factor the (already assembled, lower) N x N matrix in dA, with y in d_y; produce ll terms.
+static int harvest_gemm_profile(gpt_ctx *c);
+
 static int factor_and_ll(gpt_ctx *c, int64_t N, double *ll_data_out, double *logdet_half_out, bool padded = false)
 {
     hipStream_t st = c->stream;
@@ -621,6 +639,7 @@ static int factor_and_ll(gpt_ctx *c, int64_t N, double *ll_data_out, double *log
     GPT_HIP_CHECK(hipMemcpyAsync(c->h_info, c->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[4], st));
     GPT_HIP_CHECK(hipStreamSynchronize(st));
+    if (c->gprof_used) GPT_TRY(harvest_gemm_profile(c));
     if (c->timing) {
         float ms = 0;
         for (int i = 0; i < 4; i++) {
@@ -722,23 +741,32 @@ extern "C" int gpt_last_timings(gpt_ctx *c, double *out_ms, int n)
     return cnt;
 }
 
+// Fold the finished launches' event pairs into the running sums.  Must run after the streams have drained and before
+// the next factorisation re-records the edge events that double as stop events.
+static int harvest_gemm_profile(gpt_ctx *c)
+{
+    for (size_t i = 0; i < c->gprof_used; i++) {
+        float t = 0;
+        GPT_HIP_CHECK(hipEventElapsedTime(&t, c->gprof[i].e0, c->gprof[i].stop));
+        c->prof_ms += t;
+        c->prof_flops += c->gprof[i].flops;
+    }
+    c->prof_count += (double)c->gprof_used;
+    c->gprof_used = 0;
+    return GPT_OK;
+}
+
 extern "C" int gpt_gemm_profile_read(gpt_ctx *c, double *out3)
 {
     CTX_ENTER(c);
     if (!out3) return GPT_E_ARG;
     GPT_HIP_CHECK(hipStreamSynchronize(c->stream));
     GPT_HIP_CHECK(hipStreamSynchronize(c->panel_stream));
-    double flops = 0, ms = 0;
-    for (size_t i = 0; i < c->gprof_used; i++) {
-        float t = 0;
-        GPT_HIP_CHECK(hipEventElapsedTime(&t, c->gprof[i].e0, c->gprof[i].e1));
-        ms += t;
-        flops += c->gprof[i].flops;
-    }
-    out3[0] = flops;
-    out3[1] = ms;
-    out3[2] = (double)c->gprof_used;
-    c->gprof_used = 0;
+    GPT_TRY(harvest_gemm_profile(c));
+    out3[0] = c->prof_flops;
+    out3[1] = c->prof_ms;
+    out3[2] = c->prof_count;
+    c->prof_flops = c->prof_ms = c->prof_count = 0.0;
     return GPT_OK;
 }
 

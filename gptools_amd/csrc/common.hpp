@@ -59,7 +59,8 @@ int launch_kbuild(hipStream_t st, const KParams &kp, const double *dXi, const in
                   const double *d_err_y, double noise_var, double diag_add, double *dK, int64_t ldk);
 int launch_check_orders(hipStream_t st, const int32_t *dn, int64_t M, int D, int32_t *d_flag);
 int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A, int64_t lda,
-                   const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile, int lds_pad);
+                   const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile, int lds_pad,
+                   hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base);
 int launch_trsm_panel(hipStream_t st, int64_t m, const double *L, int64_t ldl, const double *invd,
                       double *B, int64_t ldb, hipEvent_t done = nullptr);

@@ -423,7 +423,7 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
 template <int BM, int BN, int WPS, int NSTAGE>
 static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A,
                          int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri,
-                         int lds_pad)
+                         int lds_pad, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
 {
     const int64_t ntm = (m + BM - 1) / BM, ntn = (n + BN - 1) / BN;
     int64_t nwg = tri ? ntn * (ntn + 1) / 2 + (ntm - ntn) * ntn : ntm * ntn;
@@ -437,8 +437,14 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
     // update on the main stream asks for 8 KiB -> three workgroups per CU, leaving 40 KiB of LDS and over 40 % of the
     // register file on every CU to the high-priority panel stream (whose own GEMMs and TRSMs need 32 / 9 KiB).
     const size_t dyn = (BM == 64) ? (size_t)lds_pad : 0;
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg), dim3(256), dyn, st, m, n, k, alpha,
-                       A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order);
+    // timing events (roofline line of bench.py) ride on the dispatch packet itself: separate hipEventRecord calls
+    // would add two barrier packets per launch to the stream being measured
+    if (ev0 || ev1)
+        hipExtLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg), dim3(256), dyn, st, ev0, ev1, 0,
+                              m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order);
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg), dim3(256), dyn, st, m, n, k, alpha,
+                           A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
@@ -463,7 +469,8 @@ static int gemm_launch_persist(hipStream_t st, int64_t m, int64_t n, int64_t k, 
 }
 
 int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A, int64_t lda,
-                   const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile, int lds_pad)
+                   const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile, int lds_pad,
+                   hipEvent_t ev0, hipEvent_t ev1)
 {
     if (m <= 0 || n <= 0) return GPT_OK;
     if (alpha == 0.0) {
@@ -490,5 +497,5 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
     // small panel updates (8064x128x128: 12 us either way): they are bound by launch + prologue latency, not by the
     // DMA wait, so everything uses the 2-stage kernel.
     if (force_tile == 65) return gemm_launch_t<64, 64, 1, 4>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0);
-    return gemm_launch_t<64, 64, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, lds_pad);
+    return gemm_launch_t<64, 64, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, lds_pad, ev0, ev1);
 }
