@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--nb", type=int, default=0, help="outer block width (0 = default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--dist", action="store_true", help="use the block-cyclic DistributedLML path even with one rank")
+    ap.add_argument("--no-ref", action="store_true", help="N>1: skip the single-GPU run of the same workload on rank 0")
     args = ap.parse_args()
 
     import torch
@@ -185,6 +186,22 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         parallelism = "1-D block-cyclic block columns (nb=%d) over %d ranks, RCCL panel broadcast" % (plan.nb, world)
+        # Same workload on ONE GPU (rank 0, single-context path), measured in the same run, so that the speed-up of
+        # the partitioned factorisation can be read off this line (the N=1 bench line is a different workload, C3).
+        if (world > 1 or args.dist) and not args.no_ref:
+            if rank == 0:
+                ctx = _lib.Context(local_rank)
+                ctx.set_data(X, n)
+                ctx.set_option("timing", 1)
+                tref = []
+                for _ in range(3):
+                    ll1, ld1 = ctx.fit(KID[kernel], params, 0.0, y, err, diag_add)
+                    tref.append(ctx.last_timings()["total"])
+                extra["single_gpu_same_workload"] = {
+                    "ms_per_step": min(tref), "value": flops_fit(N) / min(tref) * 1e-6, "unit": "GFLOP/s",
+                    "ll_rel_diff_vs_partitioned": abs(ll1 - ll) / abs(ll1)}
+                del ctx
+            barrier()
 
     if rank == 0:
         per_step = elapsed / args.steps

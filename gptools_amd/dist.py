@@ -32,29 +32,81 @@ import torch.distributed as dist
 
 from . import _lib
 
-__all__ = ["HipPanelOps", "DistributedLML"]
+__all__ = ["PanelOps", "HipPanelOps", "DistributedLML"]
 
 BIG_PIVOT = 1e300
 
 
-class HipPanelOps(object):
-    """Dense local operations on CUDA tensors through the device API of include/gpt_hip.h."""
+class _NoEvent(object):
+    """Stand-in for a stream event where everything runs in program order (CPU test ops)."""
+
+    def record(self):
+        pass
+
+    def wait(self):
+        pass
+
+
+class PanelOps(object):
+    """Interface of the dense local operations.  Two in-order queues exist per rank: ``"panel"`` (the
+    latency-bound chain: staging, look-ahead column update, panel factorisation, broadcasts) and ``"main"``
+    (K build and trailing updates).  This base class is the serial version: one queue, events are no-ops."""
+    device = torch.device("cpu")
+
+    def queue(self, q):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def new_event(self):
+        return _NoEvent()
+
+    def synchronize(self):
+        pass
+
+
+class _StreamEvent(object):
+    def __init__(self):
+        self.ev = torch.cuda.Event()
+
+    def record(self):
+        self.ev.record(torch.cuda.current_stream())
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
+class HipPanelOps(PanelOps):
+    """Dense local operations on CUDA tensors through the device API of include/gpt_hip.h.
+
+    Two library contexts, one per queue: the main one owns the library's CU-masked stream (the trailing updates leave
+    a few CUs to the panel kernels), the panel one runs on a high-priority torch stream.
+    torch's tensor ops and the RCCL collectives are issued with the matching stream current, so each queue is one
+    ordered HIP stream; cross-queue edges are torch events."""
 
     def __init__(self, device):
         if not torch.cuda.is_available():
             raise _lib.GPTBackendError("HipPanelOps needs a GPU (gptools_amd has no CPU fallback)")
         self.device = torch.device("cuda", device) if not isinstance(device, torch.device) else device
         torch.cuda.set_device(self.device)
-        # A dedicated torch stream shared with the library: torch's tensor ops, the RCCL collectives and the
-        # HIP kernels launched through the C ABI are then ordered on one queue (the legacy default stream has
-        # handle 0, which the library would replace by a private, unordered stream).
-        self.stream = torch.cuda.Stream(self.device)
-        self.ctx = _lib.Context(self.device.index, stream=self.stream.cuda_stream)
         self.lib = _lib.load()
-        self.ctx.set_option("lookahead", 0)
+        self.ctx_main = _lib.Context(self.device.index)
+        self.main_stream = torch.cuda.ExternalStream(int(self.ctx_main.stream), device=self.device)
+        self.panel_stream = torch.cuda.Stream(self.device, priority=-1)
+        self.ctx_panel = _lib.Context(self.device.index, stream=self.panel_stream.cuda_stream)
+        self._ctx = {"main": self.ctx_main, "panel": self.ctx_panel}
+        self._stream = {"main": self.main_stream, "panel": self.panel_stream}
+        for c in self._ctx.values():
+            c.set_option("lookahead", 0)
 
-    def stream_ctx(self):
-        return torch.cuda.stream(self.stream)
+    def queue(self, q):
+        return torch.cuda.stream(self._stream[q])
+
+    def new_event(self):
+        return _StreamEvent()
+
+    def synchronize(self):
+        self.main_stream.synchronize()
+        self.panel_stream.synchronize()
 
     def kbuild_block(self, kernel_id, params, X, n, r0, r1, c0, c1, err_y, noise_var, diag_add, out, ld):
         """out[(i - r0) * ld + (j - c0)] = K_tot[i][j] for i in [r0, r1), j in [c0, c1) (global indices)."""
@@ -62,17 +114,17 @@ class HipPanelOps(object):
         D = X.shape[1]
         esz_d, esz_i = 8, 4
         _lib.check(self.lib.gpt_dev_kbuild(
-            self.ctx.handle, int(kernel_id), _lib.dptr(params), len(params),
+            self.ctx_main.handle, int(kernel_id), _lib.dptr(params), len(params),
             X.data_ptr() + r0 * D * esz_d, n.data_ptr() + r0 * D * esz_i, r1 - r0,
             X.data_ptr() + c0 * D * esz_d, n.data_ptr() + c0 * D * esz_i, c1 - c0, D,
             -1, 1, None, 1, r0, c0, err_y.data_ptr(), float(noise_var), float(diag_add), out, ld))
 
     def potrf_panel(self, m, nb, A, lda, invd, info, info_base):
-        _lib.check(self.lib.gpt_dev_potrf_panel(self.ctx.handle, m, nb, A, lda, invd.data_ptr(), info.data_ptr(),
-                                                info_base))
+        _lib.check(self.lib.gpt_dev_potrf_panel(self.ctx_panel.handle, m, nb, A, lda, invd.data_ptr(),
+                                                info.data_ptr(), info_base))
 
-    def gemm_nt(self, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri):
-        _lib.check(self.lib.gpt_dev_gemm_nt(self.ctx.handle, m, n, k, float(alpha), A, lda, B, ldb, float(beta),
+    def gemm_nt(self, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, q="main"):
+        _lib.check(self.lib.gpt_dev_gemm_nt(self._ctx[q].handle, m, n, k, float(alpha), A, lda, B, ldb, float(beta),
                                             C, ldc, int(tri)))
 
 
@@ -103,7 +155,7 @@ class DistributedLML(object):
         # RCCL call pattern can be exercised on a 1-GPU box (tests/test_gpu_parity.py).
         import os
         self.force_collectives = bool(int(os.environ.get("GPT_DIST_FORCE_COLLECTIVES", "0"))) and dist.is_initialized()
-        self.lookahead = bool(lookahead) and (self.world > 1 or self.force_collectives)
+        self.lookahead = bool(lookahead)
         X = np.ascontiguousarray(X, dtype=np.float64)
         n = np.ascontiguousarray(n, dtype=np.int32)
         self.N, self.D = X.shape
@@ -116,7 +168,9 @@ class DistributedLML(object):
         self.X = torch.from_numpy(X).to(dev)
         self.n = torch.from_numpy(n).to(dev)
         self.A = torch.empty((self.NP, max(self.nloc, 1) * nb), dtype=torch.float64, device=dev)
-        self.P = [torch.empty((self.NP, nb), dtype=torch.float64, device=dev) for _ in range(2)]
+        # three panel buffers: panel k is read by the main queue's updates while panel k+1 is staged / received and
+        # panel k-1 may still be in use by updates that have not drained
+        self.P = [torch.empty((self.NP, nb), dtype=torch.float64, device=dev) for _ in range(3)]
         self.invd = torch.empty(((nb // 128) * 9216,), dtype=torch.float64, device=dev)     # GPT_WS_BLOCK per 128 columns
         self.info = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.y = torch.empty((self.NP,), dtype=torch.float64, device=dev)
@@ -178,7 +232,7 @@ class DistributedLML(object):
             self.red[1] += (z * z).sum()
         self._factored = []
 
-    def _update_block(self, k, J, buf, C=None, ldc=None):
+    def _update_block(self, k, J, buf, C=None, ldc=None, q="main"):
         """A[J*nb:, block J] -= P_k[rows of J..] * P_k[rows of block J]^T  (lower trapezoid); with ``C`` given the
         target is a staged panel buffer instead of the local matrix."""
         nb, A = self.nb, self.A
@@ -187,68 +241,106 @@ class DistributedLML(object):
         off = (J - k) * nb
         if C is None:
             C, ldc = _ptr(A, J * nb, lj * nb), A.stride(0)
-        self.ops.gemm_nt(mJ, nb, nb, -1.0, _ptr(buf, off, 0), nb, _ptr(buf, off, 0), nb, 1.0, C, ldc, 1)
+        self.ops.gemm_nt(mJ, nb, nb, -1.0, _ptr(buf, off, 0), nb, _ptr(buf, off, 0), nb, 1.0, C, ldc, 1, q=q)
 
     def fit(self, kernel_id, params, y, err_y, noise_var=0.0, diag_factor=1e2):
-        import contextlib
-        sc = self.ops.stream_ctx() if hasattr(self.ops, "stream_ctx") else contextlib.nullcontext()
-        with sc:
-            return self._fit(kernel_id, params, y, err_y, noise_var, diag_factor)
+        """One LML evaluation; returns ``(ll_data, logdet_half)`` on every rank.
 
-    def _fit(self, kernel_id, params, y, err_y, noise_var, diag_factor):
+        Schedule per step k (panel k = block column k of L, contiguous in P[k % 3] on every rank):
+          panel queue: [owner of k+1: stage block column k+1 into P[(k+1) % 3]] -> panel k has arrived ->
+                       [owner: apply panel k to the staged column, factor it] -> start broadcast k+1 (async)
+          main queue : panel k has arrived -> apply it to the owned block columns right of k+1, the one that is staged
+                       next (k+2) first.
+        Edges: "urgent" (column k+2 is up to date with panel k) main -> panel, "done" (step k no longer reads P[k % 3])
+        main -> panel before that buffer is staged / received into again, "arrived" panel -> main."""
+        ops = self.ops
         N, nb, NP, world, rank = self.N, self.nb, self.NP, self.world, self.rank
+        nblk = self.nblk
         y = np.ascontiguousarray(y, dtype=np.float64)
         err_y = np.array(np.broadcast_to(err_y, (N,)), dtype=np.float64)
-        self.y[:N] = torch.from_numpy(y).to(self.device)
-        self.err[:N] = torch.from_numpy(err_y).to(self.device)
-        self.info.zero_()
-        self._assemble(kernel_id, params, noise_var, diag_factor * sys.float_info.epsilon)
+        owner = lambda J: J % world == rank
 
-        nblk = self.nblk
-        self.red = red = torch.zeros((3,), dtype=torch.float64, device=self.device)
+        with ops.queue("main"):
+            self.y[:N] = torch.from_numpy(y).to(self.device)
+            self.err[:N] = torch.from_numpy(err_y).to(self.device)
+            self.info.zero_()
+            self.red = torch.zeros((3,), dtype=torch.float64, device=self.device)
+            self._assemble(kernel_id, params, noise_var, diag_factor * sys.float_info.epsilon)
+            ev_asm = ops.new_event()
+            ev_asm.record()
         self._factored = []
-        pending = None
-        if rank == 0 % world:
-            self._stage_panel(0, self.P[0])
-            self._factor_staged(0, self.P[0])
-        pending = self._bcast(self.P[0][:NP], 0, async_op=True)
-        self._accumulate_scalars()
+        ev_urg, ev_done = {}, {}
+
+        with ops.queue("panel"):
+            ev_asm.wait()
+            if owner(0):
+                self._stage_panel(0, self.P[0])
+                self._factor_staged(0, self.P[0])
+            pending = self._bcast(self.P[0][:NP], 0, async_op=True)
+            self._accumulate_scalars()
+
         for k in range(nblk):
-            buf = self.P[k % 2]
+            buf = self.P[k % 3]
             nxt = k + 1
-            nbuf = self.P[nxt % 2]
-            own_next = nxt < nblk and nxt % world == rank
-            if own_next and self.lookahead:
-                self._stage_panel(nxt, nbuf)          # before the wait: overlaps the tail of broadcast k
-            if pending is not None:
-                pending.wait()
-                pending = None
-            mine = [J for J in self.my_blocks if J > k]
-            if nxt < nblk and self.lookahead:
-                if own_next:
-                    self._update_block(k, nxt, buf, nbuf.data_ptr(), nb)
-                    self._factor_staged(nxt, nbuf)
-                    mine = [J for J in mine if J != nxt]
-                pending = self._bcast(nbuf[:NP - nxt * nb], nxt % world, async_op=True)
-                self._accumulate_scalars()
-            for J in mine:
-                self._update_block(k, J, buf)
-            if nxt < nblk and not self.lookahead:
-                if own_next:
-                    self._stage_panel(nxt, nbuf)
-                    self._factor_staged(nxt, nbuf)
-                pending = self._bcast(nbuf[:NP - nxt * nb], nxt % world, async_op=True)
-                self._accumulate_scalars()
+            nbuf = self.P[nxt % 3]
+            own_next = nxt < nblk and owner(nxt)
+            la = self.lookahead and nxt < nblk
+            with ops.queue("panel"):
+                if la:
+                    if k - 2 in ev_done:
+                        ev_done.pop(k - 2).wait()          # nbuf held panel k-2
+                    if own_next:
+                        if k - 1 in ev_urg:
+                            ev_urg.pop(k - 1).wait()       # column k+1 is up to date with panel k-1
+                        self._stage_panel(nxt, nbuf)       # before the wait: overlaps the tail of broadcast k
+                if pending is not None:
+                    pending.wait()
+                    pending = None
+                ev_arr = ops.new_event()
+                ev_arr.record()
+                if la:
+                    if own_next:
+                        self._update_block(k, nxt, buf, nbuf.data_ptr(), nb, q="panel")
+                        self._factor_staged(nxt, nbuf)
+                    pending = self._bcast(nbuf[:NP - nxt * nb], nxt % world, async_op=True)
+                    self._accumulate_scalars()
+            with ops.queue("main"):
+                ev_arr.wait()
+                mine = [J for J in self.my_blocks if J > k and not (la and J == nxt)]
+                urgent = k + 2
+                if la and urgent in mine:
+                    self._update_block(k, urgent, buf)
+                    mine.remove(urgent)
+                    ev_urg[k] = ops.new_event()
+                    ev_urg[k].record()
+                for J in mine:
+                    self._update_block(k, J, buf)
+                ev_done[k] = ops.new_event()
+                ev_done[k].record()
+            if nxt < nblk and not la:
+                # no look-ahead: the next panel is factored only after every update of this step
+                with ops.queue("panel"):
+                    ev_done.pop(k).wait()
+                    if k - 2 in ev_done:
+                        ev_done.pop(k - 2).wait()
+                    if own_next:
+                        self._stage_panel(nxt, nbuf)
+                        self._factor_staged(nxt, nbuf)
+                    pending = self._bcast(nbuf[:NP - nxt * nb], nxt % world, async_op=True)
+                    self._accumulate_scalars()
 
         # ---- scalars: sum(log L_ii) over i < N, z.z from the augmented row, info ----
-        red[2] = self.info.to(torch.float64)[0]
-        if world > 1 or self.force_collectives:
-            # info: non-zero on the owner of the failing panel only; max picks it up
-            info_t = red[2:3].clone()
-            dist.all_reduce(red[:2], op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_reduce(info_t, op=dist.ReduceOp.MAX, group=self.group)
-            red[2] = info_t[0]
-        logdet_half, zz, info = (float(v) for v in red.cpu())
+        with ops.queue("panel"):
+            red = self.red
+            red[2] = self.info.to(torch.float64)[0]
+            if world > 1 or self.force_collectives:
+                # info: non-zero on the owner of the failing panel only; max picks it up
+                info_t = red[2:3].clone()
+                dist.all_reduce(red[:2], op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(info_t, op=dist.ReduceOp.MAX, group=self.group)
+                red[2] = info_t[0]
+            logdet_half, zz, info = (float(v) for v in red.cpu())
+        ops.synchronize()
         if info != 0 and info <= N:
             raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % int(info))
         ll_data = -0.5 * zz - logdet_half - 0.5 * N * math.log(2.0 * math.pi)

@@ -24,8 +24,17 @@ def _view(ptr, rows, cols, ld):
     return np.lib.stride_tricks.as_strided(base, shape=(rows, cols), strides=(ld * 8, 8))
 
 
-class NumpyPanelOps(object):
-    """Same interface as gptools_amd.dist.HipPanelOps, on CPU tensors, built from the oracle + scipy."""
+def _numpy_ops():
+    """Same interface as gptools_amd.dist.HipPanelOps, on CPU tensors, built from the oracle + scipy (the serial
+    queue / event defaults of gptools_amd.dist.PanelOps: everything runs in program order)."""
+    from gptools_amd.dist import PanelOps
+
+    class NumpyPanelOps(PanelOps, _NumpyDense):
+        pass
+    return NumpyPanelOps()
+
+
+class _NumpyDense(object):
     device = torch.device("cpu")
 
     def __init__(self):
@@ -54,7 +63,7 @@ class NumpyPanelOps(object):
         if m > nb:
             P[nb:] = scipy.linalg.solve_triangular(L, P[nb:].T, lower=True).T
 
-    def gemm_nt(self, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri):
+    def gemm_nt(self, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, q="main"):
         Av, Bv, Cv = _view(A, m, k, lda).copy(), _view(B, n, k, ldb).copy(), _view(C, m, n, ldc)
         Cv[:, :] = beta * Cv + alpha * Av.dot(Bv.T)
 
@@ -79,7 +88,7 @@ def _worker(rank, world, port, N, d, nb, kernel_id, lookahead, bad, q):
         if bad:
             X[1] = X[0]
             n[:] = 0
-        plan = DistributedLML(X, n, nb=nb, ops=NumpyPanelOps(), lookahead=lookahead)
+        plan = DistributedLML(X, n, nb=nb, ops=_numpy_ops(), lookahead=lookahead)
         p = np.concatenate(([1.0], 0.3 * np.ones(d)))
         try:
             res = plan.fit(kernel_id, p, y, 0.0 if bad else 0.05, diag_factor=0.0 if bad else 1e2)
