@@ -69,6 +69,7 @@ struct gpt_ctx {
     int32_t *d_info = nullptr;
     double *d_y = nullptr, *d_erry = nullptr, *d_scal = nullptr, *d_alpha = nullptr;
     double *h_scal = nullptr;  // pinned
+    double *h_yerr = nullptr;  // pinned staging for y | err_y (a pageable source would make the upload synchronous)
     int32_t *h_info = nullptr; // pinned
     bool factored = false, alpha_valid = false, have_kernel = false;
     KParams kp;
@@ -427,7 +428,8 @@ static void free_factor(gpt_ctx *c)
     if (c->dA) hipFree(c->dA);
     if (c->d_invd) hipFree(c->d_invd);
     if (c->d_y) hipFree(c->d_y);
-    if (c->d_erry) hipFree(c->d_erry);
+    if (c->h_yerr) hipHostFree(c->h_yerr);
+    c->h_yerr = nullptr;
     if (c->d_alpha) hipFree(c->d_alpha);
     c->dA = c->d_invd = c->d_y = c->d_erry = c->d_alpha = nullptr;
     c->NP = 0;
@@ -613,8 +615,9 @@ static int ensure_factor_storage(gpt_ctx *c, int64_t N)
     free_factor(c);
     GPT_HIP_CHECK(hipMalloc(&c->dA, (size_t)NP * NP * sizeof(double)));
     GPT_HIP_CHECK(hipMalloc(&c->d_invd, (size_t)(NP / 128) * GPT_WS_BLOCK * sizeof(double)));
-    GPT_HIP_CHECK(hipMalloc(&c->d_y, (size_t)NP * sizeof(double)));
-    GPT_HIP_CHECK(hipMalloc(&c->d_erry, (size_t)NP * sizeof(double)));
+    GPT_HIP_CHECK(hipMalloc(&c->d_y, (size_t)2 * NP * sizeof(double)));          // y | err_y, one upload per evaluation
+    c->d_erry = c->d_y + NP;
+    GPT_HIP_CHECK(hipHostMalloc((void **)&c->h_yerr, (size_t)2 * NP * sizeof(double), hipHostMallocDefault));
     GPT_HIP_CHECK(hipMalloc(&c->d_alpha, (size_t)NP * sizeof(double)));
     c->NP = NP;
     return GPT_OK;
@@ -634,9 +637,8 @@ static int factor_and_ll(gpt_ctx *c, int64_t N, double *ll_data_out, double *log
     if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[2], st));
     GPT_TRY(potrf_run(c, NP, c->dA, NP, c->d_invd, c->d_info));
     if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[3], st));
-    GPT_TRY(launch_logdet_dot(st, c->dA, NP, N, c->d_scal));
-    GPT_HIP_CHECK(hipMemcpyAsync(c->h_scal, c->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-    GPT_HIP_CHECK(hipMemcpyAsync(c->h_info, c->d_info, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GPT_TRY(launch_logdet_dot(st, c->dA, NP, N, c->d_info, c->d_scal));
+    GPT_HIP_CHECK(hipMemcpyAsync(c->h_scal, c->d_scal, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[4], st));
     GPT_HIP_CHECK(hipStreamSynchronize(st));
     if (c->gprof_used) GPT_TRY(harvest_gemm_profile(c));
@@ -650,7 +652,7 @@ static int factor_and_ll(gpt_ctx *c, int64_t N, double *ll_data_out, double *log
         c->timings[4] = ms;
     }
     c->alpha_valid = false;
-    const int32_t info = *c->h_info;
+    const int32_t info = (int32_t)c->h_scal[2];
     if (info != 0) {
         c->factored = false;
         if (info > N) {          // only the augmented / padding pivots failed: z.z overflowed
@@ -688,8 +690,9 @@ extern "C" int gpt_fit(gpt_ctx *c, int kernel_id, const double *params, int npar
     hipStream_t st = c->stream;
     c->factored = false;
     if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[0], st));
-    GPT_HIP_CHECK(hipMemcpyAsync(c->d_y, y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, st));
-    GPT_HIP_CHECK(hipMemcpyAsync(c->d_erry, err_y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, st));
+    memcpy(c->h_yerr, y, (size_t)N * sizeof(double));
+    memcpy(c->h_yerr + c->NP, err_y, (size_t)N * sizeof(double));
+    GPT_HIP_CHECK(hipMemcpyAsync(c->d_y, c->h_yerr, (size_t)(c->NP + N) * sizeof(double), hipMemcpyHostToDevice, st));
     if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[1], st));
     // The columns the first panel touches are built first so that its pivot chain overlaps the rest of the build.
     const int64_t NP = c->NP;

@@ -35,9 +35,11 @@ int launch_fill_pad(hipStream_t st, double *A, int64_t lda, int64_t n_valid, int
     return GPT_OK;
 }
 
-// out[0] = sum_{i<n} log A[i][i] ; out[1] = sum_{c<n} A[n][c]^2 (the augmented row z)
+// out[0] = sum_{i<n} log A[i][i] ; out[1] = sum_{c<n} A[n][c]^2 (the augmented row z) ; out[2] = *info, so that one
+// small device-to-host copy returns everything an LML evaluation needs
 __global__ __launch_bounds__(1024) void logdet_dot_kernel(const double *__restrict__ A, int64_t lda, int64_t n,
-                                                          int has_z, double *__restrict__ out)
+                                                          int has_z, const int32_t *__restrict__ info,
+                                                          double *__restrict__ out)
 {
     __shared__ double s0[16], s1[16];
     double a = 0.0, b = 0.0;
@@ -66,12 +68,13 @@ __global__ __launch_bounds__(1024) void logdet_dot_kernel(const double *__restri
         }
         out[0] = ta;
         out[1] = tb;
+        out[2] = info ? (double)*info : 0.0;
     }
 }
 
-int launch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_t n, double *d_out2)
+int launch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_t n, const int32_t *d_info, double *d_out3)
 {
-    hipLaunchKernelGGL(logdet_dot_kernel, dim3(1), dim3(1024), 0, st, A, lda, n, 1, d_out2);
+    hipLaunchKernelGGL(logdet_dot_kernel, dim3(1), dim3(1024), 0, st, A, lda, n, 1, d_info, d_out3);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }

@@ -388,6 +388,34 @@ def test_fit_matches_oracle(ctx, oracle, kern, N, d, deriv):
     np.testing.assert_allclose(c, cr, rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("kern", ["se", "m52"])
+def test_tiny_and_wide_inputs(ctx, oracle, kern):
+    """Edge shapes: one to a handful of points (every matrix is padding + the augmented row) and up to the
+    maximum input dimension (GPT_MAX_DIM = 16): ll, log|K|, alpha and predict against the oracle."""
+    rs = np.random.RandomState(5)
+    for N in (1, 2, 3, 17, 130):
+        for D in (1, 5, 16):
+            X = rs.rand(N, D)
+            n = np.zeros((N, D), dtype=np.int32)
+            if N > 2:
+                n[N - 1, D - 1] = 1
+            y = rs.randn(N)
+            err = 0.1 * np.ones(N)
+            p = np.concatenate(([1.3], 0.5 + rs.rand(D)))
+            ref = oracle.fit(kern, p, X, n, y, err, chol="c")
+            ctx.set_data(X, n)
+            ll, ld = ctx.fit(KID[kern], p, 0.0, y, err, 1e2 * EPS)
+            assert abs(ll - ref["ll_data"]) <= 1e-10 * max(1.0, abs(ref["ll_data"])), (N, D)
+            assert abs(ld - ref["logdet_half"]) <= 1e-10 * max(1.0, abs(ref["logdet_half"])), (N, D)
+            np.testing.assert_allclose(ctx.get_alpha(N), ref["alpha"].ravel(), rtol=1e-9, atol=1e-10)
+            Xs = rs.rand(3, D)
+            ns = np.zeros((3, D), dtype=np.int32)
+            m, s, c = ctx.predict(Xs, ns, 2)
+            mr, sr, cr = oracle.predict(kern, p, X, n, ref["L"], ref["alpha"], Xs, ns)
+            np.testing.assert_allclose(m, mr, rtol=0, atol=1e-9)
+            np.testing.assert_allclose(c, cr, rtol=0, atol=1e-9)
+
+
 def test_graph_capture_with_fresh_tile_tables(ctx):
     """hipGraph option at a size whose trailing updates need XCD tile-order tables that do not exist yet: the
     tables are uploaded while the stream is capturing.  Same ll as the eager schedule, twice (graph replay)."""
