@@ -50,7 +50,7 @@ struct gpt_ctx {
     std::vector<hipEvent_t> events;       // sync-only events (look-ahead fork/join)
     hipEvent_t tev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     // options
-    int64_t nb_outer = 512;
+    int64_t nb_outer = 0;              // outer block width; 0 = by size (outer_width())
     int lookahead = 1;
     int use_graph = 0;
     int timing = 0;
@@ -224,6 +224,15 @@ static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, 
     return rc;
 }
 
+// Outer block width of the factorisation.  Measured on MI355X (scratch/fit_loop.py): 384 wins while the panel chain
+// dominates (N=8192: 5.90 ms against 6.07 at 512 and 6.05 at 256; N=4096: 2.01 against 2.07), 512 once the trailing
+// updates do (N=16384: 30.9 ms against 31.9 at 384 and 32.0 at 640).
+static inline int64_t outer_width(const gpt_ctx *c, int64_t n)
+{
+    if (c->nb_outer > 0) return c->nb_outer;
+    return (n <= 12288) ? 384 : 512;
+}
+
 // Factor the block column Ap (m x w, diag block on top): recursive halving down to 128 columns.
 static int panel_rec(gpt_ctx *c, hipStream_t st, double *Ap, int64_t lda, int64_t m, int64_t w, double *invd,
                      int32_t *info, int64_t base)
@@ -271,7 +280,7 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
         gpt_set_error("potrf: n must be a multiple of 128 (n=%lld)", (long long)n);
         return GPT_E_ARG;
     }
-    const int64_t nbo = c->nb_outer;
+    const int64_t nbo = outer_width(c, n);
     const int64_t nblk = (n + nbo - 1) / nbo;
     hipStream_t S = c->stream, P = c->panel_stream;
     const bool la = c->lookahead && nblk > 1;
@@ -465,8 +474,8 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
 {
     if (!c || !key) return GPT_E_ARG;
     if (!strcmp(key, "nb_outer")) {
-        if (value < 128 || value % 128) {
-            gpt_set_error("nb_outer must be a positive multiple of 128");
+        if (value < 0 || value % 128) {
+            gpt_set_error("nb_outer must be 0 (chosen by size) or a positive multiple of 128");
             return GPT_E_ARG;
         }
         c->nb_outer = value;
@@ -698,7 +707,7 @@ extern "C" int gpt_fit(gpt_ctx *c, int kernel_id, const double *params, int npar
     const int64_t NP = c->NP;
     GPT_HIP_CHECK(hipMemsetAsync(c->d_info, 0, sizeof(int32_t), st));
     GPT_TRY(launch_fill_pad(st, c->dA, NP, N, NP, c->d_y, 1e300));
-    int64_t head = round_up(c->nb_outer + GPT_PANEL_EXT, 256);
+    int64_t head = round_up(outer_width(c, NP) + GPT_PANEL_EXT, 256);
     hipEvent_t e_head = nullptr;
     if (c->lookahead && !c->use_graph && head < N && (e_head = get_event(c, 0)) != nullptr) {
         GPT_TRY(launch_kbuild(st, kp, c->dX, c->dn, N, c->dX, c->dn, head, 1, 0, 0, c->d_erry, noise_var, diag_add,

@@ -60,7 +60,7 @@ const char *gpt_last_error(void);
  * caller's hipStream_t is used for all work (pass torch.cuda.current_stream().cuda_stream). */
 int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out);
 int gpt_ctx_destroy(gpt_ctx *ctx);
-/* Options: "nb_outer" (outer block width, multiple of 128), "lookahead" (0/1), "graph" (0/1:
+/* Options: "nb_outer" (outer block width, multiple of 128; 0 = chosen by size: 384 up to n = 12288, 512 above), "lookahead" (0/1), "graph" (0/1:
  * replay the factorisation from a captured hipGraph), "timing" (0/1: record per-phase HIP
  * events), "profile_gemm" (0/1: HIP-event timing of each large GEMM launch, see
  * gpt_gemm_profile_read), "tile" (0 auto, 64, 128: force the GEMM macro-tile). */
