@@ -42,19 +42,21 @@ print("\n".join(lines))
 
 # ---- HBM traffic per large trailing-update launch (the launches bench.py's roofline line times: >= 1 GFLOP, i.e. the
 # rank-512 updates on the main stream's queue with >= 240 workgroups) ----
+K_OUTER = 384            # outer block width the library picks at N=8192
+MIN_GRID = -(-10**9 // (2 * K_OUTER * 64 * 64)) * 256     # threads of a launch with >= 1 GFLOP (64x64 tiles, 256 threads)
 def big_launch_bytes(path, counter):
     rows = list(csv.DictReader(open(path)))
     mainq = [r['Queue_Id'] for r in rows if 'kbuild_kernel' in r['Kernel_Name']][0]
     per = collections.defaultdict(float)
     for r in rows:
         if r['Counter_Name'] == counter and 'gemm_nt_kernel' in r['Kernel_Name'] and r['Queue_Id'] == mainq \
-                and int(r['Grid_Size']) >= 61440:
+                and int(r['Grid_Size']) >= MIN_GRID:
             per[r['Dispatch_Id']] += float(r['Counter_Value'])
     return len(per), sum(per.values()) * 1024.0
 nf, fb = big_launch_bytes(src + '/pmc_fetch/t_counter_collection.csv', 'FETCH_SIZE')
 nw, wb = big_launch_bytes(src + '/pmc_write/t_counter_collection.csv', 'WRITE_SIZE')
 tj = {"round": 1, "kernel": "gemm_nt_kernel<64,64>",
-      "launch_filter": "main-stream queue, Grid_Size >= 61440 threads (the >= 1 GFLOP rank-512 trailing updates)",
+      "launch_filter": "main-stream queue, Grid_Size >= %d threads (the >= 1 GFLOP rank-%d trailing updates)" % (MIN_GRID, K_OUTER),
       "launches": nf, "fetch_bytes_per_launch_x2_corrected": 2 * fb / nf, "write_bytes_per_launch": wb / nw,
       "hbm_bytes_per_launch": 2 * fb / nf + wb / nw,
       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, scratch/prof_all.sh); FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md"}
