@@ -26,6 +26,7 @@ import scipy.linalg
 import scipy.optimize
 
 from . import _lib
+from . import replicas
 from .error_handling import GPArgumentError, GPImpossibleParamsError
 from .kernel import Kernel, ZeroKernel, DiagonalNoiseKernel
 from .utils import CombinedBounds
@@ -453,8 +454,10 @@ class GaussianProcess(object):
                                  num_proc=None, max_tries=1):
         """Maximise the log-posterior with ``scipy.optimize.minimize`` from ``random_starts`` draws
         of the hyperprior (0: start from the current values).  Every objective evaluation is one GPU
-        fit.  ``num_proc`` is accepted for compatibility; starts run one after another because a
-        HIP context must not be shared across forked workers."""
+        fit.  ``num_proc`` is accepted for compatibility: a HIP context must not be shared across forked
+        workers, so inside one process the starts run one after another; under a ``torch.distributed`` job
+        (one process per GPU) they are spread over the ranks instead (``gptools_amd.replicas``) and every
+        rank returns the same best result."""
         opt_kwargs = dict(opt_kwargs or {})
         if "method" in opt_kwargs:
             method = opt_kwargs["method"]
@@ -495,7 +498,12 @@ class GaussianProcess(object):
             if trial >= 1 and random_starts != 0:
                 param_samples = draw()
             trial += 1
-            res = [r for r in (run(s) for s in param_samples) if r is not None]
+            if replicas.world_size() > 1 and len(param_samples) > 1:
+                # one start per GPU: the ranks of the torch.distributed job replace the reference's process pool
+                param_samples = replicas.shared(np.asarray(param_samples))
+                res = [r for r in replicas.distributed_map(run, list(param_samples)) if r is not None]
+            else:
+                res = [r for r in (run(s) for s in param_samples) if r is not None]
             finite = [r for r in res if np.isfinite(r.fun)]
             res_min = min(finite, key=lambda r: r.fun) if finite else None
         if res_min is None:

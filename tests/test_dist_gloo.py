@@ -151,3 +151,55 @@ def test_distributed_not_positive_definite_raises_on_every_rank():
     out = _run(2, 300, 2, 128, 0, True, bad=True)
     for rank, res, _, _ in out:
         assert res[0] == "LinAlgError" and "not positive definite" in res[1]
+
+
+# ---- replicas: independent items over the ranks (gptools_amd/replicas.py) ------------------------------------
+def _replica_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gptools_amd import replicas
+        draws = replicas.shared(np.random.RandomState(100 + rank).rand(7, 2))    # rank 0's draws everywhere
+        seen = []
+
+        def f(x):
+            seen.append(float(x[0]))
+            return {"rank": rank, "val": float(x.sum()) ** 2}
+        out = replicas.distributed_map(f, list(draws))
+        try:
+            replicas.distributed_map(lambda x: 1 // (0 if x == 4 else 1), range(6))    # item 4 belongs to rank 1
+            err = None
+        except RuntimeError as e:
+            err = str(e)
+        q.put((rank, draws, out, len(seen), err))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replicas_map_over_ranks():
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replica_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref_draws = np.random.RandomState(100).rand(7, 2)
+    for rank, draws, res, nseen, err in out:
+        np.testing.assert_array_equal(draws, ref_draws)                 # everyone works on rank 0's draws
+        assert [r["rank"] for r in res] == [i % world for i in range(7)]  # round-robin ownership
+        np.testing.assert_allclose([r["val"] for r in res], ref_draws.sum(1) ** 2)
+        assert nseen == len(range(rank, 7, world))                      # each item evaluated exactly once
+        assert err is not None and "ZeroDivisionError" in err           # a failure surfaces on every rank
+
+
+def test_replicas_single_process_is_plain_map():
+    from gptools_amd import replicas
+    assert replicas.world_size() == 1
+    assert replicas.shared({"a": 1}) == {"a": 1}
+    assert replicas.distributed_map(lambda v: v * v, [1, 2, 3]) == [1, 4, 9]

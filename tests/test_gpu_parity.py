@@ -558,3 +558,52 @@ def test_distributed_plan_rccl_single_rank(oracle):
         assert abs(float(v[0]) - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"])
         assert abs(float(v[1]) - ref["logdet_half"]) <= 1e-10 * abs(ref["logdet_half"])
     assert len(vals) == 2
+
+
+def test_replicated_random_starts_two_ranks_one_gpu():
+    """SURVEY 8f-2 / the reference's pool over random starts (gaussian_process.py:723-735): two gloo ranks, both on
+    cuda:0, split four starts of optimize_hyperparameters; both return the same optimum, equal to the one a single
+    process finds from the same draws."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, json, warnings, numpy as np\n"
+        "warnings.simplefilter('ignore')\n"
+        "sys.path.insert(0, %r)\n"
+        "rank, world = int(sys.argv[1]), int(sys.argv[2])\n"
+        "if world > 1:\n"
+        "    import torch.distributed as dist\n"
+        "    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29519')\n"
+        "    dist.init_process_group('gloo', rank=rank, world_size=world)\n"
+        "import gptools_amd as g\n"
+        "rs = np.random.RandomState(3)\n"
+        "X = rs.rand(300, 2); y = np.sin(3 * X.sum(1)) + 0.05 * rs.randn(300)\n"
+        "k = g.SquaredExponentialKernel(num_dim=2, initial_params=[1.0, 0.5, 0.5], param_bounds=[(0.05, 10.0)] * 3)\n"
+        "gp = g.GaussianProcess(k, X=X, y=y, err_y=0.05)\n"
+        "np.random.seed(11)                       # the draws come from numpy's global state: same on every rank\n"
+        "res, nres = gp.optimize_hyperparameters(method='L-BFGS-B', random_starts=4, opt_kwargs={'options': {'maxiter': 30}})\n"
+        "print('RESULT', json.dumps({'rank': rank, 'fun': float(res.fun), 'x': [float(v) for v in res.x], 'n': nres,\n"
+        "                            'params': [float(v) for v in gp.free_params[:]]}))\n"
+        "if world > 1: dist.destroy_process_group()\n"
+    ) % root
+
+    def launch(rank, world):
+        return subprocess.Popen([sys.executable, "-c", code, str(rank), str(world)], stdout=subprocess.PIPE,
+                                stderr=subprocess.PIPE, text=True)
+
+    def result(proc):
+        out, err = proc.communicate(timeout=600)
+        assert proc.returncode == 0, err[-2000:]
+        return json.loads([l for l in out.splitlines() if l.startswith("RESULT")][-1].split(" ", 1)[1])
+
+    import json
+    single = result(launch(0, 1))
+    procs = [launch(r, 2) for r in range(2)]
+    r0, r1 = sorted((result(p) for p in procs), key=lambda d: d["rank"])
+    assert r0["n"] == r1["n"] == single["n"] == 4
+    assert r0["fun"] == r1["fun"] and r0["x"] == r1["x"]                 # every rank ends with the same optimum
+    assert abs(r0["fun"] - single["fun"]) <= 1e-9 * abs(single["fun"])    # ... the one a single process finds
+    np.testing.assert_allclose(r0["x"], single["x"], rtol=1e-6)
+    np.testing.assert_allclose(r0["params"], r0["x"], rtol=0, atol=0)     # and the GP is left at it
