@@ -713,8 +713,9 @@ extern "C" int gpt_fit(gpt_ctx *c, int kernel_id, const double *params, int npar
         GPT_TRY(launch_kbuild(st, kp, c->dX, c->dn, N, c->dX, c->dn, head, 1, 0, 0, c->d_erry, noise_var, diag_add,
                               c->dA, NP));
         GPT_HIP_CHECK(hipEventRecord(e_head, st));
-        GPT_TRY(launch_kbuild(st, kp, c->dX, c->dn, N, c->dX + head * c->D, c->dn + head * c->D, N - head, 1, 0, head,
-                              c->d_erry, noise_var, diag_add, c->dA + head, NP));
+        GPT_TRY(launch_kbuild(st, kp, c->dX + head * c->D, c->dn + head * c->D, N - head, c->dX + head * c->D,
+                              c->dn + head * c->D, N - head, 1, head, head, c->d_erry, noise_var, diag_add,
+                              c->dA + head * NP + head, NP));
     } else {
         GPT_TRY(launch_kbuild(st, kp, c->dX, c->dn, N, c->dX, c->dn, N, 1, 0, 0, c->d_erry, noise_var, diag_add, c->dA,
                               NP));
