@@ -1014,6 +1014,15 @@ extern "C" int gpt_dev_gemm_nt(gpt_ctx *c, int64_t m, int64_t n, int64_t k, doub
     return gemm_nt(c, c->stream, m, n, k, alpha, dA, lda, dB, ldb, beta, dC, ldc, tri);
 }
 
+extern "C" int gpt_dev_gemm_nt_stair(gpt_ctx *c, int64_t m, int64_t nseg, int64_t seg_cols, int64_t k, double alpha,
+                                     const double *dA, int64_t lda, const double *dB, int64_t ldb, int64_t b_stride,
+                                     int64_t row_step, double beta, double *dC, int64_t ldc)
+{
+    CTX_ENTER(c);
+    return launch_gemm_nt_stair(c->stream, m, nseg, seg_cols, k, alpha, dA, lda, dB, ldb, b_stride, row_step, beta, dC,
+                                ldc, 0);
+}
+
 extern "C" int gpt_dev_potrf_panel(gpt_ctx *c, int64_t m, int64_t nb, double *dA, int64_t lda, double *d_invd,
                                    int32_t *d_info, int64_t info_base)
 {

@@ -138,7 +138,7 @@ template <int BM, int BN, int WPS, int NSTAGE>
 __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     int64_t m, int64_t n, int64_t k, double alpha, const double *__restrict__ A, int64_t lda,
     const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
-    int tri, int64_t ntm, int64_t ntn, int64_t nwg, const int2 *__restrict__ order)
+    int tri, int64_t ntm, int64_t ntn, int64_t nwg, const int2 *__restrict__ order, int64_t seg_cols, int64_t bskip)
 {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int RM = WM / 16, RN = WN / 16;
@@ -167,7 +167,10 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
 
     const double *srcA[BM / 32], *srcB[BN / 32];
     stage_ptrs<BM>(A, lda, row0, m, wave, lane, srcA);
-    stage_ptrs<BN>(B, ldb, col0, n, wave, lane, srcB);
+    // "staircase" launches (block-cyclic column segments): the B rows of column segment q start bskip rows further
+    // down per segment; plain launches have seg_cols == 0
+    const int64_t brow0 = seg_cols ? col0 + (col0 / seg_cols) * bskip : col0;
+    stage_ptrs<BN>(B, ldb, brow0, seg_cols ? (int64_t)1 << 62 : n, wave, lane, srcB);
     const unsigned ldsA = lds_addr(&sA[0][0]), ldsB = lds_addr(&sB[0][0]);
     constexpr unsigned ABYTES = BM * GM_BK * sizeof(double), BBYTES = BN * GM_BK * sizeof(double);
     const int64_t nk = k / GM_BK;
@@ -357,20 +360,34 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_persist_kernel(
 struct TileOrder {
     int64_t ntm, ntn;
     int tri, dev;
+    int64_t seg_t, rss_t;          // staircase tables: tiles per column segment, row-start step per segment (tiles)
     int2 *d_tab;
     int64_t grid;
 };
 static std::vector<TileOrder> g_orders;
 static std::mutex g_orders_mu;
 
-static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64_t *grid)
+// tri == 2: staircase.  Column segment q = j / seg_t starts (its diagonal block) at tile row q * rss_t; tile (i, j) is
+// needed iff i >= q * rss_t + (j - q * seg_t).
+static inline bool tile_needed(int tri, int64_t i, int64_t j, int64_t seg_t, int64_t rss_t)
+{
+    if (tri == 1) return j <= i;
+    if (tri == 2) {
+        const int64_t q = j / seg_t;
+        return i >= q * rss_t + (j - q * seg_t);
+    }
+    return true;
+}
+
+static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64_t *grid, int64_t seg_t = 0,
+                      int64_t rss_t = 0)
 {
     constexpr int SG = 8;
     int dev = 0;
     GPT_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_orders_mu);
     for (const auto &o : g_orders)
-        if (o.ntm == ntm && o.ntn == ntn && o.tri == tri && o.dev == dev) {
+        if (o.ntm == ntm && o.ntn == ntn && o.tri == tri && o.dev == dev && o.seg_t == seg_t && o.rss_t == rss_t) {
             *tab = o.d_tab;
             *grid = o.grid;
             return GPT_OK;
@@ -380,12 +397,11 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
     int64_t sidx = 0;
     for (int64_t si = 0; si < sm; si++)
         for (int64_t sj = 0; sj < sn; sj++) {
-            if (tri && sj > si) continue;
             std::vector<int2> &dst = per[sidx % 8];
             bool any = false;
             for (int64_t i = si * SG; i < (si + 1) * SG && i < ntm; i++)
                 for (int64_t j = sj * SG; j < (sj + 1) * SG && j < ntn; j++) {
-                    if (tri && j > i) continue;
+                    if (!tile_needed(tri, i, j, seg_t, rss_t)) continue;
                     dst.push_back(make_int2((int)i, (int)j));
                     any = true;
                 }
@@ -401,6 +417,8 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
     o.ntn = ntn;
     o.tri = tri;
     o.dev = dev;
+    o.seg_t = seg_t;
+    o.rss_t = rss_t;
     o.grid = (int64_t)flat.size();
     o.d_tab = nullptr;
     GPT_HIP_CHECK(hipMalloc(&o.d_tab, flat.size() * sizeof(int2)));
@@ -423,16 +441,22 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
 template <int BM, int BN, int WPS, int NSTAGE>
 static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A,
                          int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri,
-                         int lds_pad, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr)
+                         int lds_pad, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int64_t seg_cols = 0,
+                         int64_t bskip = 0, int64_t row_step = 0)
 {
     const int64_t ntm = (m + BM - 1) / BM, ntn = (n + BN - 1) / BN;
-    int64_t nwg = tri ? ntn * (ntn + 1) / 2 + (ntm - ntn) * ntn : ntm * ntn;
+    int64_t nwg = (tri == 1) ? ntn * (ntn + 1) / 2 + (ntm - ntn) * ntn : ntm * ntn;
     const int2 *order = nullptr;
-    if (nwg >= 512) {                      // large launches only: small ones live in L2 anyway
+    if (tri == 2) {                        // staircase: the tile list always comes from a table
+        int64_t grid = 0;
+        GPT_TRY_RC(tile_order(ntm, ntn, 2, &order, &grid, seg_cols / BN, row_step / BM));
+        nwg = grid;
+    } else if (nwg >= 512) {               // large launches only: small ones live in L2 anyway
         int64_t grid = 0;
         GPT_TRY_RC(tile_order(ntm, ntn, tri, &order, &grid));
         nwg = grid;
     }
+    if (nwg <= 0) return GPT_OK;
     // lds_pad bytes of unused dynamic LDS cap the residency of the 64x64 kernel (32 KiB static): the trailing
     // update on the main stream asks for 8 KiB -> three workgroups per CU, leaving 40 KiB of LDS and over 40 % of the
     // register file on every CU to the high-priority panel stream (whose own GEMMs and TRSMs need 32 / 9 KiB).
@@ -441,10 +465,10 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
     // would add two barrier packets per launch to the stream being measured
     if (ev0 || ev1)
         hipExtLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg), dim3(256), dyn, st, ev0, ev1, 0,
-                              m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order);
+                              m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip);
     else
         hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg), dim3(256), dyn, st, m, n, k, alpha,
-                           A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order);
+                           A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
@@ -498,4 +522,24 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
     // DMA wait, so everything uses the 2-stage kernel.
     if (force_tile == 65) return gemm_launch_t<64, 64, 1, 4>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0);
     return gemm_launch_t<64, 64, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, lds_pad, ev0, ev1);
+}
+
+// Staircase update: C (m x nseg*seg_cols) += alpha * A B_q^T per column segment q, where segment q (seg_cols
+// columns of C) takes its B rows from B + q * b_stride rows and only its rows >= q * row_step are touched, lower
+// trapezoid inside (its "diagonal block" sits at row q * row_step).  This is the shape of a block-cyclic rank's
+// trailing update -- its block columns are adjacent in local storage but W * nb apart in the global matrix -- done in
+// ONE launch (one tail, one XCD-aware tile order) instead of one launch per block column.
+int launch_gemm_nt_stair(hipStream_t st, int64_t m, int64_t nseg, int64_t seg_cols, int64_t k, double alpha,
+                         const double *A, int64_t lda, const double *B, int64_t ldb, int64_t b_stride, int64_t row_step,
+                         double beta, double *C, int64_t ldc, int lds_pad)
+{
+    if (m <= 0 || nseg <= 0) return GPT_OK;
+    if (alpha == 0.0 || k <= 0 || (k % GM_BK) != 0 || (lda & 1) || (ldb & 1) || ((uintptr_t)A & 15) ||
+        ((uintptr_t)B & 15) || seg_cols <= 0 || (seg_cols % 64) || (row_step % 64) || b_stride < seg_cols) {
+        gpt_set_error("gemm_nt_stair: bad arguments (k multiple of %d, seg_cols / row_step multiples of 64, 16-byte "
+                      "aligned operands)", GM_BK);
+        return GPT_E_ARG;
+    }
+    return gemm_launch_t<64, 64, 2, 2>(st, m, nseg * seg_cols, k, alpha, A, lda, B, ldb, beta, C, ldc, 2, lds_pad, nullptr,
+                                       nullptr, seg_cols, b_stride - seg_cols, row_step);
 }

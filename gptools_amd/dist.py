@@ -63,6 +63,13 @@ class PanelOps(object):
     def synchronize(self):
         pass
 
+    def gemm_nt_stair(self, m, nseg, seg_cols, k, alpha, A, lda, B, ldb, b_stride, row_step, beta, C, ldc, q="main"):
+        """Default: one lower-trapezoid ``gemm_nt`` per column segment (8-byte elements)."""
+        for s in range(nseg):
+            r = s * row_step
+            self.gemm_nt(m - r, seg_cols, k, alpha, A + r * lda * 8, lda, B + s * b_stride * ldb * 8, ldb, beta,
+                         C + (r * ldc + s * seg_cols) * 8, ldc, 1, q=q)
+
 
 class _StreamEvent(object):
     def __init__(self):
@@ -126,6 +133,11 @@ class HipPanelOps(PanelOps):
     def gemm_nt(self, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, q="main"):
         _lib.check(self.lib.gpt_dev_gemm_nt(self._ctx[q].handle, m, n, k, float(alpha), A, lda, B, ldb, float(beta),
                                             C, ldc, int(tri)))
+
+    def gemm_nt_stair(self, m, nseg, seg_cols, k, alpha, A, lda, B, ldb, b_stride, row_step, beta, C, ldc, q="main"):
+        """All block columns a rank owns right of the panel in ONE launch (gpt_dev_gemm_nt_stair)."""
+        _lib.check(self.lib.gpt_dev_gemm_nt_stair(self._ctx[q].handle, m, nseg, seg_cols, k, float(alpha), A, lda, B, ldb,
+                                                  b_stride, row_step, float(beta), C, ldc))
 
 
 def _ptr(t, row, col):
@@ -243,6 +255,16 @@ class DistributedLML(object):
             C, ldc = _ptr(A, J * nb, lj * nb), A.stride(0)
         self.ops.gemm_nt(mJ, nb, nb, -1.0, _ptr(buf, off, 0), nb, _ptr(buf, off, 0), nb, 1.0, C, ldc, 1, q=q)
 
+    def _update_blocks(self, k, Js, buf):
+        """Panel k applied to the owned block columns ``Js`` (ascending, adjacent in local storage, ``world`` apart in
+        the matrix) in one staircase launch: segment s is block column Js[0] + s * world."""
+        nb, A, W = self.nb, self.A, self.world
+        J0 = Js[0]
+        assert all(J == J0 + s * W for s, J in enumerate(Js))
+        off = (J0 - k) * nb
+        self.ops.gemm_nt_stair(self.NP - J0 * nb, len(Js), nb, nb, -1.0, _ptr(buf, off, 0), nb, _ptr(buf, off, 0), nb,
+                               W * nb, W * nb, 1.0, _ptr(A, J0 * nb, (J0 // W) * nb), A.stride(0), q="main")
+
     def fit(self, kernel_id, params, y, err_y, noise_var=0.0, diag_factor=1e2):
         """One LML evaluation; returns ``(ll_data, logdet_half)`` on every rank.
 
@@ -313,8 +335,8 @@ class DistributedLML(object):
                     mine.remove(urgent)
                     ev_urg[k] = ops.new_event()
                     ev_urg[k].record()
-                for J in mine:
-                    self._update_block(k, J, buf)
+                if mine:
+                    self._update_blocks(k, mine, buf)
                 ev_done[k] = ops.new_event()
                 ev_done[k].record()
             if nxt < nblk and not la:

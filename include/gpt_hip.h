@@ -178,6 +178,15 @@ int gpt_dev_kbuild(gpt_ctx *ctx, int kernel_id, const double *params_host, int n
 int gpt_dev_gemm_nt(gpt_ctx *ctx, int64_t m, int64_t n, int64_t k, double alpha,
                     const double *dA, int64_t lda, const double *dB, int64_t ldb,
                     double beta, double *dC, int64_t ldc, int tri);
+/* Block-cyclic trailing update in one launch: C (m x nseg*seg_cols, ldc) += alpha * A * B_q^T + beta-scaled C, where
+ * column segment q (seg_cols columns) uses the B rows starting at row q * b_stride and only its rows >= q * row_step
+ * are updated (lower trapezoid inside the segment; its diagonal block sits at row q * row_step).  With A = B = the
+ * received panel this applies panel k to all block columns a rank owns to the right of it (they are adjacent in the
+ * rank's storage, world * nb apart in the matrix): gptools_amd/dist.py, SURVEY.md section 8e.
+ * seg_cols, row_step multiples of 64; k a multiple of 16; b_stride >= seg_cols. */
+int gpt_dev_gemm_nt_stair(gpt_ctx *ctx, int64_t m, int64_t nseg, int64_t seg_cols, int64_t k, double alpha,
+                          const double *dA, int64_t lda, const double *dB, int64_t ldb, int64_t b_stride,
+                          int64_t row_step, double beta, double *dC, int64_t ldc);
 
 /* Factor one block column ("panel"): A is (m x nb), its top nb x nb block is the diagonal block.
  * On exit the top block holds L_kk (lower) and the rows below hold A21 * L_kk^-T.  d_invd:

@@ -417,6 +417,36 @@ def test_tiny_and_wide_inputs(ctx, oracle, kern):
             np.testing.assert_allclose(c, cr, rtol=0, atol=1e-9)
 
 
+def test_staircase_update_against_numpy():
+    """gpt_dev_gemm_nt_stair (the block-cyclic trailing update in one launch) on torch tensors against numpy:
+    every column segment gets C -= P[rows] P[segment rows]^T on and below its own diagonal block, nothing above."""
+    import torch
+    from gptools_amd.dist import HipPanelOps
+    ops = HipPanelOps(0)
+    rs = np.random.RandomState(2)
+    for (nb, W, nseg, k, tail) in ((128, 2, 3, 128, 64), (256, 3, 2, 256, 0), (512, 8, 2, 512, 1024)):
+        m = (nseg - 1) * W * nb + nb + tail               # rows from the first segment's diagonal block down
+        P = rs.randn(m, k)
+        C0 = rs.randn(m, nseg * nb)
+        with ops.queue("main"):
+            dP = torch.from_numpy(P).cuda()
+            dC = torch.from_numpy(C0).cuda()
+            ops.gemm_nt_stair(m, nseg, nb, k, -1.0, dP.data_ptr(), k, dP.data_ptr(), k, W * nb, W * nb, 1.0,
+                              dC.data_ptr(), nseg * nb)
+            got = dC.cpu().numpy()
+        ops.synchronize()
+        for s_ in range(nseg):
+            r0 = s_ * W * nb
+            ref = C0[r0:, s_ * nb:(s_ + 1) * nb] - P[r0:].dot(P[r0:r0 + nb].T)
+            blk = got[r0:, s_ * nb:(s_ + 1) * nb]
+            low = np.tril(np.ones((nb, nb), bool))
+            np.testing.assert_allclose(blk[:nb][low], ref[:nb][low], rtol=0, atol=1e-11 * k)      # diagonal block: lower part
+            np.testing.assert_allclose(blk[nb:], ref[nb:], rtol=0, atol=1e-11 * k)
+            # rows above a segment's diagonal block belong to other ranks' work: never touched (64x64 tile granularity
+            # may rewrite the strictly-upper part of the diagonal tiles only)
+            np.testing.assert_array_equal(got[:r0, s_ * nb:(s_ + 1) * nb], C0[:r0, s_ * nb:(s_ + 1) * nb])
+
+
 def test_graph_capture_with_fresh_tile_tables(ctx):
     """hipGraph option at a size whose trailing updates need XCD tile-order tables that do not exist yet: the
     tables are uploaded while the stream is capturing.  Same ll as the eager schedule, twice (graph replay)."""
