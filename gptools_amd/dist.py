@@ -153,12 +153,16 @@ class DistributedLML(object):
     raises ``numpy.linalg.LinAlgError`` if K_tot is not positive definite.
     """
 
-    def __init__(self, X, n, nb=512, group=None, ops=None, device=None, lookahead=True):
+    def __init__(self, X, n, nb=512, group=None, ops=None, device=None, lookahead=True, layout=None):
         if nb <= 0 or nb % 128:
             raise ValueError("nb must be a positive multiple of 128")
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if layout is not None:
+            # (rank, world) of the block-cyclic layout given explicitly: a subclass then supplies ``_bcast`` /
+            # ``_allreduce`` itself (scratch/sim_ranks.py replays one rank's schedule of an 8-rank job on one GPU)
+            self.rank, self.world = layout
         if ops is None:
             ops = HipPanelOps(0 if device is None else device)
         self.ops = ops
@@ -215,6 +219,9 @@ class DistributedLML(object):
             return None
         gsrc = dist.get_global_rank(self.group, src) if self.group is not None else src
         return dist.broadcast(buf, src=gsrc, group=self.group, async_op=async_op)
+
+    def _allreduce(self, t, op):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX, group=self.group)
 
     def _stage_panel(self, k, buf):
         """Owner side: copy block column k (every update before panel k-1 applied) into the contiguous panel
@@ -358,8 +365,8 @@ class DistributedLML(object):
             if world > 1 or self.force_collectives:
                 # info: non-zero on the owner of the failing panel only; max picks it up
                 info_t = red[2:3].clone()
-                dist.all_reduce(red[:2], op=dist.ReduceOp.SUM, group=self.group)
-                dist.all_reduce(info_t, op=dist.ReduceOp.MAX, group=self.group)
+                self._allreduce(red[:2], "sum")
+                self._allreduce(info_t, "max")
                 red[2] = info_t[0]
             logdet_half, zz, info = (float(v) for v in red.cpu())
         ops.synchronize()

@@ -1,0 +1,62 @@
+"""Compute-side bound of the 8-GPU factorisation, measured on ONE GPU: replay the schedule of one rank of a W-rank
+block-cyclic job with every panel that rank does not own injected (device-to-device copy of the true panel, i.e. an
+infinitely fast interconnect).  What is timed is exactly the GPU work rank r would do: its K columns, its panels, its
+staircase updates.  max_r T_r is a lower bound of the W-GPU time; the gap to the real time is broadcast + chain stalls.
+
+  python scratch/sim_ranks.py c4 8        # workload, world size
+"""
+import sys, time, numpy as np, torch
+sys.path.insert(0, '/root/repo')
+import bench
+from gptools_amd.dist import DistributedLML, HipPanelOps
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "c4"
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+ranks = [int(v) for v in sys.argv[3:]] or list(range(W))
+kernel, N, d, deriv = bench.WORKLOADS[wl]
+X, n, y, err, params = bench.synth(kernel, N, d, deriv)
+kid = bench.KID[kernel]
+ops = HipPanelOps(0)
+
+
+class Recorder(DistributedLML):
+    """World size 1, keeps a copy of every factored panel."""
+    def _factor_staged(self, k, buf):
+        DistributedLML._factor_staged(self, k, buf)
+        self.saved[k] = buf[:self.NP - k * self.nb].clone()
+
+
+class OneRank(DistributedLML):
+    """Rank r of W; foreign panels are copied in from the recorder."""
+    def _bcast(self, buf, src, async_op=False):
+        k = self.NP // self.nb - buf.shape[0] // self.nb          # panel index from the slice length
+        if src != self.rank:
+            buf.copy_(self.panels[k])
+        return None
+
+    def _allreduce(self, t, op):
+        pass
+
+
+rec = Recorder(X, n, nb=512, ops=ops)
+rec.saved = {}
+ll_ref, ld_ref = rec.fit(kid, params, y, err)
+t0 = time.perf_counter(); rec.saved = {}; rec.fit(kid, params, y, err); torch.cuda.synchronize(); t1 = time.perf_counter()
+print("world 1 (block-cyclic engine): %.1f ms" % ((t1 - t0) * 1e3))
+panels = rec.saved
+tot = []
+for r in ranks:
+    plan = OneRank(X, n, nb=512, ops=ops, layout=(r, W))
+    plan.force_collectives = True          # takes the world > 1 code path (scalar reduction included, as a no-op)
+    plan.panels = panels
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ll, ld = plan.fit(kid, params, y, err)
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    tot.append(min(ts))
+    print("rank %d of %d: %.1f ms (owns %d block columns)" % (r, W, min(ts) * 1e3, plan.nloc))
+    del plan
+T = max(tot)
+print("%s N=%d, %d ranks: max over ranks %.1f ms -> compute-side bound %.1f TFLOP/s = %.1f %% of %d x 78.6" % (
+    wl, N, W, T * 1e3, bench.flops_fit(N) / T * 1e-12, 100 * bench.flops_fit(N) / T * 1e-12 / (78.6 * W), W))
