@@ -5,6 +5,8 @@ import bench
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 ctx = _lib.Context(0)
+import os
+idle = [_lib.Context(0) for _ in range(int(os.environ.get("IDLE_CTX", "0")))]
 ctx.set_option("timing", 1)
 for a in sys.argv[3:]:
     k, v = a.split("=")

@@ -637,3 +637,33 @@ def test_replicated_random_starts_two_ranks_one_gpu():
     assert abs(r0["fun"] - single["fun"]) <= 1e-9 * abs(single["fun"])    # ... the one a single process finds
     np.testing.assert_allclose(r0["x"], single["x"], rtol=1e-6)
     np.testing.assert_allclose(r0["params"], r0["x"], rtol=0, atol=0)     # and the GP is left at it
+
+
+def test_compute_ll_matrix_batched_equals_sequential():
+    """compute_ll_matrix (ref gaussian_process.py:1607-1692) through the batched evaluator (two evaluations in flight
+    on the GPU) against one update_hyperparameters call per grid point; out-of-bounds points give -inf in both, the
+    GP's hyperparameters are restored, and data added afterwards reaches every pooled context."""
+    import warnings
+    import gptools_amd as g
+    rs = np.random.RandomState(8)
+    X = rs.rand(400, 2)
+    y = np.sin(3 * X.sum(1)) + 0.05 * rs.randn(400)
+    k = g.SquaredExponentialKernel(num_dim=2, initial_params=[1.0, 0.4, 0.6], fixed_params=[False, False, True],
+                                   param_bounds=[(0.2, 5.0), (0.05, 2.0), (0.05, 2.0)])
+    gp = g.GaussianProcess(k, X=X, y=y, err_y=0.05)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ll, pv = gp.compute_ll_matrix([(0.1, 3.0), (0.1, 1.0)], [4, 5])       # sigma_f = 0.1 lies outside its bounds
+        assert ll.shape == (4, 5) and len(pv) == 2
+        np.testing.assert_array_equal(gp.free_params[:], [1.0, 0.4])
+        seq = np.array([[-gp.update_hyperparameters([a, b]) for b in pv[1]] for a in pv[0]])
+        assert np.all(np.isneginf(ll[0])) and np.all(np.isneginf(seq[0]))
+        np.testing.assert_allclose(ll[1:], seq[1:], rtol=1e-12, atol=0)
+        gp.batch_concurrency = 1
+        ll1, _ = gp.compute_ll_matrix([(0.1, 3.0), (0.1, 1.0)], [4, 5])
+        np.testing.assert_allclose(ll1[1:], seq[1:], rtol=1e-12, atol=0)
+        gp.batch_concurrency = 2
+        gp.add_data(rs.rand(50, 2), rs.randn(50), err_y=0.05)
+        b = gp.ll_batch([[1.0, 0.4], [1.5, 0.3], [2.0, 0.2]])
+        s = np.array([-gp.update_hyperparameters(p) for p in ([1.0, 0.4], [1.5, 0.3], [2.0, 0.2])])
+        np.testing.assert_allclose(b, s, rtol=1e-12, atol=0)
