@@ -560,6 +560,38 @@ class GaussianProcess(object):
             t.join()
         return out
 
+    def _batched_fd(self, eps, bounds):
+        """``(fun, jac)`` for scipy.optimize.minimize: ``fun`` is ``update_hyperparameters``; ``jac`` is the
+        forward-difference gradient scipy would form itself (``approx_derivative(..., '2-point', abs_step=eps,
+        bounds=...)``), with the perturbed points evaluated through the batched evaluator.  scipy's routine is run
+        twice -- once to record the points it asks for, once on the cached values -- so step signs near bounds and
+        the rounding of ``(x + h) - x`` are exactly its own."""
+        from scipy.optimize._numdiff import approx_derivative
+        last = {}
+
+        def fun(x):
+            x = np.array(x, dtype=float)
+            v = self.update_hyperparameters(x)
+            last["x"], last["f"] = x, v
+            return v
+
+        def jac(x):
+            x = np.array(x, dtype=float)
+            f0 = last["f"] if ("x" in last and np.array_equal(last["x"], x)) else fun(x)
+            kw = dict(method="2-point", abs_step=eps, f0=f0, bounds=(bounds[:, 0], bounds[:, 1]))
+            pts = []
+            approx_derivative(lambda z: (pts.append(np.array(z, dtype=float)), 0.0)[1], x, **kw)
+            vals = -1.0 * self._ll_batch_local(pts, True)
+            nk, nn = len(self.k.free_params), len(self.noise_k.free_params)
+            self.k.set_hyperparams(x[:nk])                       # back to the expansion point
+            self.noise_k.set_hyperparams(x[nk:nk + nn])
+            if self.mu is not None:
+                self.mu.set_hyperparams(x[nk + nn:])
+            self.K_up_to_date = False
+            table = {p.tobytes(): v for p, v in zip(pts, vals)}
+            return approx_derivative(lambda z: table[np.array(z, dtype=float).tobytes()], x, **kw)
+        return fun, jac
+
     def compute_ll_matrix(self, bounds, num_pts):
         """Log-posterior over a regular grid of the free hyperparameters (ref: gptools/gaussian_process.py:1607-1692):
         returns ``(ll_vals, param_vals)`` with ``ll_vals.shape == num_pts``.  The reference walks the grid
@@ -586,7 +618,7 @@ class GaussianProcess(object):
 
     # ---- MAP estimate (ref: gptools/gaussian_process.py:623-783, :2443-2486) ------------------
     def optimize_hyperparameters(self, method="SLSQP", opt_kwargs={}, verbose=False, random_starts=None,
-                                 num_proc=None, max_tries=1):
+                                 num_proc=None, max_tries=1, batch_fd=None):
         """Maximise the log-posterior with ``scipy.optimize.minimize`` from ``random_starts`` draws
         of the hyperprior (0: start from the current values).  Every objective evaluation is one GPU
         fit.  ``num_proc`` is accepted for compatibility: a HIP context must not be shared across forked
@@ -619,9 +651,19 @@ class GaussianProcess(object):
         if self.use_hyper_deriv:
             opt_kwargs["jac"] = True
 
+        objective = self.update_hyperparameters
+        # Finite-difference gradients (what scipy does itself when no `jac` is given) through ll_batch: the p
+        # perturbed points of one gradient are independent evaluations, kept two in flight on the GPU.  The points
+        # and the difference formula are scipy's own (approx_derivative is replayed), so the iterates are the same.
+        fd_eps = {"L-BFGS-B": 1e-8, "TNC": 1e-8, "SLSQP": 1.4901161193847656e-08}
+        if (batch_fd is not False and int(self.batch_concurrency) > 1 and not self.use_hyper_deriv
+                and "jac" not in opt_kwargs and method in fd_eps and self._fast_fit_possible()):
+            eps = (opt_kwargs.get("options") or {}).get("eps", fd_eps[method])
+            objective, opt_kwargs["jac"] = self._batched_fd(eps, np.asarray(opt_kwargs["bounds"], dtype=float))
+
         def run(samp):
             try:
-                return scipy.optimize.minimize(self.update_hyperparameters, samp, **opt_kwargs)
+                return scipy.optimize.minimize(objective, samp, **opt_kwargs)
             except Exception:
                 if self.verbose:
                     warnings.warn("Minimizer failed, skipping sample. Error is: {:s}. State of params is: "

@@ -667,3 +667,27 @@ def test_compute_ll_matrix_batched_equals_sequential():
         b = gp.ll_batch([[1.0, 0.4], [1.5, 0.3], [2.0, 0.2]])
         s = np.array([-gp.update_hyperparameters(p) for p in ([1.0, 0.4], [1.5, 0.3], [2.0, 0.2])])
         np.testing.assert_allclose(b, s, rtol=1e-12, atol=0)
+
+
+def test_batched_finite_difference_map_matches_scipy_fd():
+    """optimize_hyperparameters with the batched forward-difference gradient (two perturbed evaluations in flight)
+    takes the same L-BFGS-B / SLSQP path as scipy's own finite differences: same points, same formula."""
+    import warnings
+    import gptools_amd as g
+    rs = np.random.RandomState(9)
+    X = rs.rand(500, 2)
+    y = np.sin(3 * X.sum(1)) + 0.05 * rs.randn(500)
+    for method in ("L-BFGS-B", "SLSQP"):
+        res = {}
+        for batch in (True, False):
+            k = g.SquaredExponentialKernel(num_dim=2, initial_params=[1.0, 0.5, 0.5], param_bounds=[(0.05, 10.0)] * 3)
+            gp = g.GaussianProcess(k, X=X, y=y, err_y=0.05)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                r, _ = gp.optimize_hyperparameters(method=method, random_starts=0, batch_fd=batch,
+                                                   opt_kwargs={"options": {"maxiter": 25}})
+            res[batch] = r
+        assert res[True].nit == res[False].nit, method
+        np.testing.assert_allclose(res[True].x, res[False].x, rtol=1e-9, err_msg=method)
+        np.testing.assert_allclose(res[True].fun, res[False].fun, rtol=1e-12, err_msg=method)
+        assert res[True].nfev < res[False].nfev          # the perturbed points no longer count as objective calls
