@@ -47,6 +47,8 @@ struct gpt_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t panel_stream = nullptr;
+    hipStream_t helper_stream = nullptr;   // CU-masked to part of the reserved CUs (own streams only)
+    int helper_cus = 0;
     std::vector<hipEvent_t> events;       // sync-only events (look-ahead fork/join)
     hipEvent_t tev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     // options
@@ -56,6 +58,8 @@ struct gpt_ctx {
     int timing = 0;
     int tile = 0;
     int gemm_pad = 1024;
+    int helper_tf = 35;                // assumed rate of the helper stream, in 0.1 TFLOP/s per 24 CUs (0 = no helper);
+                                       // measured: 0 / 25 / 35 / 50 -> 212 / 209 / 206 / 214 ms at N=32768, 30.8 / 30.6 / 30.2 / 32.0 at N=16384
     int ramp = 0;                      // first panels 128, 256, ... wide (see potrf_enqueue); measured slower, off
     hipEvent_t head_event = nullptr;   // set by gpt_fit: the first nb_outer+128 columns of K_tot are built (panel 0 may start)
     // resident training inputs
@@ -323,29 +327,70 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
             w += 128;
         }
     }
-    hipEvent_t e_cu_prev = nullptr;
-    int64_t c0 = 0;
+    // Helper: while the trailing updates dominate, the panel stream leaves its reserved CUs idle most of the time.
+    // The bottom-right triangle [s, n)^2 of the rank-w update of panel k therefore runs on H, a stream masked to
+    // those CUs (minus 8 that stay free for the diagonal-block kernel), concurrently with S's share; the split is
+    // sized by the two streams' rates so that they finish together.  The split column only moves right: a helper
+    // region lies inside the previous one, so H needs nothing but "panel k is final"; S waits for helper k before
+    // it next touches columns >= s.
+    // (only where the updates dominate: at n = 8192 the helper costs 0.5-1 %, at 16384 / 32768 it gains 2 / 3 %)
+    hipStream_t H = (c->helper_stream && !c->use_graph && c->helper_tf > 0 && n > 12288) ? c->helper_stream : nullptr;
+    const double rate_s = 46e12, rate_h = 1e11 * (double)c->helper_tf * (double)c->helper_cus / 24.0;
+    hipEvent_t e_cu_prev = nullptr, e_help_prev = nullptr;
+    int64_t c0 = 0, s_prev = 0;
     for (size_t k = 0; k < widths.size(); k++) {
         const int64_t w = widths[k];
         const int64_t wn = (k + 1 < widths.size()) ? widths[k + 1] : 0;      // width of the next panel
-        hipEvent_t e_panel = get_event(c, 2 + 2 * k), e_cu = get_event(c, 3 + 2 * k);
-        if (!e_panel || !e_cu) return GPT_E_HIP;
+        hipEvent_t e_panel = get_event(c, 2 + 4 * k), e_cu = get_event(c, 3 + 4 * k), e_help = get_event(c, 4 + 4 * k);
+        hipEvent_t e_sdone = get_event(c, 5 + 4 * k);
+        if (!e_panel || !e_cu || !e_help || !e_sdone) return GPT_E_HIP;
         GPT_TRY(panel_ext(c, P, A, lda, n, c0, w, invd, info, e_cu_prev, e_panel));
         e_cu_prev = nullptr;
         const int64_t u0 = c0 + w + GPT_PANEL_EXT;
         if (u0 < n) {
             // urgent: the columns panel k+1 touches beyond its first leaf, [c0' + 128, c0' + w' + 128)
             const int64_t u1 = (u0 + wn < n) ? u0 + wn : n;
+            int64_t split = n;                                        // S takes columns [u1, split), H [split, n)
+            if (H && u1 < n) {
+                const double side0 = (double)(n - u1);
+                int64_t side = (int64_t)(sqrt(rate_h / (rate_s + rate_h)) * side0) / 64 * 64;
+                if (n - side < s_prev) side = n - s_prev;
+                // worth a launch only while the update is large (>= ~10 GFLOP) and the slice a real triangle
+                if (side >= 1024 && n - side > u1 && (double)w * side0 * side0 >= 1e10) split = n - side;
+            }
+            if (split < n && !e_help_prev) {
+                // first helper (or first after a gap): its region was last written by S (K build / a whole update)
+                GPT_HIP_CHECK(hipEventRecord(e_sdone, S));
+                GPT_HIP_CHECK(hipStreamWaitEvent(H, e_sdone, 0));
+            }
             GPT_HIP_CHECK(hipStreamWaitEvent(S, e_panel, 0));
+            if (split < n) {
+                GPT_HIP_CHECK(hipStreamWaitEvent(H, e_panel, 0));
+                GPT_TRY(gemm_nt(c, H, n - split, n - split, w, -1.0, A + split * lda + c0, lda, A + split * lda + c0,
+                                lda, 1.0, A + split * lda + split, lda, 1, e_help));
+            }
+            bool waited = false;
+            if (e_help_prev && u1 > s_prev) {
+                GPT_HIP_CHECK(hipStreamWaitEvent(S, e_help_prev, 0));
+                waited = true;
+            }
             GPT_TRY(gemm_nt(c, S, n - u0, u1 - u0, w, -1.0, A + u0 * lda + c0, lda, A + u0 * lda + c0, lda, 1.0,
                             A + u0 * lda + u0, lda, 1, e_cu));
             e_cu_prev = e_cu;
-            if (u1 < n)
-                GPT_TRY(gemm_nt(c, S, n - u1, n - u1, w, -1.0, A + u1 * lda + c0, lda, A + u1 * lda + c0, lda, 1.0,
+            if (u1 < n) {
+                if (e_help_prev && !waited) GPT_HIP_CHECK(hipStreamWaitEvent(S, e_help_prev, 0));
+                e_help_prev = nullptr;
+                GPT_TRY(gemm_nt(c, S, n - u1, split - u1, w, -1.0, A + u1 * lda + c0, lda, A + u1 * lda + c0, lda, 1.0,
                                 A + u1 * lda + u1, lda, 1));
+                if (split < n) {
+                    s_prev = split;
+                    e_help_prev = e_help;
+                }
+            }
         }
         c0 += w;
     }
+    if (e_help_prev) GPT_HIP_CHECK(hipStreamWaitEvent(S, e_help_prev, 0));
     hipEvent_t e_end = get_event(c, 1);
     if (!e_end) return GPT_E_HIP;
     GPT_HIP_CHECK(hipEventRecord(e_end, P));
@@ -427,6 +472,18 @@ extern "C" int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out)
             for (int i = reserve; i < ncu; i++) mask[i / 32] |= (1u << (i % 32));
             masked = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()) == hipSuccess;
             if (!masked) (void)hipGetLastError();
+            // helper stream: the reserved CUs except the first 8 (those stay free for the diagonal-block kernel, which
+            // needs a whole CU's LDS).  While the trailing updates dominate, the panel stream leaves the reserved CUs
+            // idle most of the time; a slice of every update runs there (potrf_enqueue).
+            if (masked && reserve >= 16) {
+                std::vector<uint32_t> hm((ncu + 31) / 32, 0u);
+                for (int i = 8; i < reserve; i++) hm[i / 32] |= (1u << (i % 32));
+                if (hipExtStreamCreateWithCUMask(&c->helper_stream, (uint32_t)hm.size(), hm.data()) != hipSuccess) {
+                    (void)hipGetLastError();
+                    c->helper_stream = nullptr;
+                }
+                c->helper_cus = reserve - 8;
+            }
         }
         if (!masked) GPT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
@@ -484,6 +541,7 @@ extern "C" int gpt_ctx_destroy(gpt_ctx *c)
     if (c->h_scal) hipHostFree(c->h_scal);
     if (c->h_info) hipHostFree(c->h_info);
     hipStreamDestroy(c->panel_stream);
+    if (c->helper_stream) hipStreamDestroy(c->helper_stream);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return GPT_OK;
@@ -504,6 +562,7 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "profile_gemm")) c->prof_gemm = value ? 1 : 0;
     else if (!strcmp(key, "gemm_pad")) c->gemm_pad = (int)value;
     else if (!strcmp(key, "ramp")) c->ramp = value ? 1 : 0;
+    else if (!strcmp(key, "helper_tf")) c->helper_tf = (int)value;
     else if (!strcmp(key, "tile")) {
         if (value != 0 && value != 64 && value != 65 && value != 128 && value != 129) {
             gpt_set_error("tile must be 0, 64 or 128");
