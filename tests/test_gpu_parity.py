@@ -691,3 +691,33 @@ def test_batched_finite_difference_map_matches_scipy_fd():
         np.testing.assert_allclose(res[True].x, res[False].x, rtol=1e-9, err_msg=method)
         np.testing.assert_allclose(res[True].fun, res[False].fun, rtol=1e-12, err_msg=method)
         assert res[True].nfev < res[False].nfev          # the perturbed points no longer count as objective calls
+
+
+def test_helper_stream_schedule_agrees_with_sequential(ctx):
+    """Above n = 12288 a slice of every large trailing update runs on the helper stream (third HIP stream on the
+    reserved CUs).  Same ll / log|K| as the schedule without it and as the sequential (no look-ahead) schedule; the
+    factor reproduces K_tot."""
+    N, d = 12800, 2
+    X, n, y = c3_inputs(N, d)
+    n[:] = 0
+    p = np.array([1.0, 0.3, 0.3])
+    err = 0.05 * np.ones(N)
+    ctx.set_data(X, n)
+    try:
+        with_helper = ctx.fit(0, p, 0.0, y, err, 1e2 * EPS)
+        alpha = ctx.get_alpha(N)
+        ctx.set_option("helper_tf", 0)
+        without = ctx.fit(0, p, 0.0, y, err, 1e2 * EPS)
+        ctx.set_option("lookahead", 0)
+        seq = ctx.fit(0, p, 0.0, y, err, 1e2 * EPS)
+    finally:
+        ctx.set_option("helper_tf", 35)
+        ctx.set_option("lookahead", 1)
+    for other in (without, seq):
+        assert abs(with_helper[0] - other[0]) <= 1e-11 * abs(other[0])
+        assert abs(with_helper[1] - other[1]) <= 1e-12 * abs(other[1])
+    # K_tot alpha = y on a sample of rows (K rows rebuilt by the pair kernel)
+    rows = np.arange(0, N, 997)
+    Kr = ctx.kbuild(0, p, X[rows], n[rows], X, n)
+    Kr[np.arange(len(rows)), rows] += err[rows] ** 2 + 1e2 * EPS
+    np.testing.assert_allclose(Kr.dot(alpha), y[rows], rtol=0, atol=1e-7)
