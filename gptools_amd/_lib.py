@@ -35,6 +35,7 @@ SIGNATURES = {
     "gpt_kpairs": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, _dp, _ip, _ip, _i64, C.c_int, C.c_int, C.c_int, _ip, _dp]),
     "gpt_kbuild": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, _ip, _i64, _dp, _ip, _i64, C.c_int, C.c_int, _ip, _dp]),
     "gpt_set_data": (C.c_int, [_vp, _dp, _ip, _i64, C.c_int]),
+    "gpt_set_T": (C.c_int, [_vp, _dp, _i64]),
     "gpt_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, C.c_double, _dp, _dp]),
     "gpt_fit_matrix": (C.c_int, [_vp, _dp, _i64, _dp, _dp, _dp]),
     "gpt_get_L": (C.c_int, [_vp, _dp]),
@@ -204,6 +205,16 @@ class Context(object):
     def set_data(self, X, n):
         X, n = f64(X), i32(n)
         check(self._lib.gpt_set_data(self.handle, dptr(X), iptr(n), X.shape[0], X.shape[1]))
+
+    def set_T(self, T):
+        """Resident linear transform (Ny, N) for the data set given to set_data; ``None`` removes it."""
+        if T is None:
+            check(self._lib.gpt_set_T(self.handle, None, 0))
+            return
+        T = f64(T)
+        if T.ndim != 2:
+            raise ValueError("T must be 2-dimensional")
+        check(self._lib.gpt_set_T(self.handle, dptr(T), T.shape[0]))
 
     def fit(self, kernel_id, params, noise_var, y, err_y, diag_add):
         params, y, err_y = f64(params), f64(y), f64(err_y)

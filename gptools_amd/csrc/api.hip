@@ -40,7 +40,7 @@ struct DevBuf {
 };
 
 enum { SLOT_XI = 0, SLOT_XJ, SLOT_NI, SLOT_NJ, SLOT_OUT, SLOT_KST, SLOT_KSS, SLOT_XS, SLOT_NS, SLOT_VEC, SLOT_VEC2,
-       SLOT_RHS, SLOT_LOW, SLOT_COUNT };
+       SLOT_RHS, SLOT_LOW, SLOT_KFULL, SLOT_TK, SLOT_ZERO, SLOT_COUNT };
 
 struct gpt_ctx {
     int device = 0;
@@ -63,8 +63,11 @@ struct gpt_ctx {
     int ramp = 0;                      // first panels 128, 256, ... wide (see potrf_enqueue); measured slower, off
     hipEvent_t head_event = nullptr;   // set by gpt_fit: the first nb_outer+128 columns of K_tot are built (panel 0 may start)
     // resident training inputs
-    int64_t N = 0;
+    int64_t N = 0;             // order of the factorised matrix (= Nx without T, = Ny with T)
+    int64_t Nx = 0;            // resident points
     int D = 0;
+    double *dT = nullptr;      // linear transform T (Ny x Nx), zero-padded to (round_up(Ny,64) x round_up(Nx,16))
+    int64_t Ny = 0, NxP = 0;
     double *dX = nullptr;
     int32_t *dn = nullptr;
     // factorisation state
@@ -530,6 +533,7 @@ extern "C" int gpt_ctx_destroy(gpt_ctx *c)
     free_factor(c);
     if (c->dX) hipFree(c->dX);
     if (c->dn) hipFree(c->dn);
+    if (c->dT) hipFree(c->dT);
     for (auto &b : c->slots)
         if (b.p) hipFree(b.p);
     for (auto e : c->events) hipEventDestroy(e);
@@ -688,10 +692,43 @@ extern "C" int gpt_set_data(gpt_ctx *c, const double *X, const int32_t *n, int64
     GPT_HIP_CHECK(hipMemcpyAsync(c->dn, n, (size_t)N * D * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     GPT_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->N = N;
+    c->Nx = N;
     c->D = D;
     c->factored = false;
     c->alpha_valid = false;
     c->have_kernel = false;
+    if (c->dT) hipFree(c->dT);          // a transform belongs to one data set
+    c->dT = nullptr;
+    c->Ny = 0;
+    return GPT_OK;
+}
+
+// Linear transform of the latent values (ref: gptools/gaussian_process.py:376-503 `T`, :1443-1446): the observations are
+// y = T f(X) + noise, K_tot = T (K + noise_K) T^T + diag(err_y^2) + diag_add I  (Ny x Ny).  T stays resident until the
+// data change; T == NULL removes it.
+extern "C" int gpt_set_T(gpt_ctx *c, const double *T, int64_t Ny)
+{
+    CTX_ENTER(c);
+    if (!c->dX) {
+        gpt_set_error("gpt_set_T: call gpt_set_data first");
+        return GPT_E_STATE;
+    }
+    GPT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->dT) hipFree(c->dT);
+    c->dT = nullptr;
+    c->Ny = 0;
+    c->factored = false;
+    c->alpha_valid = false;
+    c->have_kernel = false;
+    if (!T || Ny <= 0) return GPT_OK;
+    const int64_t NyP = round_up(Ny, 64), NxP = round_up(c->Nx, 16);
+    GPT_HIP_CHECK(hipMalloc(&c->dT, (size_t)NyP * NxP * sizeof(double)));
+    GPT_HIP_CHECK(hipMemsetAsync(c->dT, 0, (size_t)NyP * NxP * sizeof(double), c->stream));
+    GPT_HIP_CHECK(hipMemcpy2DAsync(c->dT, (size_t)NxP * sizeof(double), T, (size_t)c->Nx * sizeof(double),
+                                   (size_t)c->Nx * sizeof(double), (size_t)Ny, hipMemcpyHostToDevice, c->stream));
+    GPT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->Ny = Ny;
+    c->NxP = NxP;
     return GPT_OK;
 }
 
@@ -771,7 +808,9 @@ extern "C" int gpt_fit(gpt_ctx *c, int kernel_id, const double *params, int npar
         gpt_set_error("gpt_fit: kernel_id must be SE or Matern52");
         return GPT_E_ARG;
     }
-    const int64_t N = c->N;
+    const int64_t Nx = c->Nx;
+    const int64_t N = c->dT ? c->Ny : Nx;          // order of K_tot
+    c->N = N;
     KParams kp;
     GPT_TRY(make_kparams(kernel_id, params, nparams, c->D, -1, 1, nullptr, &kp));
     GPT_TRY(ensure_factor_storage(c, N));
@@ -782,9 +821,30 @@ extern "C" int gpt_fit(gpt_ctx *c, int kernel_id, const double *params, int npar
     memcpy(c->h_yerr + c->NP, err_y, (size_t)N * sizeof(double));
     GPT_HIP_CHECK(hipMemcpyAsync(c->d_y, c->h_yerr, (size_t)(c->NP + N) * sizeof(double), hipMemcpyHostToDevice, st));
     if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[1], st));
-    // The columns the first panel touches are built first so that its pivot chain overlaps the rest of the build.
     const int64_t NP = c->NP;
     GPT_HIP_CHECK(hipMemsetAsync(c->d_info, 0, sizeof(int32_t), st));
+    if (c->dT) {
+        // ---- T path: K_tot = T (K + noise_var I) T^T + diag(err_y^2) + diag_add I, assembled on the device by the
+        // K-builder (full symmetric K over the Nx latent points) and two fp64-MFMA GEMMs (ref :1443-1451)
+        const int64_t NxP = c->NxP, NyP = round_up(N, 64);
+        double *dK, *dTK, *dzero;
+        GPT_TRY(ensure(c, SLOT_KFULL, (size_t)NxP * NxP * sizeof(double), (void **)&dK));
+        GPT_TRY(ensure(c, SLOT_TK, (size_t)NyP * NxP * sizeof(double), (void **)&dTK));
+        GPT_TRY(ensure(c, SLOT_ZERO, (size_t)Nx * sizeof(double), (void **)&dzero));
+        GPT_HIP_CHECK(hipMemsetAsync(dzero, 0, (size_t)Nx * sizeof(double), st));
+        if (NxP > Nx) GPT_HIP_CHECK(hipMemsetAsync(dK, 0, (size_t)NxP * NxP * sizeof(double), st));   // zero padding of k
+        // (K + noise_K): the builder's diagonal epilogue with err = 0, diag_add = 0 adds exactly noise_var
+        GPT_TRY(launch_kbuild(st, kp, c->dX, c->dn, Nx, c->dX, c->dn, Nx, 0, 0, 0, dzero, noise_var, 0.0, dK, NxP));
+        GPT_TRY(gemm_nt(c, st, NyP, NxP, NxP, 1.0, c->dT, NxP, dK, NxP, 0.0, dTK, NxP, 0));          // T K  (K = K^T)
+        GPT_TRY(gemm_nt(c, st, NyP, NyP, NxP, 1.0, dTK, NxP, c->dT, NxP, 0.0, c->dA, NP, 1));        // (T K) T^T, lower
+        GPT_TRY(launch_add_diag(st, c->dA, NP, N, c->d_erry, diag_add));
+        GPT_TRY(launch_fill_pad(st, c->dA, NP, N, NP, c->d_y, 1e300));
+        c->kp = kp;
+        c->have_kernel = true;
+        c->head_event = nullptr;
+        return factor_and_ll(c, N, ll_data_out, logdet_half_out, true);
+    }
+    // The columns the first panel touches are built first so that its pivot chain overlaps the rest of the build.
     GPT_TRY(launch_fill_pad(st, c->dA, NP, N, NP, c->d_y, 1e300));
     int64_t head = round_up((c->ramp ? 128 : outer_width(c, NP)) + GPT_PANEL_EXT, 256);   // what panel 0 touches
     hipEvent_t e_head = nullptr;
@@ -929,6 +989,7 @@ extern "C" int gpt_predict(gpt_ctx *c, const double *Xstar, const int32_t *nstar
     if (M > 65535 * 32) return GPT_E_ARG;
     const int D = c->D;
     const int64_t N = c->N, NP = c->NP, n128 = round_up(N, 128), MP = round_up(M, 64);
+    const int64_t Nx = c->Nx;
     if (c->kp.kernel_id == GPT_KERNEL_M52) GPT_TRY(check_m52_orders(nstar, M, D));
     hipStream_t st = c->stream;
     double *dXs, *dKst, *dmean;
@@ -946,6 +1007,14 @@ extern "C" int gpt_predict(gpt_ctx *c, const double *Xstar, const int32_t *nstar
     // Kstar^T: row a = test point a, column i = training point i  (k is symmetric under swapping its
     // two (point, derivative-order) arguments, so this equals Kstar[i][a] of ref :966)
     GPT_TRY(launch_zero2d(st, MP, n128, dKst, n128));
+    if (c->dT) {
+        // with a transform the training side is T f(X): Kstar^T <- k(Xstar, X) T^T  (ref :966-970)
+        double *dKx;
+        GPT_TRY(ensure(c, SLOT_TK, (size_t)MP * c->NxP * sizeof(double), (void **)&dKx));
+        GPT_TRY(launch_zero2d(st, MP, c->NxP, dKx, c->NxP));
+        GPT_TRY(launch_kbuild(st, kp, dXs, dns, M, c->dX, c->dn, Nx, 0, 0, 0, nullptr, 0.0, 0.0, dKx, c->NxP));
+        GPT_TRY(gemm_nt(c, st, MP, round_up(N, 64), c->NxP, 1.0, dKx, c->NxP, c->dT, c->NxP, 0.0, dKst, n128, 0));
+    } else
     GPT_TRY(launch_kbuild(st, kp, dXs, dns, M, c->dX, c->dn, N, 0, 0, 0, nullptr, 0.0, 0.0, dKst, n128));
     GPT_TRY(ensure_alpha(c));
     GPT_TRY(launch_gemv_n(st, M, N, dKst, n128, c->d_alpha, dmean));

@@ -35,6 +35,24 @@ int launch_fill_pad(hipStream_t st, double *A, int64_t lda, int64_t n_valid, int
     return GPT_OK;
 }
 
+// A[i][i] = (A[i][i] + err[i]^2) + diag_add  (ref: gptools/gaussian_process.py:1447-1451 on an assembled matrix)
+__global__ void add_diag_kernel(double *__restrict__ A, int64_t lda, int64_t n, const double *__restrict__ err,
+                                double diag_add)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double e = err[i];
+    A[i * lda + i] = (A[i * lda + i] + e * e) + diag_add;
+}
+
+int launch_add_diag(hipStream_t st, double *A, int64_t lda, int64_t n, const double *err, double diag_add)
+{
+    if (n <= 0) return GPT_OK;
+    hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, lda, n, err, diag_add);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
 // out[0] = sum_{i<n} log A[i][i] ; out[1] = sum_{c<n} A[n][c]^2 (the augmented row z) ; out[2] = *info, so that one
 // small device-to-host copy returns everything an LML evaluation needs
 __global__ __launch_bounds__(1024) void logdet_dot_kernel(const double *__restrict__ A, int64_t lda, int64_t n,

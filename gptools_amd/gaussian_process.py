@@ -330,8 +330,14 @@ class GaussianProcess(object):
             mu_alph = self.T.dot(mu_alph)
         return self.y - mu_alph
 
+    def _upload_data(self, ctx):
+        """X, n and -- when the observations are linear transforms of the latent values -- T (ref :376-503)."""
+        ctx.set_data(self.X, self.n)
+        if self.T is not None:
+            ctx.set_T(self.T)
+
     def _fast_fit_possible(self):
-        return (self.T is None and getattr(self.k, "_gpt_kernel_id", None) in _NATIVE_FIT and
+        return (getattr(self.k, "_gpt_kernel_id", None) in _NATIVE_FIT and
                 type(self.k).__call__ in (Kernel.__call__, _M52_CALL) and
                 isinstance(self.noise_k, (ZeroKernel, DiagonalNoiseKernel)))
 
@@ -349,7 +355,7 @@ class GaussianProcess(object):
         ctx = self._ctx
         if self._fast_fit_possible():
             if not self._data_on_device:
-                ctx.set_data(self.X, self.n)
+                self._upload_data(ctx)
                 self._data_on_device = True
             if isinstance(self.noise_k, ZeroKernel):
                 noise_var = 0.0
@@ -527,13 +533,13 @@ class GaussianProcess(object):
             jobs.append((i, self.k._gpt_kernel_id, np.array(self.k.params, dtype=float), noise_var,
                          np.array(self._y_alph(), dtype=float), prior))
         if not self._data_on_device:
-            self._ctx.set_data(self.X, self.n)
+            self._upload_data(self._ctx)
             self._data_on_device = True
         version = getattr(self, "_data_version", 0)
         ctxs = [[self._ctx, version]] + self._batch_contexts(B)
         for c in ctxs[1:]:
             if c[1] != version:                                      # data added since this context last saw it
-                c[0].set_data(self.X, self.n)
+                self._upload_data(c[0])
                 c[1] = version
         self._cache = {}
         err_y = np.asarray(self.err_y, dtype=float)

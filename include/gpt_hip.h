@@ -99,6 +99,13 @@ int gpt_kbuild(gpt_ctx *ctx, int kernel_id, const double *params, int nparams,
  * host layout: X (N, D) float64, n (N, D) int).  Invalidates any factorisation. */
 int gpt_set_data(gpt_ctx *ctx, const double *X, const int32_t *n, int64_t N, int D);
 
+/* Linear transform of the latent values: observations y = T f(X) + noise (ref: gaussian_process.py:376-503 argument
+ * `T` of add_data; :1443-1446, :966-970).  T is (Ny, N) row-major over the N resident points.  With a transform set,
+ * gpt_fit expects y, err_y of length Ny and factors K_tot = T (K + noise_var I) T^T + diag(err_y^2) + diag_add I
+ * (Ny x Ny; the products are fp64-MFMA GEMMs on the device), and gpt_predict applies T to the training side of
+ * Kstar.  gpt_set_data drops the transform; T == NULL removes it. */
+int gpt_set_T(gpt_ctx *ctx, const double *T, int64_t Ny);
+
 /* ---- GaussianProcess.compute_K_L_alpha_ll ------------------------------------------------- */
 /* Replaces the T-free body of GaussianProcess.compute_K_L_alpha_ll   ref: gaussian_process.py:1428-1467
  *   K_tot = K + noise_var*I + diag(err_y^2) + diag_add*I          (ref :1431-1451; diag_add = diag_factor*eps)

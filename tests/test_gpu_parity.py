@@ -721,3 +721,47 @@ def test_helper_stream_schedule_agrees_with_sequential(ctx):
     Kr = ctx.kbuild(0, p, X[rows], n[rows], X, n)
     Kr[np.arange(len(rows)), rows] += err[rows] ** 2 + 1e2 * EPS
     np.testing.assert_allclose(Kr.dot(alpha), y[rows], rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("kern", ["se", "m52"])
+def test_linear_transform_path_on_device(g, oracle, kern):
+    """`T` (line-integral style observations, ref gaussian_process.py:1443-1451, :966-970) assembled on the device --
+    K-builder + two MFMA GEMMs -- against the host formula T (K + noise) T^T + diag(err^2) + eps I built from the
+    oracle's K and factored by LAPACK; then predict (mean, covariance) against the same host algebra."""
+    import scipy.linalg
+    rs = np.random.RandomState(12)
+    Nx, Ny, d = 1111, 203, 2                    # neither a multiple of 16 / 64: exercises every padding
+    X = rs.rand(Nx, d)
+    n = np.zeros((Nx, d), dtype=int)
+    if kern == "m52":
+        n[-50:, 0] = 1                          # some latent derivative values take part in the transform too
+    T = rs.rand(Ny, Nx) / Nx
+    f = np.sin(3 * X.sum(1))
+    y = T.dot(f) + 1e-3 * rs.randn(Ny)
+    p = np.array([1.1, 0.35, 0.45])
+    noise = 0.02
+    nk = g.DiagonalNoiseKernel(num_dim=d, initial_noise=noise, noise_bound=(0.0, 1.0))
+    gp = g.GaussianProcess(make_kernel(g, kern, d, p), noise_k=nk)
+    gp.add_data(X, y, err_y=1e-3, n=n, T=T)
+    gp.compute_K_L_alpha_ll()
+    assert gp._fit_mode == "kernel"             # the device path, not gpt_fit_matrix
+    K = oracle.kbuild(kern, p, X, n)
+    Ktot = T.dot(K + noise ** 2 * np.eye(Nx)).dot(T.T) + 1e-6 * np.eye(Ny) + 1e2 * EPS * np.eye(Ny)
+    L = scipy.linalg.cholesky(Ktot, lower=True)
+    alpha = scipy.linalg.cho_solve((L, True), y)
+    ll = -0.5 * y.dot(alpha) - np.log(np.diag(L)).sum() - 0.5 * Ny * np.log(2 * np.pi)
+    assert abs(gp.ll - gp.hyperprior(gp.params) - ll) <= 1e-8 * abs(ll)      # gp.ll is the log-posterior
+    assert_close(gp.L, L, rtol=1e-6, atol_scale=1e-9)
+    Xs = rs.rand(40, d)
+    ns = np.zeros((40, d), dtype=int)
+    ns[20:, 1] = 1 if kern == "se" else 0
+    mean, cov = gp.predict(Xs, n=ns, return_cov=True)
+    Ks = T.dot(oracle.kbuild(kern, p, X, n, Xs, ns))                       # (Ny, M)
+    v = scipy.linalg.solve_triangular(L, Ks, lower=True)
+    np.testing.assert_allclose(mean, Ks.T.dot(alpha), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(cov, oracle.kbuild(kern, p, Xs, ns) - v.T.dot(v), rtol=0, atol=1e-7)
+    # hyperparameter update keeps T resident; adding data re-uploads it
+    v0 = gp.update_hyperparameters([1.0, 0.3, 0.4, 0.03])
+    gp.add_data(rs.rand(5, d), rs.randn(5) * 0.01, err_y=1e-3)
+    v1 = gp.update_hyperparameters([1.0, 0.3, 0.4, 0.03])
+    assert np.isfinite(v0) and np.isfinite(v1) and gp.T.shape == (Ny + 5, Nx + 5)
