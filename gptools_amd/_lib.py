@@ -37,6 +37,7 @@ SIGNATURES = {
     "gpt_set_data": (C.c_int, [_vp, _dp, _ip, _i64, C.c_int]),
     "gpt_set_T": (C.c_int, [_vp, _dp, _i64]),
     "gpt_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, C.c_double, _dp, _dp]),
+    "gpt_fit_sum": (C.c_int, [_vp, C.c_int, _ip, _dp, _ip, C.c_double, _dp, _dp, C.c_double, _dp, _dp]),
     "gpt_fit_matrix": (C.c_int, [_vp, _dp, _i64, _dp, _dp, _dp]),
     "gpt_get_L": (C.c_int, [_vp, _dp]),
     "gpt_get_alpha": (C.c_int, [_vp, _dp]),
@@ -222,6 +223,18 @@ class Context(object):
         ld = C.c_double()
         check(self._lib.gpt_fit(self.handle, kernel_id, dptr(params), len(params), float(noise_var), dptr(y),
                                 dptr(err_y), float(diag_add), C.byref(ll), C.byref(ld)))
+        return ll.value, ld.value
+
+    def fit_sum(self, kernel_ids, params_list, noise_var, y, err_y, diag_add):
+        """gpt_fit for a sum of native kernels: ``kernel_ids[t]`` with parameters ``params_list[t]``."""
+        ids = i32(np.asarray(kernel_ids))
+        npar = i32(np.asarray([len(p) for p in params_list]))
+        flat = f64(np.concatenate([np.asarray(p, dtype=float) for p in params_list]))
+        y, err_y = f64(y), f64(err_y)
+        ll = C.c_double()
+        ld = C.c_double()
+        check(self._lib.gpt_fit_sum(self.handle, len(ids), iptr(ids), dptr(flat), iptr(npar), float(noise_var), dptr(y),
+                                    dptr(err_y), float(diag_add), C.byref(ll), C.byref(ld)))
         return ll.value, ld.value
 
     def fit_matrix(self, K_tot, y):

@@ -80,7 +80,8 @@ struct gpt_ctx {
     double *h_yerr = nullptr;  // pinned staging for y | err_y (a pageable source would make the upload synchronous)
     int32_t *h_info = nullptr; // pinned
     bool factored = false, alpha_valid = false, have_kernel = false;
-    KParams kp;
+    KParams kp;                      // first term (single-kernel paths)
+    std::vector<KParams> terms;      // the model kernel as a sum of native kernels (gpt_fit_sum)
     double timings[5] = {0, 0, 0, 0, 0};
     // per-launch HIP-event timing of the dominant (large) GEMM/SYRK launches, for the roofline line
     int prof_gemm = 0;
@@ -794,25 +795,64 @@ static int factor_and_ll(gpt_ctx *c, int64_t N, double *ll_data_out, double *log
     return GPT_OK;
 }
 
+// K block of the model kernel = sum of c->terms (SumKernel, ref: gptools/kernel/core.py:549-584): one builder pass per
+// term, later passes accumulate; the diagonal epilogue (err != nullptr) rides on the last pass, after the sum.
+static int kbuild_terms(gpt_ctx *c, hipStream_t st, const std::vector<KParams> &terms, int symmetric, const double *dXi,
+                        const int32_t *dni, int64_t M, const double *dXj, const int32_t *dnj, int64_t P, int lower_only,
+                        int64_t i0, int64_t j0, const double *d_err, double noise_var, double diag_add, double *dK,
+                        int64_t ldk)
+{
+    (void)c;
+    for (size_t t = 0; t < terms.size(); t++) {
+        KParams kp = terms[t];
+        kp.symmetric = symmetric;
+        kp.hyper_deriv = -1;
+        const bool last = t + 1 == terms.size();
+        GPT_TRY(launch_kbuild(st, kp, dXi, dni, M, dXj, dnj, P, lower_only, i0, j0, last ? d_err : nullptr, noise_var,
+                              diag_add, dK, ldk, t > 0 ? 1 : 0));
+    }
+    return GPT_OK;
+}
+
+static int fit_terms(gpt_ctx *c, const std::vector<KParams> &terms, double noise_var, const double *y,
+                     const double *err_y, double diag_add, double *ll_data_out, double *logdet_half_out);
+
 extern "C" int gpt_fit(gpt_ctx *c, int kernel_id, const double *params, int nparams, double noise_var,
                        const double *y, const double *err_y, double diag_add, double *ll_data_out,
                        double *logdet_half_out)
+{
+    return gpt_fit_sum(c, 1, &kernel_id, params, &nparams, noise_var, y, err_y, diag_add, ll_data_out, logdet_half_out);
+}
+
+extern "C" int gpt_fit_sum(gpt_ctx *c, int nterms, const int *kernel_ids, const double *params, const int *nparams,
+                           double noise_var, const double *y, const double *err_y, double diag_add,
+                           double *ll_data_out, double *logdet_half_out)
 {
     CTX_ENTER(c);
     if (!c->dX) {
         gpt_set_error("gpt_fit: call gpt_set_data first");
         return GPT_E_STATE;
     }
-    if (!params || !y || !err_y) return GPT_E_ARG;
-    if (kernel_id != GPT_KERNEL_SE && kernel_id != GPT_KERNEL_M52) {
-        gpt_set_error("gpt_fit: kernel_id must be SE or Matern52");
-        return GPT_E_ARG;
+    if (nterms < 1 || nterms > 8 || !kernel_ids || !params || !nparams || !y || !err_y) return GPT_E_ARG;
+    std::vector<KParams> terms((size_t)nterms);
+    const double *p = params;
+    for (int t = 0; t < nterms; t++) {
+        if (kernel_ids[t] != GPT_KERNEL_SE && kernel_ids[t] != GPT_KERNEL_M52) {
+            gpt_set_error("gpt_fit: kernel_id must be SE or Matern52");
+            return GPT_E_ARG;
+        }
+        GPT_TRY(make_kparams(kernel_ids[t], p, nparams[t], c->D, -1, 1, nullptr, &terms[(size_t)t]));
+        p += nparams[t];
     }
+    return fit_terms(c, terms, noise_var, y, err_y, diag_add, ll_data_out, logdet_half_out);
+}
+
+static int fit_terms(gpt_ctx *c, const std::vector<KParams> &terms, double noise_var, const double *y,
+                     const double *err_y, double diag_add, double *ll_data_out, double *logdet_half_out)
+{
     const int64_t Nx = c->Nx;
     const int64_t N = c->dT ? c->Ny : Nx;          // order of K_tot
     c->N = N;
-    KParams kp;
-    GPT_TRY(make_kparams(kernel_id, params, nparams, c->D, -1, 1, nullptr, &kp));
     GPT_TRY(ensure_factor_storage(c, N));
     hipStream_t st = c->stream;
     c->factored = false;
@@ -823,6 +863,8 @@ extern "C" int gpt_fit(gpt_ctx *c, int kernel_id, const double *params, int npar
     if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[1], st));
     const int64_t NP = c->NP;
     GPT_HIP_CHECK(hipMemsetAsync(c->d_info, 0, sizeof(int32_t), st));
+    c->terms = terms;
+    c->kp = terms[0];
     if (c->dT) {
         // ---- T path: K_tot = T (K + noise_var I) T^T + diag(err_y^2) + diag_add I, assembled on the device by the
         // K-builder (full symmetric K over the Nx latent points) and two fp64-MFMA GEMMs (ref :1443-1451)
@@ -834,12 +876,11 @@ extern "C" int gpt_fit(gpt_ctx *c, int kernel_id, const double *params, int npar
         GPT_HIP_CHECK(hipMemsetAsync(dzero, 0, (size_t)Nx * sizeof(double), st));
         if (NxP > Nx) GPT_HIP_CHECK(hipMemsetAsync(dK, 0, (size_t)NxP * NxP * sizeof(double), st));   // zero padding of k
         // (K + noise_K): the builder's diagonal epilogue with err = 0, diag_add = 0 adds exactly noise_var
-        GPT_TRY(launch_kbuild(st, kp, c->dX, c->dn, Nx, c->dX, c->dn, Nx, 0, 0, 0, dzero, noise_var, 0.0, dK, NxP));
+        GPT_TRY(kbuild_terms(c, st, terms, 1, c->dX, c->dn, Nx, c->dX, c->dn, Nx, 0, 0, 0, dzero, noise_var, 0.0, dK, NxP));
         GPT_TRY(gemm_nt(c, st, NyP, NxP, NxP, 1.0, c->dT, NxP, dK, NxP, 0.0, dTK, NxP, 0));          // T K  (K = K^T)
         GPT_TRY(gemm_nt(c, st, NyP, NyP, NxP, 1.0, dTK, NxP, c->dT, NxP, 0.0, c->dA, NP, 1));        // (T K) T^T, lower
         GPT_TRY(launch_add_diag(st, c->dA, NP, N, c->d_erry, diag_add));
         GPT_TRY(launch_fill_pad(st, c->dA, NP, N, NP, c->d_y, 1e300));
-        c->kp = kp;
         c->have_kernel = true;
         c->head_event = nullptr;
         return factor_and_ll(c, N, ll_data_out, logdet_half_out, true);
@@ -849,17 +890,16 @@ extern "C" int gpt_fit(gpt_ctx *c, int kernel_id, const double *params, int npar
     int64_t head = round_up((c->ramp ? 128 : outer_width(c, NP)) + GPT_PANEL_EXT, 256);   // what panel 0 touches
     hipEvent_t e_head = nullptr;
     if (c->lookahead && !c->use_graph && head < N && (e_head = get_event(c, 0)) != nullptr) {
-        GPT_TRY(launch_kbuild(st, kp, c->dX, c->dn, N, c->dX, c->dn, head, 1, 0, 0, c->d_erry, noise_var, diag_add,
-                              c->dA, NP));
+        GPT_TRY(kbuild_terms(c, st, terms, 1, c->dX, c->dn, N, c->dX, c->dn, head, 1, 0, 0, c->d_erry, noise_var, diag_add,
+                             c->dA, NP));
         GPT_HIP_CHECK(hipEventRecord(e_head, st));
-        GPT_TRY(launch_kbuild(st, kp, c->dX + head * c->D, c->dn + head * c->D, N - head, c->dX + head * c->D,
-                              c->dn + head * c->D, N - head, 1, head, head, c->d_erry, noise_var, diag_add,
-                              c->dA + head * NP + head, NP));
+        GPT_TRY(kbuild_terms(c, st, terms, 1, c->dX + head * c->D, c->dn + head * c->D, N - head, c->dX + head * c->D,
+                             c->dn + head * c->D, N - head, 1, head, head, c->d_erry, noise_var, diag_add,
+                             c->dA + head * NP + head, NP));
     } else {
-        GPT_TRY(launch_kbuild(st, kp, c->dX, c->dn, N, c->dX, c->dn, N, 1, 0, 0, c->d_erry, noise_var, diag_add, c->dA,
-                              NP));
+        GPT_TRY(kbuild_terms(c, st, terms, 1, c->dX, c->dn, N, c->dX, c->dn, N, 1, 0, 0, c->d_erry, noise_var, diag_add,
+                             c->dA, NP));
     }
-    c->kp = kp;
     c->have_kernel = true;
     c->head_event = e_head;
     return factor_and_ll(c, N, ll_data_out, logdet_half_out, true);
@@ -990,7 +1030,11 @@ extern "C" int gpt_predict(gpt_ctx *c, const double *Xstar, const int32_t *nstar
     const int D = c->D;
     const int64_t N = c->N, NP = c->NP, n128 = round_up(N, 128), MP = round_up(M, 64);
     const int64_t Nx = c->Nx;
-    if (c->kp.kernel_id == GPT_KERNEL_M52) GPT_TRY(check_m52_orders(nstar, M, D));
+    for (const auto &t : c->terms)
+        if (t.kernel_id == GPT_KERNEL_M52) {
+            GPT_TRY(check_m52_orders(nstar, M, D));
+            break;
+        }
     hipStream_t st = c->stream;
     double *dXs, *dKst, *dmean;
     int32_t *dns;
@@ -1001,9 +1045,6 @@ extern "C" int gpt_predict(gpt_ctx *c, const double *Xstar, const int32_t *nstar
     double *dvar = dmean + MP;
     GPT_HIP_CHECK(hipMemcpyAsync(dXs, Xstar, (size_t)M * D * sizeof(double), hipMemcpyHostToDevice, st));
     GPT_HIP_CHECK(hipMemcpyAsync(dns, nstar, (size_t)M * D * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    KParams kp = c->kp;
-    kp.symmetric = 0;
-    kp.hyper_deriv = -1;
     // Kstar^T: row a = test point a, column i = training point i  (k is symmetric under swapping its
     // two (point, derivative-order) arguments, so this equals Kstar[i][a] of ref :966)
     GPT_TRY(launch_zero2d(st, MP, n128, dKst, n128));
@@ -1012,10 +1053,10 @@ extern "C" int gpt_predict(gpt_ctx *c, const double *Xstar, const int32_t *nstar
         double *dKx;
         GPT_TRY(ensure(c, SLOT_TK, (size_t)MP * c->NxP * sizeof(double), (void **)&dKx));
         GPT_TRY(launch_zero2d(st, MP, c->NxP, dKx, c->NxP));
-        GPT_TRY(launch_kbuild(st, kp, dXs, dns, M, c->dX, c->dn, Nx, 0, 0, 0, nullptr, 0.0, 0.0, dKx, c->NxP));
+        GPT_TRY(kbuild_terms(c, st, c->terms, 0, dXs, dns, M, c->dX, c->dn, Nx, 0, 0, 0, nullptr, 0.0, 0.0, dKx, c->NxP));
         GPT_TRY(gemm_nt(c, st, MP, round_up(N, 64), c->NxP, 1.0, dKx, c->NxP, c->dT, c->NxP, 0.0, dKst, n128, 0));
     } else
-    GPT_TRY(launch_kbuild(st, kp, dXs, dns, M, c->dX, c->dn, N, 0, 0, 0, nullptr, 0.0, 0.0, dKst, n128));
+    GPT_TRY(kbuild_terms(c, st, c->terms, 0, dXs, dns, M, c->dX, c->dn, N, 0, 0, 0, nullptr, 0.0, 0.0, dKst, n128));
     GPT_TRY(ensure_alpha(c));
     GPT_TRY(launch_gemv_n(st, M, N, dKst, n128, c->d_alpha, dmean));
     GPT_HIP_CHECK(hipMemcpyAsync(mean_out, dmean, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1026,10 +1067,12 @@ extern "C" int gpt_predict(gpt_ctx *c, const double *Xstar, const int32_t *nstar
         if (want == 1) {
             double *dkd;
             GPT_TRY(ensure(c, SLOT_VEC2, (size_t)M * sizeof(double), (void **)&dkd));
-            KParams ks = c->kp;
-            ks.symmetric = 1;
-            ks.hyper_deriv = -1;
-            GPT_TRY(launch_kpairs(st, ks, dXs, dXs, dns, dns, M, dkd));
+            for (size_t t = 0; t < c->terms.size(); t++) {
+                KParams ks = c->terms[t];
+                ks.symmetric = 1;
+                ks.hyper_deriv = -1;
+                GPT_TRY(launch_kpairs(st, ks, dXs, dXs, dns, dns, M, dkd, t > 0 ? 1 : 0));
+            }
             GPT_TRY(launch_rowsumsq_sub(st, M, n128, dKst, n128, dkd, dvar));
             GPT_HIP_CHECK(hipMemcpyAsync(std_out, dvar, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, st));
             GPT_HIP_CHECK(hipStreamSynchronize(st));
@@ -1046,11 +1089,8 @@ extern "C" int gpt_predict(gpt_ctx *c, const double *Xstar, const int32_t *nstar
         }
         double *dcov;
         GPT_TRY(ensure(c, SLOT_KSS, (size_t)MP * MP * sizeof(double), (void **)&dcov));
-        KParams ks = c->kp;
-        ks.symmetric = 1;
-        ks.hyper_deriv = -1;
         GPT_TRY(launch_zero2d(st, MP, MP, dcov, MP));
-        GPT_TRY(launch_kbuild(st, ks, dXs, dns, M, dXs, dns, M, 0, 0, 0, nullptr, 0.0, 0.0, dcov, MP));
+        GPT_TRY(kbuild_terms(c, st, c->terms, 1, dXs, dns, M, dXs, dns, M, 0, 0, 0, nullptr, 0.0, 0.0, dcov, MP));
         if (noise_params) GPT_TRY(launch_add_noise_sym(st, kn, dXs, dns, M, dcov, MP));
         GPT_TRY(gemm_nt(c, st, MP, MP, n128, -1.0, dKst, n128, dKst, n128, 1.0, dcov, MP, 0));
         GPT_HIP_CHECK(hipMemcpy2DAsync(cov_out, (size_t)M * sizeof(double), dcov, (size_t)MP * sizeof(double),

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(KB_THREADS) void kbuild_kernel(
     KParams kp, const double *__restrict__ Xi, const int32_t *__restrict__ ni, int64_t M,
     const double *__restrict__ Xj, const int32_t *__restrict__ nj, int64_t P,
     int lower_only, int64_t i0, int64_t j0, const double *__restrict__ err_y, double noise_var,
-    double diag_add, double *__restrict__ K, int64_t ldk)
+    double diag_add, double *__restrict__ K, int64_t ldk, int accumulate)
 {
     int64_t rt, ct;
     if (lower_only == 2) {
@@ -74,6 +74,8 @@ __global__ __launch_bounds__(KB_THREADS) void kbuild_kernel(
 #pragma unroll
         for (int c = 0; c < KB_CPT; c++) {
             v[c] = any_pair<KID, D>(kp, xi, xj[c], nir, njr[c]);
+            // SumKernel (ref: gptools/kernel/core.py:549-584): later terms add to what the earlier passes stored
+            if (accumulate && jfirst + c < P) v[c] += K[i * ldk + jfirst + c];
             if (err_y != nullptr && (i + i0 == jfirst + c + j0)) {
                 const double e = err_y[i + i0];
                 v[c] = ((v[c] + noise_var) + e * e) + diag_add;
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void kpairs_kernel(KParams kp, const double *_
                                                      const double *__restrict__ Xj,
                                                      const int32_t *__restrict__ ni,
                                                      const int32_t *__restrict__ nj, int64_t M,
-                                                     double *__restrict__ out)
+                                                     double *__restrict__ out, int accumulate)
 {
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= M) return;
@@ -108,7 +110,8 @@ __global__ __launch_bounds__(256) void kpairs_kernel(KParams kp, const double *_
         nir[d] = ni[m * D + d];
         njr[d] = nj[m * D + d];
     }
-    out[m] = any_pair<KID, D>(kp, xi, xj, nir, njr);
+    const double v = any_pair<KID, D>(kp, xi, xj, nir, njr);
+    out[m] = accumulate ? out[m] + v : v;
 }
 
 // C[a][b] += noise_k(X[a], X[b], n[a], n[b]) for the symmetric predict(noise=True) term
@@ -137,7 +140,7 @@ template <int KID>
 static int kbuild_dispatch_d(hipStream_t st, const KParams &kp, const double *dXi, const int32_t *dni, int64_t M,
                              const double *dXj, const int32_t *dnj, int64_t P, int lower_only, int64_t i0,
                              int64_t j0, const double *d_err_y, double noise_var, double diag_add, double *dK,
-                             int64_t ldk)
+                             int64_t ldk, int accumulate)
 {
     dim3 grid((unsigned)((P + KB_COLS - 1) / KB_COLS), (unsigned)((M + KB_ROWS - 1) / KB_ROWS));
     dim3 block(KB_THREADS);
@@ -151,7 +154,7 @@ static int kbuild_dispatch_d(hipStream_t st, const KParams &kp, const double *dX
 #define KB_CASE(DD)                                                                                     \
     case DD:                                                                                            \
         hipLaunchKernelGGL((kbuild_kernel<KID, DD>), grid, block, 0, st, kp, dXi, dni, M, dXj, dnj, P,   \
-                           lower_only, i0, j0, d_err_y, noise_var, diag_add, dK, ldk);                  \
+                           lower_only, i0, j0, d_err_y, noise_var, diag_add, dK, ldk, accumulate);      \
         break;
     switch (kp.D) {
         KB_CASE(1) KB_CASE(2) KB_CASE(3) KB_CASE(4) KB_CASE(5) KB_CASE(6) KB_CASE(7) KB_CASE(8)
@@ -167,22 +170,22 @@ static int kbuild_dispatch_d(hipStream_t st, const KParams &kp, const double *dX
 
 int launch_kbuild(hipStream_t st, const KParams &kp, const double *dXi, const int32_t *dni, int64_t M,
                   const double *dXj, const int32_t *dnj, int64_t P, int lower_only, int64_t i0, int64_t j0,
-                  const double *d_err_y, double noise_var, double diag_add, double *dK, int64_t ldk)
+                  const double *d_err_y, double noise_var, double diag_add, double *dK, int64_t ldk, int accumulate)
 {
     if (M <= 0 || P <= 0) return GPT_OK;
     switch (kp.kernel_id) {
     case GPT_KERNEL_SE:
         return kbuild_dispatch_d<GPT_KERNEL_SE>(st, kp, dXi, dni, M, dXj, dnj, P, lower_only, i0, j0, d_err_y,
-                                                noise_var, diag_add, dK, ldk);
+                                                noise_var, diag_add, dK, ldk, accumulate);
     case GPT_KERNEL_M52:
         return kbuild_dispatch_d<GPT_KERNEL_M52>(st, kp, dXi, dni, M, dXj, dnj, P, lower_only, i0, j0, d_err_y,
-                                                 noise_var, diag_add, dK, ldk);
+                                                 noise_var, diag_add, dK, ldk, accumulate);
     case GPT_KERNEL_DIAGNOISE:
         return kbuild_dispatch_d<GPT_KERNEL_DIAGNOISE>(st, kp, dXi, dni, M, dXj, dnj, P, lower_only, i0, j0,
-                                                       d_err_y, noise_var, diag_add, dK, ldk);
+                                                       d_err_y, noise_var, diag_add, dK, ldk, accumulate);
     case GPT_KERNEL_ZERO:
         return kbuild_dispatch_d<GPT_KERNEL_ZERO>(st, kp, dXi, dni, M, dXj, dnj, P, lower_only, i0, j0, d_err_y,
-                                                  noise_var, diag_add, dK, ldk);
+                                                  noise_var, diag_add, dK, ldk, accumulate);
     default:
         gpt_set_error("kbuild: unknown kernel_id %d", kp.kernel_id);
         return GPT_E_ARG;
@@ -191,12 +194,12 @@ int launch_kbuild(hipStream_t st, const KParams &kp, const double *dXi, const in
 
 template <int KID>
 static int kpairs_dispatch_d(hipStream_t st, const KParams &kp, const double *dXi, const double *dXj,
-                             const int32_t *dni, const int32_t *dnj, int64_t M, double *dout)
+                             const int32_t *dni, const int32_t *dnj, int64_t M, double *dout, int accumulate)
 {
     dim3 grid((unsigned)((M + 255) / 256)), block(256);
 #define KP_CASE(DD)                                                                                   \
     case DD:                                                                                          \
-        hipLaunchKernelGGL((kpairs_kernel<KID, DD>), grid, block, 0, st, kp, dXi, dXj, dni, dnj, M, dout); \
+        hipLaunchKernelGGL((kpairs_kernel<KID, DD>), grid, block, 0, st, kp, dXi, dXj, dni, dnj, M, dout, accumulate); \
         break;
     switch (kp.D) {
         KP_CASE(1) KP_CASE(2) KP_CASE(3) KP_CASE(4) KP_CASE(5) KP_CASE(6) KP_CASE(7) KP_CASE(8)
@@ -211,14 +214,14 @@ static int kpairs_dispatch_d(hipStream_t st, const KParams &kp, const double *dX
 }
 
 int launch_kpairs(hipStream_t st, const KParams &kp, const double *dXi, const double *dXj,
-                  const int32_t *dni, const int32_t *dnj, int64_t M, double *dout)
+                  const int32_t *dni, const int32_t *dnj, int64_t M, double *dout, int accumulate)
 {
     if (M <= 0) return GPT_OK;
     switch (kp.kernel_id) {
-    case GPT_KERNEL_SE: return kpairs_dispatch_d<GPT_KERNEL_SE>(st, kp, dXi, dXj, dni, dnj, M, dout);
-    case GPT_KERNEL_M52: return kpairs_dispatch_d<GPT_KERNEL_M52>(st, kp, dXi, dXj, dni, dnj, M, dout);
-    case GPT_KERNEL_DIAGNOISE: return kpairs_dispatch_d<GPT_KERNEL_DIAGNOISE>(st, kp, dXi, dXj, dni, dnj, M, dout);
-    case GPT_KERNEL_ZERO: return kpairs_dispatch_d<GPT_KERNEL_ZERO>(st, kp, dXi, dXj, dni, dnj, M, dout);
+    case GPT_KERNEL_SE: return kpairs_dispatch_d<GPT_KERNEL_SE>(st, kp, dXi, dXj, dni, dnj, M, dout, accumulate);
+    case GPT_KERNEL_M52: return kpairs_dispatch_d<GPT_KERNEL_M52>(st, kp, dXi, dXj, dni, dnj, M, dout, accumulate);
+    case GPT_KERNEL_DIAGNOISE: return kpairs_dispatch_d<GPT_KERNEL_DIAGNOISE>(st, kp, dXi, dXj, dni, dnj, M, dout, accumulate);
+    case GPT_KERNEL_ZERO: return kpairs_dispatch_d<GPT_KERNEL_ZERO>(st, kp, dXi, dXj, dni, dnj, M, dout, accumulate);
     default:
         gpt_set_error("kpairs: unknown kernel_id %d", kp.kernel_id);
         return GPT_E_ARG;

@@ -28,7 +28,7 @@ import scipy.optimize
 from . import _lib
 from . import replicas
 from .error_handling import GPArgumentError, GPImpossibleParamsError
-from .kernel import Kernel, ZeroKernel, DiagonalNoiseKernel
+from .kernel import Kernel, ZeroKernel, DiagonalNoiseKernel, SumKernel
 from .utils import CombinedBounds
 
 __all__ = ["GaussianProcess"]
@@ -336,10 +336,25 @@ class GaussianProcess(object):
         if self.T is not None:
             ctx.set_T(self.T)
 
+    def _native_terms(self, k=None):
+        """The covariance kernel as a list of ``(kernel_id, params)`` terms the HIP library evaluates itself -- a native
+        kernel, or a SumKernel tree of them (ref: gptools/kernel/core.py:549-584) -- else ``None``."""
+        k = self.k if k is None else k
+        if type(k) is SumKernel:
+            a, b = self._native_terms(k.k1), self._native_terms(k.k2)
+            return None if a is None or b is None or len(a) + len(b) > 8 else a + b
+        if (getattr(k, "_gpt_kernel_id", None) in _NATIVE_FIT and type(k).__call__ in (Kernel.__call__, _M52_CALL)):
+            return [(k._gpt_kernel_id, np.array(k.params, dtype=float))]
+        return None
+
     def _fast_fit_possible(self):
-        return (getattr(self.k, "_gpt_kernel_id", None) in _NATIVE_FIT and
-                type(self.k).__call__ in (Kernel.__call__, _M52_CALL) and
+        return (self._native_terms() is not None and
                 isinstance(self.noise_k, (ZeroKernel, DiagonalNoiseKernel)))
+
+    def _device_fit(self, ctx, terms, noise_var, y_alph, diag_add):
+        if len(terms) == 1:
+            return ctx.fit(terms[0][0], terms[0][1], noise_var, y_alph, self.err_y, diag_add)
+        return ctx.fit_sum([t[0] for t in terms], [t[1] for t in terms], noise_var, y_alph, self.err_y, diag_add)
 
     def compute_K_L_alpha_ll(self):
         """Build ``K_tot``, factor it and evaluate the log-posterior ``ll`` on the GPU (no-op while
@@ -361,7 +376,7 @@ class GaussianProcess(object):
                 noise_var = 0.0
             else:
                 noise_var = self.noise_k.params[0] ** 2.0
-            ll_data, _ = ctx.fit(self.k._gpt_kernel_id, self.k.params, noise_var, y_alph, self.err_y, diag_add)
+            ll_data, _ = self._device_fit(ctx, self._native_terms(), noise_var, y_alph, diag_add)
             self._fit_mode = "kernel"
         else:
             # T (linear transform) or a Python-defined kernel: K is still built by the GPU builder
@@ -530,7 +545,7 @@ class GaussianProcess(object):
             if exit_on_bounds and np.isinf(prior):
                 continue                                            # impossible parameters: stays -inf
             noise_var = 0.0 if isinstance(self.noise_k, ZeroKernel) else self.noise_k.params[0] ** 2.0
-            jobs.append((i, self.k._gpt_kernel_id, np.array(self.k.params, dtype=float), noise_var,
+            jobs.append((i, self._native_terms(), None, noise_var,
                          np.array(self._y_alph(), dtype=float), prior))
         if not self._data_on_device:
             self._upload_data(self._ctx)
@@ -553,9 +568,9 @@ class GaussianProcess(object):
                     job = next(it, None)
                 if job is None:
                     return
-                i, kid, kparams, noise_var, y_alph, prior = job
+                i, terms, _, noise_var, y_alph, prior = job
                 try:
-                    ll_data, _ = ctx.fit(kid, kparams, noise_var, y_alph, err_y, diag_add)
+                    ll_data, _ = self._device_fit(ctx, terms, noise_var, y_alph, diag_add)
                     out[i] = ll_data + prior
                 except (np.linalg.LinAlgError, ValueError, ArithmeticError):
                     pass                                            # the +inf policy of update_hyperparameters

@@ -118,6 +118,14 @@ int gpt_fit(gpt_ctx *ctx, int kernel_id, const double *params, int nparams, doub
             const double *y, const double *err_y, double diag_add,
             double *ll_data_out, double *logdet_half_out);
 
+/* The same for a model kernel that is a SUM of native kernels (SumKernel, ref: kernel/core.py:549-584, k1 + k2 + ...):
+ * nterms <= 8 kernel ids, their parameter vectors concatenated in `params` (nparams[t] entries each).  One builder pass
+ * per term, accumulated on the device; everything else as gpt_fit (which is the nterms == 1 case).  gpt_predict
+ * afterwards uses the same sum. */
+int gpt_fit_sum(gpt_ctx *ctx, int nterms, const int *kernel_ids, const double *params, const int *nparams,
+                double noise_var, const double *y, const double *err_y, double diag_add, double *ll_data_out,
+                double *logdet_half_out);
+
 /* Same as gpt_fit but for an explicit, caller-assembled symmetric K_tot (host, (N, N) row-major;
  * only the lower triangle is read): used for the `T` (linear transform) branch,
  * ref: gaussian_process.py:1443-1446, where K_tot = T (K + noise_K) T^T + ... is (N_y, N_y). */

@@ -765,3 +765,43 @@ def test_linear_transform_path_on_device(g, oracle, kern):
     gp.add_data(rs.rand(5, d), rs.randn(5) * 0.01, err_y=1e-3)
     v1 = gp.update_hyperparameters([1.0, 0.3, 0.4, 0.03])
     assert np.isfinite(v0) and np.isfinite(v1) and gp.T.shape == (Ny + 5, Nx + 5)
+
+
+def test_sum_of_native_kernels_on_device(g, oracle):
+    """k1 + k2 (SumKernel, ref kernel/core.py:549-584) of native kernels: accumulated builder passes on the device
+    (gpt_fit_sum) against the oracle's K1 + K2 factored by LAPACK; predict uses the same sum; the batched evaluator
+    goes through it too."""
+    import scipy.linalg
+    rs = np.random.RandomState(21)
+    N, d = 900, 2
+    X = rs.rand(N, d)
+    n = np.zeros((N, d), dtype=int)
+    n[-100:, 1] = 1
+    y = np.sin(3 * X.sum(1)) + 0.05 * rs.randn(N)
+    p1, p2 = np.array([1.0, 0.3, 0.5]), np.array([0.4, 1.5, 2.0])
+    k = make_kernel(g, "se", d, p1) + make_kernel(g, "m52", d, p2)
+    gp = g.GaussianProcess(k, X=X, y=y, err_y=0.05, n=n)
+    gp.compute_K_L_alpha_ll()
+    assert gp._fit_mode == "kernel" and len(gp._native_terms()) == 2
+    K = oracle.kbuild("se", p1, X, n) + oracle.kbuild("m52", p2, X, n)
+    Ktot = K + (0.05 ** 2 + 1e2 * EPS) * np.eye(N)
+    L = scipy.linalg.cholesky(Ktot, lower=True)
+    alpha = scipy.linalg.cho_solve((L, True), y)
+    ll = -0.5 * y.dot(alpha) - np.log(np.diag(L)).sum() - 0.5 * N * np.log(2 * np.pi)
+    assert abs(gp.ll - gp.hyperprior(gp.params) - ll) <= 1e-8 * abs(ll)
+    assert_close(gp.L, L, rtol=1e-6, atol_scale=1e-9)
+    Xs = rs.rand(30, d)
+    ns = np.zeros((30, d), dtype=int)
+    ns[15:, 0] = 1
+    Ks = oracle.kbuild("se", p1, X, n, Xs, ns) + oracle.kbuild("m52", p2, X, n, Xs, ns)
+    v = scipy.linalg.solve_triangular(L, Ks, lower=True)
+    Kss = oracle.kbuild("se", p1, Xs, ns) + oracle.kbuild("m52", p2, Xs, ns)
+    mean, std = gp.predict(Xs, n=ns)
+    np.testing.assert_allclose(mean, Ks.T.dot(alpha), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(std ** 2, np.diag(Kss - v.T.dot(v)), rtol=0, atol=1e-7)
+    mean2, cov = gp.predict(Xs, n=ns, return_cov=True)
+    np.testing.assert_allclose(cov, Kss - v.T.dot(v), rtol=0, atol=1e-7)
+    thetas = [list(p1) + list(p2), list(1.1 * p1) + list(0.9 * p2)]
+    b = gp.ll_batch(thetas)
+    s = np.array([-gp.update_hyperparameters(t) for t in thetas])
+    np.testing.assert_allclose(b, s, rtol=1e-12, atol=0)
