@@ -6,7 +6,12 @@ code = """
 import sys; sys.path.insert(0, '/root/repo')
 from gptools_amd import _lib
 import os
-if os.environ.get('GPT_AB_LIB'): _lib.LIB_PATH = os.environ['GPT_AB_LIB']
+if os.environ.get('GPT_AB_LIB'):
+    _lib.LIB_PATH = os.environ['GPT_AB_LIB']
+    import ctypes
+    probe = ctypes.CDLL(_lib.LIB_PATH)
+    for name in list(_lib.SIGNATURES):
+        if not hasattr(probe, name): del _lib.SIGNATURES[name]      # an older build lacks the newer entry points
 import runpy; sys.argv = ['fit_loop.py', %r, %r] + %r; runpy.run_path('/root/repo/scratch/fit_loop.py', run_name='__main__')
 """
 for rnd in range(2):

@@ -28,5 +28,5 @@ if len(sys.argv) > 1:
 import os
 BETA = float(os.environ.get("BETA", "1.0"))
 for (m, n, k, tri) in cases:
-    for tile in (128, 129, 64):
+    for tile in [int(v) for v in os.environ.get("TILES", "128,129,64").split(",")]:
         run(m, n, k, tri, tile)
