@@ -84,6 +84,7 @@ class GaussianProcess(object):
     # ---- device plumbing -------------------------------------------------------------------
     def _reset_device_state(self):
         self._ctx_obj = None
+        self._scratch_ctx = None
         self._ctx_pool = None
         self._data_on_device = False
         self._cache = {}
@@ -106,6 +107,7 @@ class GaussianProcess(object):
         # device handles never cross a pickle: they are re-created lazily in the new process.
         st = dict(self.__dict__)
         st["_ctx_obj"] = None
+        st["_scratch_ctx"] = None
         st["_ctx_pool"] = None
         st["_data_on_device"] = False
         st["_cache"] = {}
@@ -732,10 +734,11 @@ class GaussianProcess(object):
         """Predictive mean (and std / covariance) at ``Xstar`` (M, D) for derivative orders ``n``.
 
         Returns ``mean``, ``(mean, std)``, ``(mean, cov)`` or the ``full_output`` dict exactly like the
-        reference's non-MCMC branch.  Sampling / MCMC options are outside the accelerated path."""
-        if use_MCMC or return_samples or full_MC:
-            raise NotImplementedError("MCMC marginalisation and posterior sampling are outside the accelerated "
-                                      "hot path (SURVEY.md section 8).")
+        reference's non-MCMC branch (``return_samples`` / ``full_MC`` draw through :meth:`draw_sample`); marginalising
+        the hyperparameters by MCMC is outside the accelerated path."""
+        if use_MCMC:
+            raise NotImplementedError("MCMC marginalisation of the hyperparameters is outside the accelerated hot "
+                                      "path (SURVEY.md section 8).")
         Xstar = np.atleast_2d(np.asarray(Xstar, dtype=float))
         if self.num_dim == 1 and Xstar.shape[0] == 1:
             Xstar = Xstar.T
@@ -766,7 +769,8 @@ class GaussianProcess(object):
             raise ValueError("All elements of n must be non-negative integers!")
 
         self.compute_K_L_alpha_ll()
-        need_cov = return_cov or full_output or (output_transform is not None and (return_std or return_cov))
+        need_cov = (return_cov or full_output or return_samples or full_MC or
+                    (output_transform is not None and (return_std or return_cov)))
         need_std = return_std or need_cov
         if self._fit_mode == "kernel":
             want = 2 if need_cov else (1 if need_std else 0)
@@ -789,8 +793,22 @@ class GaussianProcess(object):
                 std = np.sqrt(np.diagonal(covariance))
         if not need_std:
             return mean
+        samps = None
+        if return_samples or full_MC:                                    # ref :990-1005
+            samps = self.draw_sample(Xstar, n=n, num_samp=num_samples, mean=mean, cov=covariance, **samp_kwargs)
+            if rejection_func:
+                good = [samp for samp in samps.T if rejection_func(samp)]
+                if len(good) == 0:
+                    raise ValueError("Did not get any good samples!")
+                samps = np.asarray(good, dtype=float).T
+            if full_MC:
+                mean = np.mean(samps, axis=1)
+                covariance = np.cov(samps, rowvar=1, ddof=ddof)
+                std = np.sqrt(np.diagonal(covariance))
         if full_output:
             out = {"mean": mean, "std": std, "cov": covariance}
+            if samps is not None:
+                out["samp"] = samps
             if return_mean_func and mean_func is not None:
                 out["mean_func"] = mean_func
                 out["cov_func"] = np.zeros((len(mean_func), len(mean_func)), dtype=float)
@@ -802,6 +820,63 @@ class GaussianProcess(object):
         if return_cov:
             return (mean, covariance)
         return (mean, std)
+
+    # ---- posterior samples (ref: gptools/gaussian_process.py:1155-1330) --------------------------------------
+    def draw_sample(self, Xstar, n=0, num_samp=1, rand_vars=None, rand_type="standard normal", diag_factor=1e3,
+                    method="cholesky", num_eig=None, mean=None, cov=None, modify_sign=None, **kwargs):
+        """Samples ``y* = mean + L u`` of the GP at ``Xstar`` -> (M, num_samp), like the reference: without
+        ``rand_vars`` and with ``method='cholesky'`` the draw goes through ``numpy.random.multivariate_normal``
+        (falling back on ``'eig'`` if that fails); with ``rand_vars`` (standard normal, or uniform mapped through
+        the normal quantile function) the square root ``L`` of ``cov + diag_factor * eps * I`` is the lower Cholesky
+        factor -- computed on the GPU -- or ``Q sqrt(Lambda)`` from ``scipy.linalg.eigh``.  The predictive mean and
+        covariance come from :meth:`predict` (device path) unless given."""
+        if mean is None or cov is None:
+            out = self.predict(Xstar, n=n, full_output=True, **kwargs)
+            mean, cov = out["mean"], out["cov"]
+        mean, cov = np.asarray(mean, dtype=float), np.asarray(cov, dtype=float)
+        if rand_vars is None and method != "eig":
+            try:
+                return np.random.multivariate_normal(mean, cov, num_samp).T
+            except np.linalg.LinAlgError as e:
+                if self.verbose:
+                    warnings.warn("Failure when drawing from MVN! Falling back on eig. Exception was:\n{:s}".format(
+                        str(e)), RuntimeWarning)
+                method = "eig"
+        if num_eig is None or num_eig > len(mean):
+            num_eig = len(mean)
+        elif num_eig < 1:
+            num_eig = 1
+        if rand_vars is None:
+            rand_vars = np.random.standard_normal((num_eig, num_samp))
+        valid_types = ("standard normal", "uniform")
+        if rand_type not in valid_types:
+            raise ValueError("rand_type {:s} not recognized! Valid options are: {}.".format(rand_type, valid_types))
+        rand_vars = np.asarray(rand_vars, dtype=float)
+        if rand_type == "uniform":
+            from scipy.stats import norm as _norm
+            rand_vars = _norm.ppf(rand_vars)
+        loaded = cov + diag_factor * sys.float_info.epsilon * np.eye(cov.shape[0])
+        if method == "cholesky":
+            # a context of its own: factoring here must not disturb the resident factor of the fit
+            if getattr(self, "_scratch_ctx", None) is None:
+                self._scratch_ctx = _lib.Context(self.device)
+            L = np.tril(self._scratch_ctx.potrf_host(loaded))
+        elif method == "eig":
+            M = len(mean)
+            eig, Q = scipy.linalg.eigh(loaded, subset_by_index=(M - 1 - (num_eig - 1), M - 1))
+            if modify_sign is not None:
+                masks = {"left value": lambda q: q[0, :] < 0.0, "right value": lambda q: q[-1, :] < 0.0,
+                         "left slope": lambda q: (q[1, :] - q[0, :]) < 0.0,
+                         "right slope": lambda q: (q[-1, :] - q[-2, :]) < 0.0,
+                         "left concavity": lambda q: (q[2, :] - 2 * q[1, :] + q[0, :]) < 0.0,
+                         "right concavity": lambda q: (q[-1, :] - 2 * q[-2, :] + q[-3, :]) < 0.0}
+                if modify_sign not in masks:
+                    raise ValueError("modify_sign {:s} not recognized!".format(modify_sign))
+                Q[:, masks[modify_sign](Q)] *= -1.0
+            L = Q.dot(np.diag(np.sqrt(eig)))
+        else:
+            raise ValueError("method {:s} not recognized!".format(method))
+        return np.atleast_2d(mean).T + L.dot(rand_vars[:num_eig, :])
 
     def _predict_general(self, Xstar, n, noise, need_std):
         """predict for fits that went through ``gpt_fit_matrix`` (``T`` present or a Python kernel):

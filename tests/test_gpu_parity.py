@@ -805,3 +805,43 @@ def test_sum_of_native_kernels_on_device(g, oracle):
     b = gp.ll_batch(thetas)
     s = np.array([-gp.update_hyperparameters(t) for t in thetas])
     np.testing.assert_allclose(b, s, rtol=1e-12, atol=0)
+
+
+def test_draw_sample_cholesky_and_eig(g):
+    """draw_sample (ref gaussian_process.py:1155-1330): with given random variables the samples are
+    mean + L u with L the lower Cholesky factor (GPU) of cov + diag_factor eps I, or Q sqrt(Lambda); the resident
+    factor of the fit is untouched; predict(return_samples=True) returns them in the full_output dict."""
+    import scipy.linalg
+    rs = np.random.RandomState(4)
+    X = rs.rand(200, 1)
+    y = np.sin(6 * X[:, 0]) + 0.05 * rs.randn(200)
+    gp = g.GaussianProcess(make_kernel(g, "se", 1, [1.0, 0.2]), X=X, y=y, err_y=0.05)
+    Xs = np.linspace(0, 1, 150)[:, None]
+    out = gp.predict(Xs, full_output=True)
+    u = rs.randn(150, 7)
+    loaded = out["cov"] + 1e3 * EPS * np.eye(150)
+    # with the identity as "random variables" the call returns mean + L: L is lower triangular and L L^T is the loaded
+    # covariance (the matrix is numerically singular, so L itself is compared through that product, not entrywise)
+    L = gp.draw_sample(Xs, rand_vars=np.eye(150)) - out["mean"][:, None]
+    assert np.abs(np.triu(L, 1)).max() == 0.0
+    np.testing.assert_allclose(L.dot(L.T), loaded, rtol=0, atol=1e-12)
+    s_chol = gp.draw_sample(Xs, rand_vars=u)
+    np.testing.assert_allclose(s_chol, out["mean"][:, None] + L.dot(u), rtol=0, atol=1e-12)
+    s_eig = gp.draw_sample(Xs, rand_vars=u, method="eig", num_eig=10, modify_sign="left value")
+    assert s_eig.shape == (150, 7)
+    # the eigen square root reproduces the covariance restricted to its 10 leading modes
+    lam, Q = scipy.linalg.eigh(loaded, subset_by_index=(140, 149))
+    Q[:, Q[0, :] < 0] *= -1
+    np.testing.assert_allclose(s_eig, out["mean"][:, None] + (Q * np.sqrt(lam)).dot(u[:10]), rtol=0, atol=1e-8)
+    uu = rs.rand(150, 3)
+    s_uni = gp.draw_sample(Xs, rand_vars=uu, rand_type="uniform")
+    import scipy.stats
+    np.testing.assert_allclose(s_uni, out["mean"][:, None] + L.dot(scipy.stats.norm.ppf(uu)), rtol=0, atol=1e-8)
+    again = gp.predict(Xs, full_output=True)                       # the fit's factor is still resident and valid
+    np.testing.assert_array_equal(again["mean"], out["mean"])
+    np.random.seed(5)
+    full = gp.predict(Xs, full_output=True, return_samples=True, num_samples=4)
+    assert full["samp"].shape == (150, 4)
+    assert np.abs(full["samp"] - out["mean"][:, None]).max() < 6 * out["std"].max() + 1e-6
+    with pytest.raises(ValueError):
+        gp.draw_sample(Xs, rand_vars=u, rand_type="triangular")
