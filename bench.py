@@ -258,9 +258,19 @@ def main():
         if world == 1 and not args.no_cpu and not args.dist:
             ref, cb = cpu_baseline(kernel, X, n, y, err, params)
             out["cpu_baseline"] = cb
+            # parity gate of SURVEY.md section 8(d): ll, sum(log L_ii), predictive mean / std at 64 random points
+            from oracle import oracle as O
+            rs = np.random.RandomState(64)
+            Xs, ns = rs.rand(64, d), np.zeros((64, d), dtype=np.int32)
+            ctx.fit(KID[kernel], params, 0.0, y, err, diag_add)
+            gm, gs, _ = ctx.predict(Xs, ns, 1)
+            cm, cs, _ = O.predict(kernel, params, X, n, ref["L"], ref["alpha"], Xs, ns, want_cov=False)
             out["parity"] = {"ll_rel_err_vs_cpu": abs(ll - ref["ll_data"]) / abs(ref["ll_data"]),
                              "logdet_rel_err_vs_cpu": abs(ld - ref["logdet_half"]) / abs(ref["logdet_half"]),
-                             "tolerance": 1e-8}
+                             "tolerance": 1e-8,
+                             "predict_mean_max_abs_err": float(np.abs(gm - cm).max()),
+                             "predict_std_max_abs_err": float(np.abs(gs - cs).max()),
+                             "predict_tolerance": 1e-6}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
