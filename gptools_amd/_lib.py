@@ -41,6 +41,7 @@ SIGNATURES = {
     "gpt_fit_matrix": (C.c_int, [_vp, _dp, _i64, _dp, _dp, _dp]),
     "gpt_get_L": (C.c_int, [_vp, _dp]),
     "gpt_get_alpha": (C.c_int, [_vp, _dp]),
+    "gpt_ll_grad": (C.c_int, [_vp, C.c_int, _ip, _ip, _dp]),
     "gpt_predict": (C.c_int, [_vp, _dp, _ip, _i64, C.c_int, _dp, _ip, _dp, _dp, _dp]),
     "gpt_solve_L": (C.c_int, [_vp, _dp, _i64]),
     "gpt_cho_solve": (C.c_int, [_vp, _dp, _i64]),
@@ -236,6 +237,13 @@ class Context(object):
         check(self._lib.gpt_fit_sum(self.handle, len(ids), iptr(ids), dptr(flat), iptr(npar), float(noise_var), dptr(y),
                                     dptr(err_y), float(diag_add), C.byref(ll), C.byref(ld)))
         return ll.value, ld.value
+
+    def ll_grad(self, term_idx, local_idx):
+        """Data-term gradient for the listed (term, parameter) pairs plus the noise trace term (last entry)."""
+        ti, li = i32(np.asarray(term_idx)), i32(np.asarray(local_idx))
+        out = np.empty(len(ti) + 1)
+        check(self._lib.gpt_ll_grad(self.handle, len(ti), iptr(ti), iptr(li), dptr(out)))
+        return out
 
     def fit_matrix(self, K_tot, y):
         K_tot, y = f64(K_tot), f64(y)

@@ -40,7 +40,7 @@ struct DevBuf {
 };
 
 enum { SLOT_XI = 0, SLOT_XJ, SLOT_NI, SLOT_NJ, SLOT_OUT, SLOT_KST, SLOT_KSS, SLOT_XS, SLOT_NS, SLOT_VEC, SLOT_VEC2,
-       SLOT_RHS, SLOT_LOW, SLOT_KFULL, SLOT_TK, SLOT_ZERO, SLOT_COUNT };
+       SLOT_RHS, SLOT_LOW, SLOT_KFULL, SLOT_TK, SLOT_ZERO, SLOT_UINV, SLOT_WINV, SLOT_GPART, SLOT_COUNT };
 
 struct gpt_ctx {
     int device = 0;
@@ -1005,6 +1005,108 @@ extern "C" int gpt_get_alpha(gpt_ctx *c, double *alpha_out)
     GPT_TRY(ensure_alpha(c));
     GPT_HIP_CHECK(hipMemcpyAsync(alpha_out, c->d_alpha, (size_t)c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     GPT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return GPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// analytic gradient of the LML data term (ref: gptools/gaussian_process.py:1471-1520)
+// ------------------------------------------------------------------------------------------------
+// U = L^-T (upper triangular, row-major) for the block range [lo, hi) of the resident factor.  U must hold the identity
+// on its 128x128 diagonal blocks and zeros elsewhere on entry.  [[U11, U12], [0, U22]] with
+// U12 = -(U11 L21^T) L22^-T: one NT GEMM and one right-TRSM per level, leaves by the packed-inverse panel kernel.
+static int trtri_u(gpt_ctx *c, hipStream_t st, int64_t lo, int64_t hi, const double *L, int64_t ldl, const double *ws,
+                   double *U, int64_t ldu)
+{
+    const int64_t n = hi - lo;
+    if (n == 128)
+        return launch_trsm_panel(st, 128, L + lo * ldl + lo, ldl, ws + (lo / 128) * GPT_WS_BLOCK, U + lo * ldu + lo, ldu);
+    const int64_t h = (n / 256) * 128 > 0 ? (n / 256) * 128 : 128, mid = lo + h;
+    GPT_TRY(trtri_u(c, st, lo, mid, L, ldl, ws, U, ldu));
+    GPT_TRY(trtri_u(c, st, mid, hi, L, ldl, ws, U, ldu));
+    double *U12 = U + lo * ldu + mid;
+    GPT_TRY(gemm_nt(c, st, h, hi - mid, h, -1.0, U + lo * ldu + lo, ldu, L + mid * ldl + lo, ldl, 0.0, U12, ldu, 0));
+    return trsm_rlt(c, st, h, hi - mid, L + mid * ldl + mid, ldl, ws + (mid / 128) * GPT_WS_BLOCK, U12, ldu);
+}
+
+__global__ void eye_blocks_kernel(double *__restrict__ U, int64_t ldu, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) U[i * ldu + i] = 1.0;
+}
+
+extern "C" int gpt_ll_grad(gpt_ctx *c, int nh, const int *term_idx, const int *local_idx, double *out)
+{
+    CTX_ENTER(c);
+    NEED_FACTOR(c);
+    if (!c->have_kernel || c->dT) {
+        gpt_set_error("gpt_ll_grad needs a factorisation produced by gpt_fit / gpt_fit_sum without a transform");
+        return GPT_E_STATE;
+    }
+    if (nh < 0 || (nh > 0 && (!term_idx || !local_idx)) || !out) return GPT_E_ARG;
+    for (int h = 0; h < nh; h++) {
+        if (term_idx[h] < 0 || term_idx[h] >= (int)c->terms.size()) return GPT_E_ARG;
+        const KParams &t = c->terms[(size_t)term_idx[h]];
+        if (t.kernel_id != GPT_KERNEL_SE) {
+            gpt_set_error("hyper-parameter derivatives exist for the squared-exponential kernel only "
+                          "(ref: matern.py:543-544)");
+            return GPT_E_NOTIMPL;
+        }
+        if (local_idx[h] < 0 || local_idx[h] > c->D) return GPT_E_ARG;
+    }
+    const int64_t N = c->N, NP = c->NP;
+    hipStream_t st = c->stream;
+    double *U, *W, *dpart;
+    GPT_TRY(ensure(c, SLOT_UINV, (size_t)NP * NP * sizeof(double), (void **)&U));
+    GPT_TRY(ensure(c, SLOT_WINV, (size_t)NP * NP * sizeof(double), (void **)&W));
+    GPT_TRY(ensure_alpha(c));
+    // K_tot^-1 = L^-T L^-1 = U U^T: triangular inverse (~N^3/2 flop as organised here), then the lower half of U U^T
+    // block row by block row with k starting at the diagonal (N^3/3) -- all on the fp64-MFMA GEMM
+    GPT_HIP_CHECK(hipMemsetAsync(U, 0, (size_t)NP * NP * sizeof(double), st));
+    hipLaunchKernelGGL(eye_blocks_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, st, U, NP, NP);
+    GPT_LAUNCH_CHECK();
+    GPT_TRY(trtri_u(c, st, 0, NP, c->dA, NP, c->d_invd, U, NP));
+    const int64_t nb = 512;
+    for (int64_t r0 = 0; r0 < NP; r0 += nb) {
+        const int64_t rows = (NP - r0 < nb) ? NP - r0 : nb;
+        GPT_TRY(gemm_nt(c, st, rows, r0 + rows, NP - r0, 1.0, U + r0 * NP + r0, NP, U + r0, NP, 0.0, W + r0 * NP, NP, 0));
+    }
+    // sum_ab (alpha_a alpha_b - W_ab) dK_h[a][b], per kernel term, GPT_GRAD_MAXH parameters per launch
+    const int nblk = grad_reduce_blocks(N);
+    GPT_TRY(ensure(c, SLOT_GPART, (size_t)nblk * (GPT_GRAD_MAXH + 1) * sizeof(double), (void **)&dpart));
+    std::vector<double> hpart((size_t)nblk * (GPT_GRAD_MAXH + 1));
+    bool have_trace = false;
+    for (size_t t = 0; t < c->terms.size() || !have_trace; t++) {
+        std::vector<int> hs, where;
+        if (t < c->terms.size())
+            for (int h = 0; h < nh; h++)
+                if ((size_t)term_idx[h] == t) {
+                    hs.push_back(local_idx[h]);
+                    where.push_back(h);
+                }
+        if (hs.empty() && have_trace) continue;
+        const KParams &kp = c->terms[t < c->terms.size() ? t : 0];
+        for (size_t b0 = 0; b0 < hs.size() || !have_trace; b0 += GPT_GRAD_MAXH) {
+            const int cnt = (int)((hs.size() - b0 < (size_t)GPT_GRAD_MAXH) ? hs.size() - b0 : (size_t)GPT_GRAD_MAXH);
+            KParams ks = kp;
+            ks.symmetric = 1;
+            GPT_TRY(launch_grad_reduce(st, ks, cnt > 0 ? cnt : 0, cnt > 0 ? hs.data() + b0 : nullptr, c->dX, c->dn, N,
+                                       c->d_alpha, W, NP, dpart));
+            GPT_HIP_CHECK(hipMemcpyAsync(hpart.data(), dpart, hpart.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+            GPT_HIP_CHECK(hipStreamSynchronize(st));
+            for (int q = 0; q < cnt; q++) {
+                double sum = 0.0;
+                for (int b = 0; b < nblk; b++) sum += hpart[(size_t)b * (GPT_GRAD_MAXH + 1) + q];
+                out[where[b0 + q]] = 0.5 * sum;
+            }
+            if (!have_trace) {
+                double sum = 0.0;
+                for (int b = 0; b < nblk; b++) sum += hpart[(size_t)b * (GPT_GRAD_MAXH + 1) + GPT_GRAD_MAXH];
+                out[nh] = 0.5 * sum;
+                have_trace = true;
+            }
+            if (cnt <= 0) break;
+        }
+    }
     return GPT_OK;
 }
 

@@ -68,6 +68,10 @@ int launch_gemm_nt_stair(hipStream_t st, int64_t m, int64_t nseg, int64_t seg_co
                          double beta, double *C, int64_t ldc, int lds_pad);
 int launch_trsm_panel(hipStream_t st, int64_t m, const double *L, int64_t ldl, const double *invd,
                       double *B, int64_t ldb, hipEvent_t done = nullptr);
+#define GPT_GRAD_MAXH 8
+int grad_reduce_blocks(int64_t N);
+int launch_grad_reduce(hipStream_t st, const KParams &kp, int nh, const int *hl, const double *dX, const int32_t *dn,
+                       int64_t N, const double *dalpha, const double *dW, int64_t ldw, double *dpartial);
 int launch_add_diag(hipStream_t st, double *A, int64_t lda, int64_t n, const double *err, double diag_add);
 int launch_fill_pad(hipStream_t st, double *A, int64_t lda, int64_t n_valid, int64_t n_pad, const double *dy,
                     double big);

@@ -417,17 +417,32 @@ class GaussianProcess(object):
             return 0.5 * (alpha.dot(dK.dot(alpha)) - np.trace(W2))
 
         ll_deriv = np.zeros(len(self.free_params))
-        if isinstance(self.noise_k, ZeroKernel):
+        terms = self._native_terms() if (self._fit_mode == "kernel" and self.T is None) else None
+        if terms is not None and all(t[0] == _lib.KERNEL_SE for t in terms):
+            # device path (gpt_ll_grad): K_tot^-1 once (~N^3 flop on the MFMA GEMM, whatever the number of
+            # parameters), then one fused pass over the pairs per group of parameters; dK never exists
             knk = self.k
-        elif isinstance(self.noise_k, DiagonalNoiseKernel):
-            knk = self.k
-            if not self.noise_k.fixed_params[0]:
-                ll_deriv[len(self.k.free_params)] = term(2.0 * self.noise_k.params[0] * np.eye(Ny))
+            free_idx = np.arange(0, len(knk.params), dtype=int)[~np.asarray(knk.fixed_params, dtype=bool)]
+            bounds = np.cumsum([0] + [len(t[1]) for t in terms])
+            tix = [int(np.searchsorted(bounds, pi, side="right") - 1) for pi in free_idx]
+            lix = [int(pi - bounds[t]) for pi, t in zip(free_idx, tix)]
+            g_dev = ctx.ll_grad(tix, lix)
+            ll_deriv[:len(free_idx)] = g_dev[:-1]
+            if isinstance(self.noise_k, DiagonalNoiseKernel) and not isinstance(self.noise_k, ZeroKernel) \
+                    and not self.noise_k.fixed_params[0]:
+                ll_deriv[len(self.k.free_params)] = 2.0 * self.noise_k.params[0] * g_dev[-1]
         else:
-            knk = self.k + self.noise_k
-        free_idx = np.arange(0, len(knk.params), dtype=int)[~np.asarray(knk.fixed_params, dtype=bool)]
-        for i, pi in enumerate(free_idx):
-            ll_deriv[i] = term(self.compute_Kij(self.X, None, self.n, None, k=knk, hyper_deriv=int(pi)))
+            if isinstance(self.noise_k, ZeroKernel):
+                knk = self.k
+            elif isinstance(self.noise_k, DiagonalNoiseKernel):
+                knk = self.k
+                if not self.noise_k.fixed_params[0]:
+                    ll_deriv[len(self.k.free_params)] = term(2.0 * self.noise_k.params[0] * np.eye(Ny))
+            else:
+                knk = self.k + self.noise_k
+            free_idx = np.arange(0, len(knk.params), dtype=int)[~np.asarray(knk.fixed_params, dtype=bool)]
+            for i, pi in enumerate(free_idx):
+                ll_deriv[i] = term(self.compute_Kij(self.X, None, self.n, None, k=knk, hyper_deriv=int(pi)))
         if self.mu is not None:
             free_idx = np.arange(0, len(self.mu.params), dtype=int)[~self.mu.fixed_params]
             for i, pi in enumerate(free_idx):

@@ -138,6 +138,15 @@ int gpt_get_L(gpt_ctx *ctx, double *L_out);
 int gpt_get_alpha(gpt_ctx *ctx, double *alpha_out);
 
 /* ---- GaussianProcess.predict (non-MCMC branch) -------------------------------------------- */
+/* Analytic gradient of the LML data term (ref: gaussian_process.py:1471-1520), after gpt_fit / gpt_fit_sum (no transform):
+ *   out[h]  = 1/2 * sum_ab (alpha_a alpha_b - (K_tot^-1)_ab) * dK[a][b] / d theta_h      for h < nh, where theta_h is
+ *             parameter local_idx[h] (0 = sigma_f, j = l_j) of kernel term term_idx[h];
+ *   out[nh] = 1/2 * (alpha^T alpha - tr K_tot^-1)   (times 2 sigma_n this is the derivative for a DiagonalNoiseKernel).
+ * K_tot^-1 is formed on the device from the resident factor (triangular inverse + U U^T on the MFMA GEMM, ~N^3 flop
+ * whatever nh is -- the reference spends 2 N^3 per parameter in cho_solve); dK is never materialised.
+ * Squared-exponential terms only (GPT_E_NOTIMPL otherwise, like matern.py:543-544). */
+int gpt_ll_grad(gpt_ctx *ctx, int nh, const int *term_idx, const int *local_idx, double *out);
+
 /* Replaces  ref: gaussian_process.py:965-1006 for the T-free, untransformed case:
  *   Kstar = K(X, Xstar) ; mean = Kstar^T alpha ; v = L^-1 Kstar ; cov = K(Xstar,Xstar) - v^T v ;
  *   std = sqrt(diag(cov)).
