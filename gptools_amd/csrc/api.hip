@@ -1024,7 +1024,13 @@ static int trtri_u(gpt_ctx *c, hipStream_t st, int64_t lo, int64_t hi, const dou
     GPT_TRY(trtri_u(c, st, lo, mid, L, ldl, ws, U, ldu));
     GPT_TRY(trtri_u(c, st, mid, hi, L, ldl, ws, U, ldu));
     double *U12 = U + lo * ldu + mid;
-    GPT_TRY(gemm_nt(c, st, h, hi - mid, h, -1.0, U + lo * ldu + lo, ldu, L + mid * ldl + lo, ldl, 0.0, U12, ldu, 0));
+    // U11 is upper triangular: row chunk q only has non-zeros from its own first column on, so its k range starts there
+    const int64_t nq = (h >= 2048) ? 8 : (h >= 512 ? 4 : 1), hc = h / nq;
+    for (int64_t q = 0; q < nq; q++) {
+        const int64_t o = q * hc;
+        GPT_TRY(gemm_nt(c, st, hc, hi - mid, h - o, -1.0, U + (lo + o) * ldu + lo + o, ldu, L + mid * ldl + lo + o, ldl,
+                        0.0, U12 + o * ldu, ldu, 0));
+    }
     return trsm_rlt(c, st, h, hi - mid, L + mid * ldl + mid, ldl, ws + (mid / 128) * GPT_WS_BLOCK, U12, ldu);
 }
 
@@ -1061,15 +1067,24 @@ extern "C" int gpt_ll_grad(gpt_ctx *c, int nh, const int *term_idx, const int *l
     GPT_TRY(ensure_alpha(c));
     // K_tot^-1 = L^-T L^-1 = U U^T: triangular inverse (~N^3/2 flop as organised here), then the lower half of U U^T
     // block row by block row with k starting at the diagonal (N^3/3) -- all on the fp64-MFMA GEMM
+    const bool gt = getenv("GPT_GRAD_TIMING") != nullptr;
+    hipEvent_t ge[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (gt) {
+        for (auto &e : ge) GPT_HIP_CHECK(hipEventCreate(&e));
+        GPT_HIP_CHECK(hipEventRecord(ge[0], st));
+    }
     GPT_HIP_CHECK(hipMemsetAsync(U, 0, (size_t)NP * NP * sizeof(double), st));
     hipLaunchKernelGGL(eye_blocks_kernel, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, st, U, NP, NP);
     GPT_LAUNCH_CHECK();
     GPT_TRY(trtri_u(c, st, 0, NP, c->dA, NP, c->d_invd, U, NP));
-    const int64_t nb = 512;
+    // (block rows of about NP/8: skinnier launches exploit more of U's zeros but run the GEMM far below its rate)
+    if (gt) GPT_HIP_CHECK(hipEventRecord(ge[1], st));
+    const int64_t nb = (NP / 8 >= 512) ? (NP / 8) / 128 * 128 : 512;
     for (int64_t r0 = 0; r0 < NP; r0 += nb) {
         const int64_t rows = (NP - r0 < nb) ? NP - r0 : nb;
         GPT_TRY(gemm_nt(c, st, rows, r0 + rows, NP - r0, 1.0, U + r0 * NP + r0, NP, U + r0, NP, 0.0, W + r0 * NP, NP, 0));
     }
+    if (gt) GPT_HIP_CHECK(hipEventRecord(ge[2], st));
     // sum_ab (alpha_a alpha_b - W_ab) dK_h[a][b], per kernel term, GPT_GRAD_MAXH parameters per launch
     const int nblk = grad_reduce_blocks(N);
     GPT_TRY(ensure(c, SLOT_GPART, (size_t)nblk * (GPT_GRAD_MAXH + 1) * sizeof(double), (void **)&dpart));
@@ -1106,6 +1121,16 @@ extern "C" int gpt_ll_grad(gpt_ctx *c, int nh, const int *term_idx, const int *l
             }
             if (cnt <= 0) break;
         }
+    }
+    if (gt) {
+        GPT_HIP_CHECK(hipEventRecord(ge[3], st));
+        GPT_HIP_CHECK(hipStreamSynchronize(st));
+        float a = 0, b = 0, d = 0;
+        hipEventElapsedTime(&a, ge[0], ge[1]);
+        hipEventElapsedTime(&b, ge[1], ge[2]);
+        hipEventElapsedTime(&d, ge[2], ge[3]);
+        fprintf(stderr, "gpt_ll_grad N=%lld: triangular inverse %.2f ms, U U^T %.2f ms, pair pass %.2f ms\n", (long long)N, a, b, d);
+        for (auto &e : ge) hipEventDestroy(e);
     }
     return GPT_OK;
 }

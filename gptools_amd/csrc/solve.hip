@@ -154,37 +154,48 @@ int launch_zero2d(hipStream_t st, int64_t rows, int64_t cols, double *dst, int64
 //       row arrives from LDS, the pivot is broadcast with v_readlane; 1/L_ii comes from invd);
 //   (2) trsv_lt_update_kernel: w[0 : b*128) -= L[b-block rows, 0 : b*128)^T x_b, one column per
 //       lane, rows of L read as contiguous coalesced segments.
-__global__ __launch_bounds__(64) void trsv_lt_diag_kernel(const double *__restrict__ Lbb, int64_t ldl,
-                                                          const double *__restrict__ invd, double *__restrict__ x)
+// 256 threads: the packed workspace of the diagonal block (inverses of its eight 16x16 diagonal blocks + its 28
+// strictly-lower 16x16 blocks, 72 KB) is staged into LDS with coalesced loads, then the 128 unknowns fall in eight
+// block steps, last block first:  x_b = inv(L_bb)^T w_b  (16 lanes, 16 FMAs),  w_j -= L_bj^T x_b for every j < b
+// (16 lanes per block j, 16 FMAs).  Packed element (r, c) of a 16x16 block sits at (c >> 2) * 64 + r + 16 * (c & 3)
+// (MFMA B-operand lane order, see potrf.hip), i.e. a column of the block is 16 consecutive doubles.
+// (The first version walked the 128 columns one by one on a single wave that also loaded the 128 KB block by
+// itself: 100 us per block, 7 ms at N = 8192 -- more than the factorisation.)
+__global__ __launch_bounds__(256) void trsv_lt_diag_kernel(const double *__restrict__ Lbb, int64_t ldl,
+                                                           const double *__restrict__ invd, double *__restrict__ x)
 {
-    extern __shared__ __attribute__((aligned(16))) double tsm[];
-    double (*S)[129] = reinterpret_cast<double (*)[129]>(tsm);
-    double *rdiag = tsm + 128 * 129;
-    const int lane = threadIdx.x;
-    for (int idx = lane; idx < 128 * 128; idx += 64) {
-        const int r = idx >> 7, c = idx & 127;
-        S[r][c] = Lbb[(int64_t)r * ldl + c];
-    }
-    for (int i = lane; i < 128; i += 64) rdiag[i] = invd[(i >> 4) * 256 + ((i & 15) >> 2) * 64 + (i & 15) + 16 * (i & 3)];   // packed (r, r) of block i/16
-    double w0 = x[lane], w1 = x[lane + 64];
+    (void)Lbb;
+    (void)ldl;
+    __shared__ double ws[GPT_WS_BLOCK];
+    __shared__ double w[128], xb[16];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < GPT_WS_BLOCK; i += 256) ws[i] = invd[i];
+    if (tid < 128) w[tid] = x[tid];
     __syncthreads();
-    for (int j = 127; j >= 0; j--) {
-        const double src = (j >= 64) ? w1 : w0;
-        const int sl = j & 63;
-        const int lo = __builtin_amdgcn_readlane(__double2loint(src), sl);
-        const int hi = __builtin_amdgcn_readlane(__double2hiint(src), sl);
-        const double xj = __hiloint2double(hi, lo) * rdiag[j];
-        if (j >= 64) {
-            if (lane == sl) w1 = xj;
-            if (lane + 64 < j) w1 = fma(-S[j][lane + 64], xj, w1);
-            w0 = fma(-S[j][lane], xj, w0);
-        } else {
-            if (lane == sl) w0 = xj;
-            if (lane < j) w0 = fma(-S[j][lane], xj, w0);
+    const int j = tid >> 4, i = tid & 15;                       // lane i of 16-block j (threads 0..127)
+    const int col = (i >> 2) * 64 + 16 * (i & 3);               // start of packed column i
+    for (int b = 7; b >= 0; b--) {
+        if (tid < 128 && j == b) {
+            const double *inv = ws + b * 256 + col;            // column i of inv(L_bb): entries (k, i)
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc = fma(inv[k], w[b * 16 + k], acc);
+            xb[i] = acc;
         }
+        __syncthreads();
+        if (tid < 128) {
+            if (j == b) w[tid] = xb[i];
+            else if (j < b) {
+                const double *lb = ws + GPT_WS_LOFF + (b * (b - 1) / 2 + j) * 256 + col;     // column i of L_bj
+                double acc = w[tid];
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc = fma(-lb[k], xb[k], acc);
+                w[tid] = acc;
+            }
+        }
+        __syncthreads();
     }
-    x[lane] = w0;
-    x[lane + 64] = w1;
+    if (tid < 128) x[tid] = w[tid];
 }
 
 __global__ __launch_bounds__(256) void trsv_lt_update_kernel(int64_t ncols, const double *__restrict__ Lrow,
@@ -208,16 +219,9 @@ int launch_trsv_lt(hipStream_t st, int64_t n, const double *L, int64_t ldl, cons
         gpt_set_error("trsv_lt: n must be a multiple of 128");
         return GPT_E_ARG;
     }
-    static bool attr_set = false;
-    const size_t shmem = (size_t)(128 * 129 + 128) * sizeof(double);
-    if (!attr_set) {
-        GPT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(trsv_lt_diag_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        attr_set = true;
-    }
     for (int64_t b = n / 128 - 1; b >= 0; b--) {
         const double *Lbb = L + (b * 128) * ldl + b * 128;
-        hipLaunchKernelGGL(trsv_lt_diag_kernel, dim3(1), dim3(64), shmem, st, Lbb, ldl, invd + b * GPT_WS_BLOCK, x + b * 128);
+        hipLaunchKernelGGL(trsv_lt_diag_kernel, dim3(1), dim3(256), 0, st, Lbb, ldl, invd + b * GPT_WS_BLOCK, x + b * 128);
         if (b > 0) {
             const int64_t ncols = b * 128;
             hipLaunchKernelGGL(trsv_lt_update_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, st, ncols,
