@@ -20,7 +20,7 @@ def agg(path):
             seen.add((r['Dispatch_Id'], k)); cnt[k] += 1
             acc[k]['_dur_ns_' + path.split('/')[-2]] += float(r['End_Timestamp']) - float(r['Start_Timestamp'])
     return acc, cnt
-lines.append("\n# PMC passes (separate runs, rocprofv3 --kernel-trace --pmc <...> -- python3 bench.py --steps 2 --warmup 1 --no-cpu; 3 LML evaluations each)")
+lines.append("\n# PMC passes (separate runs, rocprofv3 --kernel-trace --pmc <...> -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-batched; 3 LML evaluations each)")
 res = {}
 for name in ('pmc_fetch', 'pmc_write', 'pmc_sq'):
     acc, cnt = agg(src + '/' + name + '/t_counter_collection.csv')
