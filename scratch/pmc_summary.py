@@ -5,7 +5,7 @@ def short(n): return re.sub(r'\(.*', '', n).replace('void ', '')
 lines = []
 # kernel stats
 rows = list(csv.DictReader(open(src + '/trace/t_kernel_stats.csv')))
-lines.append("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu   (C3: Matern52, N=8192, d=3)")
+lines.append("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-batched   (C3: Matern52, N=8192, d=3)")
 lines.append("%-44s %7s %14s %12s %10s %10s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "%"))
 for r in rows:
     lines.append("%-44s %7s %14s %12.0f %10s %10s %7s" % (short(r['Name'])[:44], r['Calls'], r['TotalDurationNs'], float(r['AverageNs']), r['MinNs'], r['MaxNs'], r['Percentage']))
