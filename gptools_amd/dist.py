@@ -25,6 +25,7 @@ partitioning / communication logic under the ``gloo`` backend.
 """
 import math
 import sys
+import time
 
 import numpy as np
 import torch
@@ -283,6 +284,7 @@ class DistributedLML(object):
         Edges: "urgent" (column k+2 is up to date with panel k) main -> panel, "done" (step k no longer reads P[k % 3])
         main -> panel before that buffer is staged / received into again, "arrived" panel -> main."""
         ops = self.ops
+        t_host0 = time.perf_counter()
         N, nb, NP, world, rank = self.N, self.nb, self.NP, self.world, self.rank
         nblk = self.nblk
         y = np.ascontiguousarray(y, dtype=np.float64)
@@ -358,6 +360,7 @@ class DistributedLML(object):
                     pending = self._bcast(nbuf[:NP - nxt * nb], nxt % world, async_op=True)
                     self._accumulate_scalars()
 
+        self.timings["host_enqueue_s"] = time.perf_counter() - t_host0      # the host ran this far ahead of the GPU
         # ---- scalars: sum(log L_ii) over i < N, z.z from the augmented row, info ----
         with ops.queue("panel"):
             red = self.red
