@@ -492,15 +492,6 @@ extern "C" int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out)
         if (!masked) GPT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
-    if (const char *e = getenv("GPT_PANEL_CUS")) {        // experiment: confine the panel stream to the first CUs
-        const int pc = atoi(e);
-        hipDeviceProp_t prop;
-        GPT_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
-        const int ncu = prop.multiProcessorCount;
-        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-        for (int i = 0; i < pc && i < ncu; i++) mask[i / 32] |= (1u << (i % 32));
-        GPT_HIP_CHECK(hipExtStreamCreateWithCUMask(&c->panel_stream, (uint32_t)mask.size(), mask.data()));
-    } else
     GPT_HIP_CHECK(hipStreamCreateWithPriority(&c->panel_stream, hipStreamNonBlocking, hi));
     for (int i = 0; i < 5; i++) GPT_HIP_CHECK(hipEventCreate(&c->tev[i]));
     GPT_HIP_CHECK(hipMalloc(&c->d_info, sizeof(int32_t)));

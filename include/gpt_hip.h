@@ -60,10 +60,18 @@ const char *gpt_last_error(void);
  * caller's hipStream_t is used for all work (pass torch.cuda.current_stream().cuda_stream). */
 int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out);
 int gpt_ctx_destroy(gpt_ctx *ctx);
-/* Options: "nb_outer" (outer block width, multiple of 128; 0 = chosen by size: 384 up to n = 12288, 512 above), "lookahead" (0/1), "graph" (0/1:
- * replay the factorisation from a captured hipGraph), "timing" (0/1: record per-phase HIP
- * events), "profile_gemm" (0/1: HIP-event timing of each large GEMM launch, see
- * gpt_gemm_profile_read), "tile" (0 auto, 64, 128: force the GEMM macro-tile). */
+/* Options (gpt_ctx_set_option):
+ *   "nb_outer"     outer block width of the factorisation, multiple of 128; 0 = by size (384 up to n = 12288, 512 above)
+ *   "lookahead"    0/1: factor panel k+1 on the high-priority panel stream while the main stream applies panel k
+ *   "helper_tf"    assumed rate of the helper stream (0.1 TFLOP/s per 24 CUs) that takes a slice of the large trailing
+ *                  updates on the reserved CUs when n > 12288; 0 = off
+ *   "ramp"         0/1: first panels 128, 256, ... wide (measured slower, off)
+ *   "gemm_pad"     bytes of dummy dynamic LDS of the main-stream GEMM (residency cap)
+ *   "graph"        0/1: replay the factorisation from a captured hipGraph
+ *   "timing"       0/1: record per-phase HIP events (gpt_last_timings)
+ *   "profile_gemm" 0/1: HIP-event timing of each large GEMM launch (gpt_gemm_profile_read)
+ *   "tile"         0 auto, 64, 65 (4-stage), 128 (persistent), 129: force the GEMM macro-tile
+ * Environment: GPT_RESERVE_CUS (CUs the main stream leaves to the panel stream, default 32), GPT_GRAD_TIMING. */
 int gpt_ctx_set_option(gpt_ctx *ctx, const char *key, int64_t value);
 int gpt_ctx_synchronize(gpt_ctx *ctx);
 void *gpt_ctx_stream(gpt_ctx *ctx);
