@@ -45,21 +45,36 @@ struct RsqPipe {
     }
 };
 
-// One column J of the pivot block; on entry rp.inv = 1/sqrt(pivot J).  The NEXT pivot is formed in the uniform
-// domain as a[J+1][J+1] - l^2 with l = L[J+1][J] (two scalar broadcasts), and its rsqrt pipeline is advanced one
-// step per broadcast/FMA group of this column.  Each group {2 x v_readlane, 2 x v_fma} is fenced with
-// sched_barrier: left alone, hipcc hoists all broadcasts of a column ahead of the FMAs, runs out of SGPRs and
-// spills every multiplier with v_writelane/s_nop, which doubled the instruction count of this issue-bound chain.
+// Row broadcasts by DPP.  The four quarters of the wave hold the same 16 matrix rows, so "the value lane C holds" is
+// a broadcast inside each row of 16 lanes: gfx950 has it as a modifier of the DP multiply-add itself,
+//   v_fmac_f64_dpp  acc, src row_newbcast:C, mult      acc += (src of lane C of my row) * mult,
+// one instruction where v_readlane x2 -> SGPR pair -> v_fma took three (and an SGPR round trip).  A DPP read of a VGPR
+// that a VALU instruction has just written needs two wait states; the s_nop sits in the statements that can follow
+// such a write directly.
+template <int C>
+__device__ __forceinline__ void fmac_bcast(double &acc, double src, double mult)
+{
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mult), "i"(C));
+}
+template <int C>
+__device__ __forceinline__ double mov_bcast_nop(double src)
+{
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "i"(C));
+    return r;
+}
+
+// One column J of the pivot block; on entry rp.inv = 1/sqrt(pivot J) (the same value in every lane).  The NEXT pivot
+// is a[J+1][J+1] - l^2 with l = L[J+1][J] (two row broadcasts), and its rsqrt pipeline is advanced one step per
+// update group of this column.
 template <int J, int C>
-__device__ __forceinline__ void pivot_group(double (&a)[16], double (&x)[16], RsqPipe &np)
+__device__ __forceinline__ void pivot_group(double (&a)[16], double (&x)[16], double naj, double nxj, RsqPipe &np)
 {
     if constexpr (C < 16) {
-        const double l = bcast_lane(a[J], C);            // L[c][j], wave-uniform (SGPR pair)
-        a[C] = fma(-a[J], l, a[C]);
-        x[C] = fma(-l, x[J], x[C]);
+        fmac_bcast<C>(a[C], a[J], naj);                    // a[r][C] -= L[r][J] * L[C][J]
+        fmac_bcast<C>(x[C], a[J], nxj);                    // x[C]    -= L[C][J] * x[J]
         np.step(C - J - 1);                                // C = J+1 carries step 0 (v_rsq), ... J+4 the last
-        __builtin_amdgcn_sched_barrier(0);
-        pivot_group<J, C + 1>(a, x, np);
+        pivot_group<J, C + 1>(a, x, naj, nxj, np);
     }
 }
 
@@ -71,15 +86,17 @@ __device__ __forceinline__ void pivot_col(double (&a)[16], double (&x)[16], RsqP
     x[J] *= inv;
     if constexpr (J + 1 < 16) {
         RsqPipe np;
-        const double l = bcast_lane(a[J], J + 1), q = bcast_lane(a[J + 1], J + 1);
+        const double l = mov_bcast_nop<J + 1>(a[J]), q = mov_bcast_nop<J + 1>(a[J + 1]);
         double dn = fma(-l, l, q);
         if (!(dn > 0.0)) {                                // not positive definite (LAPACK info = j + 2)
             if (bad == 0) bad = J + 2;
             dn = 1.0;
         }
         np.d = dn;
-        __builtin_amdgcn_sched_barrier(0);
-        pivot_group<J, J + 1>(a, x, np);
+        const double naj = -a[J], nxj = -x[J];
+        // (no scheduling fences inside the block: measured 24.4 us per 128-block against 26.9 with one per group and
+        // 27.1 with one per column -- left alone, hipcc overlaps the head of column J+1 with the tail of column J)
+        pivot_group<J, J + 1>(a, x, naj, nxj, np);
 #pragma unroll
         for (int k = 15 - J; k < 4; k++) np.step(k);      // columns with fewer than four groups finish the pipeline here
         rp = np;
