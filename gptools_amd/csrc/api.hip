@@ -58,6 +58,9 @@ struct gpt_ctx {
     int timing = 0;
     int tile = 0;
     int gemm_pad = 1024;
+    int64_t fuse_trsm = 4096;          // panels with at most this many rows below the leaf use potf2_trsm_kernel (0 = never)
+    unsigned *d_flag = nullptr;        // progress word of potf2_trsm_kernel (only ever raised)
+    unsigned flag_epoch = 0;
     int helper_tf = 35;                // assumed rate of the helper stream, in 0.1 TFLOP/s per 24 CUs (0 = no helper);
                                        // measured: 0 / 25 / 35 / 50 -> 212 / 209 / 206 / 214 ms at N=32768, 30.8 / 30.6 / 30.2 / 32.0 at N=16384
     int ramp = 0;                      // first panels 128, 256, ... wide (see potrf_enqueue); measured slower, off
@@ -270,11 +273,22 @@ static int panel_ext(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64_t
         double *Ad = A + lc * lda + lc;
         double *ws = invd + (lc / 128) * GPT_WS_BLOCK;
         const int64_t r1 = lc + 128;
-        GPT_TRY(launch_potf2_diag(st, Ad, lda, ws, info, lc));
         const bool last = (r1 == c0 + w) && done_ev;
-        // (a stop event on the launch is not recorded by stream capture: under a graph use a plain record)
-        GPT_TRY(launch_trsm_panel(st, n - r1, Ad, lda, ws, Ad + 128 * lda, lda, (last && !c->use_graph) ? done_ev : nullptr));
-        if (last && c->use_graph) GPT_HIP_CHECK(hipEventRecord(done_ev, st));
+        const int64_t m = n - r1;
+        if (c->fuse_trsm > 0 && m >= 128 && m <= c->fuse_trsm && !c->use_graph) {
+            // short panel: diagonal block and TRSM in one launch, the substitution trailing the pivots (potrf.hip)
+            if (c->flag_epoch > 0x3fffff00u) {
+                GPT_HIP_CHECK(hipMemsetAsync(c->d_flag, 0, 64, st));
+                c->flag_epoch = 0;
+            }
+            c->flag_epoch += 16;
+            GPT_TRY(launch_potf2_trsm(st, Ad, lda, ws, info, lc, m, c->d_flag, c->flag_epoch, last ? done_ev : nullptr));
+        } else {
+            GPT_TRY(launch_potf2_diag(st, Ad, lda, ws, info, lc));
+            // (a stop event on the launch is not recorded by stream capture: under a graph use a plain record)
+            GPT_TRY(launch_trsm_panel(st, m, Ad, lda, ws, Ad + 128 * lda, lda, (last && !c->use_graph) ? done_ev : nullptr));
+            if (last && c->use_graph) GPT_HIP_CHECK(hipEventRecord(done_ev, st));
+        }
         if (lc == c0 && wait_ev) GPT_HIP_CHECK(hipStreamWaitEvent(st, wait_ev, 0));
         if (cend > r1)
             GPT_TRY(gemm_nt(c, st, n - r1, cend - r1, 128, -1.0, A + r1 * lda + lc, lda, A + r1 * lda + lc, lda, 1.0,
@@ -495,6 +509,8 @@ extern "C" int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out)
     GPT_HIP_CHECK(hipStreamCreateWithPriority(&c->panel_stream, hipStreamNonBlocking, hi));
     for (int i = 0; i < 5; i++) GPT_HIP_CHECK(hipEventCreate(&c->tev[i]));
     GPT_HIP_CHECK(hipMalloc(&c->d_info, sizeof(int32_t)));
+    GPT_HIP_CHECK(hipMalloc((void **)&c->d_flag, 64));
+    GPT_HIP_CHECK(hipMemset(c->d_flag, 0, 64));
     GPT_HIP_CHECK(hipMalloc(&c->d_scal, 4 * sizeof(double)));
     GPT_HIP_CHECK(hipHostMalloc((void **)&c->h_scal, 4 * sizeof(double), hipHostMallocDefault));
     GPT_HIP_CHECK(hipHostMalloc((void **)&c->h_info, sizeof(int32_t), hipHostMallocDefault));
@@ -533,6 +549,7 @@ extern "C" int gpt_ctx_destroy(gpt_ctx *c)
     for (int i = 0; i < 5; i++)
         if (c->tev[i]) hipEventDestroy(c->tev[i]);
     if (c->d_info) hipFree(c->d_info);
+    if (c->d_flag) hipFree(c->d_flag);
     if (c->d_scal) hipFree(c->d_scal);
     if (c->h_scal) hipHostFree(c->h_scal);
     if (c->h_info) hipHostFree(c->h_info);
@@ -559,6 +576,7 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "gemm_pad")) c->gemm_pad = (int)value;
     else if (!strcmp(key, "ramp")) c->ramp = value ? 1 : 0;
     else if (!strcmp(key, "helper_tf")) c->helper_tf = (int)value;
+    else if (!strcmp(key, "fuse_trsm")) c->fuse_trsm = value;
     else if (!strcmp(key, "tile")) {
         if (value != 0 && value != 64 && value != 65 && value != 128 && value != 129) {
             gpt_set_error("tile must be 0, 64 or 128");

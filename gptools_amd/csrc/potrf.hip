@@ -160,11 +160,21 @@ __device__ __forceinline__ void pivot_block_16(double (*S)[PD_PITCH], double (*T
 }
 
 #define PD_THREADS 512
+#define TP_SP 18              // pitch of the per-wave 16x16 re-layout scratch of the TRSM kernels
 #define PD_WAVES (PD_THREADS / 64)
 
-__global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restrict__ A, int64_t lda,
-                                                                double *__restrict__ invd, int32_t *info,
-                                                                int64_t info_col0)
+// ws store of the storing wave.  PUBLISH: agent-scope (write-through) so that workgroups of the same launch on other
+// XCDs can read the value as soon as the block's flag is up (potf2_trsm_kernel); otherwise a plain store.
+template <bool PUBLISH>
+__device__ __forceinline__ void ws_store(double *p, double v)
+{
+    if (PUBLISH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+template <bool PUBLISH>
+__device__ __forceinline__ void potf2_body(double *__restrict__ A, int64_t lda, double *__restrict__ invd, int32_t *info,
+                                           int64_t info_col0, unsigned *flag, unsigned flag_base)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double (*S)[PD_PITCH] = reinterpret_cast<double (*)[PD_PITCH]>(smem);
@@ -226,11 +236,18 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restri
             }
             double *ip = invd + jb * 256, *lp = invd + GPT_WS_LOFF;
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) ip[kk * 64 + lane] = T[jb][fr][fk + 4 * kk];     // packed element (fr, fk + 4kk)
+            for (int kk = 0; kk < 4; kk++) ws_store<PUBLISH>(ip + kk * 64 + lane, T[jb][fr][fk + 4 * kk]);   // packed element (fr, fk + 4kk)
             for (int j = jb + 1; j < NB16; j++) {                               // packed blocks (j, jb)
                 const int b = j * (j - 1) / 2 + jb;
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++) lp[b * 256 + kk * 64 + lane] = S[j * 16 + fr][jb * 16 + fk + 4 * kk];
+                for (int kk = 0; kk < 4; kk++)
+                    ws_store<PUBLISH>(lp + b * 256 + kk * 64 + lane, S[j * 16 + fr][jb * 16 + fk + 4 * kk]);
+            }
+            if (PUBLISH) {
+                // everything step jb of a forward substitution needs is out: inv(L_jb,jb) just now, the blocks (jb, c < jb)
+                // in earlier rounds.  Release at agent scope, then raise the flag.
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane == 0) __hip_atomic_store(flag, flag_base + (unsigned)jb + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else if (jb + 1 < NB16) {
             const int rem = NB16 - 1 - jb;
@@ -264,6 +281,117 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restri
     }
 }
 
+__global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restrict__ A, int64_t lda,
+                                                                double *__restrict__ invd, int32_t *info,
+                                                                int64_t info_col0)
+{
+    potf2_body<false>(A, lda, invd, info, info_col0, nullptr, 0u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// potf2_trsm_kernel: the diagonal block AND the TRSM of the rows below it in one launch, for the latency-bound end of
+// the factorisation.  Workgroup 0 is potf2_body; it publishes the packed workspace block by block (agent-scope
+// stores, release, flag = flag_base + blocks done).  Workgroups 1.. own 128 rows of the panel each (16 per wave, as
+// trsm_panel_kernel): they load their rows while the pivots run, and take step j of the forward substitution as soon
+// as flag >= flag_base + j + 1, reading inv(L_jj) and the blocks (j, c < j) straight into MFMA operand registers with
+// agent-scope loads.  The substitution therefore trails the pivot chain by one step instead of starting after it:
+// the pair costs ~28 us where potf2 (24.4) + trsm_panel (10, of which ~5 are launch + prologue) cost ~34.
+// Workgroup 0 is dispatched first and waits for nobody, so the spinning consumers cannot starve it.  Every workgroup
+// of the launch gets potf2's 135 KB of LDS, i.e. a CU to itself: used only while the panel is short (few workgroups,
+// idle chip); above that the two plain kernels run (host side, api.hip).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restrict__ A, int64_t lda,
+                                                                double *__restrict__ invd, int32_t *info,
+                                                                int64_t info_col0, int64_t m, double *__restrict__ B,
+                                                                int64_t ldb, unsigned *flag, unsigned flag_base)
+{
+    if (blockIdx.x == 0) {
+        potf2_body<true>(A, lda, invd, info, info_col0, flag, flag_base);
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    constexpr int NB16 = PD_NB / 16;
+    double (*X)[TP_SP] = reinterpret_cast<double (*)[TP_SP]>(smem + wave * 16 * TP_SP);
+    const int64_t row0 = ((int64_t)(blockIdx.x - 1) * PD_WAVES + wave) * 16;
+    const bool active = row0 < m;
+    f64x4 bt[NB16];
+    double xa[NB16][4];
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < NB16; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) bt[j][r] = B[(row0 + fk + 4 * r) * ldb + j * 16 + fr];
+    }
+    const double *lpk = invd + GPT_WS_LOFF;
+#pragma unroll
+    for (int j = 0; j < NB16; j++) {
+        if (tid == 0) {
+            // (signed difference: a value left by an earlier launch lies below flag_base)
+            while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - flag_base) < j + 1)
+                __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+        if (!active) continue;
+        double dv[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+            dv[kk] = __hip_atomic_load(invd + j * 256 + kk * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f64x4 acc = bt[j];
+#pragma unroll
+        for (int c = 0; c < j; c++) {
+            double lv[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+                lv[kk] = __hip_atomic_load(lpk + (j * (j - 1) / 2 + c) * 256 + kk * 64 + lane, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[c][kk], lv[kk], acc, 0, 0, 0);
+        }
+        // accumulator (C layout) -> A operand through the per-wave scratch
+#pragma unroll
+        for (int r = 0; r < 4; r++) X[fk + 4 * r][fr] = acc[r];
+        double av[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) av[kk] = X[fr][fk + 4 * kk];
+        f64x4 res = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) res = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], dv[kk], res, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            B[(row0 + fk + 4 * r) * ldb + j * 16 + fr] = res[r];
+            X[fk + 4 * r][fr] = res[r];
+        }
+        if (j + 1 < NB16) {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) xa[j][kk] = -X[fr][fk + 4 * kk];
+        }
+    }
+}
+
+// m rows below the 128x128 diagonal block at A (B = A + 128 * lda).  `flag` is a device word only ever raised;
+// flag_base must exceed every value written to it before (the caller counts: 16 per launch).
+int launch_potf2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
+                      unsigned *flag, unsigned flag_base, hipEvent_t done)
+{
+    static bool attr_set = false;
+    const size_t shmem = (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
+    if (!attr_set) {
+        GPT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(potf2_trsm_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        attr_set = true;
+    }
+    const unsigned grid = 1u + (unsigned)((m + 16 * PD_WAVES - 1) / (16 * PD_WAVES));
+    if (done) hipExtLaunchKernelGGL(potf2_trsm_kernel, dim3(grid), dim3(PD_THREADS), shmem, st, nullptr, done, 0, A, lda, invd,
+                                    info, info_base, m, A + 128 * lda, lda, flag, flag_base);
+    else hipLaunchKernelGGL(potf2_trsm_kernel, dim3(grid), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base, m,
+                            A + 128 * lda, lda, flag, flag_base);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
 int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base)
 {
     static bool attr_set = false;
@@ -287,7 +415,6 @@ int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int3
 // (A variant that streams the L fragments from global memory needs only 9 KB of LDS but measured 12.6 us against
 // 10.8 us for this one, and did not improve the overlap with a concurrent trailing update.)
 #define TP_WAVES 4
-#define TP_SP 18
 __global__ __launch_bounds__(64 * TP_WAVES, 2) void trsm_panel_kernel(int64_t m, const double *__restrict__ L,
                                                                       int64_t ldl, const double *__restrict__ invd,
                                                                       double *__restrict__ B, int64_t ldb)
