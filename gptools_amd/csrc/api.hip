@@ -510,7 +510,10 @@ extern "C" int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out)
     for (int i = 0; i < 5; i++) GPT_HIP_CHECK(hipEventCreate(&c->tev[i]));
     GPT_HIP_CHECK(hipMalloc(&c->d_info, sizeof(int32_t)));
     GPT_HIP_CHECK(hipMalloc((void **)&c->d_flag, 64));
-    GPT_HIP_CHECK(hipMemset(c->d_flag, 0, 64));
+    // (hipMemsetAsync on the context's stream, never hipMemset: one call on the legacy null stream and from then on
+    // every kernel of this process starts ~40 us late on every stream -- measured on the block-cyclic engine,
+    // 31 -> 41 ms per rank at N=32768 over 8 ranks, potf2 26 -> 45..90 us in the trace)
+    GPT_HIP_CHECK(hipMemsetAsync(c->d_flag, 0, 64, c->stream));
     GPT_HIP_CHECK(hipMalloc(&c->d_scal, 4 * sizeof(double)));
     GPT_HIP_CHECK(hipHostMalloc((void **)&c->h_scal, 4 * sizeof(double), hipHostMallocDefault));
     GPT_HIP_CHECK(hipHostMalloc((void **)&c->h_info, sizeof(int32_t), hipHostMallocDefault));

@@ -17,6 +17,13 @@ pool over independent hyperparameter samples); what must match is the *result* o
     finishes applying panel k, so the transfer and the latency-bound panel hide behind the updates.
   * ``z = L^-1 y`` rides along as the augmented row N of the matrix, so the only
     other collective is one all-reduce of three scalars (log-det part, z.z part, info).
+  * Two schedules (``schedule=``): ``"bcast"`` factors a panel whole and then broadcasts it; ``"pipelined"``
+    cuts every panel into a few row chunks of growing size (2, 6, 24, ... blocks): the owner factors the
+    diagonal block with the first chunk and sends it at once, the TRSM of the later chunks, their transfer and
+    the next owner's column update proceed chunk by chunk behind it, so the serial chain through the panels
+    carries only the small head chunks (its own communicator) instead of whole panels.  Two ways to move a
+    chunk (``exchange=``): one broadcast, or scatter + all-gather (every xGMI link of the root carries 1/world
+    of the chunk, then all links carry the all-gather) for chunks above ``sag_min_bytes``.
 
 All dense work goes through a small ``ops`` object.  The product implementation is
 :class:`HipPanelOps` (C ABI of libgpt_hip.so on CUDA tensors; raises without a GPU).  The
@@ -64,6 +71,11 @@ class PanelOps(object):
     def synchronize(self):
         pass
 
+    def new_timing_event(self):
+        """An event whose position on the device timeline can be read back (``elapsed_ms``); None where there is no
+        device timeline (CPU test ops)."""
+        return None
+
     def gemm_nt_stair(self, m, nseg, seg_cols, k, alpha, A, lda, B, ldb, b_stride, row_step, beta, C, ldc, q="main"):
         """Default: one lower-trapezoid ``gemm_nt`` per column segment (8-byte elements)."""
         for s in range(nseg):
@@ -73,8 +85,11 @@ class PanelOps(object):
 
 
 class _StreamEvent(object):
-    def __init__(self):
-        self.ev = torch.cuda.Event()
+    def __init__(self, timing=False):
+        self.ev = torch.cuda.Event(enable_timing=timing)
+
+    def elapsed_ms(self, later):
+        return self.ev.elapsed_time(later.ev)
 
     def record(self):
         self.ev.record(torch.cuda.current_stream())
@@ -101,8 +116,13 @@ class HipPanelOps(PanelOps):
         self.main_stream = torch.cuda.ExternalStream(int(self.ctx_main.stream), device=self.device)
         self.panel_stream = torch.cuda.Stream(self.device, priority=-1)
         self.ctx_panel = _lib.Context(self.device.index, stream=self.panel_stream.cuda_stream)
+        # "recv": where a rank that does not own a panel posts its side of the exchange -- an otherwise empty stream,
+        # so that the receive never queues up behind this rank's own panel work
+        import os
+        self.recv_stream = (self.panel_stream if os.environ.get("GPT_DIST_RECV_ON_PANEL", "0") == "1"
+                            else torch.cuda.Stream(self.device, priority=-1))
         self._ctx = {"main": self.ctx_main, "panel": self.ctx_panel}
-        self._stream = {"main": self.main_stream, "panel": self.panel_stream}
+        self._stream = {"main": self.main_stream, "panel": self.panel_stream, "recv": self.recv_stream}
         for c in self._ctx.values():
             c.set_option("lookahead", 0)
 
@@ -112,9 +132,13 @@ class HipPanelOps(PanelOps):
     def new_event(self):
         return _StreamEvent()
 
+    def new_timing_event(self):
+        return _StreamEvent(timing=True)
+
     def synchronize(self):
         self.main_stream.synchronize()
         self.panel_stream.synchronize()
+        self.recv_stream.synchronize()
 
     def kbuild_block(self, kernel_id, params, X, n, r0, r1, c0, c1, err_y, noise_var, diag_add, out, ld):
         """out[(i - r0) * ld + (j - c0)] = K_tot[i][j] for i in [r0, r1), j in [c0, c1) (global indices)."""
@@ -131,6 +155,10 @@ class HipPanelOps(PanelOps):
         _lib.check(self.lib.gpt_dev_potrf_panel(self.ctx_panel.handle, m, nb, A, lda, invd.data_ptr(),
                                                 info.data_ptr(), info_base))
 
+    def trsm_rlt(self, m, nb, L, ldl, invd, B, ldb):
+        """B (m x nb) <- B L^-T on the panel queue, L the factored diagonal block of the same panel."""
+        _lib.check(self.lib.gpt_dev_trsm_rlt(self.ctx_panel.handle, m, nb, L, ldl, invd.data_ptr(), B, ldb))
+
     def gemm_nt(self, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, q="main"):
         _lib.check(self.lib.gpt_dev_gemm_nt(self._ctx[q].handle, m, n, k, float(alpha), A, lda, B, ldb, float(beta),
                                             C, ldc, int(tri)))
@@ -146,20 +174,45 @@ def _ptr(t, row, col):
     return t.data_ptr() + (row * t.stride(0) + col) * t.element_size()
 
 
+class _Arrival(object):
+    """One row chunk of a panel becoming readable on this rank: the exchange's work handle (None when no collective was
+    issued) and, on the owner, the event after the kernels that produced it.  ``wait()`` orders the current queue
+    behind both; it may be called from several queues."""
+    __slots__ = ("works", "ev")
+
+    def __init__(self, works, ev):
+        self.works = works
+        self.ev = ev
+
+    def wait(self):
+        if self.ev is not None:
+            self.ev.wait()
+        for w in self.works:
+            w.wait()
+
+
 class DistributedLML(object):
     """Evaluate the LML data term of a GP whose K_tot is partitioned over the ranks of ``group``.
 
     ``X`` (N, D) float64 and ``n`` (N, D) integer derivative orders are replicated on every rank.
     ``fit(kernel_id, params, y, err_y, ...)`` returns ``(ll_data, logdet_half)`` on every rank and
     raises ``numpy.linalg.LinAlgError`` if K_tot is not positive definite.
-    """
 
-    def __init__(self, X, n, nb=512, group=None, ops=None, device=None, lookahead=True, layout=None):
+    ``schedule``: ``"pipelined"`` (row-chunked panels, the default with look-ahead) or ``"bcast"`` (whole panels);
+    ``exchange``: ``"bcast"`` or ``"scatter_gather"`` (chunks of at least ``sag_min_bytes`` whose row count divides by
+    the world size; smaller ones are broadcast); ``chunk_blocks``: panel-local block rows at which a panel is cut.
+    All three may be changed between ``fit`` calls (bench.py times the combinations during warm-up).
+    """
+    NBUF = 4
+
+    def __init__(self, X, n, nb=512, group=None, ops=None, device=None, lookahead=True, layout=None,
+                 schedule="pipelined", exchange="bcast", chunk_blocks=(2, 8, 32), sag_min_bytes=8 << 20):
         if nb <= 0 or nb % 128:
             raise ValueError("nb must be a positive multiple of 128")
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.grank = self.rank                  # position in the process group (``layout`` does not change it)
         if layout is not None:
             # (rank, world) of the block-cyclic layout given explicitly: a subclass then supplies ``_bcast`` /
             # ``_allreduce`` itself (scratch/sim_ranks.py replays one rank's schedule of an 8-rank job on one GPU)
@@ -173,6 +226,22 @@ class DistributedLML(object):
         import os
         self.force_collectives = bool(int(os.environ.get("GPT_DIST_FORCE_COLLECTIVES", "0"))) and dist.is_initialized()
         self.lookahead = bool(lookahead)
+        if schedule not in ("pipelined", "bcast") or exchange not in ("bcast", "scatter_gather"):
+            raise ValueError("schedule must be 'pipelined' or 'bcast', exchange 'bcast' or 'scatter_gather'")
+        self.schedule = schedule
+        self.exchange = exchange
+        self.chunk_blocks = tuple(int(b) for b in chunk_blocks)
+        if not self.chunk_blocks or self.chunk_blocks[0] < 2 or list(self.chunk_blocks) != sorted(set(self.chunk_blocks)):
+            raise ValueError("chunk_blocks must be increasing and start at 2 or more (the head chunk holds L_kk and L_k+1,k)")
+        self.sag_min_bytes = int(sag_min_bytes)
+        # the later chunks of the pipelined schedule travel on a communicator of their own, so that a head chunk never
+        # queues behind the bulk of an earlier panel (collectives of one communicator run in issue order)
+        self.group_tail = group
+        # RCCL runs the collectives of a communicator in issue order on its stream; other backends need explicit waits
+        self._stream_ordered = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        if dist.is_initialized() and layout is None and (self.world > 1 or self.force_collectives):
+            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+            self.group_tail = dist.new_group(ranks=ranks)
         X = np.ascontiguousarray(X, dtype=np.float64)
         n = np.ascontiguousarray(n, dtype=np.int32)
         self.N, self.D = X.shape
@@ -185,14 +254,15 @@ class DistributedLML(object):
         self.X = torch.from_numpy(X).to(dev)
         self.n = torch.from_numpy(n).to(dev)
         self.A = torch.empty((self.NP, max(self.nloc, 1) * nb), dtype=torch.float64, device=dev)
-        # three panel buffers: panel k is read by the main queue's updates while panel k+1 is staged / received and
-        # panel k-1 may still be in use by updates that have not drained
-        self.P = [torch.empty((self.NP, nb), dtype=torch.float64, device=dev) for _ in range(3)]
+        # panel buffers: panel k is read by the main queue's updates while panel k+1 is staged / received and earlier
+        # ones may still be in use by updates that have not drained (the slowest rank sets the pace of the exchanges)
+        self.P = [torch.empty((self.NP, nb), dtype=torch.float64, device=dev) for _ in range(self.NBUF)]
         self.invd = torch.empty(((nb // 128) * 9216,), dtype=torch.float64, device=dev)     # GPT_WS_BLOCK per 128 columns
         self.info = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.y = torch.empty((self.NP,), dtype=torch.float64, device=dev)
         self.err = torch.zeros((self.NP,), dtype=torch.float64, device=dev)
         self.timings = {}
+        self.trace = False          # record the device-timeline position of every step (timings["steps_ms"])
 
     # ------------------------------------------------------------------------------------------
     def _assemble(self, kernel_id, params, noise_var, diag_add):
@@ -215,11 +285,39 @@ class DistributedLML(object):
                 if c0 <= N < (J + 1) * nb:
                     A[N, lj * nb + (N - c0)] = BIG_PIVOT
 
-    def _bcast(self, buf, src, async_op=False):
-        if self.world == 1 and not self.force_collectives:
+    def _collectives_on(self):
+        return self.world > 1 or self.force_collectives
+
+    def _bcast(self, buf, src, async_op=False, group=None):
+        if not self._collectives_on():
             return None
-        gsrc = dist.get_global_rank(self.group, src) if self.group is not None else src
-        return dist.broadcast(buf, src=gsrc, group=self.group, async_op=async_op)
+        group = self.group if group is None else group
+        gsrc = dist.get_global_rank(group, src) if group is not None else src
+        return dist.broadcast(buf, src=gsrc, group=group, async_op=async_op)
+
+    def _exchange(self, buf, src, group=None, tag=None):
+        """Start moving the contiguous rows ``buf`` from rank ``src`` to everyone; returns the list of work handles to
+        wait for (empty when no collective is needed).  scatter + all-gather: the root's links each carry 1/world of
+        the rows, then every link carries the all-gather; a broadcast moves the whole chunk along one path.  ``tag`` = (panel, first row) is not used here
+        (scratch/sim_ranks.py overrides this method and needs to know what is being moved)."""
+        if not self._collectives_on():
+            return []
+        W = self.world
+        rows = buf.shape[0]
+        if (self.exchange == "scatter_gather" and rows % W == 0
+                and buf.numel() * buf.element_size() >= self.sag_min_bytes):
+            group = self.group if group is None else group
+            gsrc = dist.get_global_rank(group, src) if group is not None else src
+            c = rows // W
+            pieces = [buf[r * c:(r + 1) * c] for r in range(W)]
+            mine = pieces[self.grank]
+            w1 = dist.scatter(mine, scatter_list=pieces if self.grank == src else None, src=gsrc, group=group,
+                              async_op=True)
+            if not self._stream_ordered:
+                w1.wait()      # (gloo runs asynchronous operations on a thread pool, in no particular order)
+            w2 = dist.all_gather_into_tensor(buf, mine, group=group, async_op=True)      # in place
+            return [w1, w2]
+        return [self._bcast(buf, src, async_op=True, group=group)]
 
     def _allreduce(self, t, op):
         dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX, group=self.group)
@@ -273,70 +371,117 @@ class DistributedLML(object):
         self.ops.gemm_nt_stair(self.NP - J0 * nb, len(Js), nb, nb, -1.0, _ptr(buf, off, 0), nb, _ptr(buf, off, 0), nb,
                                W * nb, W * nb, 1.0, _ptr(A, J0 * nb, (J0 // W) * nb), A.stride(0), q="main")
 
-    def fit(self, kernel_id, params, y, err_y, noise_var=0.0, diag_factor=1e2):
-        """One LML evaluation; returns ``(ll_data, logdet_half)`` on every rank.
-
-        Schedule per step k (panel k = block column k of L, contiguous in P[k % 3] on every rank):
-          panel queue: [owner of k+1: stage block column k+1 into P[(k+1) % 3]] -> panel k has arrived ->
-                       [owner: apply panel k to the staged column, factor it] -> start broadcast k+1 (async)
-          main queue : panel k has arrived -> apply it to the owned block columns right of k+1, the one that is staged
-                       next (k+2) first.
-        Edges: "urgent" (column k+2 is up to date with panel k) main -> panel, "done" (step k no longer reads P[k % 3])
-        main -> panel before that buffer is staged / received into again, "arrived" panel -> main."""
-        ops = self.ops
-        t_host0 = time.perf_counter()
-        N, nb, NP, world, rank = self.N, self.nb, self.NP, self.world, self.rank
-        nblk = self.nblk
+    def _begin(self, kernel_id, params, y, err_y, noise_var, diag_factor):
+        """Common head of both schedules: upload y / err_y, build the local block columns (main queue)."""
+        ops, N = self.ops, self.N
         y = np.ascontiguousarray(y, dtype=np.float64)
         err_y = np.array(np.broadcast_to(err_y, (N,)), dtype=np.float64)
-        owner = lambda J: J % world == rank
-
         with ops.queue("main"):
             self.y[:N] = torch.from_numpy(y).to(self.device)
             self.err[:N] = torch.from_numpy(err_y).to(self.device)
             self.info.zero_()
             self.red = torch.zeros((3,), dtype=torch.float64, device=self.device)
+            self._t0 = ops.new_timing_event() if self.trace else None
+            if self._t0 is not None:
+                self._t0.record()
             self._assemble(kernel_id, params, noise_var, diag_factor * sys.float_info.epsilon)
             ev_asm = ops.new_event()
             ev_asm.record()
         self._factored = []
+        self._marks = []
+        return ev_asm
+
+    def _mark(self, k, tag):
+        """(trace) device-timeline stamp on the current (main) queue: panel k has arrived / has been applied."""
+        if self._t0 is not None:
+            e = self.ops.new_timing_event()
+            e.record()
+            self._marks.append((k, tag, e))
+
+    def _finish(self, t_host0):
+        """Common tail: the three scalars (sum(log L_ii) over i < N, z.z from the augmented row, info) and ll."""
+        ops, N, world = self.ops, self.N, self.world
+        self.timings["host_enqueue_s"] = time.perf_counter() - t_host0      # the host ran this far ahead of the GPU
+        with ops.queue("panel"):
+            red = self.red
+            red[2] = self.info.to(torch.float64)[0]
+            if self._collectives_on():
+                # info: non-zero on the owner of the failing panel only; max picks it up
+                info_t = red[2:3].clone()
+                self._allreduce(red[:2], "sum")
+                self._allreduce(info_t, "max")
+                red[2] = info_t[0]
+            logdet_half, zz, info = (float(v) for v in red.cpu())
+        ops.synchronize()
+        if self._t0 is not None:
+            self.timings["steps_ms"] = [(k, tag, self._t0.elapsed_ms(e)) for k, tag, e in self._marks]
+        if info != 0 and info <= N:
+            raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % int(info))
+        ll_data = -0.5 * zz - logdet_half - 0.5 * N * math.log(2.0 * math.pi)
+        return ll_data, logdet_half
+
+    def fit(self, kernel_id, params, y, err_y, noise_var=0.0, diag_factor=1e2):
+        """One LML evaluation; returns ``(ll_data, logdet_half)`` on every rank."""
+        if self.schedule == "pipelined" and self.lookahead:
+            return self._fit_pipelined(kernel_id, params, y, err_y, noise_var, diag_factor)
+        return self._fit_bcast(kernel_id, params, y, err_y, noise_var, diag_factor)
+
+    # ------------------------------------------------------------------------------------------
+    def _fit_bcast(self, kernel_id, params, y, err_y, noise_var, diag_factor):
+        """Whole-panel schedule.  Per step k (panel k = block column k of L, contiguous in P[k % NBUF] on every rank):
+          panel queue: [owner of k+1: stage block column k+1 into P[(k+1) % NBUF]] -> panel k has arrived ->
+                       [owner: apply panel k to the staged column, factor it] -> start exchange k+1 (async)
+          main queue : panel k has arrived -> apply it to the owned block columns right of k+1, the one that is staged
+                       next (k+2) first.
+        Edges: "urgent" (column k+2 is up to date with panel k) main -> panel, "done" (step k no longer reads its
+        buffer) main -> panel before that buffer is staged / received into again, "arrived" panel -> main."""
+        ops = self.ops
+        t_host0 = time.perf_counter()
+        nb, NP, world, rank, NBUF = self.nb, self.NP, self.world, self.rank, self.NBUF
+        nblk = self.nblk
+        owner = lambda J: J % world == rank
+        ev_asm = self._begin(kernel_id, params, y, err_y, noise_var, diag_factor)
         ev_urg, ev_done = {}, {}
+
+        def wait_all(ws):
+            for w in ws:
+                w.wait()
 
         with ops.queue("panel"):
             ev_asm.wait()
             if owner(0):
                 self._stage_panel(0, self.P[0])
                 self._factor_staged(0, self.P[0])
-            pending = self._bcast(self.P[0][:NP], 0, async_op=True)
+            pending = self._exchange(self.P[0][:NP], 0, tag=(0, 0))
             self._accumulate_scalars()
 
         for k in range(nblk):
-            buf = self.P[k % 3]
+            buf = self.P[k % NBUF]
             nxt = k + 1
-            nbuf = self.P[nxt % 3]
+            nbuf = self.P[nxt % NBUF]
             own_next = nxt < nblk and owner(nxt)
             la = self.lookahead and nxt < nblk
             with ops.queue("panel"):
                 if la:
-                    if k - 2 in ev_done:
-                        ev_done.pop(k - 2).wait()          # nbuf held panel k-2
+                    if nxt - NBUF in ev_done:
+                        ev_done.pop(nxt - NBUF).wait()     # nbuf held panel k+1-NBUF
                     if own_next:
                         if k - 1 in ev_urg:
                             ev_urg.pop(k - 1).wait()       # column k+1 is up to date with panel k-1
-                        self._stage_panel(nxt, nbuf)       # before the wait: overlaps the tail of broadcast k
-                if pending is not None:
-                    pending.wait()
-                    pending = None
+                        self._stage_panel(nxt, nbuf)       # before the wait: overlaps the tail of exchange k
+                wait_all(pending)
+                pending = []
                 ev_arr = ops.new_event()
                 ev_arr.record()
                 if la:
                     if own_next:
                         self._update_block(k, nxt, buf, nbuf.data_ptr(), nb, q="panel")
                         self._factor_staged(nxt, nbuf)
-                    pending = self._bcast(nbuf[:NP - nxt * nb], nxt % world, async_op=True)
+                    pending = self._exchange(nbuf[:NP - nxt * nb], nxt % world, tag=(nxt, 0))
                     self._accumulate_scalars()
             with ops.queue("main"):
                 ev_arr.wait()
+                self._mark(k, "arrived")
                 mine = [J for J in self.my_blocks if J > k and not (la and J == nxt)]
                 urgent = k + 2
                 if la and urgent in mine:
@@ -348,32 +493,119 @@ class DistributedLML(object):
                     self._update_blocks(k, mine, buf)
                 ev_done[k] = ops.new_event()
                 ev_done[k].record()
+                self._mark(k, "applied")
             if nxt < nblk and not la:
                 # no look-ahead: the next panel is factored only after every update of this step
                 with ops.queue("panel"):
                     ev_done.pop(k).wait()
-                    if k - 2 in ev_done:
-                        ev_done.pop(k - 2).wait()
+                    if nxt - NBUF in ev_done:
+                        ev_done.pop(nxt - NBUF).wait()
                     if own_next:
                         self._stage_panel(nxt, nbuf)
                         self._factor_staged(nxt, nbuf)
-                    pending = self._bcast(nbuf[:NP - nxt * nb], nxt % world, async_op=True)
+                    pending = self._exchange(nbuf[:NP - nxt * nb], nxt % world, tag=(nxt, 0))
                     self._accumulate_scalars()
+        return self._finish(t_host0)
 
-        self.timings["host_enqueue_s"] = time.perf_counter() - t_host0      # the host ran this far ahead of the GPU
-        # ---- scalars: sum(log L_ii) over i < N, z.z from the augmented row, info ----
-        with ops.queue("panel"):
-            red = self.red
-            red[2] = self.info.to(torch.float64)[0]
-            if world > 1 or self.force_collectives:
-                # info: non-zero on the owner of the failing panel only; max picks it up
-                info_t = red[2:3].clone()
-                self._allreduce(red[:2], "sum")
-                self._allreduce(info_t, "max")
-                red[2] = info_t[0]
-            logdet_half, zz, info = (float(v) for v in red.cpu())
-        ops.synchronize()
-        if info != 0 and info <= N:
-            raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % int(info))
-        ll_data = -0.5 * zz - logdet_half - 0.5 * N * math.log(2.0 * math.pi)
-        return ll_data, logdet_half
+    # ------------------------------------------------------------------------------------------
+    def _chunk_bounds(self, k):
+        """Panel-local block rows at which panel k is cut: [0, 2, 8, 32, ..., blocks of panel k] (``chunk_blocks``);
+        a cut that would leave a last chunk smaller than half of what precedes it is dropped."""
+        mb = self.nblk - k
+        b = [0] + [e for e in self.chunk_blocks if e < mb and 2 * (mb - e) >= e]
+        return b + [mb]
+
+    def _fit_pipelined(self, kernel_id, params, y, err_y, noise_var, diag_factor):
+        """Row-chunked schedule.  Panel k lives in P[k % NBUF], cut at ``_chunk_bounds(k)``.  Its owner, on the panel
+        queue, takes the chunks top down: rows [lo, hi) of the staged column get panel k-1 applied as soon as rows
+        [lo + nb, hi + nb) of panel k-1 are there (block row 1 of panel k-1 is the other operand), then the first chunk
+        is factored (diagonal block + the TRSM of its remaining rows), later ones are solved against the factored
+        diagonal block, and each chunk starts travelling at once -- head chunks on ``group``, the rest on
+        ``group_tail``.  The chain from panel to panel therefore is: head of k-1 arrives -> 2-block update ->
+        diagonal block -> head of k leaves, while the bulk TRSM, the bulk transfer and the next owner's column update
+        overlap chunk by chunk.  Other ranks post their side of every exchange on the idle "recv" queue.
+          main queue, step k: every chunk of panel k has arrived -> apply it to the owned block columns right of k+1
+                              (k+1 is its owner's business on the panel queue), column k+2 first ("urgent").
+        Buffer reuse: P[k % NBUF] is written again (staged or received into) only after this rank's main queue is done
+        with step k - NBUF and its panel queue has finished reading panel k - NBUF."""
+        ops = self.ops
+        t_host0 = time.perf_counter()
+        nb, NP, world, rank, NBUF = self.nb, self.NP, self.world, self.rank, self.NBUF
+        nblk = self.nblk
+        owner = lambda J: J % world == rank
+        ev_asm = self._begin(kernel_id, params, y, err_y, noise_var, diag_factor)
+        ev_urg, ev_done, ev_pq = {}, {}, {}
+        arrivals = {}
+
+        def produce(k):
+            buf = self.P[k % NBUF]
+            own = owner(k)
+            bl = self._chunk_bounds(k)
+            prev = arrivals.get(k - 1)
+            pbuf = self.P[(k - 1) % NBUF]
+            pb = self._chunk_bounds(k - 1) if k > 0 else None
+            arr = arrivals[k] = []
+            with ops.queue("panel" if own else "recv"):
+                if k == 0:
+                    ev_asm.wait()
+                if k - NBUF in ev_done:
+                    ev_done.pop(k - NBUF).wait()
+                if k - NBUF in ev_pq:
+                    ev_pq.pop(k - NBUF).wait()
+                if own:
+                    if k - 2 in ev_urg:
+                        ev_urg.pop(k - 2).wait()           # column k is up to date with panel k-2
+                    self._stage_panel(k, buf)              # before any wait for panel k-1
+                waited = 0
+                for c in range(len(bl) - 1):
+                    lo, hi = bl[c] * nb, bl[c + 1] * nb
+                    ev = None
+                    if own:
+                        if k > 0:
+                            # last block row of panel k-1 this chunk reads: local block bl[c+1]
+                            need = max(j for j in range(len(pb) - 1) if pb[j] <= bl[c + 1])
+                            while waited <= need:
+                                prev[waited].wait()
+                                waited += 1
+                            ops.gemm_nt(hi - lo, nb, nb, -1.0, _ptr(pbuf, lo + nb, 0), nb, _ptr(pbuf, nb, 0), nb, 1.0,
+                                        _ptr(buf, lo, 0), nb, 1 if c == 0 else 0, q="panel")
+                        if c == 0:
+                            ops.potrf_panel(hi, nb, buf.data_ptr(), nb, self.invd, self.info, k * nb)
+                        else:
+                            ops.trsm_rlt(hi - lo, nb, buf.data_ptr(), nb, self.invd, _ptr(buf, lo, 0), nb)
+                        ev = ops.new_event()
+                        ev.record()
+                    works = self._exchange(buf[lo:hi], k % world, group=self.group if c == 0 else self.group_tail,
+                                           tag=(k, lo))
+                    arr.append(_Arrival(works, ev))
+                if own:
+                    self._factored.append((k, buf))
+                    self._accumulate_scalars()
+                    if k > 0:
+                        ev_pq[k - 1] = ops.new_event()     # this queue no longer reads panel k-1 ...
+                        ev_pq[k - 1].record()
+                    ev_pq[k] = ops.new_event()             # ... nor (scalars) its own panel
+                    ev_pq[k].record()
+
+        produce(0)
+        for k in range(nblk):
+            buf = self.P[k % NBUF]
+            if k + 1 < nblk:
+                produce(k + 1)
+            with ops.queue("main"):
+                for a in arrivals.pop(k):
+                    a.wait()
+                self._mark(k, "arrived")
+                mine = [J for J in self.my_blocks if J > k + 1]
+                urgent = k + 2
+                if urgent in mine:
+                    self._update_block(k, urgent, buf)
+                    mine.remove(urgent)
+                    ev_urg[k] = ops.new_event()
+                    ev_urg[k].record()
+                if mine:
+                    self._update_blocks(k, mine, buf)
+                ev_done[k] = ops.new_event()
+                ev_done[k].record()
+                self._mark(k, "applied")
+        return self._finish(t_host0)

@@ -3,7 +3,7 @@ block-cyclic job with every panel that rank does not own injected (device-to-dev
 infinitely fast interconnect).  What is timed is exactly the GPU work rank r would do: its K columns, its panels, its
 staircase updates.  max_r T_r is a lower bound of the W-GPU time; the gap to the real time is broadcast + chain stalls.
 
-  python scratch/sim_ranks.py c4 8        # workload, world size
+  python scratch/sim_ranks.py c4 8 [pipelined|bcast] [ranks ...]       # workload, world size, schedule
 """
 import sys, time, numpy as np, torch
 sys.path.insert(0, '/root/repo')
@@ -12,7 +12,8 @@ from gptools_amd.dist import DistributedLML, HipPanelOps
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c4"
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-ranks = [int(v) for v in sys.argv[3:]] or list(range(W))
+sched = sys.argv[3] if len(sys.argv) > 3 else "pipelined"
+ranks = [int(v) for v in sys.argv[4:]] or list(range(W))
 kernel, N, d, deriv = bench.WORKLOADS[wl]
 X, n, y, err, params = bench.synth(kernel, N, d, deriv)
 kid = bench.KID[kernel]
@@ -26,19 +27,31 @@ class Recorder(DistributedLML):
         self.saved[k] = buf[:self.NP - k * self.nb].clone()
 
 
+class CopyDone(object):
+    """Work-handle stand-in: wait() orders the current stream behind the injected copy."""
+    def __init__(self):
+        self.ev = torch.cuda.Event()
+        self.ev.record(torch.cuda.current_stream())
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
 class OneRank(DistributedLML):
     """Rank r of W; foreign panels are copied in from the recorder."""
-    def _bcast(self, buf, src, async_op=False):
-        k = self.NP // self.nb - buf.shape[0] // self.nb          # panel index from the slice length
+    def _exchange(self, buf, src, group=None, tag=None):
+        k, lo = tag
         if src != self.rank:
-            buf.copy_(self.panels[k])
-        return None
+            # (a receiver posts its side on the "recv" queue; here that is where the copy runs)
+            buf.copy_(self.panels[k][lo:lo + buf.shape[0]])
+            return [CopyDone()]
+        return []
 
     def _allreduce(self, t, op):
         pass
 
 
-rec = Recorder(X, n, nb=512, ops=ops)
+rec = Recorder(X, n, nb=512, ops=ops, schedule="bcast")
 rec.saved = {}
 ll_ref, ld_ref = rec.fit(kid, params, y, err)
 t0 = time.perf_counter(); rec.saved = {}; rec.fit(kid, params, y, err); torch.cuda.synchronize(); t1 = time.perf_counter()
@@ -46,7 +59,7 @@ print("world 1 (block-cyclic engine): %.1f ms" % ((t1 - t0) * 1e3))
 panels = rec.saved
 tot = []
 for r in ranks:
-    plan = OneRank(X, n, nb=512, ops=ops, layout=(r, W))
+    plan = OneRank(X, n, nb=512, ops=ops, layout=(r, W), schedule=sched)
     plan.force_collectives = True          # takes the world > 1 code path (scalar reduction included, as a no-op)
     plan.panels = panels
     ts = []
@@ -58,5 +71,5 @@ for r in ranks:
     print("rank %d of %d: %.1f ms (owns %d block columns)" % (r, W, min(ts) * 1e3, plan.nloc))
     del plan
 T = max(tot)
-print("%s N=%d, %d ranks: max over ranks %.1f ms -> compute-side bound %.1f TFLOP/s = %.1f %% of %d x 78.6" % (
-    wl, N, W, T * 1e3, bench.flops_fit(N) / T * 1e-12, 100 * bench.flops_fit(N) / T * 1e-12 / (78.6 * W), W))
+print("%s N=%d, %d ranks, schedule %s: max over ranks %.1f ms -> compute-side bound %.1f TFLOP/s = %.1f %% of %d x 78.6" % (
+    wl, N, W, sched, T * 1e3, bench.flops_fit(N) / T * 1e-12, 100 * bench.flops_fit(N) / T * 1e-12 / (78.6 * W), W))

@@ -63,6 +63,11 @@ class _NumpyDense(object):
         if m > nb:
             P[nb:] = scipy.linalg.solve_triangular(L, P[nb:].T, lower=True).T
 
+    def trsm_rlt(self, m, nb, L, ldl, invd, B, ldb):
+        import scipy.linalg
+        Lv, Bv = np.tril(_view(L, nb, nb, ldl)), _view(B, m, nb, ldb)
+        Bv[:, :] = scipy.linalg.solve_triangular(Lv, Bv.T.copy(), lower=True).T
+
     def gemm_nt(self, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, q="main"):
         Av, Bv, Cv = _view(A, m, k, lda).copy(), _view(B, n, k, ldb).copy(), _view(C, m, n, ldc)
         Cv[:, :] = beta * Cv + alpha * Av.dot(Bv.T)
@@ -78,7 +83,7 @@ def _inputs(N, d, seed=4):
     return X, n, y
 
 
-def _worker(rank, world, port, N, d, nb, kernel_id, lookahead, bad, q):
+def _worker(rank, world, port, N, d, nb, kernel_id, lookahead, bad, q, plan_kw=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -88,7 +93,7 @@ def _worker(rank, world, port, N, d, nb, kernel_id, lookahead, bad, q):
         if bad:
             X[1] = X[0]
             n[:] = 0
-        plan = DistributedLML(X, n, nb=nb, ops=_numpy_ops(), lookahead=lookahead)
+        plan = DistributedLML(X, n, nb=nb, ops=_numpy_ops(), lookahead=lookahead, **(plan_kw or {}))
         p = np.concatenate(([1.0], 0.3 * np.ones(d)))
         try:
             res = plan.fit(kernel_id, p, y, 0.0 if bad else 0.05, diag_factor=0.0 if bad else 1e2)
@@ -109,11 +114,11 @@ def _free_port():
     return port
 
 
-def _run(world, N, d, nb, kernel_id, lookahead, bad=False):
+def _run(world, N, d, nb, kernel_id, lookahead, bad=False, plan_kw=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, d, nb, kernel_id, lookahead, bad, q))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, d, nb, kernel_id, lookahead, bad, q, plan_kw))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -124,15 +129,26 @@ def _run(world, N, d, nb, kernel_id, lookahead, bad=False):
     return sorted(out)
 
 
-@pytest.mark.parametrize("world,N,d,nb,kid,lookahead", [
-    (2, 700, 3, 128, 1, True),      # Matern52 with derivative rows, 6 block columns over 2 ranks
-    (2, 700, 3, 128, 1, False),
-    (3, 500, 2, 128, 0, True),      # SE, uneven block ownership (5 block columns over 3 ranks)
-    (2, 100, 2, 256, 0, True),      # fewer block columns than ranks -> an idle rank must still take part
+_WHOLE = {"schedule": "bcast"}
+_WHOLE_SAG = {"schedule": "bcast", "exchange": "scatter_gather", "sag_min_bytes": 0}
+_PIPE = {"schedule": "pipelined"}                                                  # chunks cut at 2, 8, 32 blocks
+_PIPE_FINE = {"schedule": "pipelined", "chunk_blocks": (2, 3, 5), "exchange": "scatter_gather", "sag_min_bytes": 0}
+
+
+@pytest.mark.parametrize("world,N,d,nb,kid,lookahead,plan_kw", [
+    (2, 700, 3, 128, 1, True, _WHOLE),      # Matern52 with derivative rows, 6 block columns over 2 ranks
+    (2, 700, 3, 128, 1, False, _WHOLE),
+    (3, 500, 2, 128, 0, True, _WHOLE),      # SE, uneven block ownership (5 block columns over 3 ranks)
+    (2, 100, 2, 256, 0, True, _WHOLE),      # fewer block columns than ranks -> an idle rank must still take part
+    (2, 700, 3, 128, 1, True, _WHOLE_SAG),  # panels moved by scatter + all-gather
+    (2, 1500, 3, 128, 1, True, _PIPE),      # 12 block columns: panels of 12, 11, ... blocks cut into 2-3 row chunks
+    (3, 1500, 2, 128, 0, True, _PIPE_FINE), # up to 4 chunks per panel; scatter + all-gather where rows divide by 3
+    (2, 100, 2, 256, 0, True, _PIPE),       # one block column, idle rank
+    (4, 900, 2, 128, 0, True, _PIPE_FINE),  # more ranks than panel buffers minus one
 ])
-def test_distributed_fit_matches_single_process_oracle(world, N, d, nb, kid, lookahead):
+def test_distributed_fit_matches_single_process_oracle(world, N, d, nb, kid, lookahead, plan_kw):
     from oracle import oracle as O
-    out = _run(world, N, d, nb, kid, lookahead)
+    out = _run(world, N, d, nb, kid, lookahead, plan_kw=plan_kw)
     X, n, y = _inputs(N, d)
     p = np.concatenate(([1.0], 0.3 * np.ones(d)))
     ref = O.fit(kid, p, X, n, y, 0.05 * np.ones(N))
@@ -148,9 +164,10 @@ def test_distributed_fit_matches_single_process_oracle(world, N, d, nb, kid, loo
 
 
 def test_distributed_not_positive_definite_raises_on_every_rank():
-    out = _run(2, 300, 2, 128, 0, True, bad=True)
-    for rank, res, _, _ in out:
-        assert res[0] == "LinAlgError" and "not positive definite" in res[1]
+    for plan_kw in (_WHOLE, _PIPE):
+        out = _run(2, 300, 2, 128, 0, True, bad=True, plan_kw=plan_kw)
+        for rank, res, _, _ in out:
+            assert res[0] == "LinAlgError" and "not positive definite" in res[1]
 
 
 # ---- replicas: independent items over the ranks (gptools_amd/replicas.py) ------------------------------------
