@@ -206,7 +206,8 @@ class DistributedLML(object):
     NBUF = 4
 
     def __init__(self, X, n, nb=512, group=None, ops=None, device=None, lookahead=True, layout=None,
-                 schedule="pipelined", exchange="bcast", chunk_blocks=(2, 8, 32), sag_min_bytes=8 << 20):
+                 schedule="pipelined", exchange="bcast", chunk_blocks=(2, 8, 32), sag_min_bytes=8 << 20,
+                 owner_first=None):
         if nb <= 0 or nb % 128:
             raise ValueError("nb must be a positive multiple of 128")
         self.group = group
@@ -234,6 +235,13 @@ class DistributedLML(object):
         if not self.chunk_blocks or self.chunk_blocks[0] < 2 or list(self.chunk_blocks) != sorted(set(self.chunk_blocks)):
             raise ValueError("chunk_blocks must be increasing and start at 2 or more (the head chunk holds L_kk and L_k+1,k)")
         self.sag_min_bytes = int(sag_min_bytes)
+        # owner_first: the owner of panel k+1 starts its own trailing update of step k only after it has produced panel
+        # k+1.  Everybody else is waiting for that panel, nobody for the owner's update; and a panel kernel that has to
+        # share the chip with a trailing update already in flight gets a third of it, whatever the stream priority
+        # (N=32768, 8 ranks replayed on one GPU: 3.0 ms from first to last chunk of an early panel, against
+        # ~0.8 ms when it has the chip).  Pointless with one or two ranks (the owner is always the same / every
+        # other step), on by default from three.
+        self.owner_first = (self.world > 2) if owner_first is None else bool(owner_first)
         # the later chunks of the pipelined schedule travel on a communicator of their own, so that a head chunk never
         # queues behind the bulk of an earlier panel (collectives of one communicator run in issue order)
         self.group_tail = group
@@ -473,14 +481,20 @@ class DistributedLML(object):
                 pending = []
                 ev_arr = ops.new_event()
                 ev_arr.record()
+                ev_own = None
                 if la:
                     if own_next:
                         self._update_block(k, nxt, buf, nbuf.data_ptr(), nb, q="panel")
                         self._factor_staged(nxt, nbuf)
+                        if self.owner_first:
+                            ev_own = ops.new_event()
+                            ev_own.record()
                     pending = self._exchange(nbuf[:NP - nxt * nb], nxt % world, tag=(nxt, 0))
                     self._accumulate_scalars()
             with ops.queue("main"):
                 ev_arr.wait()
+                if ev_own is not None:
+                    ev_own.wait()                          # own panel first (see __init__)
                 self._mark(k, "arrived")
                 mine = [J for J in self.my_blocks if J > k and not (la and J == nxt)]
                 urgent = k + 2
@@ -593,6 +607,8 @@ class DistributedLML(object):
             if k + 1 < nblk:
                 produce(k + 1)
             with ops.queue("main"):
+                if self.owner_first and k + 1 < nblk and owner(k + 1):
+                    arrivals[k + 1][-1].ev.wait()          # own panel first (see __init__)
                 for a in arrivals.pop(k):
                     a.wait()
                 self._mark(k, "arrived")

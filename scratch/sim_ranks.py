@@ -5,7 +5,7 @@ staircase updates.  max_r T_r is a lower bound of the W-GPU time; the gap to the
 
   python scratch/sim_ranks.py c4 8 [pipelined|bcast] [ranks ...]       # workload, world size, schedule
 """
-import sys, time, numpy as np, torch
+import os, sys, time, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 import bench
 from gptools_amd.dist import DistributedLML, HipPanelOps
@@ -59,7 +59,8 @@ print("world 1 (block-cyclic engine): %.1f ms" % ((t1 - t0) * 1e3))
 panels = rec.saved
 tot = []
 for r in ranks:
-    plan = OneRank(X, n, nb=512, ops=ops, layout=(r, W), schedule=sched)
+    plan = OneRank(X, n, nb=512, ops=ops, layout=(r, W), schedule=sched,
+                   owner_first=bool(int(os.environ.get("SIM_OWNER_FIRST", "1"))))
     plan.force_collectives = True          # takes the world > 1 code path (scalar reduction included, as a no-op)
     plan.panels = panels
     ts = []
