@@ -56,6 +56,7 @@ SIGNATURES = {
     "gpt_dev_potrf_panel": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64]),
     "gpt_dev_potrf": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
     "gpt_dev_trsm_rlt": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64]),
+    "gpt_dev_trinv": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64]),
 }
 
 _lib = None

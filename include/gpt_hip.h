@@ -237,6 +237,13 @@ int gpt_dev_potrf(gpt_ctx *ctx, int64_t n, double *dA, int64_t lda, double *d_in
 int gpt_dev_trsm_rlt(gpt_ctx *ctx, int64_t m, int64_t n, const double *dL, int64_t ldl,
                      const double *d_invd, double *dB, int64_t ldb);
 
+/* dW (n x n, row-major, ldw; zeros above the diagonal) <- L^-1, L (n x n) a factored diagonal block, d_invd from its
+ * factorisation.  The TRSM of many rows then is one GEMM: gpt_dev_gemm_nt(m, n, n, 1, B, ldb, dW, ldw, 0, X, ldx, 0)
+ * gives X = B L^-T (the reference reaches the same quantity through scipy.linalg.cho_factor / LAPACK dtrsm inside
+ * dpotrf, gaussian_process.py:1452). */
+int gpt_dev_trinv(gpt_ctx *ctx, int64_t n, const double *dL, int64_t ldl, const double *d_invd,
+                  double *dW, int64_t ldw);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,7 +60,8 @@ panels = rec.saved
 tot = []
 for r in ranks:
     plan = OneRank(X, n, nb=512, ops=ops, layout=(r, W), schedule=sched,
-                   owner_first=bool(int(os.environ.get("SIM_OWNER_FIRST", "1"))))
+                   owner_first=bool(int(os.environ.get("SIM_OWNER_FIRST", "1"))),
+                   inv_trsm=bool(int(os.environ.get("SIM_INV_TRSM", "1"))))
     plan.force_collectives = True          # takes the world > 1 code path (scalar reduction included, as a no-op)
     plan.panels = panels
     ts = []

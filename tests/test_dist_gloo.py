@@ -68,9 +68,13 @@ class _NumpyDense(object):
         Lv, Bv = np.tril(_view(L, nb, nb, ldl)), _view(B, m, nb, ldb)
         Bv[:, :] = scipy.linalg.solve_triangular(Lv, Bv.T.copy(), lower=True).T
 
+    def trinv(self, nb, L, ldl, invd, W, ldw):
+        import scipy.linalg
+        _view(W, nb, nb, ldw)[:, :] = scipy.linalg.solve_triangular(np.tril(_view(L, nb, nb, ldl)), np.eye(nb), lower=True)
+
     def gemm_nt(self, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, q="main"):
         Av, Bv, Cv = _view(A, m, k, lda).copy(), _view(B, n, k, ldb).copy(), _view(C, m, n, ldc)
-        Cv[:, :] = beta * Cv + alpha * Av.dot(Bv.T)
+        Cv[:, :] = alpha * Av.dot(Bv.T) + (beta * Cv if beta != 0.0 else 0.0)
 
 
 def _inputs(N, d, seed=4):
@@ -132,6 +136,7 @@ def _run(world, N, d, nb, kernel_id, lookahead, bad=False, plan_kw=None):
 _WHOLE = {"schedule": "bcast"}
 _WHOLE_SAG = {"schedule": "bcast", "exchange": "scatter_gather", "sag_min_bytes": 0}
 _PIPE = {"schedule": "pipelined"}                                                  # chunks cut at 2, 8, 32 blocks
+_PIPE_SUBST = {"schedule": "pipelined", "inv_trsm": False}                         # tail chunks by substitution
 _PIPE_FINE = {"schedule": "pipelined", "chunk_blocks": (2, 3, 5), "exchange": "scatter_gather", "sag_min_bytes": 0}
 
 
@@ -143,6 +148,7 @@ _PIPE_FINE = {"schedule": "pipelined", "chunk_blocks": (2, 3, 5), "exchange": "s
     (2, 700, 3, 128, 1, True, _WHOLE_SAG),  # panels moved by scatter + all-gather
     (2, 1500, 3, 128, 1, True, _PIPE),      # 12 block columns: panels of 12, 11, ... blocks cut into 2-3 row chunks
     (3, 1500, 2, 128, 0, True, _PIPE_FINE), # up to 4 chunks per panel; scatter + all-gather where rows divide by 3
+    (2, 1500, 3, 128, 1, True, _PIPE_SUBST),
     (2, 100, 2, 256, 0, True, _PIPE),       # one block column, idle rank
     (4, 900, 2, 128, 0, True, _PIPE_FINE),  # more ranks than panel buffers minus one
 ])

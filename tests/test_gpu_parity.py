@@ -9,6 +9,8 @@ relative (north_star), tightened to 1e-9 on the fixtures; predictive mean/varian
 import sys
 import warnings
 
+import gc
+
 import numpy as np
 import pytest
 
@@ -559,77 +561,8 @@ def test_distributed_plan_on_one_gpu(ctx, oracle):
         assert abs(ld - ref["logdet_half"]) <= 1e-10 * abs(ref["logdet_half"]), (nb, kw)
         ll2, _ = plan.fit(1, p, y, err)
         assert ll2 == ll
-
-
-def test_distributed_plan_rccl_single_rank(oracle):
-    """The RCCL call pattern of gptools_amd.dist (async panel broadcasts on the ops stream, scalar all-reduces)
-    on the one GPU that is available: a 1-rank nccl process group with the collectives forced on."""
-    import os
-    import subprocess
-    import sys
-    code = (
-        "import os, sys, numpy as np, torch, torch.distributed as dist\n"
-        "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
-        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29517', GPT_DIST_FORCE_COLLECTIVES='1')\n"
-        "torch.cuda.set_device(0)\n"
-        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
-        "from gptools_amd.dist import DistributedLML\n"
-        "from test_gpu_parity import c3_inputs\n"
-        "X, n, y = c3_inputs(1500, 3)\n"
-        "plan = DistributedLML(X, n, nb=128, device=0, sag_min_bytes=0)\n"
-        "assert plan.force_collectives and plan.lookahead and plan.schedule == 'pipelined'\n"
-        "for sched, exch in (('bcast', 'bcast'), ('bcast', 'scatter_gather'), ('pipelined', 'bcast'), ('pipelined', 'scatter_gather')):\n"
-        "    plan.schedule, plan.exchange = sched, exch\n"
-        "    print('RESULT', *plan.fit(1, np.array([1.0, 0.3, 0.3, 0.3]), y, 0.05 * np.ones(1500)))\n"
-        "    print('RESULT2', *plan.fit(1, np.array([1.0, 0.3, 0.3, 0.3]), y, 0.05 * np.ones(1500)))\n"
-        "dist.destroy_process_group()\n" % ((os.path.dirname(os.path.dirname(os.path.abspath(__file__))),) * 2))
-    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
-    vals = [l.split()[1:] for l in out.stdout.splitlines() if l.startswith("RESULT")]
-    X, n, y = c3_inputs(1500, 3)
-    ref = oracle.fit("m52", np.array([1.0, 0.3, 0.3, 0.3]), X, n, y, 0.05 * np.ones(1500), chol="scipy")
-    for v in vals:
-        assert abs(float(v[0]) - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"])
-        assert abs(float(v[1]) - ref["logdet_half"]) <= 1e-10 * abs(ref["logdet_half"])
-    assert len(vals) == 8
-
-
-def test_distributed_plan_two_ranks_sharing_the_gpu(oracle):
-    """The product ops under a real two-rank data flow: two gloo ranks, both on cuda:0 (gloo moves CUDA tensors through
-    the host), whole-panel and row-chunked schedules.  Exercises what a single rank cannot: receiving into panel
-    buffers on the idle queue, waiting for foreign chunks from the panel and the main queue, buffer reuse."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import os, sys, numpy as np, torch, torch.distributed as dist\n"
-        "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
-        "rank = int(sys.argv[1])\n"
-        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29523')\n"
-        "torch.cuda.set_device(0)\n"
-        "dist.init_process_group('gloo', rank=rank, world_size=2)\n"
-        "from gptools_amd.dist import DistributedLML\n"
-        "from test_gpu_parity import c3_inputs\n"
-        "X, n, y = c3_inputs(2500, 3)\n"
-        "plan = DistributedLML(X, n, nb=128, device=0)\n"
-        "for sched, cb in (('bcast', (2, 8, 32)), ('pipelined', (2, 8, 32)), ('pipelined', (2, 4, 6, 10))):\n"
-        "    plan.schedule, plan.chunk_blocks = sched, cb\n"
-        "    for rep in range(3):\n"
-        "        print('RESULT', *plan.fit(1, np.array([1.0, 0.3, 0.3, 0.3]), y, 0.05 * np.ones(2500)))\n"
-        "dist.destroy_process_group()\n" % (root, root))
-    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-             for r in range(2)]
-    outs = [p.communicate(timeout=600) for p in procs]
-    X, n, y = c3_inputs(2500, 3)
-    ref = oracle.fit("m52", np.array([1.0, 0.3, 0.3, 0.3]), X, n, y, 0.05 * np.ones(2500), chol="scipy")
-    for p, (so, se) in zip(procs, outs):
-        assert p.returncode == 0, se[-2000:]
-        vals = [l.split()[1:] for l in so.splitlines() if l.startswith("RESULT")]
-        assert len(vals) == 9
-        for v in vals:
-            assert abs(float(v[0]) - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"])
-            assert abs(float(v[1]) - ref["logdet_half"]) <= 1e-10 * abs(ref["logdet_half"])
+        del plan                # (its streams go with it: every plan owns two library contexts)
+        gc.collect()
 
 
 def test_replicated_random_starts_two_ranks_one_gpu():
