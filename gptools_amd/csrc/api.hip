@@ -1066,8 +1066,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const double *__restrict
         if (c0 + i < n && r0 + tx < n) W[(c0 + i) * ldw + r0 + tx] = t[tx][i];
 }
 
-// dW (n x n, row-major, zeros above the diagonal) <- L^-1 for a factored diagonal block and its workspace: the blocked
-// triangular inverse of the gradient path (trtri_u, U = L^-T) and one transpose.  With it the TRSM of a tall block of
+// dW (n x n, row-major, zeros above the diagonal) <- L^-1 for a factored diagonal block and its workspace: the identity
+// pushed through the panel TRSM (U = I L^-T) and one transpose.  With it the TRSM of a tall block of
 // rows becomes ONE fp64-MFMA GEMM, X = B * (L^-1)^T = gemm_nt(B, dW) -- twice the flops of the substitution, but at the
 // GEMM's rate instead of four latency-bound 128-column leaves and three narrow updates (31k x 512: 0.33 against
 // 0.86 ms).  Used by gptools_amd/dist.py for the rows of a panel below its head.
@@ -1085,7 +1085,9 @@ extern "C" int gpt_dev_trinv(gpt_ctx *c, int64_t n, const double *dL, int64_t ld
     GPT_HIP_CHECK(hipMemsetAsync(U, 0, (size_t)n * n * sizeof(double), st));
     hipLaunchKernelGGL(eye_blocks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, U, n, n);
     GPT_LAUNCH_CHECK();
-    GPT_TRY(trtri_u(c, st, 0, n, dL, ldl, d_invd, U, n));
+    // U = I L^-T by the panel TRSM (7 launches at n = 512; the structured trtri_u of the gradient path needs 12 and the
+    // zeros it would skip are not worth a launch at this size)
+    GPT_TRY(trsm_rlt(c, st, n, n, dL, ldl, d_invd, U, n));
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32)), dim3(256), 0, st, U, n,
                        dW, ldw, n);
     GPT_LAUNCH_CHECK();

@@ -202,7 +202,7 @@ class DistributedLML(object):
     ``fit(kernel_id, params, y, err_y, ...)`` returns ``(ll_data, logdet_half)`` on every rank and
     raises ``numpy.linalg.LinAlgError`` if K_tot is not positive definite.
 
-    ``schedule``: ``"pipelined"`` (row-chunked panels, the default with look-ahead) or ``"bcast"`` (whole panels);
+    ``schedule``: ``"bcast"`` (whole panels, the default) or ``"pipelined"`` (row-chunked panels; needs look-ahead);
     ``exchange``: ``"bcast"`` or ``"scatter_gather"`` (chunks of at least ``sag_min_bytes`` whose row count divides by
     the world size; smaller ones are broadcast); ``chunk_blocks``: panel-local block rows at which a panel is cut.
     All three may be changed between ``fit`` calls (bench.py times the combinations during warm-up).
@@ -210,7 +210,7 @@ class DistributedLML(object):
     NBUF = 4
 
     def __init__(self, X, n, nb=512, group=None, ops=None, device=None, lookahead=True, layout=None,
-                 schedule="pipelined", exchange="bcast", chunk_blocks=(2, 8, 32), sag_min_bytes=8 << 20,
+                 schedule="bcast", exchange="bcast", chunk_blocks=(2, 8, 32), sag_min_bytes=8 << 20,
                  owner_first=None, inv_trsm=True):
         if nb <= 0 or nb % 128:
             raise ValueError("nb must be a positive multiple of 128")

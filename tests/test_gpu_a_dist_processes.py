@@ -46,7 +46,7 @@ def test_distributed_plan_rccl_single_rank(oracle):
         "from test_gpu_parity import c3_inputs\n"
         "X, n, y = c3_inputs(1500, 3)\n"
         "plan = DistributedLML(X, n, nb=128, device=0, sag_min_bytes=0)\n"
-        "assert plan.force_collectives and plan.lookahead and plan.schedule == 'pipelined'\n"
+        "assert plan.force_collectives and plan.lookahead and plan.schedule == 'bcast'\n"
         "for sched, exch in (('bcast', 'bcast'), ('bcast', 'scatter_gather'), ('pipelined', 'bcast'), ('pipelined', 'scatter_gather')):\n"
         "    plan.schedule, plan.exchange = sched, exch\n"
         "    print('RESULT', *plan.fit(1, np.array([1.0, 0.3, 0.3, 0.3]), y, 0.05 * np.ones(1500)))\n"

@@ -497,6 +497,33 @@ def test_dense_kernels_against_numpy(ctx):
     assert "2-th leading minor" in str(ei.value)
 
 
+def test_panel_inverse_and_gemm_solve_against_numpy():
+    """gpt_dev_potrf_panel on the diagonal block, gpt_dev_trinv, then the rows below as ONE GEMM against the inverse --
+    the tail chunks of the row-chunked multi-GPU schedule -- against numpy (L^-1 itself and X = B L^-T)."""
+    import torch
+    from gptools_amd.dist import HipPanelOps
+    ops = HipPanelOps(0)
+    rs = np.random.RandomState(5)
+    for nb, m in ((128, 256), (512, 1536)):
+        A = rs.randn(nb, nb)
+        A = A.dot(A.T) + nb * np.eye(nb)
+        Bm = rs.randn(m, nb)
+        with ops.queue("panel"):
+            P = torch.from_numpy(np.vstack([A, Bm])).cuda()
+            invd = torch.empty(((nb // 128) * 9216,), dtype=torch.float64, device="cuda")
+            info = torch.zeros((1,), dtype=torch.int32, device="cuda")
+            W = torch.empty((nb, nb), dtype=torch.float64, device="cuda")
+            Xo = torch.empty((m, nb), dtype=torch.float64, device="cuda")
+            ops.potrf_panel(nb, nb, P.data_ptr(), nb, invd, info, 0)
+            ops.trinv(nb, P.data_ptr(), nb, invd, W.data_ptr(), nb)
+            ops.gemm_nt(m, nb, nb, 1.0, P.data_ptr() + nb * nb * 8, nb, W.data_ptr(), nb, 0.0, Xo.data_ptr(), nb, 0, q="panel")
+        ops.synchronize()
+        L = np.linalg.cholesky(A)
+        assert int(info.cpu()[0]) == 0
+        np.testing.assert_allclose(W.cpu().numpy(), np.linalg.inv(L), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(Xo.cpu().numpy(), np.linalg.solve(L, Bm.T).T, rtol=0, atol=1e-11)
+
+
 # ---------------------------------------------------------------- full BASELINE sizes ---------
 @pytest.mark.parametrize("cfg", ["C2", "C3"])
 def test_full_size_properties(ctx, oracle, cfg):
