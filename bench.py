@@ -272,8 +272,16 @@ def main():
         extra["kbuild_GBps_written"] = (8.0 * N * (N + 1) / 2.0) / (tk / args.steps * 1e-3) * 1e-9
         parallelism = "1 GPU, look-ahead on a second HIP stream"
     else:
-        from gptools_amd.dist import DistributedLML
-        plan = DistributedLML(X, n, nb=args.nb or 512, device=local_rank)
+        from gptools_amd.dist import DistributedLML, HipPanelOps
+        ops = HipPanelOps(local_rank)
+        plans = {}
+        plan = None
+
+        def get_plan(nb_):
+            if nb_ not in plans:
+                shared = next(iter(plans.values())).group_tail if plans else None
+                plans[nb_] = DistributedLML(X, n, nb=nb_, ops=ops, group_tail=shared)
+            return plans[nb_]
 
         def step():
             return plan.fit(KID[kernel], params, y, err)
@@ -291,21 +299,40 @@ def main():
                 t_ = float(tt.item())
             return t_ / nsteps, r_
 
-        # Untimed tuning pass (before the W warm-up steps): the schedule / exchange combinations of gptools_amd.dist are
-        # each run once to set up their communicators and then timed over two evaluations; the fastest (max over ranks,
-        # so every rank picks the same one) is what the warm-up and the K timed steps run.  All of them are reported.
-        combos = [("pipelined", "bcast"), ("pipelined", "scatter_gather"), ("bcast", "bcast"), ("bcast", "scatter_gather")]
+        # Untimed tuning pass (before the W warm-up steps): block width / schedule / exchange combinations of
+        # gptools_amd.dist are each run once (communicator set-up) and then timed over two evaluations; the fastest (max
+        # over ranks, so every rank picks the same one) is what the warm-up and the K timed steps run.  All are reported.
+        nb0 = args.nb or 512
+        combos = [(nb0, "pipelined", "bcast"), (nb0, "pipelined", "scatter_gather"), (nb0, "bcast", "bcast"),
+                  (nb0, "bcast", "scatter_gather")]
+        if not args.nb:
+            combos += [(256, "bcast", "bcast"), (256, "pipelined", "bcast")]
         if args.schedule:
-            combos = [tuple(args.schedule.split("+"))]
+            combos = [(nb0,) + tuple(args.schedule.split("+"))]
         if world == 1:
-            combos = [c_ for c_ in combos if c_[1] == "bcast"]
-        tune = {}
-        for sched_, exch_ in combos:
-            plan.schedule, plan.exchange = sched_, exch_
-            step()
-            tune["%s+%s" % (sched_, exch_)] = timed(2)[0] * 1e3
+            combos = [c_ for c_ in combos if c_[2] == "bcast"]
+        tune, failed = {}, {}
+        for nb_, sched_, exch_ in combos:
+            name = "%s+%s@%d" % (sched_, exch_, nb_)
+            try:
+                plan = get_plan(nb_)
+                plan.schedule, plan.exchange = sched_, exch_
+                step()
+                tune[name] = timed(2)[0] * 1e3
+            except (RuntimeError, ValueError, NotImplementedError) as e:
+                # (an error every rank raises alike, e.g. an operation the backend does not offer: skip the combination)
+                failed[name] = repr(e)[:200]
+        if failed:
+            extra["schedules_failed"] = failed
+        if not tune:
+            raise SystemExit("no schedule of gptools_amd.dist ran: %r" % failed)
         best = min(tune, key=tune.get)
-        plan.schedule, plan.exchange = best.split("+")
+        se_, nb_ = best.split("@")
+        plan = plans[int(nb_)]
+        plan.schedule, plan.exchange = se_.split("+")
+        for k_ in [k_ for k_ in plans if k_ != int(nb_)]:
+            del plans[k_]                       # (frees the other block width's matrix and panel buffers)
+        torch.cuda.empty_cache()
         extra["schedules_ms"] = tune
         extra["schedule"] = best
         for _ in range(args.warmup):

@@ -205,13 +205,14 @@ class DistributedLML(object):
     ``schedule``: ``"bcast"`` (whole panels, the default) or ``"pipelined"`` (row-chunked panels; needs look-ahead);
     ``exchange``: ``"bcast"`` or ``"scatter_gather"`` (chunks of at least ``sag_min_bytes`` whose row count divides by
     the world size; smaller ones are broadcast); ``chunk_blocks``: panel-local block rows at which a panel is cut.
-    All three may be changed between ``fit`` calls (bench.py times the combinations during warm-up).
+    All three may be changed between ``fit`` calls (bench.py times the combinations during warm-up).  Several plans
+    (e.g. of different ``nb``) may share one ``ops`` object and one ``group_tail`` communicator.
     """
     NBUF = 4
 
     def __init__(self, X, n, nb=512, group=None, ops=None, device=None, lookahead=True, layout=None,
                  schedule="bcast", exchange="bcast", chunk_blocks=(2, 8, 32), sag_min_bytes=8 << 20,
-                 owner_first=None, inv_trsm=True):
+                 owner_first=None, inv_trsm=True, group_tail=None):
         if nb <= 0 or nb % 128:
             raise ValueError("nb must be a positive multiple of 128")
         self.group = group
@@ -252,10 +253,10 @@ class DistributedLML(object):
         self.inv_trsm = bool(inv_trsm)
         # the later chunks of the pipelined schedule travel on a communicator of their own, so that a head chunk never
         # queues behind the bulk of an earlier panel (collectives of one communicator run in issue order)
-        self.group_tail = group
+        self.group_tail = group if group_tail is None else group_tail
         # RCCL runs the collectives of a communicator in issue order on its stream; other backends need explicit waits
         self._stream_ordered = dist.is_initialized() and dist.get_backend(group) == "nccl"
-        if dist.is_initialized() and layout is None and (self.world > 1 or self.force_collectives):
+        if group_tail is None and dist.is_initialized() and layout is None and (self.world > 1 or self.force_collectives):
             ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
             self.group_tail = dist.new_group(ranks=ranks)
         X = np.ascontiguousarray(X, dtype=np.float64)

@@ -51,7 +51,7 @@ class OneRank(DistributedLML):
         pass
 
 
-rec = Recorder(X, n, nb=512, ops=ops, schedule="bcast")
+rec = Recorder(X, n, nb=int(os.environ.get("SIM_NB", "512")), ops=ops, schedule="bcast")
 rec.saved = {}
 ll_ref, ld_ref = rec.fit(kid, params, y, err)
 t0 = time.perf_counter(); rec.saved = {}; rec.fit(kid, params, y, err); torch.cuda.synchronize(); t1 = time.perf_counter()
@@ -59,7 +59,7 @@ print("world 1 (block-cyclic engine): %.1f ms" % ((t1 - t0) * 1e3))
 panels = rec.saved
 tot = []
 for r in ranks:
-    plan = OneRank(X, n, nb=512, ops=ops, layout=(r, W), schedule=sched,
+    plan = OneRank(X, n, nb=int(os.environ.get("SIM_NB", "512")), ops=ops, layout=(r, W), schedule=sched,
                    owner_first=bool(int(os.environ.get("SIM_OWNER_FIRST", "1"))),
                    inv_trsm=bool(int(os.environ.get("SIM_INV_TRSM", "1"))))
     plan.force_collectives = True          # takes the world > 1 code path (scalar reduction included, as a no-op)
