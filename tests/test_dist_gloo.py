@@ -134,6 +134,7 @@ def _run(world, N, d, nb, kernel_id, lookahead, bad=False, plan_kw=None):
 
 
 _WHOLE = {"schedule": "bcast"}
+_WHOLE_INV = {"schedule": "bcast", "inv_min_rows": 0}        # rows below the diagonal block by inverse + GEMM
 _WHOLE_SAG = {"schedule": "bcast", "exchange": "scatter_gather", "sag_min_bytes": 0}
 _PIPE = {"schedule": "pipelined"}                                                  # chunks cut at 2, 8, 32 blocks
 _PIPE_SUBST = {"schedule": "pipelined", "inv_trsm": False}                         # tail chunks by substitution
@@ -146,6 +147,8 @@ _PIPE_FINE = {"schedule": "pipelined", "chunk_blocks": (2, 3, 5), "exchange": "s
     (3, 500, 2, 128, 0, True, _WHOLE),      # SE, uneven block ownership (5 block columns over 3 ranks)
     (2, 100, 2, 256, 0, True, _WHOLE),      # fewer block columns than ranks -> an idle rank must still take part
     (2, 700, 3, 128, 1, True, _WHOLE_SAG),  # panels moved by scatter + all-gather
+    (3, 700, 3, 128, 1, True, _WHOLE_INV),
+    (2, 700, 3, 128, 1, False, _WHOLE_INV),
     (2, 1500, 3, 128, 1, True, _PIPE),      # 12 block columns: panels of 12, 11, ... blocks cut into 2-3 row chunks
     (3, 1500, 2, 128, 0, True, _PIPE_FINE), # up to 4 chunks per panel; scatter + all-gather where rows divide by 3
     (2, 1500, 3, 128, 1, True, _PIPE_SUBST),

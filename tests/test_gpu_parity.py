@@ -580,6 +580,7 @@ def test_distributed_plan_on_one_gpu(ctx, oracle):
     err = 0.05 * np.ones(1500)
     ref = oracle.fit("m52", p, X, n, y, err, chol="scipy")
     for nb, kw in ((128, {"schedule": "bcast"}), (256, {"schedule": "bcast"}), (512, {"schedule": "bcast"}),
+                   (128, {"schedule": "bcast", "inv_min_rows": 0}), (512, {"schedule": "bcast", "inv_min_rows": 0}),
                    (128, {"schedule": "pipelined"}), (128, {"schedule": "pipelined", "chunk_blocks": (2, 3, 5)}),
                    (256, {"schedule": "pipelined"})):
         plan = DistributedLML(X, n, nb=nb, device=0, **kw)
