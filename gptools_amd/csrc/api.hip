@@ -55,6 +55,7 @@ struct gpt_ctx {
     int64_t nb_outer = 0;              // outer block width; 0 = by size (outer_width())
     int lookahead = 1;
     int use_graph = 0;
+    long n_maxsum = 0;                 // largest row sum of the training derivative orders (gpt_set_data)
     int timing = 0;
     int tile = 0;
     int gemm_pad = 1024;
@@ -158,6 +159,24 @@ static int make_kparams(int kernel_id, const double *params, int nparams, int D,
             kp->inv_l[d] = 1.0 / l;
             kp->inv_var[d] = 1.0 / (l * l);
         }
+    } else if (kernel_id == GPT_KERNEL_RQ) {
+        // RationalQuadraticKernel: [sigma_f, alpha, l_1 .. l_D] (ref: rational_quadratic.py:30-45)
+        if (nparams != D + 2) {
+            gpt_set_error("kernel %d expects %d params, got %d", kernel_id, D + 2, nparams);
+            return GPT_E_ARG;
+        }
+        if (hyper_deriv >= 0) {
+            gpt_set_error("Hyperparameter derivatives have not been implemented!");      // ref: core.py:723-726
+            return GPT_E_NOTIMPL;
+        }
+        kp->sigma = params[0];
+        kp->alpha = params[1];
+        for (int d = 0; d < D; d++) {
+            const double l = params[2 + d];
+            kp->l[d] = l;
+            kp->inv_l[d] = 1.0 / l;
+            kp->inv_var[d] = 1.0 / (l * l);
+        }
     } else if (kernel_id == GPT_KERNEL_DIAGNOISE || kernel_id == GPT_KERNEL_ZERO) {
         if (nparams != 1) {
             gpt_set_error("noise kernels expect 1 param, got %d", nparams);
@@ -186,6 +205,36 @@ static int check_m52_orders(const int32_t *n, int64_t M, int D)
             gpt_set_error("Matern52Kernel only supports 0th and 1st order derivatives");
             return GPT_E_VALUE;
         }
+    }
+    return GPT_OK;
+}
+
+// The device builder of the rational-quadratic kernel carries GPT_RQ_MAXORD + 1 Faa di Bruno coefficients: the derivative
+// orders of any pair (row of ni + row of nj) may sum to GPT_RQ_MAXORD at most.  `pairwise`: rows are matched one to
+// one (gpt_kpairs); otherwise every row of ni meets every row of nj (Gram blocks).
+static int check_rq_orders(const int32_t *ni, int64_t M, const int32_t *nj, int64_t P, int D, bool pairwise)
+{
+    long mi = 0, mj = 0, mp = 0;
+    for (int64_t i = 0; i < M; i++) {
+        long s = 0;
+        for (int d = 0; d < D; d++) s += ni[i * D + d];
+        if (pairwise && i < P) {
+            long t = s;
+            for (int d = 0; d < D; d++) t += nj[i * D + d];
+            if (t > mp) mp = t;
+        }
+        if (s > mi) mi = s;
+    }
+    for (int64_t j = 0; j < P && !pairwise; j++) {
+        long s = 0;
+        for (int d = 0; d < D; d++) s += nj[j * D + d];
+        if (s > mj) mj = s;
+    }
+    const long worst = pairwise ? mp : mi + mj;
+    if (worst > GPT_RQ_MAXORD) {
+        gpt_set_error("RationalQuadraticKernel: derivative orders of a pair sum to %ld, the device builder supports %d",
+                      worst, GPT_RQ_MAXORD);
+        return GPT_E_VALUE;
     }
     return GPT_OK;
 }
@@ -626,6 +675,7 @@ extern "C" int gpt_kpairs(gpt_ctx *c, int kernel_id, const double *params, int n
         GPT_TRY(check_m52_orders(ni, M, D));
         GPT_TRY(check_m52_orders(nj, M, D));
     }
+    if (kernel_id == GPT_KERNEL_RQ && M > 0) GPT_TRY(check_rq_orders(ni, M, nj, M, D, true));
     if (M == 0) return GPT_OK;
     double *dXi, *dXj, *dout;
     int32_t *dni, *dnj;
@@ -664,6 +714,7 @@ extern "C" int gpt_kbuild(gpt_ctx *c, int kernel_id, const double *params, int n
         GPT_TRY(check_m52_orders(ni, M, D));
         GPT_TRY(check_m52_orders(nj, P, D));
     }
+    if (kernel_id == GPT_KERNEL_RQ && M > 0 && P > 0 && ni && nj) GPT_TRY(check_rq_orders(ni, M, nj, P, D, false));
     if (M == 0 || P == 0) return GPT_OK;
     if (!Xi || !ni || !Xj || !nj || !K_out) return GPT_E_ARG;
     double *dXi, *dXj, *dK;
@@ -707,6 +758,12 @@ extern "C" int gpt_set_data(gpt_ctx *c, const double *X, const int32_t *n, int64
     c->N = N;
     c->Nx = N;
     c->D = D;
+    c->n_maxsum = 0;
+    for (int64_t i = 0; i < N; i++) {
+        long sn = 0;
+        for (int d = 0; d < D; d++) sn += n[i * D + d];
+        if (sn > c->n_maxsum) c->n_maxsum = sn;
+    }
     c->factored = false;
     c->alpha_valid = false;
     c->have_kernel = false;
@@ -849,9 +906,14 @@ extern "C" int gpt_fit_sum(gpt_ctx *c, int nterms, const int *kernel_ids, const 
     std::vector<KParams> terms((size_t)nterms);
     const double *p = params;
     for (int t = 0; t < nterms; t++) {
-        if (kernel_ids[t] != GPT_KERNEL_SE && kernel_ids[t] != GPT_KERNEL_M52) {
-            gpt_set_error("gpt_fit: kernel_id must be SE or Matern52");
+        if (kernel_ids[t] != GPT_KERNEL_SE && kernel_ids[t] != GPT_KERNEL_M52 && kernel_ids[t] != GPT_KERNEL_RQ) {
+            gpt_set_error("gpt_fit: kernel_id must be SE, Matern52 or RationalQuadratic");
             return GPT_E_ARG;
+        }
+        if (kernel_ids[t] == GPT_KERNEL_RQ && 2 * c->n_maxsum > GPT_RQ_MAXORD) {
+            gpt_set_error("RationalQuadraticKernel: derivative orders of a pair sum to %ld, the device builder supports %d",
+                          2 * c->n_maxsum, GPT_RQ_MAXORD);
+            return GPT_E_VALUE;
         }
         GPT_TRY(make_kparams(kernel_ids[t], p, nparams[t], c->D, -1, 1, nullptr, &terms[(size_t)t]));
         p += nparams[t];
@@ -1214,6 +1276,20 @@ extern "C" int gpt_predict(gpt_ctx *c, const double *Xstar, const int32_t *nstar
     for (const auto &t : c->terms)
         if (t.kernel_id == GPT_KERNEL_M52) {
             GPT_TRY(check_m52_orders(nstar, M, D));
+            break;
+        }
+    for (const auto &t : c->terms)
+        if (t.kernel_id == GPT_KERNEL_RQ) {
+            long ms = 0;
+            for (int64_t i = 0; i < M; i++) {
+                long sn = 0;
+                for (int d = 0; d < D; d++) sn += nstar[i * D + d];
+                if (sn > ms) ms = sn;
+            }
+            if (ms + (ms > c->n_maxsum ? ms : c->n_maxsum) > GPT_RQ_MAXORD) {
+                gpt_set_error("RationalQuadraticKernel: derivative orders of a pair sum to more than %d", GPT_RQ_MAXORD);
+                return GPT_E_VALUE;
+            }
             break;
         }
     hipStream_t st = c->stream;

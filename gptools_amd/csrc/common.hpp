@@ -45,6 +45,7 @@ struct KParams {
     int hyper_deriv;      // -1 = None
     int symmetric;        // DiagonalNoiseKernel only fires for symmetric calls
     double sigma;         // params[0]
+    double alpha;         // RationalQuadraticKernel: params[1]
     double l[GPT_MAX_DIM];      // length scales (SE / M52)
     double inv_l[GPT_MAX_DIM];  // 1 / l
     double inv_var[GPT_MAX_DIM];// 1 / l^2

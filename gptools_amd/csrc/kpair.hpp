@@ -11,6 +11,14 @@
 //   * Matern52Kernel  (ref: gptools/kernel/matern.py:545-555, gptools/kernel/src/matern.c:61-186),
 //     all four derivative classes and their r^2 == 0 limits.
 //   * DiagonalNoiseKernel / ZeroKernel  (ref: gptools/kernel/noise.py:103-110, :152).
+//   * RationalQuadraticKernel  (ref: gptools/kernel/rational_quadratic.py:30-164 through ChainRuleKernel.__call__,
+//     gptools/kernel/core.py:691-816): k = sigma^2 (-1)^{sum nj} d^n/dtau^n y^-alpha, y = 1 + sum tau_d^2/(2 alpha l_d^2).
+//     The reference walks every set partition of the derivative multiset (Faa di Bruno).  y is quadratic in tau, so only
+//     partitions into singletons (factor y1_d = tau_d/(alpha l_d^2)) and equal-index pairs (y2_d = 1/(alpha l_d^2))
+//     contribute; grouped by the number of pairs j_d per dimension the sum is
+//         sum_j prod_d [ n_d!/(j_d!(n_d-2j_d)! 2^j_d) y2_d^j_d y1_d^(n_d-2j_d) ] f^(sum_d (n_d-j_d))(y),
+//         f^(m)(y) = (-alpha)(-alpha-1)...(-alpha-m+1) y^(-alpha-m),
+//     accumulated here as a product of per-dimension polynomials in a marker for the number of blocks.
 #pragma once
 #include "common.hpp"
 
@@ -118,6 +126,73 @@ __device__ __forceinline__ double noise_pair(const KParams &kp, const double *xi
     return (kp.hyper_deriv < 0) ? val : 2.0 * val / kp.sigma;
 }
 
+template <int D>
+__device__ __forceinline__ double rq_pair(const KParams &kp, const double *xi, const double *xj,
+                                          const int *ni, const int *nj)
+{
+    double r2 = 0.0;
+    int ntot = 0, njtot = 0;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const double tau = xi[d] - xj[d];
+        const double t = (tau == 0.0) ? 0.0 : tau * kp.inv_l[d];
+        r2 = fma(t, t, r2);
+        ntot += ni[d] + nj[d];
+        njtot += nj[d];
+    }
+    const double alpha = kp.alpha;
+    const double y = 1.0 + r2 / (2.0 * alpha);
+    const double s2 = kp.sigma * kp.sigma;
+    const double p0 = pow(y, -alpha);
+    if (ntot == 0) return s2 * p0;
+    // c[m]: coefficient of f^(m)(y) so far (host code rejects ntot > GPT_RQ_MAXORD)
+    double c[GPT_RQ_MAXORD + 1];
+#pragma unroll
+    for (int m = 0; m <= GPT_RQ_MAXORD; m++) c[m] = (m == 0) ? 1.0 : 0.0;
+    int deg = 0;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const int n = ni[d] + nj[d];
+        if (n == 0) continue;
+        const double y2 = kp.inv_var[d] / alpha;
+        const double y1 = (xi[d] - xj[d]) * y2;
+        // per-dimension polynomial: pd[n - j] = n!/(j!(n-2j)! 2^j) y2^j y1^(n-2j), j = 0 .. n/2
+        double pd[GPT_RQ_MAXORD + 1];
+#pragma unroll
+        for (int m = 0; m <= GPT_RQ_MAXORD; m++) pd[m] = 0.0;
+        double y1pow[GPT_RQ_MAXORD + 1];
+        y1pow[0] = 1.0;
+#pragma unroll
+        for (int m = 1; m <= GPT_RQ_MAXORD; m++) y1pow[m] = y1pow[m - 1] * y1;
+        double coef = 1.0, y2pow = 1.0;
+        for (int j = 0; 2 * j <= n; j++) {
+            if (j > 0) {
+                coef = coef * (double)((n - 2 * j + 2) * (n - 2 * j + 1)) / (2.0 * (double)j);
+                y2pow *= y2;
+            }
+            pd[n - j] = coef * y2pow * y1pow[n - 2 * j];
+        }
+        double cn[GPT_RQ_MAXORD + 1];
+#pragma unroll
+        for (int m = 0; m <= GPT_RQ_MAXORD; m++) cn[m] = 0.0;
+        for (int a = 0; a <= deg; a++)
+            for (int b = (n + 1) / 2; b <= n; b++)
+                if (a + b <= GPT_RQ_MAXORD) cn[a + b] = fma(c[a], pd[b], cn[a + b]);
+        deg += n;
+#pragma unroll
+        for (int m = 0; m <= GPT_RQ_MAXORD; m++) c[m] = cn[m];
+    }
+    // sum_m c[m] poch(1 - alpha - m, m) y^(-alpha - m)
+    const double iy = 1.0 / y;
+    double v = 0.0, poch = 1.0, ypow = p0;
+    for (int m = 1; m <= deg && m <= GPT_RQ_MAXORD; m++) {
+        poch *= -(alpha + (double)(m - 1));
+        ypow *= iy;
+        v = fma(c[m] * poch, ypow, v);
+    }
+    return s2 * ((njtot & 1) ? -v : v);
+}
+
 template <int KID, int D>
 __device__ __forceinline__ double any_pair(const KParams &kp, const double *xi, const double *xj,
                                            const int *ni, const int *nj)
@@ -125,5 +200,6 @@ __device__ __forceinline__ double any_pair(const KParams &kp, const double *xi, 
     if (KID == GPT_KERNEL_SE) return se_pair<D>(kp, xi, xj, ni, nj);
     if (KID == GPT_KERNEL_M52) return m52_pair<D>(kp, xi, xj, ni, nj);
     if (KID == GPT_KERNEL_DIAGNOISE) return noise_pair<D>(kp, xi, xj, ni, nj);
+    if (KID == GPT_KERNEL_RQ) return rq_pair<D>(kp, xi, xj, ni, nj);
     return 0.0;
 }

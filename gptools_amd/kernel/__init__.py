@@ -3,3 +3,4 @@ from .core import *            # noqa: F401,F403
 from .squared_exponential import *   # noqa: F401,F403
 from .matern import *          # noqa: F401,F403
 from .noise import *           # noqa: F401,F403
+from .rational_quadratic import *   # noqa: F401,F403

@@ -45,6 +45,11 @@ extern "C" {
 #define GPT_KERNEL_M52 1
 #define GPT_KERNEL_DIAGNOISE 2
 #define GPT_KERNEL_ZERO 3
+#define GPT_KERNEL_RQ 4          /* RationalQuadraticKernel, params [sigma_f, alpha, l_1 .. l_D]
+                                  * (ref: gptools/kernel/rational_quadratic.py:30-164 through ChainRuleKernel.__call__,
+                                  * kernel/core.py:691-816); derivative orders of a pair may sum to GPT_RQ_MAXORD at most
+                                  * (GPT_E_VALUE beyond; the reference has no limit); no hyper-parameter derivatives */
+#define GPT_RQ_MAXORD 8
 
 #define GPT_MAX_DIM 16      /* largest supported num_dim */
 #define GPT_WS_BLOCK 9216    /* doubles of factorisation workspace per 128 columns (d_invd arguments) */

@@ -36,6 +36,8 @@
 #define ORC_KERNEL_M52 1
 #define ORC_KERNEL_DIAGNOISE 2
 #define ORC_KERNEL_ZERO 3
+#define ORC_KERNEL_RQ 4
+#define ORC_RQ_MAXORD 16        /* combined derivative order of a pair this restatement accepts */
 
 #define ORC_OK 0
 #define ORC_EVALUE 1          /* Python side raises ValueError      (matern.py:545-546) */
@@ -187,6 +189,67 @@ static double m52_pair(const double *xi, const double *xj, const int32_t *ni, co
 }
 
 /* ---- helpers --------------------------------------------------------------------------- */
+/* ---- RationalQuadraticKernel (kernel/rational_quadratic.py:30-164) through ChainRuleKernel.__call__
+ * (kernel/core.py:691-816).  params = [sigma_f, alpha, l_1 .. l_D];
+ *     k = sigma_f^2 (-1)^{sum nj} d^n/dtau^n f(y),  f(y) = y^-alpha,  y = 1 + sum_d tau_d^2 / (2 alpha l_d^2).
+ * The reference sums Faa di Bruno's formula over every set partition of the derivative multiset
+ * (core.py:794-816): a partition with p blocks contributes f^(p)(y) = poch(1 - alpha - p, p) y^(-alpha-p)
+ * (rational_quadratic.py:127-128, utils.py:1369-1395: the plain product) times, per block, dy/dtau_a =
+ * tau_a / (alpha l_a^2) for a single index, 1 / (alpha l_a^2) for a pair of equal indices and 0 otherwise
+ * (rational_quadratic.py:155-162).  Only partitions into singletons and equal-index pairs survive; those with j_d pairs
+ * in dimension d number n_d! / (j_d! (n_d - 2 j_d)! 2^j_d) per dimension, so the same sum is, grouped by (j_1..j_D),
+ *     sum_j  prod_d [ n_d!/(j_d!(n_d-2j_d)! 2^j_d) y2_d^j_d y1_d^(n_d-2j_d) ]  f^(sum_d (n_d - j_d))(y)
+ * evaluated below as a product of per-dimension polynomials in a marker z (power = number of blocks). */
+static double rq_pair(const double *params, int D, const double *xi, const double *xj, const int32_t *ni,
+                      const int32_t *nj)
+{
+    const double sigma = params[0], alpha = params[1];
+    const double *l = params + 2;
+    double c[ORC_RQ_MAXORD + 1], pd[ORC_RQ_MAXORD + 1], cn[ORC_RQ_MAXORD + 1];
+    double r2l2 = 0.0, y, v = 0.0;
+    int d, deg = 0, ntot = 0, njtot = 0, m, a, b;
+    for (d = 0; d < D; d++) {
+        double tau = xi[d] - xj[d];
+        double t = (tau == 0.0) ? 0.0 : tau / l[d];                 /* core.py:416: 0/0 counts as 0 */
+        r2l2 += t * t;
+        ntot += ni[d] + nj[d];
+        njtot += nj[d];
+    }
+    y = 1.0 + 1.0 / (2.0 * alpha) * r2l2;                            /* rational_quadratic.py:104-105 */
+    if (ntot == 0) return sigma * sigma * pow(y, -alpha);            /* rational_quadratic.py:82-83 */
+    if (ntot > ORC_RQ_MAXORD) return NAN;
+    c[0] = 1.0;
+    for (d = 0; d < D; d++) {
+        const int n = ni[d] + nj[d];
+        double tau, y1, y2, coef;
+        int j;
+        if (n == 0) continue;
+        tau = xi[d] - xj[d];
+        y1 = 1.0 / alpha * tau / (l[d] * l[d]);                      /* rational_quadratic.py:158 */
+        y2 = 1.0 / (alpha * (l[d] * l[d]));                          /* rational_quadratic.py:160 */
+        for (m = 0; m <= n; m++) pd[m] = 0.0;
+        for (j = 0; 2 * j <= n; j++) {
+            /* n! / (j! (n-2j)! 2^j) by the recurrence c_{j+1} = c_j (n-2j)(n-2j-1) / (2 (j+1)) */
+            if (j == 0) coef = 1.0;
+            else coef = coef * (double)((n - 2 * j + 2) * (n - 2 * j + 1)) / (2.0 * (double)j);
+            pd[n - j] = coef * pow(y2, (double)j) * pow(y1, (double)(n - 2 * j));
+        }
+        for (m = 0; m <= deg + n; m++) cn[m] = 0.0;
+        for (a = 0; a <= deg; a++)
+            for (b = 0; b <= n; b++) cn[a + b] += c[a] * pd[b];
+        deg += n;
+        for (m = 0; m <= deg; m++) c[m] = cn[m];
+    }
+    for (m = 1; m <= deg; m++) {
+        double poch = 1.0;
+        int q;
+        if (c[m] == 0.0) continue;
+        for (q = 0; q < m; q++) poch *= (1.0 - alpha - (double)m) + (double)q;      /* utils.py:1394-1395 */
+        v += c[m] * poch * pow(y, -alpha - (double)m);
+    }
+    return sigma * sigma * ((njtot & 1) ? -v : v);                   /* core.py:746-749 */
+}
+
 static int all_zero(const int32_t *n, int64_t count)
 {
     int64_t i;
@@ -214,6 +277,9 @@ static int check_args(int kernel_id, const double *params, int nparams, int D, i
     if (kernel_id == ORC_KERNEL_SE || kernel_id == ORC_KERNEL_M52) {
         if (nparams != D + 1) return ORC_EARG;
         if (hyper_deriv >= nparams) return ORC_EARG;
+    } else if (kernel_id == ORC_KERNEL_RQ) {
+        if (nparams != D + 2) return ORC_EARG;
+        if (hyper_deriv >= 0) return ORC_ENOTIMPL;                   /* core.py:723-726 */
     } else if (kernel_id == ORC_KERNEL_DIAGNOISE || kernel_id == ORC_KERNEL_ZERO) {
         if (nparams != 1) return ORC_EARG;
     } else {
@@ -233,6 +299,8 @@ static double any_pair(int kernel_id, const double *params, const double *var, i
         return se_pair(params, D, xi, xj, ni, nj, hyper_deriv, only_first_order);
     case ORC_KERNEL_M52:
         return params[0] * params[0] * m52_pair(xi, xj, ni, nj, D, var);   /* matern.py:555 */
+    case ORC_KERNEL_RQ:
+        return rq_pair(params, D, xi, xj, ni, nj);
     case ORC_KERNEL_DIAGNOISE: {                                            /* noise.py:103-110 */
         double val;
         if (!symmetric) return 0.0;

@@ -19,8 +19,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SE, M52, DIAGNOISE, ZERO = 0, 1, 2, 3
-KERNEL_IDS = {"se": SE, "m52": M52, "diagnoise": DIAGNOISE, "zero": ZERO}
+SE, M52, DIAGNOISE, ZERO, RQ = 0, 1, 2, 3, 4
+KERNEL_IDS = {"se": SE, "m52": M52, "diagnoise": DIAGNOISE, "zero": ZERO, "rq": RQ}
 
 _lib = None
 _ref = None

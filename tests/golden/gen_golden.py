@@ -14,6 +14,7 @@ Fixture groups follow SURVEY.md section 8(c):
   G5 ``update_hyperparameters`` sweep          (gaussian_process.py:1332-1416)
   G6 demo known-answer (config 1)              (demo/demo.py:133-253)
   G7 tests/test_matern.py scenario, seeded     (tests/test_matern.py:4-31)
+  G8 RationalQuadraticKernel: pairs, Gram, fit, predict (kernel/rational_quadratic.py:30-164, kernel/core.py:691-816)
 """
 import os
 import pickle
@@ -457,8 +458,82 @@ def gen_g7():
          K_arb=np.asarray(k1, dtype=float), K_m52=np.asarray(k2, dtype=float))
 
 
+# ----------------------------------------------------------------------------
+# G8: rational-quadratic kernel, params [sigma_f, alpha, l_1 .. l_D]
+# ----------------------------------------------------------------------------
+def rq_kernel(d, params):
+    return gptools.RationalQuadraticKernel(
+        num_dim=d, initial_params=list(params), param_bounds=[(0.0, 1e3)] * (d + 2))
+
+
+def gen_g8():
+    rs = np.random.RandomState(808)
+    out = {}
+    # pair level: derivative orders 0..2 per point and dimension, combined order of a pair capped at 6
+    for d in (1, 2, 3, 4):
+        for tag, alpha in (("a", 1.7), ("b", 2.0), ("c", 0.35)):
+            M = 160
+            Xi = rs.rand(M, d)
+            Xj = rs.rand(M, d)
+            Xj[:16] = Xi[:16]                      # tau == 0
+            Xj[16:24, 0] = Xi[16:24, 0]            # one component zero
+            ni = rs.randint(0, 3, size=(M, d))
+            nj = rs.randint(0, 3, size=(M, d))
+            ni[rs.rand(M) < 0.3] = 0
+            nj[rs.rand(M) < 0.3] = 0
+            for m in range(M):
+                while ni[m].sum() + nj[m].sum() > 6:
+                    w = ni if rs.rand() < 0.5 else nj
+                    c = rs.randint(d)
+                    if w[m, c] > 0:
+                        w[m, c] -= 1
+            params = np.concatenate(([1.3, alpha], 0.2 + 0.5 * rs.rand(d)))
+            k = rq_kernel(d, params)
+            key = "pairs_d%d%s_" % (d, tag)
+            out[key + "Xi"], out[key + "Xj"] = Xi, Xj
+            out[key + "ni"], out[key + "nj"] = ni.astype(np.int32), nj.astype(np.int32)
+            out[key + "params"] = params
+            out[key + "k"] = np.asarray(k(Xi, Xj, ni, nj), dtype=float)
+    # Gram matrices with value / first / second derivative rows
+    for d in (1, 2, 3):
+        N, P = 48, 24
+        X = rs.rand(N, d)
+        Xs = rs.rand(P, d)
+        X[5] = X[4]
+        Xs[3] = X[7]
+        n = deriv_pattern(rs, N, d, 0.3, 2)
+        ns = deriv_pattern(rs, P, d, 0.5, 1)
+        params = np.concatenate(([0.9, 1.2], 0.2 + 0.4 * rs.rand(d)))
+        gp = gptools.GaussianProcess(rq_kernel(d, params))
+        key = "gram_d%d_" % d
+        out[key + "X"], out[key + "Xs"] = X, Xs
+        out[key + "n"], out[key + "ns"] = n.astype(np.int32), ns.astype(np.int32)
+        out[key + "params"] = params
+        out[key + "K"] = gp.compute_Kij(X, None, n, None)
+        out[key + "Ks"] = gp.compute_Kij(X, Xs, n, ns)
+    # fit + predict (value and first-derivative observations / predictions)
+    for N, d in ((64, 2), (200, 3)):
+        key = "fit_N%d_d%d_" % (N, d)
+        n = deriv_pattern(rs, N, d, 0.25, 1)
+        X, y = synth(rs, N, d, n)
+        params = np.concatenate(([1.0, 1.5], 0.3 * np.ones(d)))
+        gp = gptools.GaussianProcess(rq_kernel(d, params))
+        gp.add_data(X, y, err_y=0.05, n=n)
+        record_fit(out, key, gp, with_L=False)
+        M = 24
+        Xs = rs.rand(M, d)
+        ns = np.zeros((M, d), dtype=int)
+        ns[M // 2:, 0] = 1
+        mean, std = gp.predict(Xs, n=ns)
+        out[key + "X"], out[key + "y"], out[key + "n"] = X, y, n.astype(np.int32)
+        out[key + "params"] = params
+        out[key + "Xs"], out[key + "ns"] = Xs, ns.astype(np.int32)
+        out[key + "mean"], out[key + "std"] = np.asarray(mean), np.asarray(std)
+    save("g8_rq", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g34", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g34", "g5", "g6", "g7", "g8"]
     if "g1" in which:
         gen_g1()
     if "g2" in which:
@@ -471,3 +546,5 @@ if __name__ == "__main__":
         gen_g6()
     if "g7" in which:
         gen_g7()
+    if "g8" in which:
+        gen_g8()

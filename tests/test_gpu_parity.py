@@ -166,6 +166,70 @@ def test_python_plugin_kernel_still_works(g):
     np.testing.assert_allclose(gp.alpha.ravel(), np.linalg.solve(Kt, np.arange(5.0)), rtol=1e-10)
 
 
+# ---------------------------------------------------------------- G8: rational-quadratic kernel
+@pytest.mark.parametrize("d", [1, 2, 3, 4])
+def test_g8_rational_quadratic_kernel_call(g, golden, oracle, d):
+    """RationalQuadraticKernel.__call__ on the device (kpair.hpp rq_pair) against the reference's outputs (golden g8:
+    derivative orders 0..2 per point and dimension, combined order up to 6, alpha 1.7 / 2 / 0.35, tau == 0 rows) and
+    against the CPU oracle on fresh random pairs with the largest supported combined order."""
+    G = golden("g8_rq")
+    for tag in "abc":
+        key = "pairs_d%d%s_" % (d, tag)
+        p = G[key + "params"]
+        k = g.RationalQuadraticKernel(num_dim=d, initial_params=list(p), param_bounds=[(0.0, 1e3)] * (d + 2))
+        got = k(G[key + "Xi"], G[key + "Xj"], G[key + "ni"], G[key + "nj"])
+        assert_close(got, G[key + "k"], rtol=1e-11, atol_scale=1e-13, msg=key)
+    rs = np.random.RandomState(80 + d)
+    M = 300
+    Xi, Xj = rs.rand(M, d), rs.rand(M, d)
+    ni, nj = np.zeros((M, d), int), np.zeros((M, d), int)
+    for m in range(M):                       # combined order exactly 8, spread at random
+        for _ in range(8):
+            (ni if rs.rand() < 0.5 else nj)[m, rs.randint(d)] += 1
+    assert_close(k(Xi, Xj, ni, nj), oracle.kpairs("rq", p, Xi, Xj, ni, nj), rtol=1e-10, atol_scale=1e-13, msg="order 8")
+    ni[0, 0] += 1
+    with pytest.raises(ValueError):          # beyond what the device builder carries
+        k(Xi, Xj, ni, nj)
+    with pytest.raises(NotImplementedError):  # ref: core.py:723-726
+        k(Xi, Xj, 0 * ni, 0 * nj, hyper_deriv=1)
+
+
+def test_g8_rational_quadratic_gram_fit_predict(g, golden, oracle):
+    G = golden("g8_rq")
+    for d in (1, 2, 3):
+        key = "gram_d%d_" % d
+        p, X, Xs, n, ns = (G[key + s] for s in ("params", "X", "Xs", "n", "ns"))
+        gp = g.GaussianProcess(g.RationalQuadraticKernel(num_dim=d, initial_params=list(p), param_bounds=[(0.0, 1e3)] * (d + 2)))
+        assert_close(gp.compute_Kij(X, None, n, None), G[key + "K"], rtol=1e-11, atol_scale=1e-13, msg=key + "K")
+        assert_close(gp.compute_Kij(X, Xs, n, ns), G[key + "Ks"], rtol=1e-11, atol_scale=1e-13, msg=key + "Ks")
+    for N, d in ((64, 2), (200, 3)):
+        key = "fit_N%d_d%d_" % (N, d)
+        p, X, y, n = (G[key + s] for s in ("params", "X", "y", "n"))
+        k = g.RationalQuadraticKernel(num_dim=d, initial_params=list(p), param_bounds=[(0.0, 1e3)] * (d + 2))
+        gp = g.GaussianProcess(k, X=X, y=y, err_y=0.05, n=n)
+        gp.compute_K_L_alpha_ll()
+        assert gp._fast_fit_possible()              # the fused device path, not the pair-list fallback
+        assert abs(gp.ll - G[key + "ll"]) <= 1e-9 * abs(G[key + "ll"])
+        assert abs(np.log(np.diag(gp.L)).sum() - G[key + "logdet_half"]) <= 1e-10 * abs(G[key + "logdet_half"])
+        assert_close(gp.alpha.ravel(), G[key + "alpha"], rtol=1e-6, atol_scale=1e-7, msg="alpha")
+        mean, std = gp.predict(G[key + "Xs"], n=G[key + "ns"])
+        np.testing.assert_allclose(mean, G[key + "mean"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(std ** 2, G[key + "std"] ** 2, rtol=0, atol=1e-6)
+        # a new alpha through update_hyperparameters: same number as the CPU oracle
+        p2 = p * np.array([1.1, 0.8] + [1.05] * d)
+        negll = gp.update_hyperparameters(p2)
+        ref = oracle.fit("rq", p2, X, n, y, 0.05 * np.ones(N))
+        ll_ref = ref["ll_data"] + gp.hyperprior(gp.params)
+        assert abs(-negll - ll_ref) <= 1e-9 * abs(ll_ref)
+    # SumKernel of native terms including the new one stays on the device
+    ks = g.SquaredExponentialKernel(num_dim=d, initial_params=[0.5, 0.4, 0.4, 0.4], param_bounds=[(0.0, 1e3)] * 4) + k
+    gps = g.GaussianProcess(ks, X=X, y=y, err_y=0.05, n=n)
+    gps.compute_K_L_alpha_ll()
+    assert gps._fast_fit_possible()
+    Kref = oracle.kbuild("se", [0.5, 0.4, 0.4, 0.4], X, n) + oracle.kbuild("rq", gp.k.params, X, n)
+    assert_close(gps.K, Kref, rtol=1e-11, atol_scale=1e-13, msg="SE + RQ")
+
+
 # ---------------------------------------------------------------- G3/G4: fit + predict --------
 FIT_CASES = [(k, N, d) for k in KERNELS for (N, d) in ((16, 1), (64, 2), (256, 3), (512, 2))]
 

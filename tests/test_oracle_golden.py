@@ -51,6 +51,39 @@ def test_g1_pairs_m52_bit_exact_and_ref(oracle, golden, d):
         assert np.array_equal(p[0] ** 2 * oracle.ref_matern52(Xi, Xj, ni, nj, p[1:] ** 2), want)
 
 
+@pytest.mark.parametrize("d", [1, 2, 3, 4])
+def test_g8_rational_quadratic_pairs(oracle, golden, d):
+    """RationalQuadraticKernel (ref kernel/rational_quadratic.py:30-164 via ChainRuleKernel, core.py:691-816): derivative
+    orders 0..2 per point and dimension (combined order up to 6), integer and fractional alpha, tau == 0 rows."""
+    g = golden("g8_rq")
+    for tag in "abc":
+        key = "pairs_d%d%s_" % (d, tag)
+        got = oracle.kpairs("rq", g[key + "params"], g[key + "Xi"], g[key + "Xj"], g[key + "ni"], g[key + "nj"])
+        assert_close(got, g[key + "k"], rtol=2e-12, atol_scale=1e-14, msg=key)
+    with pytest.raises(NotImplementedError):
+        oracle.kpairs("rq", g[key + "params"], g[key + "Xi"], g[key + "Xj"], g[key + "ni"], g[key + "nj"], hyper_deriv=0)
+
+
+def test_g8_rational_quadratic_gram_fit_predict(oracle, golden):
+    g = golden("g8_rq")
+    for d in (1, 2, 3):
+        key = "gram_d%d_" % d
+        p, X, Xs, n, ns = (g[key + s] for s in ("params", "X", "Xs", "n", "ns"))
+        assert_close(oracle.kbuild("rq", p, X, n), g[key + "K"], rtol=2e-12, atol_scale=1e-14, msg=key + "K")
+        assert_close(oracle.kbuild("rq", p, X, n, Xs, ns), g[key + "Ks"], rtol=2e-12, atol_scale=1e-14, msg=key + "Ks")
+    for N, d in ((64, 2), (200, 3)):
+        key = "fit_N%d_d%d_" % (N, d)
+        r = oracle.fit("rq", g[key + "params"], g[key + "X"], g[key + "n"], g[key + "y"], 0.05 * np.ones(N))
+        ll = float(g[key + "ll"])
+        assert abs(r["ll_data"] + float(g[key + "prior"]) - ll) <= 1e-10 * abs(ll)
+        assert abs(r["logdet_half"] - float(g[key + "logdet_half"])) <= 1e-10 * abs(float(g[key + "logdet_half"]))
+        assert_close(r["alpha"], g[key + "alpha"], rtol=1e-8, atol_scale=1e-10, msg="alpha")
+        m, s, _ = oracle.predict("rq", g[key + "params"], g[key + "X"], g[key + "n"], r["L"], r["alpha"], g[key + "Xs"],
+                                 g[key + "ns"], want_cov=False)
+        np.testing.assert_allclose(m, g[key + "mean"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(s, g[key + "std"], rtol=0, atol=1e-9)
+
+
 def test_m52_error_contract(oracle):
     X = np.zeros((2, 2))
     n2 = np.array([[2, 0], [0, 0]])
