@@ -342,6 +342,36 @@ def main():
         extra["host_enqueue_ms"] = plan.timings.get("host_enqueue_s", 0.0) * 1e3
         parallelism = "1-D block-cyclic block columns (nb=%d) over %d ranks, %s panels over RCCL (%s)" % (
             plan.nb, world, "row-chunked" if plan.schedule == "pipelined" else "whole", plan.exchange)
+        if (world > 1 or os.environ.get("GPT_BENCH_C5_TOO")) and wl == "c4" and not args.no_probe:
+            # SURVEY 8e also asks for the partitioned factorisation at C5's size (N = 16384): same schedule, reported
+            # beside the headline (a few evaluations after the timed region; never in `value`)
+            try:
+                k5, N5, d5, der5 = WORKLOADS["c5"]
+                X5, n5, y5, err5, params5 = synth(k5, N5, d5, der5)
+                main_plan = plan
+                plan5 = DistributedLML(X5, n5, nb=main_plan.nb, ops=ops, group_tail=main_plan.group_tail,
+                                       schedule=main_plan.schedule, exchange=main_plan.exchange)
+                plan = plan5
+                step5 = lambda: plan5.fit(KID[k5], params5, y5, err5)
+                step5()
+                barrier()
+                t5 = time.perf_counter()
+                for _ in range(5):
+                    ll5, ld5 = step5()
+                barrier()
+                t5 = (time.perf_counter() - t5) / 5
+                if world > 1:
+                    tt = torch.tensor([t5], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    t5 = float(tt.item())
+                extra["c5_partitioned"] = {"N": N5, "ms_per_step": t5 * 1e3, "value": flops_fit(N5) / t5 * 1e-9,
+                                           "unit": "GFLOP/s", "pct_fp64_mfma_peak": 100.0 * flops_fit(N5) / t5 * 1e-12
+                                           / (FP64_MFMA_PEAK_TFLOPS * world), "ll_data": ll5}
+                plan = main_plan
+                del plan5
+            except (RuntimeError, ValueError) as e:
+                plan = main_plan
+                extra["c5_partitioned"] = {"error": repr(e)[:200]}
         if not args.no_probe:
             # after the timed region: where the time of one evaluation goes on rank 0, and what the links deliver
             try:
