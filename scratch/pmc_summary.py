@@ -11,6 +11,22 @@ for r in rows:
     lines.append("%-44s %7s %14s %12.0f %10s %10s %7s" % (short(r['Name'])[:44], r['Calls'], r['TotalDurationNs'], float(r['AverageNs']), r['MinNs'], r['MaxNs'], r['Percentage']))
 bench = [l for l in open(src + '/trace.log') if l.startswith('{')]
 if bench: lines.append("\n# bench.py line of the traced run:\n" + bench[-1].strip())
+# cross-check of bench.py's roofline.avg_launch_us (HIP events around the >= 1 GFLOP trailing updates) with the trace:
+# the same launches are the gemm_nt_kernel dispatches of the main queue with >= 1 GFLOP worth of 64x64 tiles
+try:
+    K_OUTER_ = 384
+    MIN_GRID_ = -(-10**9 // (2 * K_OUTER_ * 64 * 64)) * 256
+    kt = list(csv.DictReader(open(src + '/trace/t_kernel_trace.csv')))
+    mq = [r['Queue_Id'] for r in kt if 'kbuild_kernel' in r['Kernel_Name']][0]
+    bigd = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in kt
+            if 'gemm_nt_kernel' in r['Kernel_Name'] and r['Queue_Id'] == mq and int(r['Grid_Size_X']) >= MIN_GRID_]
+    bl = json.loads(bench[-1])
+    lines.append("\n# dominant kernel, the launches bench.py's roofline times (gemm_nt_kernel on the main queue, Grid_Size >= %d): "
+                 "%d dispatches in the trace (all %d evaluations of the run), average %.1f us;  bench.py (HIP events, the %d timed "
+                 "evaluations): roofline.avg_launch_us = %.1f" % (MIN_GRID_, len(bigd), len(bigd) // 28, sum(bigd) / len(bigd) * 1e-3,
+                                                                 bl['steps'], bl['roofline']['avg_launch_us']))
+except Exception as e:
+    lines.append("# (cross-check skipped: %r)" % (e,))
 def agg(path):
     rows = list(csv.DictReader(open(path)))
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter(); seen = set()
