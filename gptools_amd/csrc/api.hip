@@ -40,7 +40,8 @@ struct DevBuf {
 };
 
 enum { SLOT_XI = 0, SLOT_XJ, SLOT_NI, SLOT_NJ, SLOT_OUT, SLOT_KST, SLOT_KSS, SLOT_XS, SLOT_NS, SLOT_VEC, SLOT_VEC2,
-       SLOT_RHS, SLOT_LOW, SLOT_KFULL, SLOT_TK, SLOT_ZERO, SLOT_UINV, SLOT_WINV, SLOT_GPART, SLOT_COUNT };
+       SLOT_RHS, SLOT_LOW, SLOT_KFULL, SLOT_TK, SLOT_ZERO, SLOT_UINV, SLOT_WINV, SLOT_GPART, SLOT_BINV, SLOT_BTMP,
+       SLOT_COUNT };
 
 struct gpt_ctx {
     int device = 0;
@@ -84,6 +85,7 @@ struct gpt_ctx {
     double *h_yerr = nullptr;  // pinned staging for y | err_y (a pageable source would make the upload synchronous)
     int32_t *h_info = nullptr; // pinned
     bool factored = false, alpha_valid = false, have_kernel = false;
+    bool binv_valid = false;           // SLOT_BINV holds the inverses of the 512x512 diagonal blocks of the resident factor
     KParams kp;                      // first term (single-kernel paths)
     std::vector<KParams> terms;      // the model kernel as a sum of native kernels (gpt_fit_sum)
     double timings[5] = {0, 0, 0, 0, 0};
@@ -581,7 +583,7 @@ static void free_factor(gpt_ctx *c)
     if (c->d_alpha) hipFree(c->d_alpha);
     c->dA = c->d_invd = c->d_y = c->d_erry = c->d_alpha = nullptr;
     c->NP = 0;
-    c->factored = c->alpha_valid = false;
+    c->factored = c->alpha_valid = c->binv_valid = false;
 }
 
 extern "C" int gpt_ctx_destroy(gpt_ctx *c)
@@ -765,7 +767,7 @@ extern "C" int gpt_set_data(gpt_ctx *c, const double *X, const int32_t *n, int64
         if (sn > c->n_maxsum) c->n_maxsum = sn;
     }
     c->factored = false;
-    c->alpha_valid = false;
+    c->alpha_valid = c->binv_valid = false;
     c->have_kernel = false;
     if (c->dT) hipFree(c->dT);          // a transform belongs to one data set
     c->dT = nullptr;
@@ -788,7 +790,7 @@ extern "C" int gpt_set_T(gpt_ctx *c, const double *T, int64_t Ny)
     c->dT = nullptr;
     c->Ny = 0;
     c->factored = false;
-    c->alpha_valid = false;
+    c->alpha_valid = c->binv_valid = false;
     c->have_kernel = false;
     if (!T || Ny <= 0) return GPT_OK;
     const int64_t NyP = round_up(Ny, 64), NxP = round_up(c->Nx, 16);
@@ -846,7 +848,7 @@ static int factor_and_ll(gpt_ctx *c, int64_t N, double *ll_data_out, double *log
         hipEventElapsedTime(&ms, c->tev[0], c->tev[4]);
         c->timings[4] = ms;
     }
-    c->alpha_valid = false;
+    c->alpha_valid = c->binv_valid = false;
     const int32_t info = (int32_t)c->h_scal[2];
     if (info != 0) {
         c->factored = false;
@@ -1252,6 +1254,90 @@ extern "C" int gpt_ll_grad(gpt_ctx *c, int nh, const int *term_idx, const int *l
 }
 
 // ------------------------------------------------------------------------------------------------
+// solves with many right-hand sides against the resident factor: 512-column leaves by explicit block inverses
+// ------------------------------------------------------------------------------------------------
+// B (m x n) <- B L^-T is a chain of n/128 (leaf TRSM + update) pairs, ~20 us each: 2.5 ms at N = 8192 however few rows B
+// has (predict at a handful of points, gpt_solve_L).  With W_j = L_jj^-1 of the 512x512 diagonal blocks at hand (built
+// once per factorisation, on first use: 10 launches per block) a leaf is one copy and one GEMM, B_j <- B_j W_j^T, and
+// the chain has a quarter of the links: predict with std at M <= 256, N = 8192 goes from 2.55 to ~0.7 ms once the
+// inverses exist.
+#define GPT_BINV_NB 512
+static int ensure_block_inverses(gpt_ctx *c, int64_t nfull, double **out)
+{
+    double *W;
+    GPT_TRY(ensure(c, SLOT_BINV, (size_t)nfull * GPT_BINV_NB * sizeof(double), (void **)&W));
+    *out = W;
+    if (c->binv_valid) return GPT_OK;
+    hipStream_t st = c->stream;
+    double *U;
+    GPT_TRY(ensure(c, SLOT_UINV, (size_t)GPT_BINV_NB * GPT_BINV_NB * sizeof(double), (void **)&U));
+    for (int64_t j = 0; j < nfull; j += GPT_BINV_NB) {
+        GPT_HIP_CHECK(hipMemsetAsync(U, 0, (size_t)GPT_BINV_NB * GPT_BINV_NB * sizeof(double), st));
+        hipLaunchKernelGGL(eye_blocks_kernel, dim3(GPT_BINV_NB / 256), dim3(256), 0, st, U, (int64_t)GPT_BINV_NB,
+                           (int64_t)GPT_BINV_NB);
+        GPT_LAUNCH_CHECK();
+        GPT_TRY(trsm_rlt(c, st, GPT_BINV_NB, GPT_BINV_NB, c->dA + j * c->NP + j, c->NP, c->d_invd + (j / 128) * GPT_WS_BLOCK, U,
+                         GPT_BINV_NB));
+        hipLaunchKernelGGL(transpose_kernel, dim3(GPT_BINV_NB / 32, GPT_BINV_NB / 32), dim3(256), 0, st, U,
+                           (int64_t)GPT_BINV_NB, W + j * GPT_BINV_NB, (int64_t)GPT_BINV_NB, (int64_t)GPT_BINV_NB);
+        GPT_LAUNCH_CHECK();
+    }
+    c->binv_valid = true;
+    return GPT_OK;
+}
+
+// columns [lo, hi) of B (multiples of 512) against the same block range of the resident factor; W: the block inverses,
+// tmp: m x 512 scratch
+static int trsm_rlt_binv(gpt_ctx *c, hipStream_t st, int64_t m, int64_t lo, int64_t hi, const double *W, double *B,
+                         int64_t ldb, double *tmp)
+{
+    const int64_t n = hi - lo;
+    if (n == GPT_BINV_NB) {
+        GPT_TRY(launch_copy2d(st, m, GPT_BINV_NB, B + lo, ldb, tmp, GPT_BINV_NB));
+        return gemm_nt(c, st, m, GPT_BINV_NB, GPT_BINV_NB, 1.0, tmp, GPT_BINV_NB, W + lo * GPT_BINV_NB, GPT_BINV_NB, 0.0, B + lo,
+                       ldb, 0);
+    }
+    const int64_t h = (n / (2 * GPT_BINV_NB)) * GPT_BINV_NB > 0 ? (n / (2 * GPT_BINV_NB)) * GPT_BINV_NB : GPT_BINV_NB;
+    const int64_t mid = lo + h;
+    GPT_TRY(trsm_rlt_binv(c, st, m, lo, mid, W, B, ldb, tmp));
+    GPT_TRY(gemm_nt(c, st, m, hi - mid, h, -1.0, B + lo, ldb, c->dA + mid * c->NP + lo, c->NP, 1.0, B + mid, ldb, 0));
+    return trsm_rlt_binv(c, st, m, mid, hi, W, B, ldb, tmp);
+}
+
+// B (m x n128, ldb) <- B L^-T for the resident factor (n128 = N rounded up to 128), 512-column leaves where they fit
+static int solve_rows_resident(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n128, double *B, int64_t ldb)
+{
+    const int64_t nfull = (n128 / GPT_BINV_NB) * GPT_BINV_NB, rem = n128 - nfull;
+    if (nfull < 2 * GPT_BINV_NB) return trsm_rlt(c, st, m, n128, c->dA, c->NP, c->d_invd, B, ldb);
+    double *W, *tmp;
+    GPT_TRY(ensure_block_inverses(c, nfull, &W));
+    GPT_TRY(ensure(c, SLOT_BTMP, (size_t)m * GPT_BINV_NB * sizeof(double), (void **)&tmp));
+    if (m <= 256) {
+        // few rows: the halving recursion ends in updates with 64..256 rows and k of thousands -- a handful of workgroups
+        // walking long k loops (1.6 ms at N = 8192).  Right-looking instead: after each 512-column leaf one rank-512 update
+        // of everything to its right (n/64 workgroups, 32 k-steps each).
+        for (int64_t j = 0; j < nfull; j += GPT_BINV_NB) {
+            GPT_TRY(trsm_rlt_binv(c, st, m, j, j + GPT_BINV_NB, W, B, ldb, tmp));
+            const int64_t r0 = j + GPT_BINV_NB;
+            if (r0 < n128)
+                GPT_TRY(gemm_nt(c, st, m, n128 - r0, GPT_BINV_NB, -1.0, B + j, ldb, c->dA + r0 * c->NP + j, c->NP, 1.0, B + r0,
+                                ldb, 0));
+        }
+        if (rem > 0)
+            GPT_TRY(trsm_rlt(c, st, m, rem, c->dA + nfull * c->NP + nfull, c->NP, c->d_invd + (nfull / 128) * GPT_WS_BLOCK,
+                             B + nfull, ldb));
+        return GPT_OK;
+    }
+    GPT_TRY(trsm_rlt_binv(c, st, m, 0, nfull, W, B, ldb, tmp));
+    if (rem > 0) {
+        GPT_TRY(gemm_nt(c, st, m, rem, nfull, -1.0, B, ldb, c->dA + nfull * c->NP, c->NP, 1.0, B + nfull, ldb, 0));
+        GPT_TRY(trsm_rlt(c, st, m, rem, c->dA + nfull * c->NP + nfull, c->NP, c->d_invd + (nfull / 128) * GPT_WS_BLOCK,
+                         B + nfull, ldb));
+    }
+    return GPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // predict
 // ------------------------------------------------------------------------------------------------
 extern "C" int gpt_predict(gpt_ctx *c, const double *Xstar, const int32_t *nstar, int64_t M, int want,
@@ -1271,7 +1357,7 @@ extern "C" int gpt_predict(gpt_ctx *c, const double *Xstar, const int32_t *nstar
     }
     if (M > 65535 * 32) return GPT_E_ARG;
     const int D = c->D;
-    const int64_t N = c->N, NP = c->NP, n128 = round_up(N, 128), MP = round_up(M, 64);
+    const int64_t N = c->N, n128 = round_up(N, 128), MP = round_up(M, 64);
     const int64_t Nx = c->Nx;
     for (const auto &t : c->terms)
         if (t.kernel_id == GPT_KERNEL_M52) {
@@ -1318,7 +1404,7 @@ extern "C" int gpt_predict(gpt_ctx *c, const double *Xstar, const int32_t *nstar
     GPT_TRY(launch_gemv_n(st, M, N, dKst, n128, c->d_alpha, dmean));
     GPT_HIP_CHECK(hipMemcpyAsync(mean_out, dmean, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, st));
     if (want >= 1) {
-        GPT_TRY(trsm_rlt(c, st, MP, n128, c->dA, NP, c->d_invd, dKst, n128));     // V' = Kstar^T L^-T
+        GPT_TRY(solve_rows_resident(c, st, MP, n128, dKst, n128));                  // V' = Kstar^T L^-T
         KParams kn;
         if (noise_params) GPT_TRY(make_kparams(GPT_KERNEL_DIAGNOISE, noise_params, 1, D, -1, 1, noise_n, &kn));
         if (want == 1) {
@@ -1379,7 +1465,7 @@ static int solve_common(gpt_ctx *c, double *B, int64_t nrhs, bool full)
     GPT_TRY(launch_zero2d(st, RP, n128, dBt, n128));
     GPT_HIP_CHECK(hipMemcpy2DAsync(dBt, (size_t)n128 * sizeof(double), Bt.data(), (size_t)N * sizeof(double),
                                    (size_t)N * sizeof(double), (size_t)nrhs, hipMemcpyHostToDevice, st));
-    GPT_TRY(trsm_rlt(c, st, RP, n128, c->dA, c->NP, c->d_invd, dBt, n128));       // rows: (L^-1 b_r)^T
+    GPT_TRY(solve_rows_resident(c, st, RP, n128, dBt, n128));                     // rows: (L^-1 b_r)^T
     if (full)
         for (int64_t r = 0; r < nrhs; r++) {
             // the padded tail of each row is (numerically) zero except a ~1e-150 entry in the augmented
