@@ -287,13 +287,14 @@ static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, 
     return rc;
 }
 
-// Outer block width of the factorisation.  Measured on MI355X (scratch/fit_loop.py): 384 wins while the panel chain
-// dominates (N=8192: 5.90 ms against 6.07 at 512 and 6.05 at 256; N=4096: 2.01 against 2.07), 512 once the trailing
-// updates do (N=16384: 30.9 ms against 31.9 at 384 and 32.0 at 640).
+// Outer block width of the factorisation.  Measured on MI355X (scratch/nb_sweep.py, with the fused diagonal-block + TRSM
+// kernel): 256 below N ~ 5k (N=4096: 1.82 ms against 1.86 at 384, 1.90 at 512), 384 while the panel chain dominates
+// (N=8192: 5.61 ms against 5.84 at 256 and 5.82 at 512), 512 once the trailing updates do (N=16384: 30.2 ms against
+// 30.9 at 384 and 31.2 at 640).
 static inline int64_t outer_width(const gpt_ctx *c, int64_t n)
 {
     if (c->nb_outer > 0) return c->nb_outer;
-    return (n <= 12288) ? 384 : 512;
+    return (n <= 5120) ? 256 : (n <= 12288) ? 384 : 512;
 }
 
 // Factor the block column Ap (m x w, diag block on top): recursive halving down to 128 columns.

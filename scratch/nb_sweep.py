@@ -7,7 +7,7 @@ for N in [int(v) for v in sys.argv[1:]]:
     X, n, y, err, params = bench.synth("se", N, 2, False)
     ctx.set_data(X, n)
     res = []
-    for nb in (384, 512, 640):
+    for nb in (256, 384, 512, 640):
         ctx.set_option("nb_outer", nb)
         best = 1e9
         for _ in range(5):
