@@ -154,6 +154,8 @@ _PIPE_FINE = {"schedule": "pipelined", "chunk_blocks": (2, 3, 5), "exchange": "s
     (2, 1500, 3, 128, 1, True, _PIPE_SUBST),
     (2, 100, 2, 256, 0, True, _PIPE),       # one block column, idle rank
     (4, 900, 2, 128, 0, True, _PIPE_FINE),  # more ranks than panel buffers minus one
+    (8, 1900, 2, 128, 0, True, _PIPE),      # the world size of the 8-GPU node: 15 block columns, owner_first on
+    (8, 1900, 2, 128, 0, True, _WHOLE_INV),
 ])
 def test_distributed_fit_matches_single_process_oracle(world, N, d, nb, kid, lookahead, plan_kw):
     from oracle import oracle as O
