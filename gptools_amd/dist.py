@@ -31,6 +31,7 @@ multi-process CPU tests inject a numpy implementation from ``tests/`` to exercis
 partitioning / communication logic under the ``gloo`` backend.
 """
 import math
+import os
 import sys
 import time
 
@@ -118,9 +119,7 @@ class HipPanelOps(PanelOps):
         self.ctx_panel = _lib.Context(self.device.index, stream=self.panel_stream.cuda_stream)
         # "recv": where a rank that does not own a panel posts its side of the exchange -- an otherwise empty stream,
         # so that the receive never queues up behind this rank's own panel work
-        import os
-        self.recv_stream = (self.panel_stream if os.environ.get("GPT_DIST_RECV_ON_PANEL", "0") == "1"
-                            else torch.cuda.Stream(self.device, priority=-1))
+        self.recv_stream = torch.cuda.Stream(self.device, priority=-1)
         self._ctx = {"main": self.ctx_main, "panel": self.ctx_panel}
         self._stream = {"main": self.main_stream, "panel": self.panel_stream, "recv": self.recv_stream}
         for c in self._ctx.values():
@@ -228,8 +227,7 @@ class DistributedLML(object):
         self.ops = ops
         self.device = getattr(ops, "device", torch.device("cpu"))
         # GPT_DIST_FORCE_COLLECTIVES=1 issues the (self-)broadcasts and all-reduces even with a single rank, so the
-        # RCCL call pattern can be exercised on a 1-GPU box (tests/test_gpu_parity.py).
-        import os
+        # RCCL call pattern can be exercised on a 1-GPU box (tests/test_gpu_a_dist_processes.py).
         self.force_collectives = bool(int(os.environ.get("GPT_DIST_FORCE_COLLECTIVES", "0"))) and dist.is_initialized()
         self.lookahead = bool(lookahead)
         if schedule not in ("pipelined", "bcast") or exchange not in ("bcast", "scatter_gather"):
