@@ -17,7 +17,7 @@ from ..error_handling import GPArgumentError
 from ..utils import UniformJointPrior, IndependentJointPrior, MaskedBounds
 from .. import _lib
 
-__all__ = ["Kernel", "BinaryKernel", "SumKernel"]
+__all__ = ["ProductKernel", "Kernel", "BinaryKernel", "SumKernel"]
 
 
 class Kernel(object):
@@ -161,7 +161,7 @@ class Kernel(object):
         return SumKernel(self, other)
 
     def __mul__(self, other):
-        raise NotImplementedError("ProductKernel is outside the accelerated hot path (SURVEY.md section 8f).")
+        return ProductKernel(self, other)
 
 
 class BinaryKernel(Kernel):
@@ -241,3 +241,40 @@ class SumKernel(BinaryKernel):
         if hyper_deriv < self.k1.num_params:
             return self.k1(Xi, Xj, ni, nj, hyper_deriv=hyper_deriv, symmetric=symmetric)
         return self.k2(Xi, Xj, ni, nj, hyper_deriv=hyper_deriv - self.k1.num_params, symmetric=symmetric)
+
+
+class ProductKernel(BinaryKernel):
+    """``k1 * k2`` with the product rule for derivative observations (ref: gptools/kernel/core.py:587-671).
+
+    The reference walks the power set of the derivative multiset of every pair (positions distinct, so equal subsets
+    recur); grouped by how many of the ``n`` derivatives of each of the 2 D slots (``ni`` then ``nj``) go to ``k1`` that
+    is the general Leibniz rule, ``sum_a prod_slots C(n, a) * k1^(a) * k2^(n - a)`` -- the same sum with each distinct
+    term evaluated once.  Both factors are evaluated through their own ``__call__`` (the GPU pair list for native
+    kernels); a product is not a native term of the fused builder, so ``GaussianProcess`` assembles its K from these
+    calls and keeps factorisation and solves on the device."""
+
+    def __call__(self, Xi, Xj, ni, nj, hyper_deriv=None, symmetric=False):
+        if hyper_deriv is not None:
+            raise NotImplementedError("hyper_deriv keyword not yet supported!")
+        import itertools
+        from math import comb
+        Xi, Xj = np.atleast_2d(np.asarray(Xi, dtype=float)), np.atleast_2d(np.asarray(Xj, dtype=float))
+        ni, nj = np.atleast_2d(np.asarray(ni, dtype=int)), np.atleast_2d(np.asarray(nj, dtype=int))
+        D = self.num_dim
+        nij = np.hstack((ni, nj))
+        result = np.zeros(Xi.shape[0])
+        for row in np.unique(nij, axis=0):
+            idxs = (nij == row).all(axis=1)
+            cnt = int(idxs.sum())
+            xi, xj = Xi[idxs], Xj[idxs]
+            for a in itertools.product(*[range(int(r) + 1) for r in row]):
+                a = np.asarray(a, dtype=int)
+                weight = 1
+                for r, ai in zip(row, a):
+                    weight *= comb(int(r), int(ai))
+                n1 = np.tile(a, (cnt, 1))
+                n2 = np.tile(row - a, (cnt, 1))
+                result[idxs] += weight * (self.k1(xi, xj, n1[:, :D], n1[:, D:], symmetric=symmetric) *
+                                          self.k2(xi, xj, n2[:, :D], n2[:, D:], symmetric=symmetric))
+        return result
+

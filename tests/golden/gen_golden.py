@@ -15,6 +15,7 @@ Fixture groups follow SURVEY.md section 8(c):
   G6 demo known-answer (config 1)              (demo/demo.py:133-253)
   G7 tests/test_matern.py scenario, seeded     (tests/test_matern.py:4-31)
   G8 RationalQuadraticKernel: pairs, Gram, fit, predict (kernel/rational_quadratic.py:30-164, kernel/core.py:691-816)
+  G9 ProductKernel (k1 * k2) with derivative orders: pairs, fit, predict (kernel/core.py:587-671)
 """
 import os
 import pickle
@@ -532,8 +533,55 @@ def gen_g8():
     save("g8_rq", **out)
 
 
+# ----------------------------------------------------------------------------
+# G9: ProductKernel
+# ----------------------------------------------------------------------------
+def gen_g9():
+    rs = np.random.RandomState(909)
+    out = {}
+    d = 2
+    M = 120
+    Xi, Xj = rs.rand(M, d), rs.rand(M, d)
+    Xj[:10] = Xi[:10]
+    # SE * SE: orders 0..2 per point and dimension
+    ni, nj = rs.randint(0, 3, size=(M, d)), rs.randint(0, 3, size=(M, d))
+    ni[rs.rand(M) < 0.3] = 0
+    nj[rs.rand(M) < 0.3] = 0
+    p1, p2 = np.array([1.2, 0.3, 0.5]), np.array([0.8, 0.7, 0.25])
+    k = se_kernel(d, p1) * se_kernel(d, p2)
+    out["sese_Xi"], out["sese_Xj"], out["sese_ni"], out["sese_nj"] = Xi, Xj, ni.astype(np.int32), nj.astype(np.int32)
+    out["sese_p1"], out["sese_p2"] = p1, p2
+    out["sese_k"] = np.asarray(k(Xi, Xj, ni, nj), dtype=float)
+    # SE * Matern52: at most one first derivative per point
+    n1 = np.zeros((M, d), dtype=int)
+    n2 = np.zeros((M, d), dtype=int)
+    for m in range(M):
+        if rs.rand() < 0.5:
+            n1[m, rs.randint(d)] = 1
+        if rs.rand() < 0.5:
+            n2[m, rs.randint(d)] = 1
+    k = se_kernel(d, p1) * m52_kernel(d, p2)
+    out["sem_ni"], out["sem_nj"] = n1.astype(np.int32), n2.astype(np.int32)
+    out["sem_k"] = np.asarray(k(Xi, Xj, n1, n2), dtype=float)
+    # fit + predict with SE * Matern52, first-derivative rows
+    N = 60
+    n = deriv_pattern(rs, N, d, 0.25, 1)
+    X, y = synth(rs, N, d, n)
+    gp = gptools.GaussianProcess(se_kernel(d, p1) * m52_kernel(d, p2))
+    gp.add_data(X, y, err_y=0.05, n=n)
+    record_fit(out, "fit_", gp, with_L=False)
+    Xs = rs.rand(16, d)
+    ns = np.zeros((16, d), dtype=int)
+    ns[8:, 1] = 1
+    mean, std = gp.predict(Xs, n=ns)
+    out["fit_X"], out["fit_y"], out["fit_n"] = X, y, n.astype(np.int32)
+    out["fit_Xs"], out["fit_ns"] = Xs, ns.astype(np.int32)
+    out["fit_mean"], out["fit_std"] = np.asarray(mean), np.asarray(std)
+    save("g9_product", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g34", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g34", "g5", "g6", "g7", "g8", "g9"]
     if "g1" in which:
         gen_g1()
     if "g2" in which:
@@ -548,3 +596,5 @@ if __name__ == "__main__":
         gen_g7()
     if "g8" in which:
         gen_g8()
+    if "g9" in which:
+        gen_g9()

@@ -166,6 +166,31 @@ def test_mean_functions(g):
                                                    np.where(n[:, 0] == 1, 2.0, np.where(n[:, 1] == 1, -1.0, 0.0))))
 
 
+def test_product_kernel_leibniz_rule_against_reference(g, golden, oracle):
+    """ProductKernel (ref: kernel/core.py:587-671) is host logic over per-factor pair evaluations: with the factors
+    evaluated by the CPU oracle (test stand-ins for the GPU pair list) the product rule must reproduce the reference's
+    outputs -- SE * SE with orders 0..2 per point and dimension, SE * Matern52 with first derivatives."""
+    from conftest import assert_close
+    from gptools_amd.kernel.core import Kernel, ProductKernel
+
+    class OracleKernel(Kernel):
+        def __init__(self, name, params):
+            Kernel.__init__(self, num_dim=2, num_params=3, initial_params=list(params), param_bounds=[(0.0, 1e3)] * 3)
+            self.name = name
+
+        def __call__(self, Xi, Xj, ni, nj, hyper_deriv=None, symmetric=False):
+            return oracle.kpairs(self.name, self.params, Xi, Xj, ni, nj, hyper_deriv=hyper_deriv, symmetric=symmetric)
+
+    G = golden("g9_product")
+    k = OracleKernel("se", G["sese_p1"]) * OracleKernel("se", G["sese_p2"])
+    assert isinstance(k, ProductKernel) and k.num_params == 6
+    assert_close(k(G["sese_Xi"], G["sese_Xj"], G["sese_ni"], G["sese_nj"]), G["sese_k"], rtol=1e-11, msg="SE * SE")
+    k = OracleKernel("se", G["sese_p1"]) * OracleKernel("m52", G["sese_p2"])
+    assert_close(k(G["sese_Xi"], G["sese_Xj"], G["sem_ni"], G["sem_nj"]), G["sem_k"], rtol=1e-11, msg="SE * M52")
+    with pytest.raises(NotImplementedError):
+        k(G["sese_Xi"], G["sese_Xj"], G["sem_ni"], G["sem_nj"], hyper_deriv=0)
+
+
 def test_gp_pickles_without_device_state(g):
     k = g.Matern52Kernel(num_dim=2, initial_params=[1, 0.5, 0.5], param_bounds=[(0, 10)] * 3)
     gp = g.GaussianProcess(k, X=np.random.rand(5, 2), y=np.random.rand(5), err_y=0.1)

@@ -230,6 +230,24 @@ def test_g8_rational_quadratic_gram_fit_predict(g, golden, oracle):
     assert_close(gps.K, Kref, rtol=1e-11, atol_scale=1e-13, msg="SE + RQ")
 
 
+def test_g9_product_kernel_on_device_factors(g, golden):
+    """k1 * k2 (ref: kernel/core.py:587-671) with both factors evaluated by the GPU pair list; K assembled from those
+    calls, factorisation / solves / predict on the device."""
+    G = golden("g9_product")
+    mk = lambda cls, p: cls(num_dim=2, initial_params=list(p), param_bounds=[(0.0, 1e3)] * 3)
+    k = mk(g.SquaredExponentialKernel, G["sese_p1"]) * mk(g.SquaredExponentialKernel, G["sese_p2"])
+    assert_close(k(G["sese_Xi"], G["sese_Xj"], G["sese_ni"], G["sese_nj"]), G["sese_k"], rtol=1e-11, msg="SE * SE")
+    k = mk(g.SquaredExponentialKernel, G["sese_p1"]) * mk(g.Matern52Kernel, G["sese_p2"])
+    assert_close(k(G["sese_Xi"], G["sese_Xj"], G["sem_ni"], G["sem_nj"]), G["sem_k"], rtol=1e-11, msg="SE * M52")
+    gp = g.GaussianProcess(k, X=G["fit_X"], y=G["fit_y"], err_y=0.05, n=G["fit_n"])
+    gp.compute_K_L_alpha_ll()
+    assert abs(gp.ll - G["fit_ll"]) <= 1e-9 * abs(G["fit_ll"])
+    assert_close(gp.alpha.ravel(), G["fit_alpha"], rtol=1e-6, atol_scale=1e-7, msg="alpha")
+    mean, std = gp.predict(G["fit_Xs"], n=G["fit_ns"])
+    np.testing.assert_allclose(mean, G["fit_mean"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(std ** 2, G["fit_std"] ** 2, rtol=0, atol=1e-6)
+
+
 # ---------------------------------------------------------------- G3/G4: fit + predict --------
 FIT_CASES = [(k, N, d) for k in KERNELS for (N, d) in ((16, 1), (64, 2), (256, 3), (512, 2))]
 
