@@ -47,6 +47,13 @@ class GaussianProcess(object):
     Parameters are those of ref: gptools/gaussian_process.py:196-238: ``k``, ``noise_k``, ``X``,
     ``y``, ``err_y``, ``n``, ``T``, ``diag_factor``, ``mu``, ``use_hyper_deriv``, ``verbose``;
     ``device`` (extra) selects the GPU.
+
+    ``partitioned`` (extra attribute, default False): in a ``torch.distributed`` job with one rank per GPU,
+    ``update_hyperparameters`` evaluates the log-posterior with the factorisation partitioned over the ranks
+    (``gptools_amd.dist.DistributedLML``: block-cyclic block columns, panels over RCCL) instead of on this rank's GPU
+    alone -- for one native kernel without ``T`` and without hyperparameter derivatives.  Every rank must then make
+    the same calls with the same hyperparameters (an optimiser run identically on every rank does: all ranks see the
+    same ``ll``).  ``L``, ``alpha``, ``predict`` ... need the factor on this GPU and refit locally on first use.
     """
 
     def __init__(self, k, noise_k=None, X=None, y=None, err_y=0, n=0, T=None, diag_factor=1e2, mu=None,
@@ -89,6 +96,19 @@ class GaussianProcess(object):
         self._data_on_device = False
         self._cache = {}
         self._fit_mode = None
+        self._dist_plan = None
+
+    partitioned = False
+    partition_block = 512
+
+    def _partitioned_possible(self):
+        if not self.partitioned or self.use_hyper_deriv or self.T is not None or not self._fast_fit_possible():
+            return False
+        terms = self._native_terms()
+        if terms is None or len(terms) != 1:
+            return False
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
 
     @property
     def _ctx(self):
@@ -112,6 +132,7 @@ class GaussianProcess(object):
         st["_data_on_device"] = False
         st["_cache"] = {}
         st["_fit_mode"] = None
+        st["_dist_plan"] = None
         st["K_up_to_date"] = False
         return st
 
@@ -256,6 +277,7 @@ class GaussianProcess(object):
         self.n = n if self.n is None else np.vstack((self.n, n))
         self.K_up_to_date = False
         self._data_on_device = False
+        self._dist_plan = None
         self._data_version = getattr(self, "_data_version", 0) + 1
 
     # ---- covariance matrices (ref: gptools/gaussian_process.py:1535-1605) --------------------
@@ -358,17 +380,33 @@ class GaussianProcess(object):
             return ctx.fit(terms[0][0], terms[0][1], noise_var, y_alph, self.err_y, diag_add)
         return ctx.fit_sum([t[0] for t in terms], [t[1] for t in terms], noise_var, y_alph, self.err_y, diag_add)
 
-    def compute_K_L_alpha_ll(self):
+    def compute_K_L_alpha_ll(self, need_factor=True):
         """Build ``K_tot``, factor it and evaluate the log-posterior ``ll`` on the GPU (no-op while
         ``K_up_to_date``).  Raises ``numpy.linalg.LinAlgError`` if ``K_tot`` is not positive
-        definite, like ``scipy.linalg.cholesky`` in the reference."""
-        if self.K_up_to_date:
+        definite, like ``scipy.linalg.cholesky`` in the reference.
+
+        ``need_factor=False`` (``update_hyperparameters``): only ``ll`` is wanted, which lets a ``partitioned`` GP
+        evaluate it with the factorisation spread over the ranks of the job; the factor then is not on this GPU and
+        the next call that needs it refits locally."""
+        if self.K_up_to_date and (self._fit_mode != "partitioned" or not need_factor):
             return
         if self.X is None:
             raise GPArgumentError("No data have been added to the GaussianProcess!")
         self._cache = {}
         y_alph = self._y_alph()
         diag_add = self.diag_factor * sys.float_info.epsilon
+        if not need_factor and self._partitioned_possible():
+            from .dist import DistributedLML
+            if self._dist_plan is None:
+                self._dist_plan = DistributedLML(self.X, self.n, nb=self.partition_block, device=self.device)
+            kid, kparams = self._native_terms()[0]
+            noise_var = 0.0 if isinstance(self.noise_k, ZeroKernel) else self.noise_k.params[0] ** 2.0
+            ll_data, _ = self._dist_plan.fit(kid, kparams, y_alph, self.err_y, noise_var=noise_var,
+                                             diag_factor=self.diag_factor)
+            self._fit_mode = "partitioned"
+            self.ll = ll_data + self.hyperprior(self.params)
+            self.K_up_to_date = True
+            return
         ctx = self._ctx
         if self._fast_fit_possible():
             if not self._data_on_device:
@@ -475,7 +513,7 @@ class GaussianProcess(object):
         try:
             if exit_on_bounds and np.isinf(self.hyperprior(self.params)):
                 raise GPImpossibleParamsError("Impossible values for params!")
-            self.compute_K_L_alpha_ll()
+            self.compute_K_L_alpha_ll(need_factor=False)
         except Exception as e:
             self.use_hyper_deriv = use_hyper_deriv
             if not inf_on_error:
@@ -694,7 +732,8 @@ class GaussianProcess(object):
         # perturbed points of one gradient are independent evaluations, kept two in flight on the GPU.  The points
         # and the difference formula are scipy's own (approx_derivative is replayed), so the iterates are the same.
         fd_eps = {"L-BFGS-B": 1e-8, "TNC": 1e-8, "SLSQP": 1.4901161193847656e-08}
-        if (batch_fd is not False and int(self.batch_concurrency) > 1 and not self.use_hyper_deriv
+        partitioned = self._partitioned_possible()       # every evaluation is a collective: no local batching,
+        if (batch_fd is not False and int(self.batch_concurrency) > 1 and not self.use_hyper_deriv and not partitioned
                 and "jac" not in opt_kwargs and method in fd_eps and self._fast_fit_possible()):
             eps = (opt_kwargs.get("options") or {}).get("eps", fd_eps[method])
             objective, opt_kwargs["jac"] = self._batched_fd(eps, np.asarray(opt_kwargs["bounds"], dtype=float))
@@ -713,7 +752,11 @@ class GaussianProcess(object):
             if trial >= 1 and random_starts != 0:
                 param_samples = draw()
             trial += 1
-            if replicas.world_size() > 1 and len(param_samples) > 1:
+            if partitioned and replicas.world_size() > 1:
+                # ... and every rank walks all the starts (rank 0's draws), in the same order
+                param_samples = list(replicas.shared(np.asarray(param_samples)))
+                res = [r for r in (run(s) for s in param_samples) if r is not None]
+            elif replicas.world_size() > 1 and len(param_samples) > 1:
                 # one start per GPU: the ranks of the torch.distributed job replace the reference's process pool
                 param_samples = replicas.shared(np.asarray(param_samples))
                 res = [r for r in replicas.distributed_map(run, list(param_samples)) if r is not None]

@@ -100,3 +100,60 @@ def test_distributed_plan_two_ranks_sharing_the_gpu(oracle):
         for v in vals:
             assert abs(float(v[0]) - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"])
             assert abs(float(v[1]) - ref["logdet_half"]) <= 1e-10 * abs(ref["logdet_half"])
+
+
+def test_gaussian_process_partitioned_update_and_map_two_ranks(oracle):
+    """``GaussianProcess.partitioned``: update_hyperparameters / optimize_hyperparameters with the factorisation spread
+    over the ranks of the job (two gloo ranks sharing cuda:0) give what one process gives, on every rank; the factor is
+    rebuilt locally when predict needs it."""
+    root = ROOT
+    code = (
+        "import faulthandler; faulthandler.dump_traceback_later(200, exit=True)\n"
+        "import os, sys, json, warnings, numpy as np\n"
+        "warnings.simplefilter('ignore')\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "rank, world = int(sys.argv[1]), int(sys.argv[2])\n"
+        "if world > 1:\n"
+        "    import torch, torch.distributed as dist\n"
+        "    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29527')\n"
+        "    torch.cuda.set_device(0)\n"
+        "    dist.init_process_group('gloo', rank=rank, world_size=world)\n"
+        "import gptools_amd as g\n"
+        "from test_gpu_parity import c3_inputs\n"
+        "X, n, y = c3_inputs(1200, 2)\n"
+        "k = g.Matern52Kernel(num_dim=2, initial_params=[1.0, 0.4, 0.4], param_bounds=[(0.05, 10.0)] * 3)\n"
+        "gp = g.GaussianProcess(k, X=X, y=y, err_y=0.05, n=n)\n"
+        "gp.partitioned = world > 1\n"
+        "gp.partition_block = 128\n"
+        "v1 = gp.update_hyperparameters([1.1, 0.35, 0.45])\n"
+        "mode1 = gp._fit_mode\n"
+        "m1, s1 = gp.predict(X[:5], n=0)\n"
+        "mode2 = gp._fit_mode\n"
+        "res, nres = gp.optimize_hyperparameters(method='L-BFGS-B', random_starts=0, opt_kwargs={'options': {'maxiter': 6}})\n"
+        "print('RESULT', json.dumps({'v1': float(v1), 'mode1': mode1, 'mode2': mode2, 'm1': [float(v) for v in m1],\n"
+        "                            'fun': float(res.fun), 'x': [float(v) for v in res.x]}))\n"
+        "if world > 1: dist.destroy_process_group()\n") % (root, root)
+
+    def launch(rank, world):
+        return subprocess.Popen([sys.executable, "-c", code, str(rank), str(world)], stdout=subprocess.PIPE,
+                                stderr=subprocess.PIPE, text=True)
+
+    def result(p):
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-2000:]
+        import json
+        return json.loads([l for l in so.splitlines() if l.startswith("RESULT")][0][7:])
+
+    single = result(launch(0, 1))
+    procs = [launch(r, 2) for r in range(2)]
+    both = [result(p) for p in procs]
+    assert single["mode1"] == "kernel"
+    for r in both:
+        assert r["mode1"] == "partitioned" and r["mode2"] == "kernel"
+        assert abs(r["v1"] - single["v1"]) <= 1e-9 * abs(single["v1"])
+        np.testing.assert_allclose(r["m1"], single["m1"], rtol=0, atol=1e-8)
+        assert abs(r["fun"] - single["fun"]) <= 1e-6 * abs(single["fun"])
+        # (finite-difference gradients amplify the 1e-13 summation-order difference of ll: same optimum, not same digits)
+        np.testing.assert_allclose(r["x"], single["x"], rtol=1e-2)
+    assert both[0]["fun"] == both[1]["fun"] and both[0]["x"] == both[1]["x"]      # the ranks walked the same iterates
+
