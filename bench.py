@@ -372,6 +372,47 @@ def main():
             except (RuntimeError, ValueError) as e:
                 plan = main_plan
                 extra["c5_partitioned"] = {"error": repr(e)[:200]}
+        if (world > 1 or os.environ.get("GPT_BENCH_C5_TOO")) and not args.no_probe:
+            # The other way to use N GPUs (below N ~ 10k a partitioned factorisation cannot beat one
+            # GPU): independent evaluations of the metric's own configuration (C3, N = 8192), two in flight per GPU, every
+            # rank its own hyperparameters -- aggregate LML evaluations/s of the job (weak scaling; never in `value`).
+            try:
+                import threading
+                k3, N3, d3, der3 = WORKLOADS["c3"]
+                X3, n3, y3, err3, p3 = synth(k3, N3, d3, der3)
+                pair = [_lib.Context(local_rank), _lib.Context(local_rank)]
+                for c_ in pair:
+                    c_.set_data(X3, n3)
+                    c_.fit(KID[k3], p3, 0.0, y3, err3, diag_add)
+                reps = max(10, args.steps)
+
+                def run3(c_, p_):
+                    for _ in range(reps):
+                        c_.fit(KID[k3], p_, 0.0, y3, err3, diag_add)
+                th = [threading.Thread(target=run3, args=(c_, p3 * (1.0 + 0.01 * (2 * rank + i_))))
+                      for i_, c_ in enumerate(pair)]
+                barrier()
+                t3 = time.perf_counter()
+                for t_ in th:
+                    t_.start()
+                for t_ in th:
+                    t_.join()
+                barrier()
+                t3 = time.perf_counter() - t3
+                if world > 1:
+                    tt = torch.tensor([t3], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    t3 = float(tt.item())
+                extra["replicas_c3"] = {"N": N3, "in_flight_per_gpu": 2, "lml_evals_per_s": 2 * reps * world / t3,
+                                        "value": 2 * reps * world * flops_fit(N3) / t3 * 1e-9, "unit": "GFLOP/s",
+                                        "pct_fp64_mfma_peak": 100.0 * 2 * reps * world * flops_fit(N3) / t3 * 1e-12
+                                        / (FP64_MFMA_PEAK_TFLOPS * world), "scaling": "weak",
+                                        "note": "contexts created after the partitioned run has used the GPU: their streams "
+                                                "share hardware queues (about 20 % below the N=1 line's `batched` figure "
+                                                "per GPU, DESIGN section 6)"}
+                del pair
+            except (RuntimeError, ValueError) as e:
+                extra["replicas_c3"] = {"error": repr(e)[:200]}
         if not args.no_probe:
             # after the timed region: where the time of one evaluation goes on rank 0, and what the links deliver
             try:
