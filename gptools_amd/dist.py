@@ -577,6 +577,11 @@ class DistributedLML(object):
         nblk = self.nblk
         owner = lambda J: J % world == rank
         ev_asm = self._begin(kernel_id, params, y, err_y, noise_var, diag_factor)
+        for q in ("panel", "recv"):
+            # nothing on the other queues may run ahead of this rank's own K build / zeroed scalars (a rank that does
+            # not own panel 0 would otherwise stage its first block column while the builder is still writing it)
+            with ops.queue(q):
+                ev_asm.wait()
         ev_urg, ev_done, ev_pq = {}, {}, {}
         arrivals = {}
 
@@ -589,8 +594,6 @@ class DistributedLML(object):
             pb = self._chunk_bounds(k - 1) if k > 0 else None
             arr = arrivals[k] = []
             with ops.queue("panel" if own else "recv"):
-                if k == 0:
-                    ev_asm.wait()
                 if k - NBUF in ev_done:
                     ev_done.pop(k - NBUF).wait()
                 if k - NBUF in ev_pq:
