@@ -154,6 +154,42 @@ def comm_probe(torch, dist, world, rank):
     return out
 
 
+class Watchdog(object):
+    """The partitioned path first measures the whole-panel schedule, then tries the newer schedules and runs the
+    diagnostics.  None of those later legs has ever run on more than one real GPU: should one of them hang, this timer
+    prints the line that is already complete (flagged) and ends the process, on every rank, instead of losing the run."""
+
+    def __init__(self, rank):
+        import threading
+        self.rank, self.lock, self.done, self.timer = rank, threading.Lock(), False, None
+        self.line, self.phase, self._threading = None, "", threading
+
+    def arm(self, seconds):
+        self.timer = self._threading.Timer(seconds, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def _fire(self):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            if self.rank == 0 and self.line is not None:
+                self.line["watchdog"] = "timed out during: %s; this is the line that was complete by then" % self.phase
+                print(json.dumps(self.line), flush=True)
+            os._exit(0)
+
+    def finish(self):
+        """True if the caller may print the final line (the timer has not fired and no longer will)."""
+        with self.lock:
+            if self.done:
+                return False
+            self.done = True
+        if self.timer is not None:
+            self.timer.cancel()
+        return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,6 +235,28 @@ def main():
 
     roof = None
     extra = {}
+    elapsed, ll, ld, parallelism = None, None, None, None
+    wd = Watchdog(rank)
+
+    def build_out():
+        per_step = elapsed / args.steps
+        value = flops_fit(N) / per_step * 1e-9
+        out_ = {
+            "metric": METRIC, "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": per_step * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %s kernel, N=%d, d=%d%s, err_y=0.05, sigma_f=1, l=0.3 (BASELINE.json configs)"
+                                   % (wl.upper(), {"se": "SquaredExponential", "m52": "Matern52"}[kernel], N, d,
+                                      ", last quarter of rows first-derivative observations" if deriv else ""),
+                       "N": N, "d": d, "parallelism": parallelism},
+            "lml_evals_per_s": 1.0 / per_step,
+            "pct_fp64_mfma_peak": 100.0 * value * 1e-3 / (FP64_MFMA_PEAK_TFLOPS * world),
+            "ll_data": ll, "logdet_half": ld,
+        }
+        out_.update(extra)
+        if roof is not None:
+            out_["roofline"] = roof
+        return out_
     if world == 1 and not args.dist:
         ctx = _lib.Context(local_rank)
         # (the second context of the throughput leg is created before the first one runs: streams created after
@@ -299,21 +357,45 @@ def main():
                 t_ = float(tt.item())
             return t_ / nsteps, r_
 
-        # Untimed tuning pass (before the W warm-up steps): block width / schedule / exchange combinations of
-        # gptools_amd.dist are each run once (communicator set-up) and then timed over two evaluations; the fastest (max
-        # over ranks, so every rank picks the same one) is what the warm-up and the K timed steps run.  All are reported.
+        # (1) The whole-panel schedule at nb = 512 -- the one this code base has run longest: W warm-up steps, K timed
+        # steps, a complete line.  (2) Only then the other block width / schedule / exchange combinations of
+        # gptools_amd.dist, each run once (communicator set-up) and timed over two evaluations; if the fastest of them
+        # beats (1) by more than 3 % it gets its own W warm-up + K timed steps and becomes the line.  Everything after
+        # (1) runs under the watchdog above.  All timings are reported (`schedules_ms`).
         nb0 = args.nb or 512
-        combos = [(nb0, "pipelined", "bcast"), (nb0, "pipelined", "scatter_gather"), (nb0, "bcast", "bcast"),
-                  (nb0, "bcast", "scatter_gather")]
+        base_name = "bcast+bcast@%d" % nb0
+        if args.schedule:
+            base_name = "%s@%d" % (args.schedule, nb0)
+        plan = get_plan(nb0)
+        plan.schedule, plan.exchange = base_name.split("@")[0].split("+")
+
+        def describe():
+            return "1-D block-cyclic block columns (nb=%d) over %d ranks, %s panels over RCCL (%s)" % (
+                plan.nb, world, "row-chunked" if plan.schedule == "pipelined" else "whole", plan.exchange)
+        for _ in range(args.warmup):
+            ll, ld = step()
+        per, (ll, ld) = timed(args.steps)
+        elapsed = per * args.steps
+        parallelism = describe()
+        tune, failed = {base_name: per * 1e3}, {}
+        extra["schedules_ms"] = tune
+        extra["schedule"] = base_name
+        wd.line = build_out()
+        wd.phase = "tuning pass over the other schedules"
+        wd.arm(float(os.environ.get("GPT_BENCH_WATCHDOG_S", 0)) or 120.0 + 30.0 * per * (args.steps + args.warmup + 20))
+        if os.environ.get("GPT_BENCH_FAKE_HANG"):        # (test hook for the watchdog: scratch/README.md)
+            time.sleep(3600)
+        combos = [(nb0, "pipelined", "bcast"), (nb0, "pipelined", "scatter_gather"), (nb0, "bcast", "scatter_gather")]
         if not args.nb:
             combos += [(256, "bcast", "bcast"), (256, "pipelined", "bcast")]
         if args.schedule:
-            combos = [(nb0,) + tuple(args.schedule.split("+"))]
+            combos = []
         if world == 1:
             combos = [c_ for c_ in combos if c_[2] == "bcast"]
-        tune, failed = {}, {}
+        base_plan = plan
         for nb_, sched_, exch_ in combos:
             name = "%s+%s@%d" % (sched_, exch_, nb_)
+            wd.phase = "tuning pass, " + name
             try:
                 plan = get_plan(nb_)
                 plan.schedule, plan.exchange = sched_, exch_
@@ -324,24 +406,32 @@ def main():
                 failed[name] = repr(e)[:200]
         if failed:
             extra["schedules_failed"] = failed
-        if not tune:
-            raise SystemExit("no schedule of gptools_amd.dist ran: %r" % failed)
         best = min(tune, key=tune.get)
-        se_, nb_ = best.split("@")
-        plan = plans[int(nb_)]
-        plan.schedule, plan.exchange = se_.split("+")
-        for k_ in [k_ for k_ in plans if k_ != int(nb_)]:
+        plan = base_plan
+        plan.schedule, plan.exchange = base_name.split("@")[0].split("+")
+        if best != base_name and tune[best] < 0.97 * tune[base_name]:
+            wd.phase = "timed steps of " + best
+            se_, nb_ = best.split("@")
+            plan = plans[int(nb_)]
+            plan.schedule, plan.exchange = se_.split("+")
+            for _ in range(args.warmup):
+                ll2, ld2 = step()
+            per2, (ll2, ld2) = timed(args.steps)
+            tune[best + " (K timed steps)"] = per2 * 1e3
+            if per2 < per:
+                per, ll, ld = per2, ll2, ld2
+                elapsed = per * args.steps
+                parallelism = describe()
+                extra["schedule"] = best
+                wd.line = build_out()
+            else:
+                plan = base_plan
+                plan.schedule, plan.exchange = base_name.split("@")[0].split("+")
+        for k_ in [k_ for k_ in plans if plans[k_] is not plan]:
             del plans[k_]                       # (frees the other block width's matrix and panel buffers)
         torch.cuda.empty_cache()
-        extra["schedules_ms"] = tune
-        extra["schedule"] = best
-        for _ in range(args.warmup):
-            ll, ld = step()
-        per, (ll, ld) = timed(args.steps)
-        elapsed = per * args.steps
+        wd.phase = "diagnostics after the timed region"
         extra["host_enqueue_ms"] = plan.timings.get("host_enqueue_s", 0.0) * 1e3
-        parallelism = "1-D block-cyclic block columns (nb=%d) over %d ranks, %s panels over RCCL (%s)" % (
-            plan.nb, world, "row-chunked" if plan.schedule == "pipelined" else "whole", plan.exchange)
         if (world > 1 or os.environ.get("GPT_BENCH_C5_TOO")) and wl == "c4" and not args.no_probe:
             # SURVEY 8e also asks for the partitioned factorisation at C5's size (N = 16384): same schedule, reported
             # beside the headline (a few evaluations after the timed region; never in `value`)
@@ -434,28 +524,14 @@ def main():
                     tref.append(ctx.last_timings()["total"])
                 extra["single_gpu_same_workload"] = {
                     "ms_per_step": min(tref), "value": flops_fit(N) / min(tref) * 1e-6, "unit": "GFLOP/s",
-                    "ll_rel_diff_vs_partitioned": abs(ll1 - ll) / abs(ll1)}
+                    "ll_rel_diff_vs_partitioned": abs(ll1 - ll) / abs(ll1),
+                    "note": "context created after the partitioned run has used the GPU (shared hardware queues): a few % "
+                            "slower than the same workload in a fresh process (DESIGN section 6: 206-213 ms for C4)"}
                 del ctx
             barrier()
 
     if rank == 0:
-        per_step = elapsed / args.steps
-        value = flops_fit(N) / per_step * 1e-9
-        out = {
-            "metric": METRIC, "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": per_step * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %s kernel, N=%d, d=%d%s, err_y=0.05, sigma_f=1, l=0.3 (BASELINE.json configs)"
-                                   % (wl.upper(), {"se": "SquaredExponential", "m52": "Matern52"}[kernel], N, d,
-                                      ", last quarter of rows first-derivative observations" if deriv else ""),
-                       "N": N, "d": d, "parallelism": parallelism},
-            "lml_evals_per_s": 1.0 / per_step,
-            "pct_fp64_mfma_peak": 100.0 * value * 1e-3 / (FP64_MFMA_PEAK_TFLOPS * world),
-            "ll_data": ll, "logdet_half": ld,
-        }
-        out.update(extra)
-        if roof is not None:
-            out["roofline"] = roof
+        out = build_out()
         if world == 1 and not args.no_cpu and not args.dist:
             ref, cb = cpu_baseline(kernel, X, n, y, err, params)
             out["cpu_baseline"] = cb
@@ -472,7 +548,9 @@ def main():
                              "predict_mean_max_abs_err": float(np.abs(gm - cm).max()),
                              "predict_std_max_abs_err": float(np.abs(gs - cs).max()),
                              "predict_tolerance": 1e-6}
-        print(json.dumps(out))
+    if wd.finish():
+        if rank == 0:
+            print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
