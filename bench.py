@@ -385,20 +385,31 @@ def main():
         wd.arm(float(os.environ.get("GPT_BENCH_WATCHDOG_S", 0)) or 120.0 + 30.0 * per * (args.steps + args.warmup + 20))
         if os.environ.get("GPT_BENCH_FAKE_HANG"):        # (test hook for the watchdog: scratch/README.md)
             time.sleep(3600)
-        combos = [(nb0, "pipelined", "bcast"), (nb0, "pipelined", "scatter_gather"), (nb0, "bcast", "scatter_gather")]
+        # name -> (nb, schedule, exchange, chunk_blocks)
+        default_chunks = (2, 8, 32)
+        combos = {"pipelined+bcast@%d" % nb0: (nb0, "pipelined", "bcast", default_chunks),
+                  "pipelined+scatter_gather@%d" % nb0: (nb0, "pipelined", "scatter_gather", default_chunks),
+                  "bcast+scatter_gather@%d" % nb0: (nb0, "bcast", "scatter_gather", default_chunks),
+                  "pipelined+bcast@%d chunks 2,16" % nb0: (nb0, "pipelined", "bcast", (2, 16))}
         if not args.nb:
-            combos += [(256, "bcast", "bcast"), (256, "pipelined", "bcast")]
+            combos.update({"bcast+bcast@384": (384, "bcast", "bcast", default_chunks),
+                           "bcast+bcast@256": (256, "bcast", "bcast", default_chunks),
+                           "pipelined+bcast@256": (256, "pipelined", "bcast", default_chunks)})
         if args.schedule:
-            combos = []
+            combos = {}
         if world == 1:
-            combos = [c_ for c_ in combos if c_[2] == "bcast"]
-        base_plan = plan
-        for nb_, sched_, exch_ in combos:
-            name = "%s+%s@%d" % (sched_, exch_, nb_)
+            combos = {k_: v_ for k_, v_ in combos.items() if v_[2] == "bcast"}
+        combos[base_name] = (nb0,) + tuple(base_name.split("@")[0].split("+")) + (default_chunks,)
+
+        def select(name):
+            nb_, sched_, exch_, chunks_ = combos[name]
+            pl = get_plan(nb_)
+            pl.schedule, pl.exchange, pl.chunk_blocks = sched_, exch_, chunks_
+            return pl
+        for name in [k_ for k_ in combos if k_ != base_name]:
             wd.phase = "tuning pass, " + name
             try:
-                plan = get_plan(nb_)
-                plan.schedule, plan.exchange = sched_, exch_
+                plan = select(name)
                 step()
                 tune[name] = timed(2)[0] * 1e3
             except (RuntimeError, ValueError, NotImplementedError) as e:
@@ -407,13 +418,10 @@ def main():
         if failed:
             extra["schedules_failed"] = failed
         best = min(tune, key=tune.get)
-        plan = base_plan
-        plan.schedule, plan.exchange = base_name.split("@")[0].split("+")
+        plan = select(base_name)
         if best != base_name and tune[best] < 0.97 * tune[base_name]:
             wd.phase = "timed steps of " + best
-            se_, nb_ = best.split("@")
-            plan = plans[int(nb_)]
-            plan.schedule, plan.exchange = se_.split("+")
+            plan = select(best)
             for _ in range(args.warmup):
                 ll2, ld2 = step()
             per2, (ll2, ld2) = timed(args.steps)
@@ -425,8 +433,7 @@ def main():
                 extra["schedule"] = best
                 wd.line = build_out()
             else:
-                plan = base_plan
-                plan.schedule, plan.exchange = base_name.split("@")[0].split("+")
+                plan = select(base_name)
         for k_ in [k_ for k_ in plans if plans[k_] is not plan]:
             del plans[k_]                       # (frees the other block width's matrix and panel buffers)
         torch.cuda.empty_cache()
