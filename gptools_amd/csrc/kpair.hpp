@@ -143,8 +143,35 @@ __device__ __forceinline__ double rq_pair(const KParams &kp, const double *xi, c
     const double alpha = kp.alpha;
     const double y = 1.0 + r2 / (2.0 * alpha);
     const double s2 = kp.sigma * kp.sigma;
-    const double p0 = pow(y, -alpha);
+    // y^-alpha as exp(-alpha log y): y >= 1, so |alpha log y| stays small and the few-ulp error of the product is far
+    // inside the parity tolerance (1e-11 relative against the reference); the correctly rounded pow() costs 3x the
+    // whole pair otherwise
+    const double p0 = exp(-alpha * log(y));
     if (ntot == 0) return s2 * p0;
+    if (ntot <= 2) {
+        // the common cases in closed form (first-derivative observations on one or both sides, one second derivative):
+        //   d/dtau_a f(y) = f'(y) y1_a,   d2/dtau_a dtau_b f(y) = f''(y) y1_a y1_b + [a == b] f'(y) y2_a
+        int da = -1, db = -1;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const int n = ni[d] + nj[d];
+            if (n >= 1) { if (da < 0) da = d; else db = d; }
+            if (n == 2) db = d;
+        }
+        const double iy = 1.0 / y;
+        const double f1 = -alpha * p0 * iy;                       // f'(y)
+        const double y2a = kp.inv_var[da] / alpha;
+        const double y1a = (xi[da] - xj[da]) * y2a;
+        double v;
+        if (ntot == 1) {
+            v = f1 * y1a;
+        } else {
+            const double y1b = (xi[db] - xj[db]) * (kp.inv_var[db] / alpha);
+            const double f2 = -(alpha + 1.0) * f1 * iy;           // f''(y)
+            v = f2 * y1a * y1b + ((da == db) ? f1 * y2a : 0.0);
+        }
+        return s2 * ((njtot & 1) ? -v : v);
+    }
     // c[m]: coefficient of f^(m)(y) so far (host code rejects ntot > GPT_RQ_MAXORD)
     double c[GPT_RQ_MAXORD + 1];
 #pragma unroll
