@@ -251,7 +251,10 @@ static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, 
     // algorithmic flop count: 2k per computed element of C (lower trapezoid when tri)
     const double elems = tri ? 0.5 * (double)n * (double)(n + 1) + (double)(m - n) * (double)n : (double)m * (double)n;
     const double flops = 2.0 * (double)k * elems;
-    const bool prof = c->prof_gemm && flops >= 1.0e9;
+    // (the roofline line of bench.py: the trailing updates on the MAIN stream only -- at large N the panel and helper
+    // streams also launch >= 1 GFLOP updates, on the few CUs reserved for them and concurrently with these; summing their
+    // durations with the main stream's would count the same wall time twice)
+    const bool prof = c->prof_gemm && flops >= 1.0e9 && st == c->stream;
     gpt_ctx::GemmProf *gp = nullptr;
     if (prof) {
         if (c->gprof_used == c->gprof.size()) {
