@@ -326,12 +326,17 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
             for (int r = 0; r < 4; r++) bt[j][r] = B[(row0 + fk + 4 * r) * ldb + j * 16 + fr];
     }
     const double *lpk = invd + GPT_WS_LOFF;
+    // acc: right-hand side of step j with the earlier steps already folded in, bt[j] - sum_{c<j} x_c L_jc^T.  The blocks
+    // (j, c < j) were published in rounds c < j, i.e. they are covered by the flag value step j-1 has waited for: the
+    // folding for step j+1 is done right after step j, while workgroup 0 is still busy with pivot block j+1, and what
+    // remains behind flag j+1 is one load of inv(L_jj), four MFMAs, the re-layout and the store.
+    f64x4 acc = bt[0];
 #pragma unroll
     for (int j = 0; j < NB16; j++) {
         if (tid == 0) {
             // (signed difference: a value left by an earlier launch lies below flag_base)
             while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - flag_base) < j + 1)
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
         }
         __syncthreads();
         if (!active) continue;
@@ -339,17 +344,6 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
 #pragma unroll
         for (int kk = 0; kk < 4; kk++)
             dv[kk] = __hip_atomic_load(invd + j * 256 + kk * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        f64x4 acc = bt[j];
-#pragma unroll
-        for (int c = 0; c < j; c++) {
-            double lv[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++)
-                lv[kk] = __hip_atomic_load(lpk + (j * (j - 1) / 2 + c) * 256 + kk * 64 + lane, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[c][kk], lv[kk], acc, 0, 0, 0);
-        }
         // accumulator (C layout) -> A operand through the per-wave scratch
 #pragma unroll
         for (int r = 0; r < 4; r++) X[fk + 4 * r][fr] = acc[r];
@@ -367,6 +361,17 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
         if (j + 1 < NB16) {
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) xa[j][kk] = -X[fr][fk + 4 * kk];
+            acc = bt[j + 1];
+#pragma unroll
+            for (int c = 0; c <= j; c++) {
+                double lv[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++)
+                    lv[kk] = __hip_atomic_load(lpk + ((j + 1) * j / 2 + c) * 256 + kk * 64 + lane, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[c][kk], lv[kk], acc, 0, 0, 0);
+            }
         }
     }
 }
