@@ -198,3 +198,29 @@ def test_gp_pickles_without_device_state(g):
     assert gp2._ctx_obj is None and gp2.K_up_to_date is False
     np.testing.assert_array_equal(gp2.X, gp.X)
     assert gp2.k.params.tolist() == gp.k.params.tolist()
+
+
+def test_bench_watchdog_prints_the_complete_line_and_exits():
+    """bench.py's partitioned path measures the whole-panel schedule first and runs everything newer under a timer: if a
+    later leg hangs, rank 0 prints the line that is already complete (flagged) and every rank's process ends with
+    status 0 (bench.Watchdog)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "wd = bench.Watchdog(int(sys.argv[1])); wd.line = {'metric': 'm', 'value': 1.0}; wd.phase = 'tuning pass, x'\n"
+            "wd.arm(0.3); time.sleep(30); print('not reached')\n" % root)
+    for rank, expect_line in ((0, True), (1, False)):
+        out = subprocess.run([sys.executable, "-c", code, str(rank)], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0 and "not reached" not in out.stdout
+        if expect_line:
+            line = json.loads(out.stdout.strip())
+            assert line["value"] == 1.0 and "tuning pass, x" in line["watchdog"]
+        else:
+            assert out.stdout.strip() == ""
+    code_ok = ("import sys; sys.path.insert(0, %r); import bench\n"
+               "wd = bench.Watchdog(0); wd.line = {}; wd.arm(30.0); print(wd.finish(), wd.finish())\n" % root)
+    out = subprocess.run([sys.executable, "-c", code_ok], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and out.stdout.split() == ["True", "False"]
+
