@@ -102,6 +102,17 @@ def test_distributed_plan_two_ranks_sharing_the_gpu(oracle):
             assert abs(float(v[1]) - ref["logdet_half"]) <= 1e-10 * abs(ref["logdet_half"])
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_schedules_under_queue_jitter(world):
+    """Missing-edge detector (tests/dist_jitter_worker.py): the schedules of gptools_amd.dist with random delay kernels
+    on every queue must return the same numbers every time, on 2 and on 3 ranks sharing the GPU."""
+    worker = os.path.join(ROOT, "tests", "dist_jitter_worker.py")
+    out = subprocess.run([sys.executable, worker, str(world)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    assert out.stdout.count(": 0 bad of ") == world, out.stdout[-1500:]
+
+
 def test_gaussian_process_partitioned_update_and_map_two_ranks(oracle):
     """``GaussianProcess.partitioned``: update_hyperparameters / optimize_hyperparameters with the factorisation spread
     over the ranks of the job (two gloo ranks sharing cuda:0) give what one process gives, on every rank; the factor is
