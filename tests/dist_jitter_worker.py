@@ -23,7 +23,12 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 world, rank = int(sys.argv[1]), int(sys.argv[2])
 os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29540 + world))
 torch.cuda.set_device(0)
-dist.init_process_group('gloo', rank=rank, world_size=world)
+if world == 1:
+    # one rank, RCCL, collectives forced on: the NCCL streams' ordering against the jittered queues, both exchanges
+    os.environ["GPT_DIST_FORCE_COLLECTIVES"] = "1"
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+else:
+    dist.init_process_group('gloo', rank=rank, world_size=world)
 from gptools_amd.dist import DistributedLML, HipPanelOps
 from test_gpu_parity import c3_inputs
 rng = random.Random(100 + rank)
@@ -76,10 +81,11 @@ class JitterOps(HipPanelOps):
 X, n, y = c3_inputs(2500, 3)
 p = np.array([1.0, 0.3, 0.3, 0.3])
 ref = DistributedLML(X, n, nb=128, device=0, schedule="bcast").fit(1, p, y, 0.05 * np.ones(2500))
-plan = DistributedLML(X, n, nb=128, ops=JitterOps(0), owner_first=(rank % 2 == 0) if world == 2 else None)
+plan = DistributedLML(X, n, nb=128, ops=JitterOps(0), owner_first=(rank % 2 == 0) if world == 2 else None, sag_min_bytes=0)
 bad = 0
 for sched, cb in (('bcast', (2, 8, 32)), ('pipelined', (2, 8, 32)), ('pipelined', (2, 4, 6, 10))):
     plan.schedule, plan.chunk_blocks = sched, cb
+    plan.exchange = "scatter_gather" if (world == 1 and cb == (2, 8, 32)) else "bcast"
     for rep in range(int(os.environ.get("JITTER_REPS", "6"))):
         try:
             r = plan.fit(1, p, y, 0.05 * np.ones(2500))

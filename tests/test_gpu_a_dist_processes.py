@@ -102,10 +102,11 @@ def test_distributed_plan_two_ranks_sharing_the_gpu(oracle):
             assert abs(float(v[1]) - ref["logdet_half"]) <= 1e-10 * abs(ref["logdet_half"])
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [1, 2, 3])
 def test_distributed_schedules_under_queue_jitter(world):
     """Missing-edge detector (tests/dist_jitter_worker.py): the schedules of gptools_amd.dist with random delay kernels
-    on every queue must return the same numbers every time, on 2 and on 3 ranks sharing the GPU."""
+    on every queue must return the same numbers every time -- on 2 and on 3 gloo ranks sharing the GPU, and on one rank
+    with the RCCL collectives (both exchanges) forced on."""
     worker = os.path.join(ROOT, "tests", "dist_jitter_worker.py")
     out = subprocess.run([sys.executable, worker, str(world)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                          timeout=900)
