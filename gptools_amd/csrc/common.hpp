@@ -76,6 +76,10 @@ int grad_reduce_blocks(int64_t N);
 int launch_grad_reduce(hipStream_t st, const KParams &kp, int nh, const int *hl, const double *dX, const int32_t *dn,
                        int64_t N, const double *dalpha, const double *dW, int64_t ldw, double *dpartial);
 int launch_add_diag(hipStream_t st, double *A, int64_t lda, int64_t n, const double *err, double diag_add);
+// Test aid (GPT_JITTER=<max microseconds> in the environment): a delay kernel of random length on `st`, called in front of
+// every dense launch.  The schedules express every dependency as an event, so results must not move with the relative
+// timing of the streams; a missing edge shows up as a wrong number (tests/test_gpu_parity.py).  Off: one branch.
+void gpt_jitter(hipStream_t st);
 int launch_fill_pad(hipStream_t st, double *A, int64_t lda, int64_t n_valid, int64_t n_pad, const double *dy,
                     double big);
 int launch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_t n, const int32_t *d_info, double *d_out3);

@@ -496,6 +496,7 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
                    const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile, int lds_pad,
                    hipEvent_t ev0, hipEvent_t ev1)
 {
+    gpt_jitter(st);
     if (m <= 0 || n <= 0) return GPT_OK;
     if (alpha == 0.0) {
         gpt_set_error("gemm_nt: alpha must be non-zero");
@@ -533,6 +534,7 @@ int launch_gemm_nt_stair(hipStream_t st, int64_t m, int64_t nseg, int64_t seg_co
                          const double *A, int64_t lda, const double *B, int64_t ldb, int64_t b_stride, int64_t row_step,
                          double beta, double *C, int64_t ldc, int lds_pad)
 {
+    gpt_jitter(st);
     if (m <= 0 || nseg <= 0) return GPT_OK;
     if (alpha == 0.0 || k <= 0 || (k % GM_BK) != 0 || (lda & 1) || (ldb & 1) || ((uintptr_t)A & 15) ||
         ((uintptr_t)B & 15) || seg_cols <= 0 || (seg_cols % 64) || (row_step % 64) || b_stride < seg_cols) {

@@ -172,6 +172,7 @@ int launch_kbuild(hipStream_t st, const KParams &kp, const double *dXi, const in
                   const double *dXj, const int32_t *dnj, int64_t P, int lower_only, int64_t i0, int64_t j0,
                   const double *d_err_y, double noise_var, double diag_add, double *dK, int64_t ldk, int accumulate)
 {
+    gpt_jitter(st);
     if (M <= 0 || P <= 0) return GPT_OK;
     switch (kp.kernel_id) {
     case GPT_KERNEL_SE:

@@ -381,6 +381,7 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
 int launch_potf2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
                       unsigned *flag, unsigned flag_base, hipEvent_t done)
 {
+    gpt_jitter(st);
     static bool attr_set = false;
     const size_t shmem = (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
     if (!attr_set) {
@@ -399,6 +400,7 @@ int launch_potf2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int3
 
 int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base)
 {
+    gpt_jitter(st);
     static bool attr_set = false;
     const size_t shmem = (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
     if (!attr_set) {
@@ -493,6 +495,7 @@ __global__ __launch_bounds__(64 * TP_WAVES, 2) void trsm_panel_kernel(int64_t m,
 int launch_trsm_panel(hipStream_t st, int64_t m, const double *L, int64_t ldl, const double *invd, double *B,
                       int64_t ldb, hipEvent_t done)
 {
+    gpt_jitter(st);
     if (m <= 0) {
         if (done) GPT_HIP_CHECK(hipEventRecord(done, st));
         return GPT_OK;

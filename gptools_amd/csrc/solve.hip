@@ -25,6 +25,27 @@ __global__ void fill_pad_kernel(double *__restrict__ A, int64_t lda, int64_t n_v
     A[row * lda + col] = v;
 }
 
+__global__ void jitter_kernel(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+void gpt_jitter(hipStream_t st)
+{
+    static int max_us = -1;
+    static unsigned long long state = 0x9E3779B97F4A7C15ull;
+    if (max_us < 0) {
+        const char *e = getenv("GPT_JITTER");
+        max_us = e ? atoi(e) : 0;
+    }
+    if (max_us <= 0) return;
+    state = state * 6364136223846793005ull + 1442695040888963407ull;
+    const double u = (double)(state >> 40) / (double)(1ull << 24);
+    const long long ticks = (long long)(u * u * u * max_us * 100.0);       // wall_clock64 ticks at 100 MHz; mostly short
+    hipLaunchKernelGGL(jitter_kernel, dim3(1), dim3(1), 0, st, ticks);
+}
+
 int launch_fill_pad(hipStream_t st, double *A, int64_t lda, int64_t n_valid, int64_t n_pad, const double *dy,
                     double big)
 {

@@ -10,6 +10,7 @@ import sys
 import warnings
 
 import gc
+import os
 
 import numpy as np
 import pytest
@@ -17,6 +18,7 @@ import pytest
 from conftest import assert_close
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = ("se", "m52")
 KID = {"se": 0, "m52": 1}
 EPS = sys.float_info.epsilon
@@ -577,6 +579,38 @@ def test_dense_kernels_against_numpy(ctx):
     with pytest.raises(np.linalg.LinAlgError) as ei:
         ctx.potrf_host(np.array([[4.0, 2.0, 0], [2.0, 1.0, 0], [0, 0, 1.0]]))
     assert "2-th leading minor" in str(ei.value)
+
+
+def test_single_gpu_schedule_under_stream_jitter(ctx):
+    """Missing-edge detector for the look-ahead schedule of gpt_fit (main / panel / helper streams): with GPT_JITTER set
+    the library puts a delay kernel of random length in front of every dense launch.  Every dependency is an event, so
+    the factorisation must come out bit-identical to the undisturbed run -- at a size that uses the fused diagonal-block
+    kernel, and at one where the helper stream takes a slice of the updates."""
+    import subprocess
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from gptools_amd import _lib\n"
+        "from test_gpu_parity import c3_inputs\n"
+        "c = _lib.Context(0)\n"
+        "for N, d, reps in ((3000, 3, 6), (12800, 2, 2)):\n"
+        "    X, n, y = c3_inputs(N, d)\n"
+        "    c.set_data(X, n)\n"
+        "    for rep in range(reps):\n"
+        "        ll, ld = c.fit(1, np.concatenate(([1.0], 0.3 * np.ones(d))), 0.0, y, 0.05 * np.ones(N), 1e2 * sys.float_info.epsilon)\n"
+        "        print('RESULT', N, repr(ll), repr(ld))\n") % (ROOT, os.path.join(ROOT, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GPT_JITTER="120"), stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = [l.split()[1:] for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    assert len(got) == 8
+    for N, d in ((3000, 3), (12800, 2)):
+        X, n, y = c3_inputs(N, d)
+        ctx.set_data(X, n)
+        ll, ld = ctx.fit(1, np.concatenate(([1.0], 0.3 * np.ones(d))), 0.0, y, 0.05 * np.ones(N), 1e2 * EPS)
+        for g_ in got:
+            if int(g_[0]) == N:
+                assert float(g_[1]) == ll and float(g_[2]) == ld, (N, g_, ll, ld)
 
 
 def test_panel_inverse_and_gemm_solve_against_numpy():
