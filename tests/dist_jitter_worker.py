@@ -29,6 +29,7 @@ if world == 1:
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
 else:
     dist.init_process_group('gloo', rank=rank, world_size=world)
+os.environ["GPT_JITTER"] = "60"          # ... and inside the library: in front of every launch of the panel routines
 from gptools_amd.dist import DistributedLML, HipPanelOps
 from test_gpu_parity import c3_inputs
 rng = random.Random(100 + rank)
