@@ -305,6 +305,17 @@ static int panel_rec(gpt_ctx *c, hipStream_t st, double *Ap, int64_t lda, int64_
                      int32_t *info, int64_t base)
 {
     if (w == 128) {
+        const int64_t mb = m - 128;
+        if (c->fuse_trsm > 0 && mb >= 128 && mb <= c->fuse_trsm && !c->use_graph) {
+            // short panel (the head chunk of the row-chunked multi-GPU schedule, the last panels of a factorisation):
+            // diagonal block and TRSM in one launch (potf2_trsm_kernel), as in panel_ext
+            if (c->flag_epoch > 0x3fffff00u) {
+                GPT_HIP_CHECK(hipMemsetAsync(c->d_flag, 0, 64, st));
+                c->flag_epoch = 0;
+            }
+            c->flag_epoch += 16;
+            return launch_potf2_trsm(st, Ap, lda, invd, info, base, mb, c->d_flag, c->flag_epoch);
+        }
         GPT_TRY(launch_potf2_diag(st, Ap, lda, invd, info, base));
         return launch_trsm_panel(st, m - 128, Ap, lda, invd, Ap + 128 * lda, lda);
     }
