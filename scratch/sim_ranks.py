@@ -18,6 +18,8 @@ kernel, N, d, deriv = bench.WORKLOADS[wl]
 X, n, y, err, params = bench.synth(kernel, N, d, deriv)
 kid = bench.KID[kernel]
 ops = HipPanelOps(0)
+if os.environ.get("SIM_FUSE") is not None:
+    ops.ctx_panel.set_option("fuse_trsm", int(os.environ["SIM_FUSE"]))
 
 
 class Recorder(DistributedLML):
