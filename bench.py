@@ -65,25 +65,55 @@ def flops_fit(N):
     return N ** 3 / 3.0 + N ** 2 / 2.0 + N / 6.0 + 2.0 * N ** 2
 
 
-def cpu_baseline(kernel, X, n, y, err, params, budget_s=20.0):
+def cpu_baseline(kernel, X, n, y, err, params, budget_s=20.0, max_reps=5):
     """Oracle K-build (all host cores, OpenMP) + LAPACK Cholesky / solve through scipy, like the reference's
-    scipy.linalg.cholesky + cho_solve (gaussian_process.py:1452,1462)."""
+    scipy.linalg.cholesky + cho_solve (gaussian_process.py:1452,1462).  K-build and factorisation are timed
+    separately."""
     from oracle import oracle as O
     cores = len(os.sched_getaffinity(0))
     N = X.shape[0]
-    t_all, reps, res = 0.0, 0, None
-    while reps < 1 or (t_all + t_all / reps < budget_s and reps < 5):
+    t_all, reps, res, tm = 0.0, 0, None, {}
+    while reps < 1 or (t_all + t_all / reps < budget_s and reps < max_reps):
         t0 = time.perf_counter()
-        res = O.fit(kernel, params, X, n, y, err, chol="scipy")
+        res = O.fit(kernel, params, X, n, y, err, chol="scipy", timings=tm)
         t_all += time.perf_counter() - t0
         reps += 1
     t = t_all / reps
+    tk, tp = tm["kbuild_s"] / reps, tm["potrf_s"] / reps
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max([i.get("num_threads", 0) for i in threadpool_info() if i.get("user_api") == "blas"] or [0])
+    except Exception:
+        blas_threads = 0
     return res, {
         "value": flops_fit(N) / t * 1e-9, "unit": "GFLOP/s", "cores": cores, "kind": "port",
-        "sample": "%d full LML evaluation(s) of the same workload (N=%d): oracle fused K-build (C, OpenMP) + "
-                  "scipy.linalg.cholesky + cho_solve; %.2f s per evaluation" % (reps, N, t),
+        "sample": "%d full LML evaluation(s) of the same workload (N=%d): oracle fused K-build (C, OpenMP, all cores) + "
+                  "scipy.linalg.cholesky + cho_solve (OpenBLAS, %d threads); %.2f s per evaluation"
+                  % (reps, N, blas_threads, t),
         "lml_evals_per_s": 1.0 / t,
+        "t_kbuild_cpu_s": tk, "t_potrf_cpu_s": tp, "t_solve_ll_cpu_s": tm["solve_ll_s"] / reps,
+        "kbuild_GBps_written_cpu": 8.0 * N * N / tk * 1e-9,
+        "potrf_GFLOPs_cpu": (N ** 3 / 3.0 + N ** 2 / 2.0 + N / 6.0) / tp * 1e-9,
     }
+
+
+def parity_report(ll, ld, ref, pred_gpu=None, pred_cpu=None):
+    """The parity gate of SURVEY.md section 8(d): ll (data term) and sum(log L_ii) within 1e-8 relative of the CPU path,
+    predictive mean / std at 64 random points within 1e-6 (sigma_f = 1).  Returns (report, ok)."""
+    rep = {"ll_rel_err_vs_cpu": abs(ll - ref["ll_data"]) / abs(ref["ll_data"]),
+           "logdet_rel_err_vs_cpu": abs(ld - ref["logdet_half"]) / abs(ref["logdet_half"]),
+           "tolerance": 1e-8}
+    ok = rep["ll_rel_err_vs_cpu"] <= 1e-8 and rep["logdet_rel_err_vs_cpu"] <= 1e-8
+    if pred_gpu is not None:
+        (gm, gs), (cm, cs) = pred_gpu, pred_cpu
+        rep.update({"predict_mean_max_abs_err": float(np.abs(gm - cm).max()),
+                    "predict_std_max_abs_err": float(np.abs(gs - cs).max()),
+                    "predict_var_max_abs_err": float(np.abs(gs ** 2 - cs ** 2).max()),
+                    "predict_tolerance": 1e-6})
+        # (std is gated through the variance: where the data pin the curve the variance is a cancellation residue)
+        ok = ok and rep["predict_mean_max_abs_err"] <= 1e-6 and rep["predict_var_max_abs_err"] <= 1e-6
+    rep["ok"] = bool(ok)
+    return rep, ok
 
 
 def dist_trace(plan, step):
@@ -177,7 +207,8 @@ class Watchdog(object):
             if self.rank == 0 and self.line is not None:
                 self.line["watchdog"] = "timed out during: %s; this is the line that was complete by then" % self.phase
                 print(json.dumps(self.line), flush=True)
-            os._exit(0)
+            # non-zero: a hung leg must be visible to the launcher (torchrun / CI); the complete line is on stdout
+            os._exit(3)
 
     def finish(self):
         """True if the caller may print the final line (the timer has not fired and no longer will)."""
@@ -200,6 +231,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--dist", action="store_true", help="use the block-cyclic DistributedLML path even with one rank")
     ap.add_argument("--no-batched", action="store_true", help="N=1: skip the two-evaluations-in-flight throughput leg")
+    ap.add_argument("--no-predict", action="store_true", help="N=1: skip the predict leg")
     ap.add_argument("--no-ref", action="store_true", help="N>1: skip the single-GPU run of the same workload on rank 0")
     ap.add_argument("--schedule", default=None, help="N>1: fix the schedule+exchange (e.g. pipelined+bcast) instead of tuning")
     ap.add_argument("--no-probe", action="store_true", help="N>1: skip the step trace and the link probes after the timed region")
@@ -220,7 +252,11 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("GPT_BENCH_BACKEND", "nccl")       # (test hook: gloo ranks sharing one GPU)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from gptools_amd import _lib
     wl = args.workload or ("c3" if world == 1 else "c4")
@@ -288,13 +324,37 @@ def main():
         if gcount:
             ach = gflops_alg / (gms * 1e-3) * 1e-12
             traffic = None        # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-            tj = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")   # FETCH doubled per the gfx950 note), committed
-            if wl == "c3" and os.path.exists(tj):
-                traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+            import glob            # FETCH doubled per the gfx950 note), committed under profiles/ per round
+            tjs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_traffic.json")))
+            if wl == "c3" and tjs:
+                traffic = json.load(open(tjs[-1])).get("hbm_bytes_per_launch")
             roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<64,64> (trailing SYRK/GEMM updates >= 1 GFLOP)",
                     "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                     "traffic": traffic, "traffic_unit": "bytes/launch", "launches_per_step": gcount / args.steps,
                     "avg_launch_us": gms * 1e3 / gcount, "flops_per_launch": gflops_alg / gcount}
+        # predict leg (SURVEY 8d "Predict (if timed): N^2 M + N M^2"; ref gaussian_process.py:965-1006) on the factor of
+        # the last timed step: K* build, mean = K*^T alpha, v = L^-1 K*, then the row norms (std) or the SYRK (cov).
+        # Host buffers in and out (Xstar up, mean / std / cov down) are inside the wall time.
+        if not args.no_predict:
+            rsp = np.random.RandomState(4096)
+            pl = {}
+            for M_, want_, tag in ((64, 1, "M64_std"), (4096, 1, "M4096_std"), (4096, 2, "M4096_cov")):
+                Xs_ = rsp.rand(M_, d)
+                ns_ = np.zeros((M_, d), dtype=np.int32)
+                ctx.predict(Xs_, ns_, want_)
+                reps_ = 5
+                barrier()
+                tp0 = time.perf_counter()
+                for _ in range(reps_):
+                    ctx.predict(Xs_, ns_, want_)
+                barrier()
+                tp_ = (time.perf_counter() - tp0) / reps_
+                fl_ = float(N) * N * M_ + (float(N) * M_ * M_ if want_ == 2 else 2.0 * N * M_)
+                pl[tag] = {"M": M_, "ms": tp_ * 1e3, "flops": fl_, "TFLOPs": fl_ / tp_ * 1e-12,
+                           "frac_fp64_mfma_peak": fl_ / tp_ * 1e-12 / FP64_MFMA_PEAK_TFLOPS}
+            pl["note"] = ("wall time of gpt_predict incl. host->device Xstar and device->host results (cov: M^2 doubles = "
+                          "134 MB over PCIe at M=4096); flops = N^2 M (triangular solve) + N M^2 (cov) or 2 N M (std)")
+            extra["predict"] = pl
         if not args.no_batched:
             # Throughput mode (reported beside `value`, never in it): two INDEPENDENT evaluations (different theta, same
             # data) in flight on the GPU, one context + host thread each -- how GaussianProcess.ll_batch /
@@ -344,7 +404,10 @@ def main():
         def step():
             return plan.fit(KID[kernel], params, y, err)
 
-        def timed(nsteps):
+        def timed(nsteps, profile=False):
+            if profile:
+                ops.ctx_main.set_option("profile_gemm", 1)
+                ops.ctx_main.gemm_profile_read()
             barrier()
             t_ = time.perf_counter()
             for _ in range(nsteps):
@@ -355,7 +418,21 @@ def main():
                 tt = torch.tensor([t_], dtype=torch.float64, device="cuda")
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 t_ = float(tt.item())
+            if profile:
+                # the dominant kernel of the partitioned path: this rank's trailing updates (staircase SYRK/GEMM launches of
+                # >= 1 GFLOP on the main queue), HIP events on that queue inside the timed steps -- rank 0's GPU, per-GPU peak
+                gfl, gms, gcnt = ops.ctx_main.gemm_profile_read()
+                ops.ctx_main.set_option("profile_gemm", 0)
+                if gcnt:
+                    ach_ = gfl / (gms * 1e-3) * 1e-12
+                    roof_box[0] = {"bound": "mfma", "kernel": "gemm_nt_kernel<64,64> (rank 0's staircase trailing updates "
+                                   ">= 1 GFLOP, one launch per panel and rank)", "achieved": ach_,
+                                   "peak": FP64_MFMA_PEAK_TFLOPS, "peak_note": "per GPU (the job's peak is %d x this)" % world,
+                                   "unit": "TFLOP/s", "frac": ach_ / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                                   "launches_per_step": gcnt / nsteps, "avg_launch_us": gms * 1e3 / gcnt,
+                                   "flops_per_launch": gfl / gcnt}
             return t_ / nsteps, r_
+        roof_box = [None]
 
         # (1) The whole-panel schedule at nb = 512 -- the one this code base has run longest: W warm-up steps, K timed
         # steps, a complete line.  (2) Only then the other block width / schedule / exchange combinations of
@@ -374,23 +451,35 @@ def main():
                 plan.nb, world, "row-chunked" if plan.schedule == "pipelined" else "whole", plan.exchange)
         for _ in range(args.warmup):
             ll, ld = step()
-        per, (ll, ld) = timed(args.steps)
+        per, (ll, ld) = timed(args.steps, profile=True)
+        roof = roof_box[0]
         elapsed = per * args.steps
         parallelism = describe()
         tune, failed = {base_name: per * 1e3}, {}
         extra["schedules_ms"] = tune
         extra["schedule"] = base_name
+        cpu_ref = None
+        if not args.no_cpu:
+            # The CPU path once on the SAME workload, now (before the legs that run under the watchdog), so that the
+            # line kept for the watchdog already carries cpu_baseline and parity: rank 0's host cores work, the other
+            # ranks wait at the barrier.
+            if rank == 0:
+                ref_, extra["cpu_baseline"] = cpu_baseline(kernel, X, n, y, err, params, max_reps=1)
+                cpu_ref = {"ll_data": ref_["ll_data"], "logdet_half": ref_["logdet_half"]}
+                del ref_
+                extra["parity"] = parity_report(ll, ld, cpu_ref)[0]
+            barrier()
         wd.line = build_out()
         wd.phase = "tuning pass over the other schedules"
         wd.arm(float(os.environ.get("GPT_BENCH_WATCHDOG_S", 0)) or 120.0 + 30.0 * per * (args.steps + args.warmup + 20))
         if os.environ.get("GPT_BENCH_FAKE_HANG"):        # (test hook for the watchdog: scratch/README.md)
             time.sleep(3600)
         # name -> (nb, schedule, exchange, chunk_blocks)
-        default_chunks = (2, 8, 32)
+        default_chunks = (2, 3, 8, 32)
         combos = {"pipelined+bcast@%d" % nb0: (nb0, "pipelined", "bcast", default_chunks),
                   "pipelined+scatter_gather@%d" % nb0: (nb0, "pipelined", "scatter_gather", default_chunks),
                   "bcast+scatter_gather@%d" % nb0: (nb0, "bcast", "scatter_gather", default_chunks),
-                  "pipelined+bcast@%d chunks 2,16" % nb0: (nb0, "pipelined", "bcast", (2, 16))}
+                  "pipelined+bcast@%d chunks 2,3,16" % nb0: (nb0, "pipelined", "bcast", (2, 3, 16))}
         if not args.nb:
             combos.update({"bcast+bcast@384": (384, "bcast", "bcast", default_chunks),
                            "bcast+bcast@256": (256, "bcast", "bcast", default_chunks),
@@ -424,8 +513,12 @@ def main():
             plan = select(best)
             for _ in range(args.warmup):
                 ll2, ld2 = step()
-            per2, (ll2, ld2) = timed(args.steps)
+            roof_keep = roof_box[0]
+            per2, (ll2, ld2) = timed(args.steps, profile=True)
             tune[best + " (K timed steps)"] = per2 * 1e3
+            if per2 >= per:
+                roof_box[0] = roof_keep
+            roof = roof_box[0]
             if per2 < per:
                 per, ll, ld = per2, ll2, ld2
                 elapsed = per * args.steps
@@ -537,29 +630,40 @@ def main():
                 del ctx
             barrier()
 
+    parity_ok = True
     if rank == 0:
         out = build_out()
-        if world == 1 and not args.no_cpu and not args.dist:
-            ref, cb = cpu_baseline(kernel, X, n, y, err, params)
-            out["cpu_baseline"] = cb
-            # parity gate of SURVEY.md section 8(d): ll, sum(log L_ii), predictive mean / std at 64 random points
+        out["flops_note"] = ("LAPACK potrf + potrs count (SURVEY 8d); of the 2 N^2 potrs flops the timed step executes the "
+                             "forward half (z = L^-1 y rides along as the augmented row), alpha = L^-T z is produced on "
+                             "demand (predict, gp.alpha): %.3f %% of the count" % (100.0 * N * N / flops_fit(N)))
+        if not args.no_cpu:
             from oracle import oracle as O
-            rs = np.random.RandomState(64)
-            Xs, ns = rs.rand(64, d), np.zeros((64, d), dtype=np.int32)
-            ctx.fit(KID[kernel], params, 0.0, y, err, diag_add)
-            gm, gs, _ = ctx.predict(Xs, ns, 1)
-            cm, cs, _ = O.predict(kernel, params, X, n, ref["L"], ref["alpha"], Xs, ns, want_cov=False)
-            out["parity"] = {"ll_rel_err_vs_cpu": abs(ll - ref["ll_data"]) / abs(ref["ll_data"]),
-                             "logdet_rel_err_vs_cpu": abs(ld - ref["logdet_half"]) / abs(ref["logdet_half"]),
-                             "tolerance": 1e-8,
-                             "predict_mean_max_abs_err": float(np.abs(gm - cm).max()),
-                             "predict_std_max_abs_err": float(np.abs(gs - cs).max()),
-                             "predict_tolerance": 1e-6}
+            if world == 1 and not args.dist:
+                ref, cb = cpu_baseline(kernel, X, n, y, err, params)
+                out["cpu_baseline"] = cb
+                # parity gate of SURVEY.md section 8(d): ll, sum(log L_ii), predictive mean / std at 64 random points
+                rs = np.random.RandomState(64)
+                Xs, ns = rs.rand(64, d), np.zeros((64, d), dtype=np.int32)
+                ctx.fit(KID[kernel], params, 0.0, y, err, diag_add)
+                gm, gs, _ = ctx.predict(Xs, ns, 1)
+                cm, cs, _ = O.predict(kernel, params, X, n, ref["L"], ref["alpha"], Xs, ns, want_cov=False)
+                out["parity"], parity_ok = parity_report(ll, ld, ref, (gm, gs), (cm, cs))
+            else:
+                # partitioned line: cpu_baseline was measured right after the first timed leg (same workload, rank 0's
+                # host cores); the gate is re-evaluated on the ll / log|K| of the schedule that became the line
+                out["parity"], parity_ok = parity_report(ll, ld, cpu_ref)
     if wd.finish():
         if rank == 0:
             print(json.dumps(out), flush=True)
     if world > 1:
+        flag = torch.tensor([0 if parity_ok else 1], dtype=torch.int32, device="cuda")
+        dist.broadcast(flag, src=0)                  # (also the barrier the other ranks wait at during rank 0's CPU leg)
+        parity_ok = int(flag.item()) == 0
         dist.destroy_process_group()
+    if not parity_ok:
+        # the gate gates: a line whose numbers differ from the CPU path's is printed (with parity.ok = false) and the
+        # run fails
+        sys.exit(4)
 
 
 if __name__ == "__main__":

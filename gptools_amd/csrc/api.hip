@@ -1565,8 +1565,34 @@ extern "C" int gpt_dev_gemm_nt_stair(gpt_ctx *c, int64_t m, int64_t nseg, int64_
                                      int64_t row_step, double beta, double *dC, int64_t ldc)
 {
     CTX_ENTER(c);
+    // profiled like the single-GPU updates (bench.py's roofline object of the partitioned line): algorithmic flops =
+    // 2k per element of the staircase (segment q: lower trapezoid of (m - q row_step) x seg_cols)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->prof_gemm && !c->use_graph) {
+        double elems = 0.0;
+        for (int64_t q = 0; q < nseg; q++) {
+            const double mq = (double)(m - q * row_step), w = (double)seg_cols;
+            if (mq > 0) elems += 0.5 * w * (w + 1.0) + (mq - w > 0 ? (mq - w) * w : 0.0);
+        }
+        const double flops = 2.0 * (double)k * elems;
+        if (flops >= 1.0e9) {
+            if (c->gprof_used == c->gprof.size()) {
+                gpt_ctx::GemmProf g;
+                GPT_HIP_CHECK(hipEventCreate(&g.e0));
+                GPT_HIP_CHECK(hipEventCreate(&g.e1));
+                g.flops = 0;
+                g.stop = g.e1;
+                c->gprof.push_back(g);
+            }
+            gpt_ctx::GemmProf *gp = &c->gprof[c->gprof_used++];
+            gp->flops = flops;
+            gp->stop = gp->e1;
+            e0 = gp->e0;
+            e1 = gp->e1;
+        }
+    }
     return launch_gemm_nt_stair(c->stream, m, nseg, seg_cols, k, alpha, dA, lda, dB, ldb, b_stride, row_step, beta, dC,
-                                ldc, 0);
+                                ldc, 0, e0, e1);
 }
 
 extern "C" int gpt_dev_potrf_panel(gpt_ctx *c, int64_t m, int64_t nb, double *dA, int64_t lda, double *d_invd,

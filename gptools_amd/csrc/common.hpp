@@ -66,7 +66,8 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
 int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base);
 int launch_gemm_nt_stair(hipStream_t st, int64_t m, int64_t nseg, int64_t seg_cols, int64_t k, double alpha,
                          const double *A, int64_t lda, const double *B, int64_t ldb, int64_t b_stride, int64_t row_step,
-                         double beta, double *C, int64_t ldc, int lds_pad);
+                         double beta, double *C, int64_t ldc, int lds_pad, hipEvent_t ev0 = nullptr,
+                         hipEvent_t ev1 = nullptr);
 int launch_potf2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
                       unsigned *flag, unsigned flag_base, hipEvent_t done = nullptr);
 int launch_trsm_panel(hipStream_t st, int64_t m, const double *L, int64_t ldl, const double *invd,

@@ -532,7 +532,7 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
 // ONE launch (one tail, one XCD-aware tile order) instead of one launch per block column.
 int launch_gemm_nt_stair(hipStream_t st, int64_t m, int64_t nseg, int64_t seg_cols, int64_t k, double alpha,
                          const double *A, int64_t lda, const double *B, int64_t ldb, int64_t b_stride, int64_t row_step,
-                         double beta, double *C, int64_t ldc, int lds_pad)
+                         double beta, double *C, int64_t ldc, int lds_pad, hipEvent_t ev0, hipEvent_t ev1)
 {
     gpt_jitter(st);
     if (m <= 0 || nseg <= 0) return GPT_OK;
@@ -542,6 +542,6 @@ int launch_gemm_nt_stair(hipStream_t st, int64_t m, int64_t nseg, int64_t seg_co
                       "aligned operands)", GM_BK);
         return GPT_E_ARG;
     }
-    return gemm_launch_t<64, 64, 2, 2>(st, m, nseg * seg_cols, k, alpha, A, lda, B, ldb, beta, C, ldc, 2, lds_pad, nullptr,
-                                       nullptr, seg_cols, b_stride - seg_cols, row_step);
+    return gemm_launch_t<64, 64, 2, 2>(st, m, nseg * seg_cols, k, alpha, A, lda, B, ldb, beta, C, ldc, 2, lds_pad, ev0,
+                                       ev1, seg_cols, b_stride - seg_cols, row_step);
 }

@@ -376,19 +376,33 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
     }
 }
 
+// The 135 KB of dynamic LDS the diagonal-block kernels ask for needs hipFuncAttributeMaxDynamicSharedMemorySize, which
+// is a property of the function ON ONE DEVICE: set once per (kernel, device), thread-safe (ll_batch and bench.py drive
+// two contexts from two host threads; a process may hold contexts on several GPUs).
+#include <mutex>
+static int ensure_big_lds(const void *fn, int which, size_t shmem)
+{
+    static std::mutex mu;
+    static bool done[2][64];
+    int dev = 0;
+    GPT_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) dev = 63;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!done[which][dev] || dev == 63) {
+        GPT_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        done[which][dev] = true;
+    }
+    return GPT_OK;
+}
+
 // m rows below the 128x128 diagonal block at A (B = A + 128 * lda).  `flag` is a device word only ever raised;
 // flag_base must exceed every value written to it before (the caller counts: 16 per launch).
 int launch_potf2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
                       unsigned *flag, unsigned flag_base, hipEvent_t done)
 {
     gpt_jitter(st);
-    static bool attr_set = false;
     const size_t shmem = (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
-    if (!attr_set) {
-        GPT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(potf2_trsm_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        attr_set = true;
-    }
+    { int rc_ = ensure_big_lds(reinterpret_cast<const void *>(potf2_trsm_kernel), 0, shmem); if (rc_ != GPT_OK) return rc_; }
     const unsigned grid = 1u + (unsigned)((m + 16 * PD_WAVES - 1) / (16 * PD_WAVES));
     if (done) hipExtLaunchKernelGGL(potf2_trsm_kernel, dim3(grid), dim3(PD_THREADS), shmem, st, nullptr, done, 0, A, lda, invd,
                                     info, info_base, m, A + 128 * lda, lda, flag, flag_base);
@@ -401,13 +415,8 @@ int launch_potf2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int3
 int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base)
 {
     gpt_jitter(st);
-    static bool attr_set = false;
     const size_t shmem = (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
-    if (!attr_set) {
-        GPT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(potf2_diag_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        attr_set = true;
-    }
+    { int rc_ = ensure_big_lds(reinterpret_cast<const void *>(potf2_diag_kernel), 1, shmem); if (rc_ != GPT_OK) return rc_; }
     hipLaunchKernelGGL(potf2_diag_kernel, dim3(1), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base);
     GPT_LAUNCH_CHECK();
     return GPT_OK;

@@ -18,7 +18,7 @@ pool over independent hyperparameter samples); what must match is the *result* o
   * ``z = L^-1 y`` rides along as the augmented row N of the matrix, so the only
     other collective is one all-reduce of three scalars (log-det part, z.z part, info).
   * Two schedules (``schedule=``): ``"bcast"`` factors a panel whole and then broadcasts it; ``"pipelined"``
-    cuts every panel into a few row chunks of growing size (2, 6, 24, ... blocks): the owner factors the
+    cuts every panel into a few row chunks of growing size (2, 1, 5, 24, ... blocks): the owner factors the
     diagonal block with the first chunk and sends it at once, the TRSM of the later chunks, their transfer and
     the next owner's column update proceed chunk by chunk behind it, so the serial chain through the panels
     carries only the small head chunks (its own communicator) instead of whole panels.  Two ways to move a
@@ -210,7 +210,7 @@ class DistributedLML(object):
     NBUF = 4
 
     def __init__(self, X, n, nb=512, group=None, ops=None, device=None, lookahead=True, layout=None,
-                 schedule="bcast", exchange="bcast", chunk_blocks=(2, 8, 32), sag_min_bytes=8 << 20,
+                 schedule="bcast", exchange="bcast", chunk_blocks=(2, 3, 8, 32), sag_min_bytes=8 << 20,
                  owner_first=None, inv_trsm=True, inv_min_rows=8192, group_tail=None):
         if nb <= 0 or nb % 128:
             raise ValueError("nb must be a positive multiple of 128")
@@ -262,6 +262,7 @@ class DistributedLML(object):
         X = np.ascontiguousarray(X, dtype=np.float64)
         n = np.ascontiguousarray(n, dtype=np.int32)
         self.N, self.D = X.shape
+        self._n_maxsum = int(n.sum(axis=1).max()) if n.size else 0
         self.nb = nb
         self.NP = (self.N + 1 + nb - 1) // nb * nb
         self.nblk = self.NP // nb
@@ -455,10 +456,20 @@ class DistributedLML(object):
         if info != 0 and info <= N:
             raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % int(info))
         ll_data = -0.5 * zz - logdet_half - 0.5 * N * math.log(2.0 * math.pi)
+        if info != 0 or not math.isfinite(ll_data):
+            # like the single-GPU path (api.hip factor_and_ll): a failure in the augmented row -- z.z overflowed, or y / K
+            # held non-finite values -- is an error, not a NaN handed to the optimiser
+            raise np.linalg.LinAlgError("factorisation failed in the augmented row (non-finite y or K_tot?)")
         return ll_data, logdet_half
 
     def fit(self, kernel_id, params, y, err_y, noise_var=0.0, diag_factor=1e2):
         """One LML evaluation; returns ``(ll_data, logdet_half)`` on every rank."""
+        # the derivative-order limits gpt_fit / gpt_fit_sum check on the host (the device API takes what it is given)
+        if kernel_id == _lib.KERNEL_M52 and self._n_maxsum > 1:
+            raise ValueError("Matern52Kernel only supports 0th and 1st order derivatives")      # ref matern.py:545-546
+        if kernel_id == _lib.KERNEL_RQ and 2 * self._n_maxsum > 8:
+            raise ValueError("RationalQuadraticKernel: derivative orders of a pair sum to %d, the device builder "
+                             "supports 8" % (2 * self._n_maxsum))
         if self.schedule == "pipelined" and self.lookahead:
             return self._fit_pipelined(kernel_id, params, y, err_y, noise_var, diag_factor)
         return self._fit_bcast(kernel_id, params, y, err_y, noise_var, diag_factor)
@@ -566,7 +577,11 @@ class DistributedLML(object):
         diagonal block, and each chunk starts travelling at once -- head chunks on ``group``, the rest on
         ``group_tail``.  The chain from panel to panel therefore is: head of k-1 arrives -> 2-block update ->
         diagonal block -> head of k leaves, while the bulk TRSM, the bulk transfer and the next owner's column update
-        overlap chunk by chunk.  Other ranks post their side of every exchange on the idle "recv" queue.
+        overlap chunk by chunk.  (Precisely: the head of panel k reads local blocks 1 AND 2 of panel k-1; block 2 is cut
+        off as a one-block chunk of its own -- ``chunk_blocks`` = (2, 3, 8, 32) -- and travels on the chain communicator
+        right behind the head, so the chain is head -> block 2 -> next head and never waits for a bulk chunk on the tail
+        communicator.  With cuts that leave block 2 inside a larger chunk the results are the same and the chain is
+        longer.)  Other ranks post their side of every exchange on the idle "recv" queue.
           main queue, step k: every chunk of panel k has arrived -> apply it to the owned block columns right of k+1
                               (k+1 is its owner's business on the panel queue), column k+2 first ("urgent").
         Buffer reuse: P[k % NBUF] is written again (staged or received into) only after this rank's main queue is done
@@ -635,7 +650,10 @@ class DistributedLML(object):
                             ops.trsm_rlt(hi - lo, nb, buf.data_ptr(), nb, self.invd, _ptr(buf, lo, 0), nb)
                         ev = ops.new_event()
                         ev.record()
-                    works = self._exchange(buf[lo:hi], k % world, group=self.group if c == 0 else self.group_tail,
+                    # The chain communicator carries the head AND local block 2: the head of panel k+1 (local blocks
+                    # 0-1 = global k+1, k+2) is updated with local blocks 1 and 2 of panel k, so block 2 must not queue
+                    # behind this panel's bulk (with the default cuts it is a chunk of its own, sent right after the head).
+                    works = self._exchange(buf[lo:hi], k % world, group=self.group if bl[c + 1] <= 3 else self.group_tail,
                                            tag=(k, lo))
                     arr.append(_Arrival(works, ev))
                     if inv and c == 0:

@@ -555,6 +555,10 @@ class GaussianProcess(object):
         param_list = [np.asarray(p, dtype=float) for p in param_list]
         keep = np.array(self.free_params[:], dtype=float)
         world = replicas.world_size()
+        # Independent evaluations are never partitioned: the ranks evaluate DIFFERENT hyperparameters here (their slices
+        # of the list), and a partitioned evaluation is a collective that every rank must enter with the same ones.
+        keep_partitioned = self.partitioned
+        self.partitioned = False
         try:
             if world > 1 and len(param_list) > 1:
                 import torch.distributed as dist
@@ -573,6 +577,7 @@ class GaussianProcess(object):
             if self.mu is not None:
                 self.mu.set_hyperparams(keep[nk + nn:])
             self.K_up_to_date = False
+            self.partitioned = keep_partitioned
 
     def _ll_batch_local(self, param_list, exit_on_bounds):
         out = np.full(len(param_list), -np.inf)

@@ -158,7 +158,7 @@ def solve_lower(L, B, trans=False):
     return B2.reshape(shp)
 
 
-def fit(kernel, params, X, n, y, err_y, noise_var=0.0, diag_factor=1e2, want_K=False, chol="c"):
+def fit(kernel, params, X, n, y, err_y, noise_var=0.0, diag_factor=1e2, want_K=False, chol="c", timings=None):
     """compute_K_L_alpha_ll without T; ``y`` already mean-subtracted.
 
     chol="c": this file's Crout Cholesky; chol="scipy": scipy.linalg (LAPACK, the library the
@@ -185,14 +185,22 @@ def fit(kernel, params, X, n, y, err_y, noise_var=0.0, diag_factor=1e2, want_K=F
             raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % info)
         return dict(K=K, L=L, alpha=alpha, ll_data=ll.value, logdet_half=ld.value)
     import scipy.linalg
+    import time
+    t0 = time.perf_counter()
     K = kbuild(kid, params, X, n)
     Kt = K.copy() if want_K else K
     idx = np.arange(N)
     Kt[idx, idx] = ((Kt[idx, idx] + noise_var) + err_y ** 2.0) + diag_add
+    t1 = time.perf_counter()
     L = scipy.linalg.cholesky(Kt, lower=True, overwrite_a=not want_K, check_finite=False)
+    t2 = time.perf_counter()
     alpha = scipy.linalg.cho_solve((L, True), y)
     ld = np.log(np.diag(L)).sum()
     ll = -0.5 * y.dot(alpha) - ld - 0.5 * N * math.log(2.0 * math.pi)
+    if timings is not None:         # (bench.py's cpu_baseline: SURVEY 8d asks for the K-build and potrf times separately)
+        timings["kbuild_s"] = timings.get("kbuild_s", 0.0) + (t1 - t0)
+        timings["potrf_s"] = timings.get("potrf_s", 0.0) + (t2 - t1)
+        timings["solve_ll_s"] = timings.get("solve_ll_s", 0.0) + (time.perf_counter() - t2)
     return dict(K=K if want_K else None, L=L, alpha=alpha, ll_data=float(ll), logdet_half=float(ld))
 
 

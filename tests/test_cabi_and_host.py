@@ -203,7 +203,7 @@ def test_gp_pickles_without_device_state(g):
 def test_bench_watchdog_prints_the_complete_line_and_exits():
     """bench.py's partitioned path measures the whole-panel schedule first and runs everything newer under a timer: if a
     later leg hangs, rank 0 prints the line that is already complete (flagged) and every rank's process ends with
-    status 0 (bench.Watchdog)."""
+    status 3 -- non-zero, so that the launcher sees the hang (bench.Watchdog)."""
     import json
     import subprocess
     import sys
@@ -213,7 +213,7 @@ def test_bench_watchdog_prints_the_complete_line_and_exits():
             "wd.arm(0.3); time.sleep(30); print('not reached')\n" % root)
     for rank, expect_line in ((0, True), (1, False)):
         out = subprocess.run([sys.executable, "-c", code, str(rank)], capture_output=True, text=True, timeout=60)
-        assert out.returncode == 0 and "not reached" not in out.stdout
+        assert out.returncode == 3 and "not reached" not in out.stdout
         if expect_line:
             line = json.loads(out.stdout.strip())
             assert line["value"] == 1.0 and "tuning pass, x" in line["watchdog"]
@@ -224,3 +224,16 @@ def test_bench_watchdog_prints_the_complete_line_and_exits():
     out = subprocess.run([sys.executable, "-c", code_ok], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0 and out.stdout.split() == ["True", "False"]
 
+
+
+def test_bench_parity_gate_reports_and_gates():
+    """bench.parity_report: within tolerance -> ok; an ll off by 1e-6 relative or a predictive mean off by
+    1e-4 -> not ok (bench.py then prints the line and exits non-zero)."""
+    import bench
+    ref = {"ll_data": -1234.5, "logdet_half": 987.0}
+    m = np.linspace(0, 1, 8)
+    rep, ok = bench.parity_report(-1234.5 * (1 + 1e-10), 987.0, ref, (m, 0.1 + m), (m + 1e-9, 0.1 + m))
+    assert ok and rep["ok"] and rep["ll_rel_err_vs_cpu"] < 1e-8
+    assert not bench.parity_report(-1234.5 * (1 + 1e-6), 987.0, ref)[1]
+    assert not bench.parity_report(-1234.5, 987.0 * (1 - 1e-7), ref)[1]
+    assert not bench.parity_report(-1234.5, 987.0, ref, (m, 0.1 + m), (m + 1e-4, 0.1 + m))[1]

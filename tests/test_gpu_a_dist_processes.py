@@ -63,10 +63,15 @@ def test_distributed_plan_rccl_single_rank(oracle):
     assert len(vals) == 8
 
 
-def test_distributed_plan_two_ranks_sharing_the_gpu(oracle):
+@pytest.mark.parametrize("case", ["m52_d3_nb128", "c4_shape_se_d4_nb512"])
+def test_distributed_plan_two_ranks_sharing_the_gpu(oracle, case):
     """The product ops under a real two-rank data flow: two gloo ranks, both on cuda:0 (gloo moves CUDA tensors through
     the host), whole-panel and row-chunked schedules.  Exercises what a single rank cannot: receiving into panel
-    buffers on the idle queue, waiting for foreign chunks from the panel and the main queue, buffer reuse."""
+    buffers on the idle queue, waiting for foreign chunks from the panel and the main queue, buffer reuse.
+    Second case: BASELINE configs[3]'s shape (SquaredExponential, d=4, no derivative rows) at the product block width
+    nb=512, N=4100 -- the C4 workload scaled to what two ranks on one GPU finish in seconds."""
+    kern, kid, N, d, nb, deriv = {"m52_d3_nb128": ("m52", 1, 2500, 3, 128, True),
+                                  "c4_shape_se_d4_nb512": ("se", 0, 4100, 4, 512, False)}[case]
     import os
     import subprocess
     import sys
@@ -81,18 +86,23 @@ def test_distributed_plan_two_ranks_sharing_the_gpu(oracle):
         "dist.init_process_group('gloo', rank=rank, world_size=2)\n"
         "from gptools_amd.dist import DistributedLML\n"
         "from test_gpu_parity import c3_inputs\n"
-        "X, n, y = c3_inputs(2500, 3)\n"
-        "plan = DistributedLML(X, n, nb=128, device=0)\n"
-        "for sched, cb in (('bcast', (2, 8, 32)), ('pipelined', (2, 8, 32)), ('pipelined', (2, 4, 6, 10))):\n"
+        "kid, N, d, nb, deriv = %d, %d, %d, %d, %d\n"
+        "X, n, y = c3_inputs(N, d)\n"
+        "if not deriv: n[:] = 0\n"
+        "p = np.concatenate(([1.0], 0.3 * np.ones(d)))\n"
+        "plan = DistributedLML(X, n, nb=nb, device=0)\n"
+        "for sched, cb in (('bcast', (2, 8, 32)), ('pipelined', (2, 3, 8, 32)), ('pipelined', (2, 4, 6, 10))):\n"
         "    plan.schedule, plan.chunk_blocks = sched, cb\n"
         "    for rep in range(3):\n"
-        "        print('RESULT', *plan.fit(1, np.array([1.0, 0.3, 0.3, 0.3]), y, 0.05 * np.ones(2500)))\n"
-        "dist.destroy_process_group()\n" % (root, root))
+        "        print('RESULT', *plan.fit(kid, p, y, 0.05 * np.ones(N)))\n"
+        "dist.destroy_process_group()\n" % (root, root, kid, N, d, nb, int(deriv)))
     procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for r in range(2)]
     outs = [p.communicate(timeout=600) for p in procs]
-    X, n, y = c3_inputs(2500, 3)
-    ref = oracle.fit("m52", np.array([1.0, 0.3, 0.3, 0.3]), X, n, y, 0.05 * np.ones(2500), chol="scipy")
+    X, n, y = c3_inputs(N, d)
+    if not deriv:
+        n[:] = 0
+    ref = oracle.fit(kern, np.concatenate(([1.0], 0.3 * np.ones(d))), X, n, y, 0.05 * np.ones(N), chol="scipy")
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-2000:]
         vals = [l.split()[1:] for l in so.splitlines() if l.startswith("RESULT")]
@@ -141,8 +151,14 @@ def test_gaussian_process_partitioned_update_and_map_two_ranks(oracle):
         "mode1 = gp._fit_mode\n"
         "m1, s1 = gp.predict(X[:5], n=0)\n"
         "mode2 = gp._fit_mode\n"
+        "# independent evaluations on a partitioned GP (ADVICE r1): the ranks evaluate DIFFERENT points, so these must\n"
+        "# stay local -- one point per rank (len == world) used to enter the collective with mixed hyperparameters\n"
+        "grid2, _ = gp.compute_ll_matrix([(0.8, 1.2), (0.4, 0.4), (0.4, 0.4)], [2, 1, 1])\n"
+        "b4 = gp.ll_batch([[1.0, 0.3, 0.4], [1.1, 0.35, 0.45], [0.9, 0.4, 0.4], [1.2, 0.3, 0.5]])\n"
+        "assert gp.partitioned == (world > 1)\n"
         "res, nres = gp.optimize_hyperparameters(method='L-BFGS-B', random_starts=0, opt_kwargs={'options': {'maxiter': 6}})\n"
         "print('RESULT', json.dumps({'v1': float(v1), 'mode1': mode1, 'mode2': mode2, 'm1': [float(v) for v in m1],\n"
+        "                            'grid2': [float(v) for v in grid2.ravel()], 'b4': [float(v) for v in b4],\n"
         "                            'fun': float(res.fun), 'x': [float(v) for v in res.x]}))\n"
         "if world > 1: dist.destroy_process_group()\n") % (root, root)
 
@@ -164,8 +180,36 @@ def test_gaussian_process_partitioned_update_and_map_two_ranks(oracle):
         assert r["mode1"] == "partitioned" and r["mode2"] == "kernel"
         assert abs(r["v1"] - single["v1"]) <= 1e-9 * abs(single["v1"])
         np.testing.assert_allclose(r["m1"], single["m1"], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(r["grid2"], single["grid2"], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(r["b4"], single["b4"], rtol=1e-12, atol=0)
         assert abs(r["fun"] - single["fun"]) <= 1e-6 * abs(single["fun"])
         # (finite-difference gradients amplify the 1e-13 summation-order difference of ll: same optimum, not same digits)
         np.testing.assert_allclose(r["x"], single["x"], rtol=1e-2)
     assert both[0]["fun"] == both[1]["fun"] and both[0]["x"] == both[1]["x"]      # the ranks walked the same iterates
 
+
+
+def test_bench_partitioned_line_is_complete_two_ranks():
+    """bench.py's N>1 branch end to end -- two gloo ranks sharing cuda:0 (test hook GPT_BENCH_BACKEND), the C2 workload:
+    rank 0 prints ONE JSON line that carries `roofline` (HIP-event timing of the staircase updates), `cpu_baseline`
+    (with the K-build / potrf split) and a passing `parity` gate; both ranks exit 0."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2", LOCAL_RANK="0",
+               GPT_BENCH_BACKEND="gloo", GPT_BENCH_WATCHDOG_S="500")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c2", "--steps", "3", "--warmup", "1",
+           "--schedule", "bcast+bcast", "--no-probe", "--no-ref"]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["N"] == 4096 and "watchdog" not in line
+    roof = line["roofline"]
+    assert roof["bound"] == "mfma" and roof["achieved"] > 0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["t_kbuild_cpu_s"] > 0 and cb["t_potrf_cpu_s"] > 0
+    par = line["parity"]
+    assert par["ok"] and par["ll_rel_err_vs_cpu"] <= 1e-8 and par["logdet_rel_err_vs_cpu"] <= 1e-8

@@ -687,6 +687,110 @@ def test_full_size_properties(ctx, oracle, cfg):
     np.testing.assert_allclose(s ** 2, sr ** 2, rtol=0, atol=1e-6)
 
 
+def test_full_size_c5_fit_and_map_loop(g, ctx, oracle):
+    """BASELINE configs[4]: the MAP loop at N=16384 (SquaredExponential, d=2) through the plugin API --
+    ``optimize_hyperparameters(method='L-BFGS-B', maxiter=50, random_starts=0)`` (ref gaussian_process.py:623-783),
+    every objective evaluation a K rebuild + Cholesky on the GPU (ref :1418-1469).
+    (a) one evaluation at the start point vs the CPU path (oracle K-build + LAPACK) within 1e-8 relative;
+    (b) the optimiser's accepted iterates decrease monotonically and stay inside the bounds;
+    (c) the value it returns equals the CPU path's log-posterior at the returned hyperparameters within 1e-8;
+    (d) the GP is left at the optimum, and the optimum beats the start."""
+    N, d = 16384, 2
+    X, n, y = c3_inputs(N, d)
+    n[:] = 0
+    err = 0.05 * np.ones(N)
+    p0 = np.array([1.0, 0.3, 0.3])
+    ctx.set_data(X, n)
+    ll, ld = ctx.fit(KID["se"], p0, 0.0, y, err, 1e2 * EPS)
+    ref = oracle.fit("se", p0, X, n, y, err, chol="scipy")
+    assert abs(ll - ref["ll_data"]) <= 1e-8 * abs(ref["ll_data"])
+    assert abs(ld - ref["logdet_half"]) <= 1e-8 * abs(ref["logdet_half"])
+    del ref
+    k = g.SquaredExponentialKernel(num_dim=d, initial_params=list(p0), param_bounds=[(1e-3, 10.0)] * 3)
+    gp = g.GaussianProcess(k, X=X, y=y, err_y=0.05)
+    v0 = gp.update_hyperparameters(p0)
+    assert abs(-v0 - gp.hyperprior(gp.params) - ll) <= 1e-12 * abs(ll)       # plugin API == C ABI, same evaluation
+    seen, iterates = {}, []
+    inner = gp.update_hyperparameters
+
+    def recording(p_, *a, **kw):
+        v = inner(p_, *a, **kw)
+        if not a and not kw:
+            seen[np.asarray(p_, dtype=float).tobytes()] = v
+        return v
+    gp.update_hyperparameters = recording
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res, nres = gp.optimize_hyperparameters(
+            method="L-BFGS-B", random_starts=0, num_proc=0,
+            opt_kwargs={"options": {"maxiter": 50}, "callback": lambda xk: iterates.append(np.array(xk, dtype=float))})
+    gp.update_hyperparameters = inner
+    assert nres == 1 and 1 <= res.nit <= 50 and len(iterates) == res.nit
+    vals = [v0] + [seen[x.tobytes()] for x in iterates]        # every accepted iterate was an objective evaluation
+    assert all(b <= a for a, b in zip(vals, vals[1:])), vals
+    assert res.fun == vals[-1] and res.fun < v0 - 1.0
+    assert np.all(res.x >= 1e-3) and np.all(res.x <= 10.0)
+    np.testing.assert_array_equal(gp.free_params[:], res.x)
+    ref = oracle.fit("se", res.x, X, n, y, err, chol="scipy")
+    post = ref["ll_data"] + gp.hyperprior(gp.params)
+    assert abs(-res.fun - post) <= 1e-8 * abs(post)
+    # the factor at the optimum: K_tot alpha = y on a sample of rows
+    alpha = gp.alpha[:, 0]
+    rows = np.arange(0, N, 1021)
+    Kr = ctx.kbuild(KID["se"], res.x, X[rows], n[rows], X, n)
+    Kr[np.arange(len(rows)), rows] += err[rows] ** 2 + 1e2 * EPS
+    np.testing.assert_allclose(Kr.dot(alpha), y[rows], rtol=0, atol=1e-6)
+
+
+def test_full_size_c4_single_gpu_and_block_cyclic(ctx, oracle):
+    """BASELINE configs[3]: SquaredExponential, N=32768, d=4, no derivative rows (K_tot = 8.6 GB).
+    (a) single-context path (gpt_fit) vs the CPU path (oracle K-build on the host cores + LAPACK) within 1e-8 relative
+        on ll and log|K|, alpha against cho_solve on a sample;
+    (b) the block-cyclic engine (gptools_amd.dist.DistributedLML, product ops, world size 1) at the same size, both
+        schedules (whole panels / row chunks): same ll and log|K|;
+    (c) size-independent properties: K_tot alpha = y on sampled rows (rows rebuilt by the pair kernel),
+        (L L^T) x = K_tot x on sampled rows, predictive mean / variance at 64 points against the CPU path."""
+    from gptools_amd.dist import DistributedLML
+    N, d = 32768, 4
+    X, n, y = c3_inputs(N, d)
+    n[:] = 0
+    p = np.concatenate(([1.0], 0.3 * np.ones(d)))
+    err = 0.05 * np.ones(N)
+    ctx.set_data(X, n)
+    ll, ld = ctx.fit(KID["se"], p, 0.0, y, err, 1e2 * EPS)
+    ref = oracle.fit("se", p, X, n, y, err, chol="scipy")
+    assert abs(ll - ref["ll_data"]) <= 1e-8 * abs(ref["ll_data"])
+    assert abs(ld - ref["logdet_half"]) <= 1e-8 * abs(ref["logdet_half"])
+    alpha = ctx.get_alpha(N)
+    assert_close(alpha, ref["alpha"], rtol=1e-5, atol_scale=1e-7)
+    rows = np.arange(0, N, 1499)
+    Kr = ctx.kbuild(KID["se"], p, X[rows], n[rows], X, n)
+    Kr[np.arange(len(rows)), rows] += err[rows] ** 2 + 1e2 * EPS
+    np.testing.assert_allclose(Kr.dot(alpha), y[rows], rtol=0, atol=1e-6)
+    Xs = np.random.RandomState(64).rand(64, d)
+    ns = np.zeros((64, d), int)
+    m, s, _ = ctx.predict(Xs, ns, 1)
+    mr, sr, _ = oracle.predict("se", p, X, n, ref["L"], ref["alpha"], Xs, ns, want_cov=False)
+    np.testing.assert_allclose(m, mr, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(s ** 2, sr ** 2, rtol=0, atol=1e-6)
+    del ref, mr, sr
+    gc.collect()
+    L = ctx.get_L(N)
+    x = np.random.RandomState(3).randn(N, 2)
+    Ltx = L.T.dot(x)
+    np.testing.assert_allclose(L[rows].dot(Ltx), Kr.dot(x), rtol=0, atol=1e-9 * np.abs(Kr.dot(x)).max())
+    assert np.array_equal(np.triu(L[:256, :256], 1), np.zeros((256, 256)))
+    del L, Ltx
+    gc.collect()
+    for sched in ("bcast", "pipelined"):
+        plan = DistributedLML(X, n, nb=512, device=0, schedule=sched)
+        ll2, ld2 = plan.fit(KID["se"], p, y, err)
+        assert abs(ll2 - ll) <= 1e-10 * abs(ll), sched
+        assert abs(ld2 - ld) <= 1e-11 * abs(ld), sched
+        del plan
+        gc.collect()
+
+
 def test_distributed_plan_on_one_gpu(ctx, oracle):
     """gptools_amd.dist with the product ops (HipPanelOps, device API of the C ABI) and world_size 1:
     same ll / log|K| as the single-context path and the oracle."""
