@@ -66,6 +66,8 @@ struct gpt_ctx {
     int helper_tf = 35;                // assumed rate of the helper stream, in 0.1 TFLOP/s per 24 CUs (0 = no helper);
                                        // measured: 0 / 25 / 35 / 50 -> 212 / 209 / 206 / 214 ms at N=32768, 30.8 / 30.6 / 30.2 / 32.0 at N=16384
     int ramp = 0;                      // first panels 128, 256, ... wide (see potrf_enqueue); measured slower, off
+    int inner = 0;                     // look-ahead panel: 0 right-looking leaves, 1 left-looking (panel_ext_ll), 2 left-looking
+    int64_t inner_rows = 4608;         //   once at most inner_rows rows remain (the chain-bound end of the factorisation)
     hipEvent_t head_event = nullptr;   // set by gpt_fit: the first nb_outer+128 columns of K_tot are built (panel 0 may start)
     // resident training inputs
     int64_t N = 0;             // order of the factorised matrix (= Nx without T, = Ny with T)
@@ -331,9 +333,64 @@ static int panel_rec(gpt_ctx *c, hipStream_t st, double *Ap, int64_t lda, int64_
 // without waiting for anybody.  `wait_ev` (the other stream's update of the columns this panel reads beyond its first
 // leaf) is waited for before the first update; `done_ev` is recorded once L of the block column is final.
 #define GPT_PANEL_EXT 128
+static int leaf_factor(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64_t n, int64_t lc, double *invd,
+                       int32_t *info, hipEvent_t done_ev)
+{
+    double *Ad = A + lc * lda + lc;
+    double *ws = invd + (lc / 128) * GPT_WS_BLOCK;
+    const int64_t m = n - (lc + 128);
+    if (c->fuse_trsm > 0 && m >= 128 && m <= c->fuse_trsm && !c->use_graph) {
+        if (c->flag_epoch > 0x3fffff00u) {
+            GPT_HIP_CHECK(hipMemsetAsync(c->d_flag, 0, 64, st));
+            c->flag_epoch = 0;
+        }
+        c->flag_epoch += 16;
+        return launch_potf2_trsm(st, Ad, lda, ws, info, lc, m, c->d_flag, c->flag_epoch, done_ev);
+    }
+    GPT_TRY(launch_potf2_diag(st, Ad, lda, ws, info, lc));
+    GPT_TRY(launch_trsm_panel(st, m, Ad, lda, ws, Ad + 128 * lda, lda, (done_ev && !c->use_graph) ? done_ev : nullptr));
+    if (done_ev && c->use_graph) GPT_HIP_CHECK(hipEventRecord(done_ev, st));
+    return GPT_OK;
+}
+
+// The same look-ahead panel, LEFT-looking inside the block column (option "inner" = 1): leaf j first receives the
+// update of the leaves 0..j-1 of this block column in ONE launch (k = 128 j, 128 columns wide), then is factored; after
+// the last leaf the 128 columns that follow the block column (the next panel's first leaf) get the whole block column's
+// update (k = w).  Same flops as the right-looking form, but every update launch on the chain is 128 columns wide --
+// the right-looking form's first leaf carries a (w + 128 - 128)-column update that shares the chip with the main stream's
+// trailing update and measured 60 us against 13-16 us for the narrow ones (profiles/r01_timeline_c3_N8192.txt).
+static int panel_ext_ll(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64_t n, int64_t c0, int64_t w,
+                        double *invd, int32_t *info, hipEvent_t wait_ev, hipEvent_t done_ev)
+{
+    bool waited = (wait_ev == nullptr);
+    for (int64_t lc = c0; lc < c0 + w; lc += 128) {
+        const int64_t kk = lc - c0;
+        if (kk > 0) {
+            if (!waited) {
+                GPT_HIP_CHECK(hipStreamWaitEvent(st, wait_ev, 0));
+                waited = true;
+            }
+            GPT_TRY(gemm_nt(c, st, n - lc, 128, kk, -1.0, A + lc * lda + c0, lda, A + lc * lda + c0, lda, 1.0,
+                            A + lc * lda + lc, lda, 1));
+        }
+        const bool last = (lc + 128 == c0 + w);
+        GPT_TRY(leaf_factor(c, st, A, lda, n, lc, invd, info, last ? done_ev : nullptr));
+    }
+    const int64_t e0 = c0 + w;
+    if (e0 < n) {
+        if (!waited) GPT_HIP_CHECK(hipStreamWaitEvent(st, wait_ev, 0));
+        const int64_t ew = (n - e0 < GPT_PANEL_EXT) ? n - e0 : GPT_PANEL_EXT;
+        GPT_TRY(gemm_nt(c, st, n - e0, ew, w, -1.0, A + e0 * lda + c0, lda, A + e0 * lda + c0, lda, 1.0,
+                        A + e0 * lda + e0, lda, 1));
+    }
+    return GPT_OK;
+}
+
 static int panel_ext(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64_t n, int64_t c0, int64_t w,
                      double *invd, int32_t *info, hipEvent_t wait_ev, hipEvent_t done_ev)
 {
+    if (c->inner == 1 || (c->inner == 2 && n - c0 <= c->inner_rows))
+        return panel_ext_ll(c, st, A, lda, n, c0, w, invd, info, wait_ev, done_ev);
     const int64_t cend = (c0 + w + GPT_PANEL_EXT < n) ? c0 + w + GPT_PANEL_EXT : n;
     for (int64_t lc = c0; lc < c0 + w; lc += 128) {
         double *Ad = A + lc * lda + lc;
@@ -644,6 +701,8 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "profile_gemm")) c->prof_gemm = value ? 1 : 0;
     else if (!strcmp(key, "gemm_pad")) c->gemm_pad = (int)value;
     else if (!strcmp(key, "ramp")) c->ramp = value ? 1 : 0;
+    else if (!strcmp(key, "inner")) c->inner = (int)value;
+    else if (!strcmp(key, "inner_rows")) c->inner_rows = value;
     else if (!strcmp(key, "helper_tf")) c->helper_tf = (int)value;
     else if (!strcmp(key, "fuse_trsm")) c->fuse_trsm = value;
     else if (!strcmp(key, "tile")) {

@@ -159,6 +159,17 @@ __device__ __forceinline__ void pivot_block_16(double (*S)[PD_PITCH], double (*T
     }
 }
 
+// Phase stamps of wave 0 (scratch/potf2_stamps.hip compiles this file with -DGPT_PD_STAMPS; absent from the library).
+#ifdef GPT_PD_STAMPS
+__device__ long long *g_pd_stamps;
+#define PD_STAMP(i)                                                             \
+    do {                                                                        \
+        if (wave == 0 && lane == 0) g_pd_stamps[(i)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PD_STAMP(i) do { } while (0)
+#endif
+
 #define PD_THREADS 512
 #define TP_SP 18              // pitch of the per-wave 16x16 re-layout scratch of the TRSM kernels
 #define PD_WAVES (PD_THREADS / 64)
@@ -206,9 +217,12 @@ __device__ __forceinline__ void potf2_body(double *__restrict__ A, int64_t lda, 
             if (idx < NCH && !(r < 16 && c2 < 16)) *reinterpret_cast<f64x2 *>(&S[r][c2]) = v[q];   // tile (0,0) is wave 0's
         }
     }
+    PD_STAMP(0);
     __syncthreads();
+    PD_STAMP(1);
 
     for (int jb = 0; jb < NB16; jb++) {
+        PD_STAMP(8 + jb * 8 + 0);
         // (b) strip solve: X_ti = B_ti * inv(L_jj)^T for the 16-row tiles below the pivot block (waves 0..6)
         {
             const int ti = jb + 1 + wave;
@@ -226,7 +240,9 @@ __device__ __forceinline__ void potf2_body(double *__restrict__ A, int64_t lda, 
                 for (int r = 0; r < 4; r++) S[ti * 16 + fk + 4 * r][jb * 16 + fr] = acc[r];
             }
         }
+        PD_STAMP(8 + jb * 8 + 1);
         __syncthreads();
+        PD_STAMP(8 + jb * 8 + 2);
         // (c) wave 0: next pivot tile update + pivot; waves 1..6: the other trailing tiles; wave 7: column block jb of L
         //     (now final) goes to global memory, row-major and packed, together with inv(L_jj).
         if (wave == PD_WAVES - 1) {
@@ -275,10 +291,14 @@ __device__ __forceinline__ void potf2_body(double *__restrict__ A, int64_t lda, 
                 for (int r = 0; r < 4; r++) S[ti * 16 + fk + 4 * r][tj * 16 + fr] = acc[r];
                 if (wave == 0) break;
             }
+            PD_STAMP(8 + jb * 8 + 3);
             if (wave == 0) pivot_block_16<false>(S, T[jb + 1], jb + 1, lane, nullptr, 0, info, info_col0);
+            PD_STAMP(8 + jb * 8 + 4);
         }
         __syncthreads();
+        PD_STAMP(8 + jb * 8 + 5);
     }
+    PD_STAMP(2);
 }
 
 __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restrict__ A, int64_t lda,
