@@ -49,6 +49,8 @@ struct gpt_ctx {
     bool own_stream = false;
     hipStream_t panel_stream = nullptr;
     hipStream_t helper_stream = nullptr;   // CU-masked to part of the reserved CUs (own streams only)
+    hipStream_t early_stream = nullptr;    // main stream of the update-bound head of a factorisation: fewer CUs reserved
+    int64_t early_rows = 0;                // panels with more than this many rows left run their updates there (0 = off)
     int helper_cus = 0;
     std::vector<hipEvent_t> events;       // sync-only events (look-ahead fork/join)
     hipEvent_t tev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -256,7 +258,8 @@ static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, 
     // (the roofline line of bench.py: the trailing updates on the MAIN stream only -- at large N the panel and helper
     // streams also launch >= 1 GFLOP updates, on the few CUs reserved for them and concurrently with these; summing their
     // durations with the main stream's would count the same wall time twice)
-    const bool prof = c->prof_gemm && flops >= 1.0e9 && st == c->stream;
+    const bool on_main = (st == c->stream) || (c->early_stream && st == c->early_stream);
+    const bool prof = c->prof_gemm && flops >= 1.0e9 && on_main;
     gpt_ctx::GemmProf *gp = nullptr;
     if (prof) {
         if (c->gprof_used == c->gprof.size()) {
@@ -271,7 +274,7 @@ static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, 
         gp->flops = flops;
     }
     // trailing updates on the main stream leave room on every CU for the panel stream (see gemm.hip)
-    const int lds_pad = (st == c->stream && c->lookahead) ? c->gemm_pad : 0;
+    const int lds_pad = (on_main && c->lookahead) ? c->gemm_pad : 0;
     // `done` (a cross-stream edge) and the timing events ride on the dispatch packet itself where possible
     // (hipExtLaunchKernelGGL): a separate hipEventRecord is a barrier packet, ~6 us of command-processor time
     const bool ext = !c->use_graph && (c->tile == 0 || c->tile == 64);
@@ -479,8 +482,30 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
     const double rate_s = 46e12, rate_h = 1e11 * (double)c->helper_tf * (double)c->helper_cus / 24.0;
     hipEvent_t e_cu_prev = nullptr, e_help_prev = nullptr;
     int64_t c0 = 0, s_prev = 0;
+    // Update-bound head (option early_rows): while more than early_rows rows remain, the trailing updates run on a
+    // stream that leaves only a few CUs to the panel stream (the diagonal-block kernel needs ONE free CU; the fused
+    // diagonal-block + TRSM kernel of the chain-bound end needs up to 33).  One event hands over between the two.
+    const bool use_early = c->early_stream && c->early_rows > 0 && !H && !c->use_graph;
+    hipStream_t S0 = S, S_cur = S;
+    if (use_early) {
+        hipEvent_t e_k = get_event(c, 2 + 4 * widths.size());
+        if (!e_k) return GPT_E_HIP;
+        GPT_HIP_CHECK(hipEventRecord(e_k, S0));                     // the K build (and everything before) on the main stream
+        GPT_HIP_CHECK(hipStreamWaitEvent(c->early_stream, e_k, 0));
+    }
     for (size_t k = 0; k < widths.size(); k++) {
         const int64_t w = widths[k];
+        if (use_early) {
+            hipStream_t want = (n - c0 > c->early_rows) ? c->early_stream : S0;
+            if (want != S_cur) {
+                hipEvent_t e_sw = get_event(c, 3 + 4 * widths.size());
+                if (!e_sw) return GPT_E_HIP;
+                GPT_HIP_CHECK(hipEventRecord(e_sw, S_cur));
+                GPT_HIP_CHECK(hipStreamWaitEvent(want, e_sw, 0));
+                S_cur = want;
+            }
+            S = S_cur;
+        }
         const int64_t wn = (k + 1 < widths.size()) ? widths[k + 1] : 0;      // width of the next panel
         hipEvent_t e_panel = get_event(c, 2 + 4 * k), e_cu = get_event(c, 3 + 4 * k), e_help = get_event(c, 4 + 4 * k);
         hipEvent_t e_sdone = get_event(c, 5 + 4 * k);
@@ -532,6 +557,13 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
         c0 += w;
     }
     if (e_help_prev) GPT_HIP_CHECK(hipStreamWaitEvent(S, e_help_prev, 0));
+    if (use_early && S_cur != S0) {
+        hipEvent_t e_sw = get_event(c, 3 + 4 * widths.size());
+        if (!e_sw) return GPT_E_HIP;
+        GPT_HIP_CHECK(hipEventRecord(e_sw, S_cur));
+        GPT_HIP_CHECK(hipStreamWaitEvent(S0, e_sw, 0));
+    }
+    S = S0;
     hipEvent_t e_end = get_event(c, 1);
     if (!e_end) return GPT_E_HIP;
     GPT_HIP_CHECK(hipEventRecord(e_end, P));
@@ -616,6 +648,16 @@ extern "C" int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out)
             // helper stream: the reserved CUs except the first 8 (those stay free for the diagonal-block kernel, which
             // needs a whole CU's LDS).  While the trailing updates dominate, the panel stream leaves the reserved CUs
             // idle most of the time; a slice of every update runs there (potrf_enqueue).
+            int reserve_early = 8;
+            if (const char *e = getenv("GPT_RESERVE_EARLY")) reserve_early = atoi(e);
+            if (masked && reserve_early > 0 && reserve_early < reserve) {
+                std::vector<uint32_t> em((ncu + 31) / 32, 0u);
+                for (int i = reserve_early; i < ncu; i++) em[i / 32] |= (1u << (i % 32));
+                if (hipExtStreamCreateWithCUMask(&c->early_stream, (uint32_t)em.size(), em.data()) != hipSuccess) {
+                    (void)hipGetLastError();
+                    c->early_stream = nullptr;
+                }
+            }
             if (masked && reserve >= 16) {
                 std::vector<uint32_t> hm((ncu + 31) / 32, 0u);
                 for (int i = 8; i < reserve; i++) hm[i / 32] |= (1u << (i % 32));
@@ -681,6 +723,7 @@ extern "C" int gpt_ctx_destroy(gpt_ctx *c)
     if (c->h_info) hipHostFree(c->h_info);
     hipStreamDestroy(c->panel_stream);
     if (c->helper_stream) hipStreamDestroy(c->helper_stream);
+    if (c->early_stream) hipStreamDestroy(c->early_stream);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return GPT_OK;
@@ -701,6 +744,7 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "profile_gemm")) c->prof_gemm = value ? 1 : 0;
     else if (!strcmp(key, "gemm_pad")) c->gemm_pad = (int)value;
     else if (!strcmp(key, "ramp")) c->ramp = value ? 1 : 0;
+    else if (!strcmp(key, "early_rows")) c->early_rows = value;
     else if (!strcmp(key, "inner")) c->inner = (int)value;
     else if (!strcmp(key, "inner_rows")) c->inner_rows = value;
     else if (!strcmp(key, "helper_tf")) c->helper_tf = (int)value;
@@ -1680,4 +1724,24 @@ extern "C" int gpt_dev_trsm_rlt(gpt_ctx *c, int64_t m, int64_t n, const double *
         return GPT_E_ARG;
     }
     return trsm_rlt(c, c->stream, m, n, dL, ldl, d_invd, dB, ldb);
+}
+
+extern "C" int gpt_dev_copy2d(gpt_ctx *c, int64_t rows, int64_t cols, const double *d_src, int64_t lds, double *d_dst,
+                              int64_t ldd)
+{
+    CTX_ENTER(c);
+    return launch_copy2d(c->stream, rows, cols, d_src, lds, d_dst, ldd);
+}
+
+extern "C" int gpt_dev_pad_block(gpt_ctx *c, double *dA, int64_t lda, int64_t c0, int64_t nb, int64_t n_valid,
+                                 int64_t n_pad, const double *d_y, double big)
+{
+    CTX_ENTER(c);
+    return launch_pad_block(c->stream, dA, lda, c0, nb, n_valid, n_pad, d_y, big);
+}
+
+extern "C" int gpt_dev_panel_scalars(gpt_ctx *c, const double *dP, int64_t ldp, int64_t w, int64_t zrow, double *d_acc)
+{
+    CTX_ENTER(c);
+    return launch_panel_scalars(c->stream, dP, ldp, w, zrow, d_acc);
 }

@@ -93,3 +93,6 @@ int launch_add_noise_sym(hipStream_t st, const KParams &kp, const double *dX, co
                          double *C, int64_t ldc);
 int launch_copy2d(hipStream_t st, int64_t rows, int64_t cols, const double *src, int64_t lds, double *dst, int64_t ldd);
 int launch_zero2d(hipStream_t st, int64_t rows, int64_t cols, double *dst, int64_t ldd);
+int launch_pad_block(hipStream_t st, double *A, int64_t lda, int64_t c0, int64_t nb, int64_t n_valid, int64_t n_pad,
+                     const double *dy, double big);
+int launch_panel_scalars(hipStream_t st, const double *P, int64_t ldp, int64_t w, int64_t zrow, double *acc);

@@ -20,6 +20,79 @@
 #define PD_PITCH 130          // LDS row pitch (doubles): 16 rows x (lane>>4) fragment reads are conflict-free
 #define PD_TP 18              // pitch of the 16x16 inverse scratch
 
+// Phase stamps of wave 0 (scratch/potf2_stamps.hip compiles this file with -DGPT_PD_STAMPS; absent from the library).
+#ifdef GPT_PD_STAMPS
+// cheap stamps: s_memtime into a small static LDS array (lane 0 of wave 0), dumped to global memory at the end of the kernel
+__device__ long long *g_pd_stamps;
+__shared__ long long pd_stamp_lds[96];
+#define PD_STAMP(i)                                                             \
+    do {                                                                        \
+        if (wave == 0 && lane == 0) pd_stamp_lds[(i)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define PD_STAMP1(i)                                                            \
+    do {                                                                        \
+        if (wave == 1 && lane == 0) pd_stamp_lds[(i)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define PD_STAMPW(i)                                                            \
+    do {                                                                        \
+        if (lane == 0) pd_stamp_lds[(i)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define PD_STAMP_DUMP()                                                         \
+    do {                                                                        \
+        __syncthreads();                                                        \
+        if (threadIdx.x < 96) g_pd_stamps[threadIdx.x] = pd_stamp_lds[threadIdx.x]; \
+    } while (0)
+#else
+#define PD_STAMP(i) do { } while (0)
+#define PD_STAMP1(i) do { } while (0)
+#define PD_STAMPW(i) do { } while (0)
+#define PD_STAMP_DUMP() do { } while (0)
+#endif
+
+// linear index of a lower-triangle tile -> (row a, column b <= a); t is wave-uniform, so this is a scalar loop
+__device__ __forceinline__ void tri_decode(int t, int &a_, int &b_)
+{
+    a_ = 0;
+    while (t > a_) {
+        t -= a_ + 1;
+        a_++;
+    }
+    b_ = t;
+}
+
+// S(ti, tj) -= S(ti, jb) S(tj, jb)^T on 16x16 tiles; the four k-steps run as two independent accumulator chains
+struct TileUpd {
+    f64x4 acc, acc2;
+    double av[4], bv[4];
+    int ti, tj;
+    __device__ __forceinline__ void load(double (*S)[PD_PITCH], int ti_, int tj_, int jb, int fr, int fk)
+    {
+        ti = ti_;
+        tj = tj_;
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] = S[ti * 16 + fk + 4 * r][tj * 16 + fr];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            av[kk] = -S[ti * 16 + fr][jb * 16 + fk + 4 * kk];
+            bv[kk] = S[tj * 16 + fr][jb * 16 + fk + 4 * kk];
+        }
+        acc2 = f64x4{0.0, 0.0, 0.0, 0.0};
+    }
+    __device__ __forceinline__ void mma()
+    {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
+    }
+    __device__ __forceinline__ void store(double (*S)[PD_PITCH], int fr, int fk)
+    {
+#pragma unroll
+        for (int r = 0; r < 4; r++) S[ti * 16 + fk + 4 * r][tj * 16 + fr] = acc[r] + acc2[r];
+    }
+};
+
+
 __device__ __forceinline__ double bcast_lane(double v, int srclane)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
@@ -56,6 +129,12 @@ __device__ __forceinline__ void fmac_bcast(double &acc, double src, double mult)
 {
     asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mult), "i"(C));
 }
+// acc -= (src of lane C of my row) * mult: the sign rides on the source modifier, no separate negation
+template <int C>
+__device__ __forceinline__ void fnmac_bcast(double &acc, double src, double mult)
+{
+    asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mult), "i"(C));
+}
 template <int C>
 __device__ __forceinline__ double mov_bcast_nop(double src)
 {
@@ -67,19 +146,28 @@ __device__ __forceinline__ double mov_bcast_nop(double src)
 // One column J of the pivot block; on entry rp.inv = 1/sqrt(pivot J) (the same value in every lane).  The NEXT pivot
 // is a[J+1][J+1] - l^2 with l = L[J+1][J] (two row broadcasts), and its rsqrt pipeline is advanced one step per
 // update group of this column.
+// One column J of the pivot block; on entry rp.inv = 1/sqrt(pivot J) (the same value in every lane).  The NEXT pivot
+// is a[J+1][J+1] - l^2 with l = L[J+1][J] (two row broadcasts), and its rsqrt pipeline is advanced one step per
+// update group of this column.  Measured with s_memtime stamps (scratch/potf2_stamps.hip): the sixteen columns take
+// ~2700 cycles, i.e. the chain is bound by the issue of its ~640 double-precision instructions (~4 cycles each), so
+// what counts is their number: the sign of the update rides on a source modifier of the DPP multiply-add, and a pivot
+// that is not positive is NOT tested here (the test, a select and the bookkeeping were 5 instructions per column) --
+// v_rsq of a negative number is NaN and 0 * rsq(0) = 0 * inf is NaN, so the first bad column leaves a NaN on the
+// diagonal of L and pivot_block_16 finds it there after the block.  (A variant built around 1/d from v_rcp_f64, whose
+// dependent chain per column is 4 operations instead of 7, needs 6 more instructions per column and measured the same.)
 template <int J, int C>
-__device__ __forceinline__ void pivot_group(double (&a)[16], double (&x)[16], double naj, double nxj, RsqPipe &np)
+__device__ __forceinline__ void pivot_group(double (&a)[16], double (&x)[16], RsqPipe &np)
 {
     if constexpr (C < 16) {
-        fmac_bcast<C>(a[C], a[J], naj);                    // a[r][C] -= L[r][J] * L[C][J]
-        fmac_bcast<C>(x[C], a[J], nxj);                    // x[C]    -= L[C][J] * x[J]
+        fnmac_bcast<C>(a[C], a[J], a[J]);                  // a[r][C] -= L[r][J] * L[C][J]
+        fnmac_bcast<C>(x[C], a[J], x[J]);                  // x[C]    -= L[C][J] * x[J]
         np.step(C - J - 1);                                // C = J+1 carries step 0 (v_rsq), ... J+4 the last
-        pivot_group<J, C + 1>(a, x, naj, nxj, np);
+        pivot_group<J, C + 1>(a, x, np);
     }
 }
 
 template <int J>
-__device__ __forceinline__ void pivot_col(double (&a)[16], double (&x)[16], RsqPipe &rp, int &bad)
+__device__ __forceinline__ void pivot_col(double (&a)[16], double (&x)[16], RsqPipe &rp)
 {
     const double inv = rp.inv;
     a[J] *= inv;                                          // lane J: d * inv = sqrt(d)
@@ -87,16 +175,10 @@ __device__ __forceinline__ void pivot_col(double (&a)[16], double (&x)[16], RsqP
     if constexpr (J + 1 < 16) {
         RsqPipe np;
         const double l = mov_bcast_nop<J + 1>(a[J]), q = mov_bcast_nop<J + 1>(a[J + 1]);
-        double dn = fma(-l, l, q);
-        if (!(dn > 0.0)) {                                // not positive definite (LAPACK info = j + 2)
-            if (bad == 0) bad = J + 2;
-            dn = 1.0;
-        }
-        np.d = dn;
-        const double naj = -a[J], nxj = -x[J];
+        np.d = fma(-l, l, q);
         // (no scheduling fences inside the block: measured 24.4 us per 128-block against 26.9 with one per group and
         // 27.1 with one per column -- left alone, hipcc overlaps the head of column J+1 with the tail of column J)
-        pivot_group<J, J + 1>(a, x, naj, nxj, np);
+        pivot_group<J, J + 1>(a, x, np);
 #pragma unroll
         for (int k = 15 - J; k < 4; k++) np.step(k);      // columns with fewer than four groups finish the pipeline here
         rp = np;
@@ -119,56 +201,56 @@ __device__ __forceinline__ void pivot_block_16(double (*S)[PD_PITCH], double (*T
         a[c] = FROM_GLOBAL ? Ag[(int64_t)row * lda + c] : S[jb * 16 + row][jb * 16 + c];
         x[c] = (c == row) ? 1.0 : 0.0;
     }
-    int bad = 0;
+    constexpr int wave = 0;                 // (PD_STAMP)
+    (void)wave;
+    PD_STAMP(8 + jb * 8 + 6);
     __builtin_amdgcn_sched_barrier(0);      // measured: letting hipcc mix the block loads / stores into the column
-    RsqPipe rp;                             // chain costs ~35% of the pivot time
+    // the pivot chain shares its SIMD with another wave of the workgroup (trailing-tile MFMAs, LDS traffic): it issues first
+    __builtin_amdgcn_s_setprio(3);
+    RsqPipe rp;
     rp.d = bcast_lane(a[0], 0);
-    if (!(rp.d > 0.0)) {
-        bad = 1;
-        rp.d = 1.0;
-    }
     rp.step(0);
     rp.step(1);
     rp.step(2);
     rp.step(3);
-    pivot_col<0>(a, x, rp, bad);
-    pivot_col<1>(a, x, rp, bad);
-    pivot_col<2>(a, x, rp, bad);
-    pivot_col<3>(a, x, rp, bad);
-    pivot_col<4>(a, x, rp, bad);
-    pivot_col<5>(a, x, rp, bad);
-    pivot_col<6>(a, x, rp, bad);
-    pivot_col<7>(a, x, rp, bad);
-    pivot_col<8>(a, x, rp, bad);
-    pivot_col<9>(a, x, rp, bad);
-    pivot_col<10>(a, x, rp, bad);
-    pivot_col<11>(a, x, rp, bad);
-    pivot_col<12>(a, x, rp, bad);
-    pivot_col<13>(a, x, rp, bad);
-    pivot_col<14>(a, x, rp, bad);
-    pivot_col<15>(a, x, rp, bad);
+    pivot_col<0>(a, x, rp);
+    pivot_col<1>(a, x, rp);
+    pivot_col<2>(a, x, rp);
+    pivot_col<3>(a, x, rp);
+    pivot_col<4>(a, x, rp);
+    pivot_col<5>(a, x, rp);
+    pivot_col<6>(a, x, rp);
+    pivot_col<7>(a, x, rp);
+    pivot_col<8>(a, x, rp);
+    pivot_col<9>(a, x, rp);
+    pivot_col<10>(a, x, rp);
+    pivot_col<11>(a, x, rp);
+    pivot_col<12>(a, x, rp);
+    pivot_col<13>(a, x, rp);
+    pivot_col<14>(a, x, rp);
+    pivot_col<15>(a, x, rp);
     asm volatile("" : "+v"(a[15]), "+v"(x[15]));
     __builtin_amdgcn_sched_barrier(0);
-    if (bad != 0 && lane == 0) atomicCAS(info, 0, (int32_t)(info_col0 + jb * 16 + bad));
+    __builtin_amdgcn_s_setprio(0);
+    PD_STAMP(8 + jb * 8 + 7);
     if (lane < 16) {
+        // whole rows, unconditionally and 16 bytes at a time: the entries above the diagonal are dead values that nobody
+        // reads as data (the column store and the packed workspace take c <= row only; the next pivot blocks read their
+        // own tiles) -- the per-entry `c <= row` test cost a branch per store, 1260 cycles per pivot block
 #pragma unroll
-        for (int c = 0; c < 16; c++) {
-            if (c <= row) S[jb * 16 + row][jb * 16 + c] = a[c];
-            T[c][row] = x[c];
+        for (int c = 0; c < 16; c += 2) {
+            f64x2 w = {a[c], a[c + 1]};
+            *reinterpret_cast<f64x2 *>(&S[jb * 16 + row][jb * 16 + c]) = w;
+        }
+        // the inverse goes out TRANSPOSED (T[l][c] = inv(L_jj)[c][l], lane l holds column l of the inverse): again 16
+        // bytes per store; the readers index it as T[column][row]
+#pragma unroll
+        for (int c = 0; c < 16; c += 2) {
+            f64x2 w = {x[c], x[c + 1]};
+            *reinterpret_cast<f64x2 *>(&T[row][c]) = w;
         }
     }
 }
-
-// Phase stamps of wave 0 (scratch/potf2_stamps.hip compiles this file with -DGPT_PD_STAMPS; absent from the library).
-#ifdef GPT_PD_STAMPS
-__device__ long long *g_pd_stamps;
-#define PD_STAMP(i)                                                             \
-    do {                                                                        \
-        if (wave == 0 && lane == 0) g_pd_stamps[(i)] = (long long)__builtin_amdgcn_s_memtime(); \
-    } while (0)
-#else
-#define PD_STAMP(i) do { } while (0)
-#endif
 
 #define PD_THREADS 512
 #define TP_SP 18              // pitch of the per-wave 16x16 re-layout scratch of the TRSM kernels
@@ -196,6 +278,11 @@ __device__ __forceinline__ void potf2_body(double *__restrict__ A, int64_t lda, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fk = lane >> 4;
     constexpr int NB16 = PD_NB / 16;
+    // Roles.  Wave 0 runs the pivot chain.  A workgroup's waves go to the four SIMDs round-robin, so wave 4 shares wave
+    // 0's SIMD -- and the double-precision vector unit of a SIMD also executes its fp64 MFMAs: a partner busy with
+    // trailing tiles slows the pivot columns by a third (3440 against 2480 cycles in the stamps).  Wave 4 therefore is
+    // the STORE wave (LDS reads and global stores only); waves 1-3 and 5-7 are the six tile workers (role 1..6).
+    const int role = (wave == 0) ? 0 : (wave == 4) ? -1 : (wave < 4) ? wave : wave - 1;
 
     // ---- stage the block into LDS (waves 1..7) while wave 0 already factors the first pivot block from global ----
     if (wave == 0) {
@@ -225,39 +312,56 @@ __device__ __forceinline__ void potf2_body(double *__restrict__ A, int64_t lda, 
         PD_STAMP(8 + jb * 8 + 0);
         // (b) strip solve: X_ti = B_ti * inv(L_jj)^T for the 16-row tiles below the pivot block (waves 0..6)
         {
-            const int ti = jb + 1 + wave;
-            if (ti < NB16) {
-                f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            const int ti = jb + 1 + role;
+            if (role >= 0 && ti < NB16) {
+                f64x4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
                 double av[4], bv[4];
 #pragma unroll
                 for (int kk = 0; kk < 4; kk++) {
                     av[kk] = S[ti * 16 + fr][jb * 16 + fk + 4 * kk];
-                    bv[kk] = T[jb][fr][fk + 4 * kk];
+                    bv[kk] = T[jb][fk + 4 * kk][fr];
                 }
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);      // two chains of two
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; r++) S[ti * 16 + fk + 4 * r][jb * 16 + fr] = acc[r];
+                for (int r = 0; r < 4; r++) S[ti * 16 + fk + 4 * r][jb * 16 + fr] = acc[r] + acc2[r];
             }
         }
         PD_STAMP(8 + jb * 8 + 1);
         __syncthreads();
         PD_STAMP(8 + jb * 8 + 2);
-        // (c) wave 0: next pivot tile update + pivot; waves 1..6: the other trailing tiles; wave 7: column block jb of L
+        // (c) wave 0: next pivot tile update + pivot; the six workers: the other trailing tiles; store wave: column block jb of L
         //     (now final) goes to global memory, row-major and packed, together with inv(L_jj).
-        if (wave == PD_WAVES - 1) {
-            for (int r4 = jb * 16 + fk; r4 < PD_NB; r4 += 4) {                  // rows jb*16.., 16 columns each
-                const int c = jb * 16 + fr;
-                if (c <= r4) A[(int64_t)r4 * lda + c] = S[r4][c];
-            }
+        if (role < 0) {
+            // (stamps: written one row group at a time, each LDS read waited for before its global store, this wave
+            // took 8400 cycles at jb = 0 and set the step time; now every read of a batch is issued before the first
+            // store, the packed workspace -- what the TRSM consumers wait for -- goes first, and the row-major copy moves
+            // 16 bytes per lane)
             double *ip = invd + jb * 256, *lp = invd + GPT_WS_LOFF;
+            {
+                double tv[4];
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) ws_store<PUBLISH>(ip + kk * 64 + lane, T[jb][fr][fk + 4 * kk]);   // packed element (fr, fk + 4kk)
-            for (int j = jb + 1; j < NB16; j++) {                               // packed blocks (j, jb)
-                const int b = j * (j - 1) / 2 + jb;
+                for (int kk = 0; kk < 4; kk++) tv[kk] = T[jb][fk + 4 * kk][fr];             // packed element (fr, fk + 4kk)
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++)
-                    ws_store<PUBLISH>(lp + b * 256 + kk * 64 + lane, S[j * 16 + fr][jb * 16 + fk + 4 * kk]);
+                for (int kk = 0; kk < 4; kk++) ws_store<PUBLISH>(ip + kk * 64 + lane, tv[kk]);
+            }
+            for (int j0 = jb + 1; j0 < NB16; j0 += 3) {                                    // packed blocks (j, jb), j > jb
+                double pv[3][4];                 // (three blocks per batch: more live values made hipcc spill the pivot's registers)
+#pragma unroll
+                for (int jj = 0; jj < 3; jj++)
+                    if (j0 + jj < NB16) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) pv[jj][kk] = S[(j0 + jj) * 16 + fr][jb * 16 + fk + 4 * kk];
+                    }
+#pragma unroll
+                for (int jj = 0; jj < 3; jj++)
+                    if (j0 + jj < NB16) {
+                        const int j = j0 + jj, b = j * (j - 1) / 2 + jb;
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) ws_store<PUBLISH>(lp + b * 256 + kk * 64 + lane, pv[jj][kk]);
+                    }
             }
             if (PUBLISH) {
                 // everything step jb of a forward substitution needs is out: inv(L_jb,jb) just now, the blocks (jb, c < jb)
@@ -265,40 +369,81 @@ __device__ __forceinline__ void potf2_body(double *__restrict__ A, int64_t lda, 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 if (lane == 0) __hip_atomic_store(flag, flag_base + (unsigned)jb + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            // not positive definite (LAPACK info = first column whose pivot was not > 0): that column's diagonal entry of
+            // L is NaN (see pivot_col); looked for here, off the pivot wave
+            {
+                const double dg = S[jb * 16 + fr][jb * 16 + fr];
+                const unsigned long long m = __ballot(!(dg > 0.0)) & 0xffffull;
+                if (m != 0ull && lane == 0) atomicCAS(info, 0, (int32_t)(info_col0 + jb * 16 + __ffsll((long long)m)));
+            }
+            // column block jb of L, row-major: lane -> (row = lane / 8 of a group of eight rows, two columns)
+            {
+                const int c2 = jb * 16 + (lane & 7) * 2, rr = lane >> 3;
+                const int ngrp = (PD_NB - jb * 16) / 8;
+                const bool vec = (((uintptr_t)A & 15) == 0) && ((lda & 1) == 0);
+                for (int g0 = 0; g0 < ngrp; g0 += 4) {
+                    f64x2 w[4];
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+                        if (g0 + g < ngrp) w[g] = *reinterpret_cast<const f64x2 *>(&S[jb * 16 + (g0 + g) * 8 + rr][c2]);
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+                        if (g0 + g < ngrp) {
+                            const int r = jb * 16 + (g0 + g) * 8 + rr;
+                            double *dst = A + (int64_t)r * lda + c2;
+                            if (c2 + 1 <= r) {
+                                if (vec) *reinterpret_cast<f64x2 *>(dst) = w[g];
+                                else {
+                                    dst[0] = w[g][0];
+                                    dst[1] = w[g][1];
+                                }
+                            } else if (c2 == r) {
+                                dst[0] = w[g][0];
+                            }
+                        }
+                }
+            }
         } else if (jb + 1 < NB16) {
             const int rem = NB16 - 1 - jb;
             const int ntile = rem * (rem + 1) / 2;
-            const int first = (wave == 0) ? 0 : wave;
-            const int step = (wave == 0) ? ntile : (PD_WAVES - 2);
-            for (int t = first; t < ntile; t += step) {
-                int a_ = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-                while (a_ * (a_ + 1) / 2 > t) a_--;
-                while ((a_ + 1) * (a_ + 2) / 2 <= t) a_++;
-                const int b_ = t - a_ * (a_ + 1) / 2;
-                const int ti = jb + 1 + a_, tj = jb + 1 + b_;
-                f64x4 acc;
-#pragma unroll
-                for (int r = 0; r < 4; r++) acc[r] = S[ti * 16 + fk + 4 * r][tj * 16 + fr];
-                double av[4], bv[4];
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++) {
-                    av[kk] = -S[ti * 16 + fr][jb * 16 + fk + 4 * kk];
-                    bv[kk] = S[tj * 16 + fr][jb * 16 + fk + 4 * kk];
+            if (wave == 0) {
+                TileUpd u;                                  // the next pivot tile, then the pivot itself
+                u.load(S, jb + 1, jb + 1, jb, fr, fk);
+                u.mma();
+                u.store(S, fr, fk);
+            } else {
+                // waves 1..6: tiles t = wave, wave + 6, ...; two tiles in flight (independent MFMA chains and LDS
+                // round trips: the trailing tiles of the first steps, not the pivot, used to set the step time)
+                constexpr int STEP = PD_WAVES - 2;
+                int it_ = 0;
+                (void)it_;
+                if (jb == 0) PD_STAMP1(80);
+                for (int t = role; t < ntile; t += 2 * STEP) {
+                    int a0, b0, a1 = 0, b1 = 0;
+                    tri_decode(t, a0, b0);
+                    const bool two = t + STEP < ntile;
+                    if (two) tri_decode(t + STEP, a1, b1);
+                    TileUpd u0, u1;
+                    u0.load(S, jb + 1 + a0, jb + 1 + b0, jb, fr, fk);
+                    if (two) u1.load(S, jb + 1 + a1, jb + 1 + b1, jb, fr, fk);
+                    u0.mma();
+                    if (two) u1.mma();
+                    u0.store(S, fr, fk);
+                    if (two) u1.store(S, fr, fk);
+                    if (jb == 0) PD_STAMP1(81 + it_);
+                    it_++;
                 }
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; r++) S[ti * 16 + fk + 4 * r][tj * 16 + fr] = acc[r];
-                if (wave == 0) break;
             }
             PD_STAMP(8 + jb * 8 + 3);
             if (wave == 0) pivot_block_16<false>(S, T[jb + 1], jb + 1, lane, nullptr, 0, info, info_col0);
             PD_STAMP(8 + jb * 8 + 4);
         }
+        if (jb == 0) PD_STAMPW(86 + wave);
         __syncthreads();
         PD_STAMP(8 + jb * 8 + 5);
     }
     PD_STAMP(2);
+    PD_STAMP_DUMP();
 }
 
 __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restrict__ A, int64_t lda,

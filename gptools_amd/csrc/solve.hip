@@ -299,3 +299,63 @@ int launch_rowsumsq_sub(hipStream_t st, int64_t m, int64_t n, const double *V, i
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
+
+// ---- helpers of the one-process-per-GPU path (gpt_dev_pad_block / gpt_dev_panel_scalars, include/gpt_hip.h) ----
+__global__ void pad_block_kernel(double *__restrict__ A, int64_t lda, int64_t c0, int64_t nb, int64_t n_valid,
+                                 int64_t n_pad, const double *__restrict__ dy, double big)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = n_valid + blockIdx.y;
+    if (c >= nb || row >= n_pad) return;
+    const int64_t gc = c0 + c;
+    double v = 0.0;
+    if (row == n_valid && gc < n_valid) v = dy[gc];
+    else if (gc == row) v = (row == n_valid) ? big : 1.0;
+    A[row * lda + c] = v;
+}
+
+int launch_pad_block(hipStream_t st, double *A, int64_t lda, int64_t c0, int64_t nb, int64_t n_valid, int64_t n_pad,
+                     const double *dy, double big)
+{
+    if (n_pad <= n_valid || nb <= 0) return GPT_OK;
+    dim3 grid((unsigned)((nb + 255) / 256), (unsigned)(n_pad - n_valid));
+    hipLaunchKernelGGL(pad_block_kernel, grid, dim3(256), 0, st, A, lda, c0, nb, n_valid, n_pad, dy, big);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
+__global__ __launch_bounds__(256) void panel_scalars_kernel(const double *__restrict__ P, int64_t ldp, int64_t w,
+                                                            int64_t zrow, double *__restrict__ acc)
+{
+    __shared__ double s0[4], s1[4];
+    double a = 0.0, b = 0.0;
+    for (int64_t i = threadIdx.x; i < w; i += 256) {
+        a += log(P[i * ldp + i]);
+        if (zrow >= 0) {
+            const double z = P[zrow * ldp + i];
+            b = fma(z, z, b);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off);
+        b += __shfl_down(b, off);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        s0[wave] = a;
+        s1[wave] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        acc[0] += ((s0[0] + s0[1]) + s0[2]) + s0[3];
+        if (zrow >= 0) acc[1] += ((s1[0] + s1[1]) + s1[2]) + s1[3];
+    }
+}
+
+int launch_panel_scalars(hipStream_t st, const double *P, int64_t ldp, int64_t w, int64_t zrow, double *acc)
+{
+    if (w <= 0) return GPT_OK;
+    hipLaunchKernelGGL(panel_scalars_kernel, dim3(1), dim3(256), 0, st, P, ldp, w, zrow, acc);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}

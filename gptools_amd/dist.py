@@ -77,6 +77,33 @@ class PanelOps(object):
         device timeline (CPU test ops)."""
         return None
 
+    # -- small data movers / reductions.  The defaults are plain torch (the CPU test ops inherit them); the product
+    #    ops override all three with library kernels so that the queues of a GPU rank carry no framework kernels.
+    def copy2d(self, dst, src, q="panel"):
+        """dst <- src, two 2-D views of equal shape (staging a block column into a panel buffer)."""
+        dst.copy_(src)
+
+    def pad_block(self, A, lj, c0, nb, N, NP, y, big):
+        """Rows [N, NP) of the local block column ``lj`` (global first column ``c0``): augmented row y^T, unit diagonal on
+        the padding, ``big`` under the augmented row, zeros elsewhere."""
+        blk = A[N:, lj * nb:(lj + 1) * nb]
+        blk.zero_()
+        c1 = min(c0 + nb, N)
+        if c0 < N:
+            blk[0, :c1 - c0] = y[c0:c1]
+        p0 = max(c0, N)
+        if p0 < c0 + nb:
+            idx = torch.arange(p0, c0 + nb, device=A.device)
+            A[idx, lj * nb + (idx - c0)] = 1.0
+            if c0 <= N < c0 + nb:
+                A[N, lj * nb + (N - c0)] = big
+
+    def panel_scalars(self, buf, w, zrow, red, q="panel"):
+        """red[0] += sum(log diag(buf[:w, :w])); red[1] += |buf[zrow, :w]|^2."""
+        red[0] += torch.log(torch.diagonal(buf[:w, :w])).sum()
+        z = buf[zrow, :w]
+        red[1] += (z * z).sum()
+
     def gemm_nt_stair(self, m, nseg, seg_cols, k, alpha, A, lda, B, ldb, b_stride, row_step, beta, C, ldc, q="main"):
         """Default: one lower-trapezoid ``gemm_nt`` per column segment (8-byte elements)."""
         for s in range(nseg):
@@ -165,6 +192,19 @@ class HipPanelOps(PanelOps):
     def gemm_nt(self, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, q="main"):
         _lib.check(self.lib.gpt_dev_gemm_nt(self._ctx[q].handle, m, n, k, float(alpha), A, lda, B, ldb, float(beta),
                                             C, ldc, int(tri)))
+
+    def copy2d(self, dst, src, q="panel"):
+        assert dst.shape == src.shape and dst.stride(1) == 1 and src.stride(1) == 1
+        _lib.check(self.lib.gpt_dev_copy2d(self._ctx[q].handle, src.shape[0], src.shape[1], src.data_ptr(), src.stride(0),
+                                           dst.data_ptr(), dst.stride(0)))
+
+    def pad_block(self, A, lj, c0, nb, N, NP, y, big):
+        _lib.check(self.lib.gpt_dev_pad_block(self.ctx_main.handle, _ptr(A, 0, lj * nb), A.stride(0), c0, nb, N, NP,
+                                              y.data_ptr(), float(big)))
+
+    def panel_scalars(self, buf, w, zrow, red, q="panel"):
+        _lib.check(self.lib.gpt_dev_panel_scalars(self._ctx[q].handle, buf.data_ptr(), buf.stride(0), w, zrow,
+                                                  red.data_ptr()))
 
     def gemm_nt_stair(self, m, nseg, seg_cols, k, alpha, A, lda, B, ldb, b_stride, row_step, beta, C, ldc, q="main"):
         """All block columns a rank owns right of the panel in ONE launch (gpt_dev_gemm_nt_stair)."""
@@ -289,21 +329,13 @@ class DistributedLML(object):
         """Each rank builds its block columns of K_tot (lower part) plus the padding / augmented row."""
         N, nb, A = self.N, self.nb, self.A
         ld = A.stride(0)
-        if self.NP > N:
-            A[N:, :].zero_()
         for lj, J in enumerate(self.my_blocks):
             c0, c1 = J * nb, min((J + 1) * nb, N)
             if c0 < N:
                 self.ops.kbuild_block(kernel_id, params, self.X, self.n, c0, N, c0, c1, self.err, noise_var, diag_add,
                                       _ptr(A, c0, lj * nb), ld)
-                A[N, lj * nb: lj * nb + (c1 - c0)] = self.y[c0:c1]        # augmented row: y^T
-            # unit diagonal on the padding, a huge pivot under the augmented row (DESIGN.md)
-            p0 = max(c0, N)
-            if p0 < (J + 1) * nb:
-                idx = torch.arange(p0, (J + 1) * nb, device=A.device)
-                A[idx, lj * nb + (idx - c0)] = 1.0
-                if c0 <= N < (J + 1) * nb:
-                    A[N, lj * nb + (N - c0)] = BIG_PIVOT
+            # rows N..NP: augmented row y^T, unit diagonal on the padding, a huge pivot under the augmented row (DESIGN.md)
+            self.ops.pad_block(A, lj, c0, nb, N, self.NP, self.y, BIG_PIVOT)
 
     def _collectives_on(self):
         return self.world > 1 or self.force_collectives
@@ -352,7 +384,7 @@ class DistributedLML(object):
         m = self.NP - k * nb
         self._inv_panel = bool(allow_inv and self.inv_trsm and m >= self.inv_min_rows and m > nb)
         dst = self.S if self._inv_panel else buf
-        dst[:m].copy_(self.A[k * nb:, lk * nb:(lk + 1) * nb])
+        self.ops.copy2d(dst[:m], self.A[k * nb:, lk * nb:(lk + 1) * nb])
 
     def _staged(self, buf):
         return self.S if self._inv_panel else buf
@@ -366,7 +398,7 @@ class DistributedLML(object):
         nb, N, ops = self.nb, self.N, self.ops
         m = self.NP - k * nb
         if self._inv_panel:
-            buf[:nb].copy_(self.S[:nb])
+            ops.copy2d(buf[:nb], self.S[:nb])
             ops.potrf_panel(nb, nb, buf.data_ptr(), nb, self.invd, self.info, k * nb)
             ops.trinv(nb, buf.data_ptr(), nb, self.invd, self.Winv.data_ptr(), nb)
             ops.gemm_nt(m - nb, nb, nb, 1.0, _ptr(self.S, nb, 0), nb, self.Winv.data_ptr(), nb, 0.0, _ptr(buf, nb, 0), nb, 0,
@@ -383,9 +415,7 @@ class DistributedLML(object):
             w = min(nb, N - k * nb)
             if w <= 0:
                 continue
-            self.red[0] += torch.log(torch.diagonal(buf[:w, :w])).sum()
-            z = buf[N - k * nb, :w]
-            self.red[1] += (z * z).sum()
+            self.ops.panel_scalars(buf, w, N - k * nb, self.red)
         self._factored = []
 
     def _update_block(self, k, J, buf, C=None, ldc=None, q="main"):
@@ -623,8 +653,8 @@ class DistributedLML(object):
                         h = bl[1] * nb
                         lk = k // world
                         col = self.A[k * nb:, lk * nb:(lk + 1) * nb]
-                        buf[:h].copy_(col[:h])
-                        self.S[h:NP - k * nb].copy_(col[h:])
+                        ops.copy2d(buf[:h], col[:h])
+                        ops.copy2d(self.S[h:NP - k * nb], col[h:])
                     else:
                         self._stage_panel(k, buf, allow_inv=False)      # before any wait for panel k-1
                 src = self.S if inv else buf

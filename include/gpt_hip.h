@@ -249,6 +249,22 @@ int gpt_dev_trsm_rlt(gpt_ctx *ctx, int64_t m, int64_t n, const double *dL, int64
 int gpt_dev_trinv(gpt_ctx *ctx, int64_t n, const double *dL, int64_t ldl, const double *d_invd,
                   double *dW, int64_t ldw);
 
+/* Small helpers of the one-process-per-GPU path (gptools_amd/dist.py), so that its queues carry no generic framework
+ * kernels.  All asynchronous on the context's stream.
+ *   gpt_dev_copy2d       : dst (rows x cols, ldd) <- src (rows x cols, lds) -- staging a block column of the local matrix
+ *                          into a contiguous panel buffer.
+ *   gpt_dev_pad_block    : rows [n_valid, n_pad) of a block column whose first column has global index c0 (nb columns,
+ *                          row-major at dA = its element (row 0 of the matrix, column c0), row stride lda): the augmented row
+ *                          n_valid gets y[c0 + c] (c0 + c < n_valid), the diagonal of the padding 1, the pivot under the
+ *                          augmented row `big`, everything else 0 (layout of DESIGN.md section 3).
+ *   gpt_dev_panel_scalars: d_acc[0] += sum_{i < w} log P[i][i]; if zrow >= 0 also d_acc[1] += sum_{c < w} P[zrow][c]^2 --
+ *                          the two scalars of ll (ref gaussian_process.py:1463-1467) taken from a factored panel buffer
+ *                          (P = its diagonal block, row stride ldp); accumulated in a fixed order (one workgroup). */
+int gpt_dev_copy2d(gpt_ctx *ctx, int64_t rows, int64_t cols, const double *d_src, int64_t lds, double *d_dst, int64_t ldd);
+int gpt_dev_pad_block(gpt_ctx *ctx, double *dA, int64_t lda, int64_t c0, int64_t nb, int64_t n_valid, int64_t n_pad,
+                      const double *d_y, double big);
+int gpt_dev_panel_scalars(gpt_ctx *ctx, const double *dP, int64_t ldp, int64_t w, int64_t zrow, double *d_acc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,12 +44,23 @@ int main()
         printf("  jb: strip  barrier  tile-upd  pivot  barrier   (sum)\n");
         for (int jb = 0; jb < 8; jb++) {
             const long long *q = h + 8 + jb * 8;
-            if (jb < 7)
-                printf("  %d: %6lld %6lld %6lld %6lld %6lld   %6lld\n", jb, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3],
-                       q[5] - q[4], q[5] - q[0]);
+            if (jb < 7) {
+                const long long *qn = h + 8 + (jb + 1) * 8;       // the pivot of block jb+1 stamps into ITS slots 6, 7
+                printf("  %d: %6lld %6lld %6lld %6lld %6lld   %6lld   pivot = load %lld + columns %lld + store %lld\n", jb, q[1] - q[0],
+                       q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[5] - q[0], qn[6] - q[3], qn[7] - qn[6], q[4] - qn[7]);
+            }
             else
                 printf("  %d: %6lld %6lld (last: stores only) %6lld\n", jb, q[1] - q[0], q[2] - q[1], q[5] - q[2]);
         }
+    }
+    {
+        long long h[128];
+        hipMemcpy(h, dst, sizeof(h), hipMemcpyDeviceToHost);
+        printf("wave 1, step jb = 0: start-of-trailing %lld after wave 0's barrier stamp; iterations (2 tiles each):", h[80] - h[8 + 2]);
+        for (int i = 81; i < 86 && h[i]; i++) printf(" %lld", h[i] - h[i - 1]);
+        printf("\n  step jb = 0, end of phase (c) per wave, cycles after barrier:");
+        for (int w = 0; w < 8; w++) printf(" w%d %lld", w, h[86 + w] - h[8 + 2]);
+        printf("\n");
     }
     int info = -1;
     hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost);
