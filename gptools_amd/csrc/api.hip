@@ -49,8 +49,14 @@ struct gpt_ctx {
     bool own_stream = false;
     hipStream_t panel_stream = nullptr;
     hipStream_t helper_stream = nullptr;   // CU-masked to part of the reserved CUs (own streams only)
+    hipStream_t late_panel_stream = nullptr;   // panel stream of the chain-bound end: masked to the reserved CUs only
+    int64_t late_rows = 0;                 // panels with at most this many rows left run on it (0 = off)
     hipStream_t early_stream = nullptr;    // main stream of the update-bound head of a factorisation: fewer CUs reserved
     int64_t early_rows = 0;                // panels with more than this many rows left run their updates there (0 = off)
+    int64_t nb_early = 0, nb_switch_rows = 4608;   // see potrf_enqueue (panel widths)
+    int64_t purg_rows = 0;                 // > 0: while more rows than this remain, the panel stream does the "urgent" update itself
+    int64_t defer_rows = 0;             // chain-bound end: with at most this many rows left, the main stream's "rest" update of
+                                           // panel k starts only after the panel stream's first update of panel k+1 (0 = off)
     int helper_cus = 0;
     std::vector<hipEvent_t> events;       // sync-only events (look-ahead fork/join)
     hipEvent_t tev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -63,6 +69,8 @@ struct gpt_ctx {
     int tile = 0;
     int gemm_pad = 1024;
     int64_t fuse_trsm = 4096;          // panels with at most this many rows below the leaf use potf2_trsm_kernel (0 = never)
+    int leaf256 = 0;                   // 256-column leaves (potf2x2_trsm_kernel) where two 128-column leaves of a short panel follow each other
+    double *d_l10pk = nullptr;         // its scratch: the packed block between the two diagonal blocks (16384 doubles)
     unsigned *d_flag = nullptr;        // progress word of potf2_trsm_kernel (only ever raised)
     unsigned flag_epoch = 0;
     int helper_tf = 35;                // assumed rate of the helper stream, in 0.1 TFLOP/s per 24 CUs (0 = no helper);
@@ -305,10 +313,29 @@ static inline int64_t outer_width(const gpt_ctx *c, int64_t n)
     return (n <= 5120) ? 256 : (n <= 12288) ? 384 : 512;
 }
 
+// Two 128-column leaves at once (potf2x2_trsm_kernel): columns [lc, lc + 256) of the n x n matrix, m = n - lc - 256 rows
+// below; usable while the panel is short enough for the fused kernels (every workgroup takes a whole CU).
+static inline bool leaf256_ok(const gpt_ctx *c, int64_t rows_below)
+{
+    return c->leaf256 && c->fuse_trsm > 0 && !c->use_graph && rows_below >= 0 && rows_below + 128 <= c->fuse_trsm;
+}
+
+static int leaf256_factor(gpt_ctx *c, hipStream_t st, double *Ad, int64_t lda, int64_t rows_below, double *ws,
+                          int32_t *info, int64_t info_base, hipEvent_t done_ev)
+{
+    if (c->flag_epoch > 0x3fffff00u) {
+        GPT_HIP_CHECK(hipMemsetAsync(c->d_flag, 0, 64, st));
+        c->flag_epoch = 0;
+    }
+    c->flag_epoch += 32;
+    return launch_potf2x2_trsm(st, Ad, lda, ws, info, info_base, rows_below, c->d_l10pk, c->d_flag, c->flag_epoch, done_ev);
+}
+
 // Factor the block column Ap (m x w, diag block on top): recursive halving down to 128 columns.
 static int panel_rec(gpt_ctx *c, hipStream_t st, double *Ap, int64_t lda, int64_t m, int64_t w, double *invd,
                      int32_t *info, int64_t base)
 {
+    if (w == 256 && leaf256_ok(c, m - 256)) return leaf256_factor(c, st, Ap, lda, m - 256, invd, info, base, nullptr);
     if (w == 128) {
         const int64_t mb = m - 128;
         if (c->fuse_trsm > 0 && mb >= 128 && mb <= c->fuse_trsm && !c->use_graph) {
@@ -318,7 +345,7 @@ static int panel_rec(gpt_ctx *c, hipStream_t st, double *Ap, int64_t lda, int64_
                 GPT_HIP_CHECK(hipMemsetAsync(c->d_flag, 0, 64, st));
                 c->flag_epoch = 0;
             }
-            c->flag_epoch += 16;
+            c->flag_epoch += 32;           // (the 256-column leaf kernel raises the word by up to 17 per launch)
             return launch_potf2_trsm(st, Ap, lda, invd, info, base, mb, c->d_flag, c->flag_epoch);
         }
         GPT_TRY(launch_potf2_diag(st, Ap, lda, invd, info, base));
@@ -347,7 +374,7 @@ static int leaf_factor(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64
             GPT_HIP_CHECK(hipMemsetAsync(c->d_flag, 0, 64, st));
             c->flag_epoch = 0;
         }
-        c->flag_epoch += 16;
+        c->flag_epoch += 32;           // (the 256-column leaf kernel raises the word by up to 17 per launch)
         return launch_potf2_trsm(st, Ad, lda, ws, info, lc, m, c->d_flag, c->flag_epoch, done_ev);
     }
     GPT_TRY(launch_potf2_diag(st, Ad, lda, ws, info, lc));
@@ -389,15 +416,33 @@ static int panel_ext_ll(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int6
     return GPT_OK;
 }
 
+// `ext`: how many columns past the block column every leaf update reaches (GPT_PANEL_EXT, or 256 when the NEXT panel starts
+// with a 256-column leaf: that kernel reads both of its leaves' columns when it starts).
 static int panel_ext(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64_t n, int64_t c0, int64_t w,
-                     double *invd, int32_t *info, hipEvent_t wait_ev, hipEvent_t done_ev)
+                     double *invd, int32_t *info, hipEvent_t wait_ev, hipEvent_t done_ev, int64_t ext = GPT_PANEL_EXT,
+                     hipEvent_t first_ev = nullptr)
 {
+    // first_ev: recorded by the panel's FIRST update launch (see "deferred rest" in potrf_enqueue)
     if (c->inner == 1 || (c->inner == 2 && n - c0 <= c->inner_rows))
         return panel_ext_ll(c, st, A, lda, n, c0, w, invd, info, wait_ev, done_ev);
-    const int64_t cend = (c0 + w + GPT_PANEL_EXT < n) ? c0 + w + GPT_PANEL_EXT : n;
+    const int64_t cend = (c0 + w + ext < n) ? c0 + w + ext : n;
     for (int64_t lc = c0; lc < c0 + w; lc += 128) {
         double *Ad = A + lc * lda + lc;
         double *ws = invd + (lc / 128) * GPT_WS_BLOCK;
+        if (lc + 256 <= c0 + w && c->inner == 0 && leaf256_ok(c, n - lc - 256)) {
+            // two leaves in one launch, then ONE rank-256 update of what follows inside the panel + its extension
+            const int64_t r2 = lc + 256;
+            const bool last2 = (r2 == c0 + w) && done_ev;
+            GPT_TRY(leaf256_factor(c, st, Ad, lda, n - r2, ws, info, lc, last2 ? done_ev : nullptr));
+            if (lc == c0 && wait_ev) GPT_HIP_CHECK(hipStreamWaitEvent(st, wait_ev, 0));
+            if (cend > r2) {
+                GPT_TRY(gemm_nt(c, st, n - r2, cend - r2, 256, -1.0, A + r2 * lda + lc, lda, A + r2 * lda + lc, lda, 1.0,
+                                A + r2 * lda + r2, lda, 1, first_ev));
+                first_ev = nullptr;
+            }
+            lc += 128;
+            continue;
+        }
         const int64_t r1 = lc + 128;
         const bool last = (r1 == c0 + w) && done_ev;
         const int64_t m = n - r1;
@@ -407,7 +452,7 @@ static int panel_ext(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64_t
                 GPT_HIP_CHECK(hipMemsetAsync(c->d_flag, 0, 64, st));
                 c->flag_epoch = 0;
             }
-            c->flag_epoch += 16;
+            c->flag_epoch += 32;           // (the 256-column leaf kernel raises the word by up to 17 per launch)
             GPT_TRY(launch_potf2_trsm(st, Ad, lda, ws, info, lc, m, c->d_flag, c->flag_epoch, last ? done_ev : nullptr));
         } else {
             GPT_TRY(launch_potf2_diag(st, Ad, lda, ws, info, lc));
@@ -416,9 +461,11 @@ static int panel_ext(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64_t
             if (last && c->use_graph) GPT_HIP_CHECK(hipEventRecord(done_ev, st));
         }
         if (lc == c0 && wait_ev) GPT_HIP_CHECK(hipStreamWaitEvent(st, wait_ev, 0));
-        if (cend > r1)
+        if (cend > r1) {
             GPT_TRY(gemm_nt(c, st, n - r1, cend - r1, 128, -1.0, A + r1 * lda + lc, lda, A + r1 * lda + lc, lda, 1.0,
-                            A + r1 * lda + r1, lda, 1));
+                            A + r1 * lda + r1, lda, 1, first_ev));
+            first_ev = nullptr;
+        }
     }
     return GPT_OK;
 }
@@ -464,7 +511,10 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
     {
         int64_t c0 = 0, w = c->ramp ? 128 : nbo;
         while (c0 < n) {
-            if (w > nbo) w = nbo;
+            // (option nb_early: wider panels while more than nb_switch_rows rows remain -- the update-bound head of the
+            // factorisation -- and nbo in the chain-bound rest)
+            const int64_t cap = (c->nb_early > 0 && n - c0 > c->nb_switch_rows) ? c->nb_early : nbo;
+            if (w > cap || (!c->ramp)) w = cap;
             if (w > n - c0) w = n - c0;
             widths.push_back(w);
             c0 += w;
@@ -480,7 +530,7 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
     // (only where the updates dominate: at n = 8192 the helper costs 0.5-1 %, at 16384 / 32768 it gains 2 / 3 %)
     hipStream_t H = (c->helper_stream && !c->use_graph && c->helper_tf > 0 && n > 12288) ? c->helper_stream : nullptr;
     const double rate_s = 46e12, rate_h = 1e11 * (double)c->helper_tf * (double)c->helper_cus / 24.0;
-    hipEvent_t e_cu_prev = nullptr, e_help_prev = nullptr;
+    hipEvent_t e_cu_prev = nullptr, e_help_prev = nullptr, e_rest_prev = nullptr;
     int64_t c0 = 0, s_prev = 0;
     // Update-bound head (option early_rows): while more than early_rows rows remain, the trailing updates run on a
     // stream that leaves only a few CUs to the panel stream (the diagonal-block kernel needs ONE free CU; the fused
@@ -493,6 +543,17 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
         GPT_HIP_CHECK(hipEventRecord(e_k, S0));                     // the K build (and everything before) on the main stream
         GPT_HIP_CHECK(hipStreamWaitEvent(c->early_stream, e_k, 0));
     }
+    // Deferred rest (chain-bound end of the factorisation, option defer_rows).  There the panel stream sets the pace and the
+    // main stream has slack, yet its large "rest" update of panel k used to start right after the urgent one and shared
+    // the chip with the panel stream's first leaf update of panel k+1 -- which is ON the chain and ran 60 us instead of
+    // ~17 (profiles/r01_timeline_c3_N8192.txt).  The rest of panel k is therefore held back until that leaf update is
+    // done (one event), and is enqueued one loop iteration late so that the event is recorded before it is waited for.
+    const bool use_late = c->late_panel_stream && c->late_rows > 0 && !c->use_graph;
+    struct PendingRest { bool on; int64_t c0, w, u1, split; hipStream_t S; } pend = {false, 0, 0, 0, 0, nullptr};
+    auto launch_rest = [&](const PendingRest &r) -> int {
+        return gemm_nt(c, r.S, n - r.u1, r.split - r.u1, r.w, -1.0, A + r.u1 * lda + r.c0, lda, A + r.u1 * lda + r.c0, lda,
+                       1.0, A + r.u1 * lda + r.u1, lda, 1);
+    };
     for (size_t k = 0; k < widths.size(); k++) {
         const int64_t w = widths[k];
         if (use_early) {
@@ -510,12 +571,34 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
         hipEvent_t e_panel = get_event(c, 2 + 4 * k), e_cu = get_event(c, 3 + 4 * k), e_help = get_event(c, 4 + 4 * k);
         hipEvent_t e_sdone = get_event(c, 5 + 4 * k);
         if (!e_panel || !e_cu || !e_help || !e_sdone) return GPT_E_HIP;
-        GPT_TRY(panel_ext(c, P, A, lda, n, c0, w, invd, info, e_cu_prev, e_panel));
+        // reach of the leaf updates past a panel: 256 columns if the panel that follows starts with a 256-column leaf
+        auto ext_after = [&](int64_t cstart, int64_t wnext) -> int64_t {
+            return (wnext >= 256 && c->inner == 0 && leaf256_ok(c, n - cstart - 256)) ? 256 : GPT_PANEL_EXT;
+        };
+        const int64_t ext_k = ext_after(c0 + w, wn);
+        const int64_t wnn = (k + 2 < widths.size()) ? widths[k + 2] : 0;
+        const int64_t ext_k1 = ext_after(c0 + w + wn, wnn);
+        if (use_late && P == c->panel_stream && n - c0 <= c->late_rows) {
+            hipEvent_t e_pl = get_event(c, 6 + 4 * widths.size());
+            if (!e_pl) return GPT_E_HIP;
+            GPT_HIP_CHECK(hipEventRecord(e_pl, P));
+            GPT_HIP_CHECK(hipStreamWaitEvent(c->late_panel_stream, e_pl, 0));
+            P = c->late_panel_stream;
+        }
+        hipEvent_t e_first = pend.on ? get_event(c, 8 + 4 * widths.size() + k) : nullptr;
+        if (pend.on && !e_first) return GPT_E_HIP;
+        GPT_TRY(panel_ext(c, P, A, lda, n, c0, w, invd, info, e_cu_prev, e_panel, ext_k, e_first));
+        if (pend.on) {
+            GPT_HIP_CHECK(hipStreamWaitEvent(pend.S, e_first, 0));
+            GPT_TRY(launch_rest(pend));
+            pend.on = false;
+        }
         e_cu_prev = nullptr;
-        const int64_t u0 = c0 + w + GPT_PANEL_EXT;
+        const int64_t u0 = c0 + w + ext_k;
         if (u0 < n) {
-            // urgent: the columns panel k+1 touches beyond its first leaf, [c0' + 128, c0' + w' + 128)
-            const int64_t u1 = (u0 + wn < n) ? u0 + wn : n;
+            // urgent: the columns panel k+1 touches beyond what panel k's own leaf updates reached,
+            // [c0' + ext_k, c0' + w' + ext_k+1)
+            const int64_t u1 = (c0 + w + wn + ext_k1 < n) ? c0 + w + wn + ext_k1 : n;
             int64_t split = n;                                        // S takes columns [u1, split), H [split, n)
             if (H && u1 < n) {
                 const double side0 = (double)(n - u1);
@@ -540,14 +623,37 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
                 GPT_HIP_CHECK(hipStreamWaitEvent(S, e_help_prev, 0));
                 waited = true;
             }
+            // Update-bound head (option purg_rows): the PANEL stream applies panel k to the columns panel k+1 touches
+            // ("urgent") itself, right behind the panel -- no event round trip panel -> main -> panel on the chain and
+            // one launch less on the main stream, which sets the pace there.  Both streams read-modify-write those
+            // columns (the main stream's rest of panel k-1 covers them too), so the panel stream waits for that rest.
+            const bool p_urgent = !H && c->purg_rows > 0 && n - c0 > c->purg_rows && !c->use_graph && u1 < n;
+            if (p_urgent) {
+                if (e_rest_prev) GPT_HIP_CHECK(hipStreamWaitEvent(P, e_rest_prev, 0));
+                GPT_TRY(gemm_nt(c, P, n - u0, u1 - u0, w, -1.0, A + u0 * lda + c0, lda, A + u0 * lda + c0, lda, 1.0,
+                                A + u0 * lda + u0, lda, 1));
+                e_cu_prev = nullptr;
+                hipEvent_t e_rest = get_event(c, 10 + 5 * widths.size() + k);
+                if (!e_rest) return GPT_E_HIP;
+                GPT_TRY(gemm_nt(c, S, n - u1, n - u1, w, -1.0, A + u1 * lda + c0, lda, A + u1 * lda + c0, lda, 1.0,
+                                A + u1 * lda + u1, lda, 1, e_rest));
+                e_rest_prev = e_rest;
+                c0 += w;
+                continue;
+            }
+            e_rest_prev = nullptr;
             GPT_TRY(gemm_nt(c, S, n - u0, u1 - u0, w, -1.0, A + u0 * lda + c0, lda, A + u0 * lda + c0, lda, 1.0,
                             A + u0 * lda + u0, lda, 1, e_cu));
             e_cu_prev = e_cu;
             if (u1 < n) {
                 if (e_help_prev && !waited) GPT_HIP_CHECK(hipStreamWaitEvent(S, e_help_prev, 0));
                 e_help_prev = nullptr;
-                GPT_TRY(gemm_nt(c, S, n - u1, split - u1, w, -1.0, A + u1 * lda + c0, lda, A + u1 * lda + c0, lda, 1.0,
-                                A + u1 * lda + u1, lda, 1));
+                if (!H && c->defer_rows > 0 && n - c0 <= c->defer_rows && k + 1 < widths.size() && !c->use_graph) {
+                    pend = PendingRest{true, c0, w, u1, split, S};
+                } else {
+                    GPT_TRY(gemm_nt(c, S, n - u1, split - u1, w, -1.0, A + u1 * lda + c0, lda, A + u1 * lda + c0, lda, 1.0,
+                                    A + u1 * lda + u1, lda, 1));
+                }
                 if (split < n) {
                     s_prev = split;
                     e_help_prev = e_help;
@@ -556,6 +662,7 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
         }
         c0 += w;
     }
+    if (pend.on) GPT_TRY(launch_rest(pend));
     if (e_help_prev) GPT_HIP_CHECK(hipStreamWaitEvent(S, e_help_prev, 0));
     if (use_early && S_cur != S0) {
         hipEvent_t e_sw = get_event(c, 3 + 4 * widths.size());
@@ -648,7 +755,19 @@ extern "C" int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out)
             // helper stream: the reserved CUs except the first 8 (those stay free for the diagonal-block kernel, which
             // needs a whole CU's LDS).  While the trailing updates dominate, the panel stream leaves the reserved CUs
             // idle most of the time; a slice of every update runs there (potrf_enqueue).
-            int reserve_early = 8;
+            // NOTE: every extra stream of a context costs: with a FIFTH stream (main, panel, helper + two more) the
+            // runtime maps two of them to one hardware queue and the whole factorisation ran 2x slower (5.5 -> 10.7 ms at
+            // N=8192) even with the extra streams unused.  The experimental streams below are therefore created only on
+            // request (environment), never by default.
+            if (getenv("GPT_LATE_STREAM")) {   // the reserved CUs as a stream of their own (see potrf_enqueue)
+                std::vector<uint32_t> lm((ncu + 31) / 32, 0u);
+                for (int i = 0; i < reserve; i++) lm[i / 32] |= (1u << (i % 32));
+                if (masked && hipExtStreamCreateWithCUMask(&c->late_panel_stream, (uint32_t)lm.size(), lm.data()) != hipSuccess) {
+                    (void)hipGetLastError();
+                    c->late_panel_stream = nullptr;
+                }
+            }
+            int reserve_early = 0;
             if (const char *e = getenv("GPT_RESERVE_EARLY")) reserve_early = atoi(e);
             if (masked && reserve_early > 0 && reserve_early < reserve) {
                 std::vector<uint32_t> em((ncu + 31) / 32, 0u);
@@ -675,6 +794,7 @@ extern "C" int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out)
     for (int i = 0; i < 5; i++) GPT_HIP_CHECK(hipEventCreate(&c->tev[i]));
     GPT_HIP_CHECK(hipMalloc(&c->d_info, sizeof(int32_t)));
     GPT_HIP_CHECK(hipMalloc((void **)&c->d_flag, 64));
+    GPT_HIP_CHECK(hipMalloc((void **)&c->d_l10pk, 16384 * sizeof(double)));
     // (hipMemsetAsync on the context's stream, never hipMemset: one call on the legacy null stream and from then on
     // every kernel of this process starts ~40 us late on every stream -- measured on the block-cyclic engine,
     // 31 -> 41 ms per rank at N=32768 over 8 ranks, potf2 26 -> 45..90 us in the trace)
@@ -718,12 +838,14 @@ extern "C" int gpt_ctx_destroy(gpt_ctx *c)
         if (c->tev[i]) hipEventDestroy(c->tev[i]);
     if (c->d_info) hipFree(c->d_info);
     if (c->d_flag) hipFree(c->d_flag);
+    if (c->d_l10pk) hipFree(c->d_l10pk);
     if (c->d_scal) hipFree(c->d_scal);
     if (c->h_scal) hipHostFree(c->h_scal);
     if (c->h_info) hipHostFree(c->h_info);
     hipStreamDestroy(c->panel_stream);
     if (c->helper_stream) hipStreamDestroy(c->helper_stream);
     if (c->early_stream) hipStreamDestroy(c->early_stream);
+    if (c->late_panel_stream) hipStreamDestroy(c->late_panel_stream);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
     return GPT_OK;
@@ -745,10 +867,16 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "gemm_pad")) c->gemm_pad = (int)value;
     else if (!strcmp(key, "ramp")) c->ramp = value ? 1 : 0;
     else if (!strcmp(key, "early_rows")) c->early_rows = value;
+    else if (!strcmp(key, "defer_rows")) c->defer_rows = value;
+    else if (!strcmp(key, "late_rows")) c->late_rows = value;
+    else if (!strcmp(key, "purg_rows")) c->purg_rows = value;
+    else if (!strcmp(key, "nb_early")) c->nb_early = value;
+    else if (!strcmp(key, "nb_switch_rows")) c->nb_switch_rows = value;
     else if (!strcmp(key, "inner")) c->inner = (int)value;
     else if (!strcmp(key, "inner_rows")) c->inner_rows = value;
     else if (!strcmp(key, "helper_tf")) c->helper_tf = (int)value;
     else if (!strcmp(key, "fuse_trsm")) c->fuse_trsm = value;
+    else if (!strcmp(key, "leaf256")) c->leaf256 = value ? 1 : 0;
     else if (!strcmp(key, "tile")) {
         if (value != 0 && value != 64 && value != 65 && value != 128 && value != 129) {
             gpt_set_error("tile must be 0, 64 or 128");
@@ -1081,7 +1209,8 @@ static int fit_terms(gpt_ctx *c, const std::vector<KParams> &terms, double noise
     }
     // The columns the first panel touches are built first so that its pivot chain overlaps the rest of the build.
     GPT_TRY(launch_fill_pad(st, c->dA, NP, N, NP, c->d_y, 1e300));
-    int64_t head = round_up((c->ramp ? 128 : outer_width(c, NP)) + GPT_PANEL_EXT, 256);   // what panel 0 touches
+    const int64_t w0 = (c->nb_early > outer_width(c, NP)) ? c->nb_early : outer_width(c, NP);
+    int64_t head = round_up((c->ramp ? 128 : w0) + (c->leaf256 ? 256 : GPT_PANEL_EXT), 256);   // what panel 0 touches
     hipEvent_t e_head = nullptr;
     if (c->lookahead && !c->use_graph && head < N && (e_head = get_event(c, 0)) != nullptr) {
         GPT_TRY(kbuild_terms(c, st, terms, 1, c->dX, c->dn, N, c->dX, c->dn, head, 1, 0, 0, c->d_erry, noise_var, diag_add,

@@ -70,6 +70,8 @@ int launch_gemm_nt_stair(hipStream_t st, int64_t m, int64_t nseg, int64_t seg_co
                          hipEvent_t ev1 = nullptr);
 int launch_potf2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
                       unsigned *flag, unsigned flag_base, hipEvent_t done = nullptr);
+int launch_potf2x2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
+                        double *l10pk, unsigned *flag, unsigned flag_base, hipEvent_t done = nullptr);
 int launch_trsm_panel(hipStream_t st, int64_t m, const double *L, int64_t ldl, const double *invd,
                       double *B, int64_t ldb, hipEvent_t done = nullptr);
 #define GPT_GRAD_MAXH 8

@@ -265,7 +265,9 @@ __device__ __forceinline__ void ws_store(double *p, double v)
     else *p = v;
 }
 
-template <bool PUBLISH>
+// STAGED: the 128x128 block is already in LDS (S), written by this workgroup and followed by a barrier (the second
+// diagonal block of the 256-column leaf kernel); otherwise it is staged from global memory here.
+template <bool PUBLISH, bool STAGED = false>
 __device__ __forceinline__ void potf2_body(double *__restrict__ A, int64_t lda, double *__restrict__ invd, int32_t *info,
                                            int64_t info_col0, unsigned *flag, unsigned flag_base)
 {
@@ -285,7 +287,9 @@ __device__ __forceinline__ void potf2_body(double *__restrict__ A, int64_t lda, 
     const int role = (wave == 0) ? 0 : (wave == 4) ? -1 : (wave < 4) ? wave : wave - 1;
 
     // ---- stage the block into LDS (waves 1..7) while wave 0 already factors the first pivot block from global ----
-    if (wave == 0) {
+    if (STAGED) {
+        if (wave == 0) pivot_block_16<false>(S, T[0], 0, lane, nullptr, 0, info, info_col0);
+    } else if (wave == 0) {
         pivot_block_16<true>(S, T[0], 0, lane, A, lda, info, info_col0);
     } else {
         constexpr int NCH = PD_NB * PD_NB / 2;                  // 16-byte chunks
@@ -365,8 +369,11 @@ __device__ __forceinline__ void potf2_body(double *__restrict__ A, int64_t lda, 
             }
             if (PUBLISH) {
                 // everything step jb of a forward substitution needs is out: inv(L_jb,jb) just now, the blocks (jb, c < jb)
-                // in earlier rounds.  Release at agent scope, then raise the flag.
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                // in earlier rounds.  The packed workspace was written with agent-scope (write-through) stores by THIS
+                // wave: draining them (vmcnt(0)) before the flag is the whole hand-off -- a release fence would also write
+                // back every dirty line of the XCD's L2 (the row-major copies of L, 1.7-6 us per step), which the
+                // consumers never read.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_store(flag, flag_base + (unsigned)jb + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             // not positive definite (LAPACK info = first column whose pivot was not > 0): that column's diagonal entry of
@@ -541,6 +548,260 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// potf2x2_trsm_kernel: a 256-COLUMN leaf in one launch -- the chain-bound end of a factorisation spends its time in
+// launches (diagonal block 21 us, TRSM tail 8, rank-128 update 13.5, the gaps between them), not in arithmetic.
+//   Workgroup 0:  L00 = chol(A00) (potf2_body, published block by block)            flags base+1 .. base+8
+//                 L10 = A10 L00^-T: sixteen rows per wave, blocked substitution on MFMA with L00 and the inverses of its
+//                 16x16 diagonal blocks still in LDS; written to A and, packed in B-operand order, to `l10pk`   flag base+9
+//                 A11 -= L10 L10^T (36 lower tiles over the eight waves, operands from LDS), assembled in LDS
+//                 L11 = chol(A11) (potf2_body<.., STAGED>)                              flags base+10 .. base+17
+//   Workgroups 1..: 128 rows of the panel below the 256x256 block each (16 per wave), as in potf2_trsm_kernel:
+//                 X0 = B0 L00^-T trailing the first pivot chain, B1 -= X0 L10^T once L10 is out (the packed L10 is
+//                 copied to the workgroup's LDS first: 64 blocks, read by all eight waves), X1 = B1 L11^-T trailing the
+//                 second chain.
+// One launch does what took two diagonal-block launches, two TRSMs and a rank-128 update; the rank-256 update of the
+// columns to the right follows as one GEMM.  Same flag protocol as potf2_trsm_kernel (workgroup 0 waits for nobody).
+// ------------------------------------------------------------------------------------------------
+#define PD_L10PK (64 * 256)     // doubles of the packed L10 (64 blocks of 16x16)
+
+// Steps 0..7 of the forward substitution of one 128-column block for the 16 rows of a consumer wave: `acc` enters as
+// the right-hand side of step 0 and the tiles bt[jt0 .. jt0+7] are the block's right-hand sides; X tiles go to B.
+__device__ __forceinline__ void consumer_phase(const double *__restrict__ ws, unsigned *flag, unsigned fb, int jt0,
+                                               f64x4 (&bt)[16], double (&xa)[8][4], double (*X)[TP_SP],
+                                               double *__restrict__ B, int64_t ldb, int64_t row0, bool active, int tid,
+                                               int lane, int fr, int fk)
+{
+    constexpr int NB16 = PD_NB / 16;
+    const double *lpk = ws + GPT_WS_LOFF;
+    f64x4 acc = bt[jt0];
+#pragma unroll
+    for (int j = 0; j < NB16; j++) {
+        if (tid == 0) {
+            while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - fb) < j + 1)
+                __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+        if (!active) continue;
+        double dv[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+            dv[kk] = __hip_atomic_load(ws + j * 256 + kk * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int r = 0; r < 4; r++) X[fk + 4 * r][fr] = acc[r];
+        double av[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) av[kk] = X[fr][fk + 4 * kk];
+        f64x4 res = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) res = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], dv[kk], res, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            B[(row0 + fk + 4 * r) * ldb + (jt0 + j) * 16 + fr] = res[r];
+            X[fk + 4 * r][fr] = res[r];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) xa[j][kk] = -X[fr][fk + 4 * kk];
+        if (j + 1 < NB16) {
+            acc = bt[jt0 + j + 1];
+#pragma unroll
+            for (int c = 0; c <= j; c++) {
+                double lv[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++)
+                    lv[kk] = __hip_atomic_load(lpk + ((j + 1) * j / 2 + c) * 256 + kk * 64 + lane, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[c][kk], lv[kk], acc, 0, 0, 0);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(PD_THREADS) void potf2x2_trsm_kernel(double *__restrict__ A, int64_t lda,
+                                                                  double *__restrict__ invd, int32_t *info,
+                                                                  int64_t info_col0, int64_t m,
+                                                                  double *__restrict__ l10pk, unsigned *flag,
+                                                                  unsigned flag_base)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    constexpr int NB16 = PD_NB / 16;
+    if (blockIdx.x == 0) {
+        double (*S)[PD_PITCH] = reinterpret_cast<double (*)[PD_PITCH]>(smem);
+        typedef double TBuf[16][PD_TP];
+        TBuf *T = reinterpret_cast<TBuf *>(smem + PD_NB * PD_PITCH);
+        // ---- L00
+        potf2_body<true>(A, lda, invd, info, info_col0, flag, flag_base);
+        PD_STAMP(72);
+        // (potf2_body ends with a barrier: S = L00 row-major, T[j] = transposed inverses of its diagonal blocks)
+        // ---- L10 = A10 L00^-T, rows 16 wave .. 16 wave + 15.  The per-wave 16x16 re-layout scratch is a tile of S's
+        // dead upper triangle: (0, wave + 1) for waves 0..6, (1, 2) for wave 7.
+        double *A10 = A + (int64_t)PD_NB * lda;
+        const int xr = (wave < 7) ? 0 : 16, xc = (wave < 7) ? (wave + 1) * 16 : 32;
+        f64x4 xt[NB16];
+        double xa[NB16][4];
+#pragma unroll
+        for (int j = 0; j < NB16; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) xt[j][r] = A10[(int64_t)(16 * wave + fk + 4 * r) * lda + j * 16 + fr];
+        PD_STAMP(73);
+#pragma unroll
+        for (int j = 0; j < NB16; j++) {
+            f64x4 acc = xt[j];
+#pragma unroll
+            for (int c = 0; c < j; c++) {
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[c][kk], S[j * 16 + fr][c * 16 + fk + 4 * kk], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) S[xr + fk + 4 * r][xc + fr] = acc[r];
+            double av[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) av[kk] = S[xr + fr][xc + fk + 4 * kk];
+            f64x4 res = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) res = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], T[j][fk + 4 * kk][fr], res, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                A10[(int64_t)(16 * wave + fk + 4 * r) * lda + j * 16 + fr] = res[r];
+                S[xr + fk + 4 * r][xc + fr] = res[r];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) xa[j][kk] = -S[xr + fr][xc + fk + 4 * kk];
+            xt[j] = res;
+        }
+        PD_STAMP(74);
+        // packed L10 for the consumers: block (row tile = wave, column block j), element (fr, fk + 4 kk) at [kk][lane]
+#pragma unroll
+        for (int j = 0; j < NB16; j++)
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+                __hip_atomic_store(l10pk + ((wave * NB16 + j) * 256 + kk * 64 + lane), -xa[j][kk], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        // EVERY wave drains its own stores before the barrier: a workgroup-scope barrier does not wait for global stores
+        // (the waves of a workgroup share the CU's L1), so the flag of wave 4 could overtake another wave's part of L10
+        // (seen: the consumers of the second launch of a factorisation read the previous leaf's block)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (write-through stores: drained = visible, no release fence needed)
+        __syncthreads();                            // ... and every wave is done with L00 / the inverses in LDS
+        if (wave == 4 && lane == 0) __hip_atomic_store(flag, flag_base + 9u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- S <- L10 (rows 16 wave ..), then A11 -= L10 L10^T on the 36 lower tiles
+#pragma unroll
+        for (int j = 0; j < NB16; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) S[16 * wave + fk + 4 * r][j * 16 + fr] = xt[j][r];
+        double *A11 = A10 + PD_NB;
+        constexpr int NT = NB16 * (NB16 + 1) / 2, PERW = (NT + PD_WAVES - 1) / PD_WAVES;
+        f64x4 ct[PERW];
+        int tis[PERW], tjs[PERW];
+#pragma unroll
+        for (int q = 0; q < PERW; q++) {
+            const int t = wave + q * PD_WAVES;
+            tis[q] = 0;
+            tjs[q] = 0;
+            if (t < NT) {
+                tri_decode(t, tis[q], tjs[q]);
+#pragma unroll
+                for (int r = 0; r < 4; r++) ct[q][r] = A11[(int64_t)(tis[q] * 16 + fk + 4 * r) * lda + tjs[q] * 16 + fr];
+            }
+        }
+        PD_STAMP(75);
+        __syncthreads();                            // L10 complete in S
+        PD_STAMP(76);
+#pragma unroll
+        for (int q = 0; q < PERW; q++) {
+            const int t = wave + q * PD_WAVES;
+            if (t < NT) {
+                f64x4 c0 = ct[q], c1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < NB16; k++) {
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) {
+                        av[kk] = -S[tis[q] * 16 + fr][k * 16 + fk + 4 * kk];
+                        bv[kk] = S[tjs[q] * 16 + fr][k * 16 + fk + 4 * kk];
+                    }
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], c1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) ct[q][r] = c0[r] + c1[r];
+            }
+        }
+        PD_STAMP(77);
+        __syncthreads();                            // every wave is done reading L10 from S
+#pragma unroll
+        for (int q = 0; q < PERW; q++) {
+            const int t = wave + q * PD_WAVES;
+            if (t < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) S[tis[q] * 16 + fk + 4 * r][tjs[q] * 16 + fr] = ct[q][r];
+            }
+        }
+        __syncthreads();
+        PD_STAMP(78);
+        // ---- L11
+        potf2_body<true, true>(A11, lda, invd + GPT_WS_BLOCK, info, info_col0 + PD_NB, flag, flag_base + 9u);
+        PD_STAMP(79);
+        PD_STAMP_DUMP();
+        return;
+    }
+    // ---- consumers
+    double *Lq = smem;                                                          // packed L10, PD_L10PK doubles
+    double (*X)[TP_SP] = reinterpret_cast<double (*)[TP_SP]>(smem + PD_L10PK + wave * 16 * TP_SP);
+    double *B = A + (int64_t)2 * PD_NB * lda;
+    const int64_t row0 = ((int64_t)(blockIdx.x - 1) * PD_WAVES + wave) * 16;
+    const bool active = row0 < m;
+    f64x4 bt[2 * NB16];
+    double xa[NB16][4];
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 2 * NB16; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) bt[j][r] = B[(row0 + fk + 4 * r) * lda + j * 16 + fr];
+    }
+    consumer_phase(invd, flag, flag_base, 0, bt, xa, X, B, lda, row0, active, tid, lane, fr, fk);
+    // L10 (64 packed blocks) into this workgroup's LDS once it is out
+    if (tid == 0) {
+        while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - flag_base) < 9)
+            __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < PD_L10PK / PD_THREADS; h += 8) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            v[q] = __hip_atomic_load(l10pk + (h + q) * PD_THREADS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int q = 0; q < 8; q++) Lq[(h + q) * PD_THREADS + tid] = v[q];
+    }
+    __syncthreads();
+    if (active) {
+        // B1 -= X0 L10^T: tile c of the second block takes the eight column blocks of X0 (xa = -X0 in A-operand form)
+#pragma unroll
+        for (int c = 0; c < NB16; c++) {
+            f64x4 a0 = bt[NB16 + c], a1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < NB16; k++) {
+                const double *blk = Lq + (c * NB16 + k) * 256 + lane;
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k][0], blk[0], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k][1], blk[64], a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k][2], blk[128], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k][3], blk[192], a1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) bt[NB16 + c][r] = a0[r] + a1[r];
+        }
+    }
+    consumer_phase(invd + GPT_WS_BLOCK, flag, flag_base + 9u, NB16, bt, xa, X, B, lda, row0, active, tid, lane, fr, fk);
+}
+
 // The 135 KB of dynamic LDS the diagonal-block kernels ask for needs hipFuncAttributeMaxDynamicSharedMemorySize, which
 // is a property of the function ON ONE DEVICE: set once per (kernel, device), thread-safe (ll_batch and bench.py drive
 // two contexts from two host threads; a process may hold contexts on several GPUs).
@@ -548,7 +809,7 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
 static int ensure_big_lds(const void *fn, int which, size_t shmem)
 {
     static std::mutex mu;
-    static bool done[2][64];
+    static bool done[3][64];
     int dev = 0;
     GPT_HIP_CHECK(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) dev = 63;
@@ -573,6 +834,25 @@ int launch_potf2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int3
                                     info, info_base, m, A + 128 * lda, lda, flag, flag_base);
     else hipLaunchKernelGGL(potf2_trsm_kernel, dim3(grid), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base, m,
                             A + 128 * lda, lda, flag, flag_base);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
+// 256-column leaf: diagonal blocks at A and A + 128 lda + 128, m rows below them; invd = the two blocks' workspaces;
+// l10pk = PD_L10PK doubles of scratch; the flag word advances by up to 17 (the caller counts 32 per launch).
+int launch_potf2x2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
+                        double *l10pk, unsigned *flag, unsigned flag_base, hipEvent_t done)
+{
+    gpt_jitter(st);
+    size_t shmem = (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
+    const size_t cons = (size_t)(PD_L10PK + PD_WAVES * 16 * TP_SP) * sizeof(double);
+    if (cons > shmem) shmem = cons;
+    { int rc_ = ensure_big_lds(reinterpret_cast<const void *>(potf2x2_trsm_kernel), 2, shmem); if (rc_ != GPT_OK) return rc_; }
+    const unsigned grid = 1u + (unsigned)((m + 16 * PD_WAVES - 1) / (16 * PD_WAVES));
+    if (done) hipExtLaunchKernelGGL(potf2x2_trsm_kernel, dim3(grid), dim3(PD_THREADS), shmem, st, nullptr, done, 0, A, lda, invd,
+                                    info, info_base, m, l10pk, flag, flag_base);
+    else hipLaunchKernelGGL(potf2x2_trsm_kernel, dim3(grid), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base, m,
+                            l10pk, flag, flag_base);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }

@@ -62,6 +62,34 @@ int main()
         for (int w = 0; w < 8; w++) printf(" w%d %lld", w, h[86 + w] - h[8 + 2]);
         printf("\n");
     }
+    {   // ---- the 256-column leaf kernel on a (256 + m) x 256 panel, m = 1024
+        const int m = 1024, n2 = 256 + m, ld = 256;
+        std::vector<double> P((size_t)n2 * ld);
+        for (int i = 0; i < n2; i++)
+            for (int j = 0; j < 256; j++) P[(size_t)i * ld + j] = (i == j ? 300.0 : 0) + 0.5 * cos(i * 0.37 + j * 0.11) * cos(j * 0.37 + i * 0.11);
+        double *dP, *dws2, *dl10;
+        unsigned *dflag;
+        hipMalloc(&dP, P.size() * 8);
+        hipMalloc(&dws2, 2 * GPT_WS_BLOCK * 8);
+        hipMalloc(&dl10, 16384 * 8);
+        hipMalloc(&dflag, 64);
+        hipMemsetAsync(dflag, 0, 64, st);
+        for (int rep = 0; rep < 3; rep++) {
+            hipMemcpyAsync(dP, P.data(), P.size() * 8, hipMemcpyHostToDevice, st);
+            hipMemsetAsync(dst, 0, 128 * 8, st);
+            hipEventRecord(e0, st);
+            launch_potf2x2_trsm(st, dP, ld, dws2, dinfo, 0, m, dl10, dflag, 32u * (rep + 1), nullptr);
+            hipEventRecord(e1, st);
+            hipStreamSynchronize(st);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            long long h[128];
+            hipMemcpy(h, dst, sizeof(h), hipMemcpyDeviceToHost);
+            printf("potf2x2 rep %d: event %.1f us | WG0 cycles after first body: load A10 %lld, TRSM %lld, publish+S %lld, barrier %lld, SYRK %lld, "
+                   "barrier+S write %lld, second body %lld\n", rep, ms * 1e3, h[73] - h[72], h[74] - h[73], h[75] - h[74], h[76] - h[75],
+                   h[77] - h[76], h[78] - h[77], h[79] - h[78]);
+        }
+    }
     int info = -1;
     hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost);
     std::vector<double> L(n * n);
