@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libgpt_hip.so")
 
 GPT_OK = 0
 GPT_E_ARG, GPT_E_VALUE, GPT_E_NOTIMPL, GPT_E_HIP, GPT_E_NOMEM, GPT_E_STATE = -1, -2, -3, -4, -5, -6
-KERNEL_SE, KERNEL_M52, KERNEL_DIAGNOISE, KERNEL_ZERO, KERNEL_RQ = 0, 1, 2, 3, 4
+KERNEL_SE, KERNEL_M52, KERNEL_DIAGNOISE, KERNEL_ZERO, KERNEL_RQ, KERNEL_MATERN = 0, 1, 2, 3, 4, 5
 MAX_DIM = 16
 
 _dp = C.POINTER(C.c_double)

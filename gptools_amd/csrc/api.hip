@@ -191,6 +191,50 @@ static int make_kparams(int kernel_id, const double *params, int nparams, int D,
             kp->inv_l[d] = 1.0 / l;
             kp->inv_var[d] = 1.0 / (l * l);
         }
+    } else if (kernel_id == GPT_KERNEL_MATERN) {
+        // MaternKernel: [sigma_f, nu, l_1 .. l_D] (ref: matern.py:299-306); the Gamma-function constants the device code
+        // needs (Temme's series, the reference's small-y series at nu or nu -+ 0.001) are formed here, in libm
+        if (nparams != D + 2) {
+            gpt_set_error("kernel %d expects %d params, got %d", kernel_id, D + 2, nparams);
+            return GPT_E_ARG;
+        }
+        if (hyper_deriv >= 0) {
+            gpt_set_error("Hyperparameter derivatives have not been implemented!");      // ref: core.py:723-726
+            return GPT_E_NOTIMPL;
+        }
+        const double nu = params[1];
+        if (!(nu > 0.0) || !(nu < 60.0)) {
+            gpt_set_error("MaternKernel: the order nu must lie in (0, 60), got %g", nu);
+            return GPT_E_VALUE;
+        }
+        kp->sigma = params[0];
+        kp->alpha = nu;
+        for (int d = 0; d < D; d++) {
+            const double l = params[2 + d];
+            kp->l[d] = l;
+            kp->inv_l[d] = 1.0 / l;
+            kp->inv_var[d] = 1.0 / (l * l);
+        }
+        kp->m_cnu = pow(2.0, 1.0 - nu) / tgamma(nu);
+        kp->m_nint = (int)floor(nu + 0.5);
+        kp->m_mu = nu - (double)kp->m_nint;
+        kp->m_isint = (nu == floor(nu)) ? 1 : 0;
+        {
+            const double mu = kp->m_mu, mu2 = mu * mu;
+            kp->m_gampl = 1.0 / tgamma(1.0 + mu);
+            kp->m_gammi = 1.0 / tgamma(1.0 - mu);
+            kp->m_gam2 = 0.5 * (kp->m_gammi + kp->m_gampl);
+            // (1/Gamma(1-mu) - 1/Gamma(1+mu)) / (2 mu); near mu = 0 from the Taylor series of 1/Gamma(1+t)
+            kp->m_gam1 = (fabs(mu) < 1.0e-3)
+                             ? -(0.57721566490153286 + mu2 * (-0.042002635034095236 + mu2 * (-0.0072189432466630995)))
+                             : (kp->m_gammi - kp->m_gampl) / (2.0 * mu);
+        }
+        for (int q = 0; q < 2; q++) {
+            const double nus = kp->m_isint ? nu + (q == 0 ? -0.001 : 0.001) : nu;      // utils.py:1481-1483 (nu_step)
+            kp->m_nus[q] = nus;
+            kp->m_g[q] = tgamma(nus);
+            kp->m_gm[q] = tgamma(-nus);
+        }
     } else if (kernel_id == GPT_KERNEL_DIAGNOISE || kernel_id == GPT_KERNEL_ZERO) {
         if (nparams != 1) {
             gpt_set_error("noise kernels expect 1 param, got %d", nparams);
@@ -923,7 +967,7 @@ extern "C" int gpt_kpairs(gpt_ctx *c, int kernel_id, const double *params, int n
         GPT_TRY(check_m52_orders(ni, M, D));
         GPT_TRY(check_m52_orders(nj, M, D));
     }
-    if (kernel_id == GPT_KERNEL_RQ && M > 0) GPT_TRY(check_rq_orders(ni, M, nj, M, D, true));
+    if ((kernel_id == GPT_KERNEL_RQ || kernel_id == GPT_KERNEL_MATERN) && M > 0) GPT_TRY(check_rq_orders(ni, M, nj, M, D, true));
     if (M == 0) return GPT_OK;
     double *dXi, *dXj, *dout;
     int32_t *dni, *dnj;
@@ -962,7 +1006,8 @@ extern "C" int gpt_kbuild(gpt_ctx *c, int kernel_id, const double *params, int n
         GPT_TRY(check_m52_orders(ni, M, D));
         GPT_TRY(check_m52_orders(nj, P, D));
     }
-    if (kernel_id == GPT_KERNEL_RQ && M > 0 && P > 0 && ni && nj) GPT_TRY(check_rq_orders(ni, M, nj, P, D, false));
+    if ((kernel_id == GPT_KERNEL_RQ || kernel_id == GPT_KERNEL_MATERN) && M > 0 && P > 0 && ni && nj)
+        GPT_TRY(check_rq_orders(ni, M, nj, P, D, false));
     if (M == 0 || P == 0) return GPT_OK;
     if (!Xi || !ni || !Xj || !nj || !K_out) return GPT_E_ARG;
     double *dXi, *dXj, *dK;
@@ -1154,12 +1199,13 @@ extern "C" int gpt_fit_sum(gpt_ctx *c, int nterms, const int *kernel_ids, const 
     std::vector<KParams> terms((size_t)nterms);
     const double *p = params;
     for (int t = 0; t < nterms; t++) {
-        if (kernel_ids[t] != GPT_KERNEL_SE && kernel_ids[t] != GPT_KERNEL_M52 && kernel_ids[t] != GPT_KERNEL_RQ) {
-            gpt_set_error("gpt_fit: kernel_id must be SE, Matern52 or RationalQuadratic");
+        if (kernel_ids[t] != GPT_KERNEL_SE && kernel_ids[t] != GPT_KERNEL_M52 && kernel_ids[t] != GPT_KERNEL_RQ &&
+            kernel_ids[t] != GPT_KERNEL_MATERN) {
+            gpt_set_error("gpt_fit: kernel_id must be SE, Matern52, RationalQuadratic or Matern");
             return GPT_E_ARG;
         }
-        if (kernel_ids[t] == GPT_KERNEL_RQ && 2 * c->n_maxsum > GPT_RQ_MAXORD) {
-            gpt_set_error("RationalQuadraticKernel: derivative orders of a pair sum to %ld, the device builder supports %d",
+        if ((kernel_ids[t] == GPT_KERNEL_RQ || kernel_ids[t] == GPT_KERNEL_MATERN) && 2 * c->n_maxsum > GPT_RQ_MAXORD) {
+            gpt_set_error("RationalQuadratic / Matern kernel: derivative orders of a pair sum to %ld, the device builder supports %d",
                           2 * c->n_maxsum, GPT_RQ_MAXORD);
             return GPT_E_VALUE;
         }
@@ -1612,7 +1658,7 @@ extern "C" int gpt_predict(gpt_ctx *c, const double *Xstar, const int32_t *nstar
             break;
         }
     for (const auto &t : c->terms)
-        if (t.kernel_id == GPT_KERNEL_RQ) {
+        if (t.kernel_id == GPT_KERNEL_RQ || t.kernel_id == GPT_KERNEL_MATERN) {
             long ms = 0;
             for (int64_t i = 0; i < M; i++) {
                 long sn = 0;

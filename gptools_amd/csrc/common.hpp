@@ -50,6 +50,13 @@ struct KParams {
     double inv_l[GPT_MAX_DIM];  // 1 / l
     double inv_var[GPT_MAX_DIM];// 1 / l^2
     int noise_n[GPT_MAX_DIM];   // DiagonalNoiseKernel.n
+    // MaternKernel (general nu): nu = alpha; constants of make_kparams (api.hip)
+    double m_cnu;             // 2^(1-nu) / Gamma(nu)
+    double m_mu;              // nu - round(nu), |mu| <= 1/2
+    int m_nint;               // round(nu)
+    int m_isint;              // nu is an integer (the reference then averages nu -+ 0.001 near the origin)
+    double m_gampl, m_gammi, m_gam1, m_gam2;      // Temme's 1/Gamma(1 +- mu) and their combinations
+    double m_g[2], m_gm[2], m_nus[2];             // Gamma(nu_s), Gamma(-nu_s), nu_s for the small-y series (nu_s = nu, or nu -+ 0.001)
 };
 
 // ---- launchers implemented in the .hip files (all asynchronous on `st`) -------------------

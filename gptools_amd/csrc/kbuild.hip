@@ -190,6 +190,9 @@ int launch_kbuild(hipStream_t st, const KParams &kp, const double *dXi, const in
     case GPT_KERNEL_RQ:
         return kbuild_dispatch_d<GPT_KERNEL_RQ>(st, kp, dXi, dni, M, dXj, dnj, P, lower_only, i0, j0, d_err_y,
                                                 noise_var, diag_add, dK, ldk, accumulate);
+    case GPT_KERNEL_MATERN:
+        return kbuild_dispatch_d<GPT_KERNEL_MATERN>(st, kp, dXi, dni, M, dXj, dnj, P, lower_only, i0, j0, d_err_y,
+                                                    noise_var, diag_add, dK, ldk, accumulate);
     default:
         gpt_set_error("kbuild: unknown kernel_id %d", kp.kernel_id);
         return GPT_E_ARG;
@@ -227,6 +230,7 @@ int launch_kpairs(hipStream_t st, const KParams &kp, const double *dXi, const do
     case GPT_KERNEL_DIAGNOISE: return kpairs_dispatch_d<GPT_KERNEL_DIAGNOISE>(st, kp, dXi, dXj, dni, dnj, M, dout, accumulate);
     case GPT_KERNEL_ZERO: return kpairs_dispatch_d<GPT_KERNEL_ZERO>(st, kp, dXi, dXj, dni, dnj, M, dout, accumulate);
     case GPT_KERNEL_RQ: return kpairs_dispatch_d<GPT_KERNEL_RQ>(st, kp, dXi, dXj, dni, dnj, M, dout, accumulate);
+    case GPT_KERNEL_MATERN: return kpairs_dispatch_d<GPT_KERNEL_MATERN>(st, kp, dXi, dXj, dni, dnj, M, dout, accumulate);
     default:
         gpt_set_error("kpairs: unknown kernel_id %d", kp.kernel_id);
         return GPT_E_ARG;

@@ -220,6 +220,248 @@ __device__ __forceinline__ double rq_pair(const KParams &kp, const double *xi, c
     return s2 * ((njtot & 1) ? -v : v);
 }
 
+// ---- MaternKernel, general order nu (ref: gptools/kernel/matern.py:251-465 on ChainRuleKernel.__call__, core.py:691-816) ----
+//   k = sigma^2 f(y),  f(y) = 2^(1-nu)/Gamma(nu) y^(nu/2) K_nu(sqrt y),  y = 2 nu sum_d tau_d^2 / l_d^2.
+// Derivatives: Faa di Bruno over the partitions of the derivative multiset as for the rational-quadratic kernel (y is
+// quadratic in tau: singletons y1_d = 4 nu tau_d / l_d^2, equal-index pairs y2_d = 4 nu / l_d^2, matern.py:392-398), with
+//   f^(m)(y) = 2^(1-nu)/Gamma(nu) (-1/2)^m y^((nu-m)/2) K_(nu-m)(sqrt y)
+// -- the closed form of what the reference sums through the general Leibniz rule and Bell polynomials of kvp
+// (utils.py:1397-1476).  K of real order: Temme's method (J. Comput. Phys. 19 (1975) 324) for K_mu, K_mu+1 with
+// |mu| <= 1/2 -- power series for x <= 2, Steed's continued fraction above -- then the upward recurrence in the order; the
+// Gamma-function constants of the series come from the host (make_kparams).  Near the origin the reference's own choices
+// are reproduced: for 0 < y <= 5e-4 a one-term power series (utils.py:1493-1516), for integer nu the mean of nu -+ 0.001
+// there (utils.py:1480-1484, :1498-1502), at y == 0 the finite limit / +-inf (utils.py:1486-1492) and the term-by-term
+// masking of matern.py:437-446 (0 if 2 (nu - |pi|) + n1 > 0, else NaN).
+__device__ __forceinline__ void bessk_temme(const KParams &kp, double mu, double x, double &kmu, double &kmu1, bool negmu)
+{
+    const double PI = 3.14159265358979323846, EPS = 1.0e-16;
+    const double mu2 = mu * mu;
+    if (x <= 2.0) {
+        // negmu: the same constants serve -mu (1/Gamma(1 +- mu) swap, gam1 and gam2 are even in mu)
+        const double gampl = negmu ? kp.m_gammi : kp.m_gampl, gammi = negmu ? kp.m_gampl : kp.m_gammi;
+        const double lg = log(2.0 / x), sg = mu * lg;
+        const double fact2 = (fabs(sg) < 1.0e-8) ? 1.0 : sinh(sg) / sg;
+        const double pimu = PI * mu;
+        const double fact = (fabs(pimu) < 1.0e-8) ? 1.0 : pimu / sin(pimu);
+        double ff = fact * (kp.m_gam1 * cosh(sg) + kp.m_gam2 * fact2 * lg);
+        const double e = exp(sg);
+        double p = 0.5 * e / gampl, q = 0.5 / (e * gammi);
+        double c = 1.0, sum = ff, sum1 = p;
+        const double d = 0.25 * x * x;
+        for (int i = 1; i <= 500; i++) {
+            const double fi = (double)i;
+            ff = (fi * ff + p + q) / (fi * fi - mu2);
+            c *= d / fi;
+            p /= fi - mu;
+            q /= fi + mu;
+            const double del = c * ff;
+            sum += del;
+            sum1 += c * (p - fi * ff);
+            if (fabs(del) < fabs(sum) * EPS) break;
+        }
+        kmu = sum;
+        kmu1 = sum1 * 2.0 / x;
+    } else {
+        double a = mu2 - 0.25, b = 2.0 * (x + 1.0), Dd = 1.0 / b, f = Dd, delta = Dd;
+        double prev = 0.0, cur = 1.0, C = -a, Q = -a, S = 1.0 + Q * delta;
+        for (int i = 2; i <= 10000; i++) {
+            a -= 2.0 * (double)(i - 1);
+            b += 2.0;
+            Dd = 1.0 / (b + a * Dd);
+            delta *= b * Dd - 1.0;
+            f += delta;
+            const double qn = (prev - (b - 2.0) * cur) / a;
+            prev = cur;
+            cur = qn;
+            C *= -a / (double)i;
+            Q += C * qn;
+            S += Q * delta;
+            if (fabs(Q * delta) < fabs(S) * EPS) break;
+        }
+        kmu = sqrt(PI / (2.0 * x)) * exp(-x) / S;
+        kmu1 = kmu * (0.5 + mu + x + (mu2 - 0.25) * f) / x;
+    }
+}
+
+__device__ __forceinline__ double matern_poch(double a, int n)
+{
+    double p = 1.0;
+    for (int k = 0; k < n; k++) p *= a + (double)k;
+    return p;
+}
+
+// utils.py:1486-1516 for one non-integer order nus (with its Gamma(nus), Gamma(-nus)): y == 0 limit or the one-term series
+__device__ __forceinline__ double matern_small(double nus, double g, double gm, double y, int n, bool at_zero)
+{
+    const double t1 = g / (exp2(1.0 - nus + 2.0 * (double)n) * matern_poch(1.0 - nus, n));
+    if (at_zero) {
+        if ((double)n > nus) return gm * matern_poch(1.0 + nus - (double)n, n) * (double)INFINITY;
+        return t1;
+    }
+    return t1 + gm * matern_poch(1.0 + nus - (double)n, n) * exp((nus - (double)n) * log(y)) / exp2(1.0 + nus);
+}
+
+// F[m] = f^(m)(y) for m = 1 .. deg (y >= 0)
+__device__ __forceinline__ void matern_F(const KParams &kp, double y, int deg, double (&F)[GPT_RQ_MAXORD + 1])
+{
+    const double nu = kp.alpha;
+    if (y > 5.0e-4) {
+        const double z = sqrt(y), lz = log(z);
+        // orders nu - m = mu + (nint - m): non-negative offsets by the upward recurrence from (K_mu, K_mu+1); negative
+        // offsets are orders (-mu) + j of the mirrored base
+        double ka, kb;
+        bessk_temme(kp, kp.m_mu, z, ka, kb, false);
+        const int jtop = kp.m_nint - 1;                       // largest offset needed (m = 1)
+        double kup[GPT_RQ_MAXORD + 1];                        // kup[m] = K_(nu-m) where nint - m >= 0
+        {
+            // walk up to offset jtop, remembering the offsets nint - m >= 0
+            double k0 = ka, k1 = kb;                          // offsets j, j+1 with j = 0
+            for (int m = 1; m <= deg; m++) kup[m] = 0.0;
+            for (int j = 0; j <= jtop || j == 0; j++) {
+                const int m = kp.m_nint - j;
+                if (m >= 1 && m <= deg) kup[m] = k0;
+                const double kn = k0 + 2.0 * (kp.m_mu + (double)(j + 1)) / z * k1;
+                k0 = k1;
+                k1 = kn;
+            }
+        }
+        bool need_neg = false;
+        for (int m = 1; m <= deg; m++) need_neg = need_neg || (kp.m_nint - m < 0);
+        double kdn[GPT_RQ_MAXORD + 1];
+        if (need_neg) {
+            double k0, k1;
+            bessk_temme(kp, -kp.m_mu, z, k0, k1, true);       // K_(-mu) (= K_mu), K_(1-mu)
+            for (int m = 1; m <= deg; m++) kdn[m] = 0.0;
+            for (int j = 0; j <= GPT_RQ_MAXORD; j++) {        // offset -j: order j - mu
+                const int m = kp.m_nint + j;
+                if (j >= 1 && m >= 1 && m <= deg) kdn[m] = k0;
+                const double kn = k0 + 2.0 * (-kp.m_mu + (double)(j + 1)) / z * k1;
+                k0 = k1;
+                k1 = kn;
+            }
+        }
+        double sgn = 1.0;
+        for (int m = 1; m <= deg; m++) {
+            sgn *= -0.5;
+            const double kv = (kp.m_nint - m >= 0) ? kup[m] : kdn[m];
+            F[m] = kp.m_cnu * sgn * exp((nu - (double)m) * lz) * kv;
+        }
+        return;
+    }
+    const bool z0 = (y == 0.0);
+    for (int m = 1; m <= deg; m++) {
+        double v = matern_small(kp.m_nus[0], kp.m_g[0], kp.m_gm[0], y, m, z0);
+        if (kp.m_isint) v = 0.5 * (v + matern_small(kp.m_nus[1], kp.m_g[1], kp.m_gm[1], y, m, z0));
+        F[m] = kp.m_cnu * v;
+    }
+}
+
+template <int D>
+__device__ __forceinline__ double matern_pair(const KParams &kp, const double *xi, const double *xj,
+                                              const int *ni, const int *nj)
+{
+    const double nu = kp.alpha, s2 = kp.sigma * kp.sigma;
+    double r2 = 0.0;
+    int ntot = 0, njtot = 0;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const double tau = xi[d] - xj[d];
+        const double t = (tau == 0.0) ? 0.0 : tau * kp.inv_l[d];
+        r2 = fma(t, t, r2);
+        ntot += ni[d] + nj[d];
+        njtot += nj[d];
+    }
+    const double y = 2.0 * nu * r2;
+    if (ntot == 0) {                                          // matern.py:322-325
+        if (r2 == 0.0) return s2;
+        const double z = sqrt(y);
+        double ka, kb;
+        bessk_temme(kp, kp.m_mu, z, ka, kb, false);
+        for (int j = 0; j < kp.m_nint; j++) {
+            const double kn = ka + 2.0 * (kp.m_mu + (double)(j + 1)) / z * kb;
+            ka = kb;
+            kb = kn;
+        }
+        return s2 * kp.m_cnu * exp(nu * log(z)) * ka;
+    }
+    double F[GPT_RQ_MAXORD + 1];
+    if (y == 0.0) {
+        // every tau_d is zero: partitions with singletons count 0 or NaN (matern.py:437-446), the all-pairs one survives
+        int jmax = 0;
+        bool all_even = true;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const int n = ni[d] + nj[d];
+            jmax += n / 2;
+            all_even = all_even && ((n & 1) == 0);
+        }
+        for (int J = 0; J <= jmax; J++) {
+            const int n1 = ntot - 2 * J, mblk = ntot - J;
+            if (n1 > 0 && 2.0 * (nu - (double)mblk) + (double)n1 <= 0.0) return (double)NAN;
+        }
+        if (!all_even) return s2 * ((njtot & 1) ? -0.0 : 0.0);
+        double fac = 1.0;
+        int mm = 0;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const int n = ni[d] + nj[d], j = n / 2;
+            double coef = 1.0, y2pow = 1.0;
+            const double y2 = 4.0 * nu * kp.inv_var[d];
+            for (int q = 1; q <= j; q++) {
+                coef = coef * (double)((n - 2 * q + 2) * (n - 2 * q + 1)) / (2.0 * (double)q);
+                y2pow *= y2;
+            }
+            fac *= coef * y2pow;
+            mm += j;
+        }
+        matern_F(kp, 0.0, mm, F);
+        const double v = F[mm] * fac;
+        return s2 * ((njtot & 1) ? -v : v);
+    }
+    // c[m]: coefficient of f^(m)(y) (host code rejects ntot > GPT_RQ_MAXORD)
+    double c[GPT_RQ_MAXORD + 1];
+#pragma unroll
+    for (int m = 0; m <= GPT_RQ_MAXORD; m++) c[m] = (m == 0) ? 1.0 : 0.0;
+    int deg = 0;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const int n = ni[d] + nj[d];
+        if (n == 0) continue;
+        const double y2 = 4.0 * nu * kp.inv_var[d];
+        const double y1 = (xi[d] - xj[d]) * y2;
+        double pd[GPT_RQ_MAXORD + 1];
+#pragma unroll
+        for (int m = 0; m <= GPT_RQ_MAXORD; m++) pd[m] = 0.0;
+        double y1pow[GPT_RQ_MAXORD + 1];
+        y1pow[0] = 1.0;
+#pragma unroll
+        for (int m = 1; m <= GPT_RQ_MAXORD; m++) y1pow[m] = y1pow[m - 1] * y1;
+        double coef = 1.0, y2pow = 1.0;
+        for (int j = 0; 2 * j <= n; j++) {
+            if (j > 0) {
+                coef = coef * (double)((n - 2 * j + 2) * (n - 2 * j + 1)) / (2.0 * (double)j);
+                y2pow *= y2;
+            }
+            pd[n - j] = coef * y2pow * y1pow[n - 2 * j];
+        }
+        double cn[GPT_RQ_MAXORD + 1];
+#pragma unroll
+        for (int m = 0; m <= GPT_RQ_MAXORD; m++) cn[m] = 0.0;
+        for (int a = 0; a <= deg; a++)
+            for (int b = (n + 1) / 2; b <= n; b++)
+                if (a + b <= GPT_RQ_MAXORD) cn[a + b] = fma(c[a], pd[b], cn[a + b]);
+        deg += n;
+#pragma unroll
+        for (int m = 0; m <= GPT_RQ_MAXORD; m++) c[m] = cn[m];
+    }
+    if (deg > GPT_RQ_MAXORD) deg = GPT_RQ_MAXORD;
+    matern_F(kp, y, deg, F);
+    double v = 0.0;
+    for (int m = 1; m <= deg; m++)
+        if (c[m] != 0.0) v = fma(c[m], F[m], v);
+    return s2 * ((njtot & 1) ? -v : v);
+}
+
 template <int KID, int D>
 __device__ __forceinline__ double any_pair(const KParams &kp, const double *xi, const double *xj,
                                            const int *ni, const int *nj)
@@ -228,5 +470,6 @@ __device__ __forceinline__ double any_pair(const KParams &kp, const double *xi, 
     if (KID == GPT_KERNEL_M52) return m52_pair<D>(kp, xi, xj, ni, nj);
     if (KID == GPT_KERNEL_DIAGNOISE) return noise_pair<D>(kp, xi, xj, ni, nj);
     if (KID == GPT_KERNEL_RQ) return rq_pair<D>(kp, xi, xj, ni, nj);
+    if (KID == GPT_KERNEL_MATERN) return matern_pair<D>(kp, xi, xj, ni, nj);
     return 0.0;
 }

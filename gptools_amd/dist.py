@@ -497,8 +497,8 @@ class DistributedLML(object):
         # the derivative-order limits gpt_fit / gpt_fit_sum check on the host (the device API takes what it is given)
         if kernel_id == _lib.KERNEL_M52 and self._n_maxsum > 1:
             raise ValueError("Matern52Kernel only supports 0th and 1st order derivatives")      # ref matern.py:545-546
-        if kernel_id == _lib.KERNEL_RQ and 2 * self._n_maxsum > 8:
-            raise ValueError("RationalQuadraticKernel: derivative orders of a pair sum to %d, the device builder "
+        if kernel_id in (_lib.KERNEL_RQ, _lib.KERNEL_MATERN) and 2 * self._n_maxsum > 8:
+            raise ValueError("RationalQuadratic / Matern kernel: derivative orders of a pair sum to %d, the device builder "
                              "supports 8" % (2 * self._n_maxsum))
         if self.schedule == "pipelined" and self.lookahead:
             return self._fit_pipelined(kernel_id, params, y, err_y, noise_var, diag_factor)

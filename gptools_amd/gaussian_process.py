@@ -33,7 +33,7 @@ from .utils import CombinedBounds
 
 __all__ = ["GaussianProcess"]
 
-_NATIVE_FIT = (_lib.KERNEL_SE, _lib.KERNEL_M52, _lib.KERNEL_RQ)
+_NATIVE_FIT = (_lib.KERNEL_SE, _lib.KERNEL_M52, _lib.KERNEL_RQ, _lib.KERNEL_MATERN)
 
 
 def _combine(a, b, c=None):

@@ -50,6 +50,8 @@ extern "C" {
                                   * kernel/core.py:691-816); derivative orders of a pair may sum to GPT_RQ_MAXORD at most
                                   * (GPT_E_VALUE beyond; the reference has no limit); no hyper-parameter derivatives */
 #define GPT_RQ_MAXORD 8
+#define GPT_KERNEL_MATERN 5      /* MaternKernel (general order nu), params [sigma_f, nu, l_1 .. l_D] (ref: kernel/matern.py:251-465
+                                  * through ChainRuleKernel.__call__); same limit on the derivative orders of a pair */
 
 #define GPT_MAX_DIM 16      /* largest supported num_dim */
 #define GPT_WS_BLOCK 9216    /* doubles of factorisation workspace per 128 columns (d_invd arguments) */

@@ -12,6 +12,8 @@
  *   - kernel/matern.py:512-555, kernel/_matern.pyx:14-32, kernel/src/matern.c:61-186
  *                                       Matern52Kernel.__call__ / matern52()
  *   - kernel/noise.py:76-110, :123-152  DiagonalNoiseKernel / ZeroKernel
+ *   - kernel/matern.py:251-465, utils.py:1369-1527   MaternKernel (general nu): ChainRuleKernel with
+ *                                       f(y) = 2^(1-nu)/Gamma(nu) y^(nu/2) K_nu(sqrt y), y = 2 nu sum tau^2/l^2
  *   - gaussian_process.py:1535-1605     compute_Kij (row-major cartesian product)
  *   - gaussian_process.py:1418-1469     compute_K_L_alpha_ll
  *   - gaussian_process.py:965-1006      predict (non-MCMC branch)
@@ -23,6 +25,10 @@
  *   - scipy.linalg.cholesky / cho_solve / solve_triangular (LAPACK dpotrf/dpotrs/dtrtrs via
  *     scipy-openblas 0.3.28): restated as the textbook column-Crout Cholesky and
  *     forward/backward substitution; tests check it against scipy.linalg at rounding level.
+ *   - scipy.special.kv / kvp / gamma (scipy 1.15.3 -> AMOS zbesk, cephes Gamma), reached by MaternKernel through
+ *     utils.yn2Kn2Der / Kn2Der: restated as Temme's method for K_mu, K_mu+1 with |mu| <= 1/2 (N. M. Temme, J.
+ *     Comput. Phys. 19 (1975) 324: power series for x <= 2, Steed's continued fraction CF2 above) + the upward
+ *     recurrence in the order, and libm tgamma; checked against scipy.special.kv in tests/test_oracle_golden.py.
  * Pinning: the golden fixtures tests/golden/g1..g7 (generated from the imported reference by
  * tests/golden/gen_golden.py), the demo known answer (demo/demo.py:190-192) and, for
  * Matern-5/2, the reference's own matern.c compiled into oracle/_ref/.
@@ -37,6 +43,7 @@
 #define ORC_KERNEL_DIAGNOISE 2
 #define ORC_KERNEL_ZERO 3
 #define ORC_KERNEL_RQ 4
+#define ORC_KERNEL_MATERN 5     /* general-nu MaternKernel (kernel/matern.py:251-465) */
 #define ORC_RQ_MAXORD 16        /* combined derivative order of a pair this restatement accepts */
 
 #define ORC_OK 0
@@ -250,6 +257,207 @@ static double rq_pair(const double *params, int D, const double *xi, const doubl
     return sigma * sigma * ((njtot & 1) ? -v : v);                   /* core.py:746-749 */
 }
 
+/* ---- modified Bessel function of the second kind, real order (scipy.special.kv) ------------------------ */
+/* K_mu(x) and K_{mu+1}(x) for |mu| <= 1/2, x > 0.  Temme's method. */
+static void bessk_temme(double mu, double x, double *kmu, double *kmu1)
+{
+    const double PI = 3.14159265358979323846, EPS = 1.0e-16;
+    const double mu2 = mu * mu;
+    int i;
+    if (x <= 2.0) {
+        /* K_mu = sum c_k f_k, K_mu+1 = (2/x) sum c_k (p_k - k f_k), c_k = (x^2/4)^k / k! */
+        const double gampl = 1.0 / tgamma(1.0 + mu), gammi = 1.0 / tgamma(1.0 - mu);
+        const double gam2 = 0.5 * (gammi + gampl);
+        /* (1/Gamma(1-mu) - 1/Gamma(1+mu)) / (2 mu); near mu = 0 from 1/Gamma(1+t) = 1 + g t + a2 t^2 + a3 t^3 + ... */
+        const double gam1 = (fabs(mu) < 1.0e-3)
+            ? -(0.57721566490153286 + mu2 * (-0.042002635034095236 + mu2 * (-0.0072189432466630995)))
+            : (gammi - gampl) / (2.0 * mu);
+        const double lg = log(2.0 / x), sg = mu * lg;
+        const double fact2 = (fabs(sg) < 1.0e-8) ? 1.0 : sinh(sg) / sg;
+        const double pimu = PI * mu;
+        const double fact = (fabs(pimu) < 1.0e-8) ? 1.0 : pimu / sin(pimu);
+        double ff = fact * (gam1 * cosh(sg) + gam2 * fact2 * lg);
+        const double e = exp(sg);
+        double p = 0.5 * e / gampl, q = 0.5 / (e * gammi);
+        double c = 1.0, sum = ff, sum1 = p;
+        const double d = 0.25 * x * x;
+        for (i = 1; i <= 500; i++) {
+            double del;
+            ff = ((double)i * ff + p + q) / ((double)i * (double)i - mu2);
+            c *= d / (double)i;
+            p /= (double)i - mu;
+            q /= (double)i + mu;
+            del = c * ff;
+            sum += del;
+            sum1 += c * (p - (double)i * ff);
+            if (fabs(del) < fabs(sum) * EPS) break;
+        }
+        *kmu = sum;
+        *kmu1 = sum1 * 2.0 / x;
+    } else {
+        /* Steed's algorithm for the continued fraction CF2 (Thompson & Barnett 1986; Temme 1975) */
+        double a = mu2 - 0.25, b = 2.0 * (x + 1.0), D = 1.0 / b, f = D, delta = D;
+        double prev = 0.0, cur = 1.0, C = -a, Q = -a, S = 1.0 + Q * delta;
+        for (i = 2; i <= 10000; i++) {
+            double qn;
+            a -= 2.0 * (double)(i - 1);
+            b += 2.0;
+            D = 1.0 / (b + a * D);
+            delta *= b * D - 1.0;
+            f += delta;
+            qn = (prev - (b - 2.0) * cur) / a;
+            prev = cur;
+            cur = qn;
+            C *= -a / (double)i;
+            Q += C * qn;
+            S += Q * delta;
+            if (fabs(Q * delta) < fabs(S) * EPS) break;
+        }
+        *kmu = sqrt(PI / (2.0 * x)) * exp(-x) / S;
+        *kmu1 = *kmu * (0.5 + mu + x + (mu2 - 0.25) * f) / x;
+    }
+}
+
+/* K_v(x), any real order v (K_-v = K_v), x > 0 */
+double orc_bessel_k(double v, double x)
+{
+    double mu, k0, k1, kn;
+    int n, i;
+    v = fabs(v);
+    n = (int)floor(v + 0.5);
+    mu = v - (double)n;                         /* |mu| <= 1/2 */
+    bessk_temme(mu, x, &k0, &k1);
+    for (i = 1; i <= n; i++) {                  /* K_{w+1} = K_{w-1} + (2 w / x) K_w, upward: stable */
+        kn = k0 + 2.0 * (mu + (double)i) / x * k1;
+        k0 = k1;
+        k1 = kn;
+    }
+    return k0;
+}
+
+static double poch_prod(double a, int n)        /* utils.py:1369-1395 fixed_poch: (a)_n as a plain product */
+{
+    double p = 1.0;
+    int k;
+    for (k = 0; k < n; k++) p *= a + (double)k;
+    return p;
+}
+
+/* utils.py:1429-1518 yn2Kn2Der(nu, y, n) for n >= 1: the n-th derivative of y^(nu/2) K_nu(sqrt y) -- including the
+ * reference's choices near the origin: a ONE-term power series for 0 < y <= 5e-4 (:1493-1516), the mean of nu -+ 0.001
+ * for integer nu there and at y == 0 (:1480-1484, :1498-1502), +-inf / the finite limit at y == 0 (:1486-1492).
+ * For y > 5e-4 the reference sums the general Leibniz rule over derivatives of K_nu(sqrt y) (Bell polynomials of kvp,
+ * :1397-1427, :1472-1476); that sum IS (d/dy)^n [y^(nu/2) K_nu(sqrt y)] = (-1/2)^n y^((nu-n)/2) K_(nu-n)(sqrt y), which
+ * is what is evaluated here (checked against fixtures generated by the reference itself). */
+static double yn2kn2der_nonint_small(double nu, double y, int n, int at_zero)
+{
+    if (at_zero) {
+        if ((double)n > nu) return tgamma(-nu) * poch_prod(1.0 + nu - (double)n, n) * INFINITY;          /* :1487 */
+        return tgamma(nu) / (pow(2.0, 1.0 - nu + 2.0 * (double)n) * poch_prod(1.0 - nu, n));             /* :1489-1492 */
+    }
+    /* :1505-1516 with nterms = 1: k = n in the first sum, k = 0 in the second */
+    return tgamma(nu) * poch_prod(1.0, n) / (pow(2.0, 1.0 - nu + 2.0 * (double)n) * poch_prod(1.0 - nu, n) * tgamma((double)n + 1.0))
+         + tgamma(-nu) * poch_prod(1.0 + nu - (double)n, n) * pow(y, nu - (double)n) / pow(2.0, 1.0 + nu);
+}
+
+static double yn2kn2der(double nu, double y, int n)
+{
+    const double tol = 5.0e-4, nu_step = 0.001;
+    if (y > tol) {
+        const double z = sqrt(y);
+        double v = pow(y, 0.5 * (nu - (double)n)) * orc_bessel_k(nu - (double)n, z);
+        int k;
+        for (k = 0; k < n; k++) v *= -0.5;
+        return v;
+    }
+    if (nu == floor(nu))
+        return 0.5 * (yn2kn2der_nonint_small(nu - nu_step, y, n, y == 0.0) + yn2kn2der_nonint_small(nu + nu_step, y, n, y == 0.0));
+    return yn2kn2der_nonint_small(nu, y, n, y == 0.0);
+}
+
+/* MaternKernel.__call__ (kernel/matern.py:251-465 on ChainRuleKernel.__call__, core.py:691-816).  params =
+ * [sigma_f, nu, l_1 .. l_D].  As for the rational-quadratic kernel only partitions into singletons (factor
+ * y1_d = 4 nu tau_d / l_d^2, matern.py:394) and equal-index pairs (y2_d = 4 nu / l_d^2, :396) contribute; grouped by the
+ * number of pairs per dimension.  At y == 0 the reference masks term by term (matern.py:437-446): a partition with n1 > 0
+ * singletons and |pi| blocks counts 0 if 2 (nu - |pi|) + n1 > 0 and NaN otherwise. */
+#define ORC_MATERN_MAXORD 16
+static double matern_pair(const double *params, int D, const double *xi, const double *xj, const int32_t *ni,
+                          const int32_t *nj)
+{
+    const double sigma = params[0], nu = params[1];
+    const double *l = params + 2;
+    const double cnu = pow(2.0, 1.0 - nu) / tgamma(nu);
+    double c[ORC_MATERN_MAXORD + 1], pd[ORC_MATERN_MAXORD + 1], cn[ORC_MATERN_MAXORD + 1];
+    double r2l2 = 0.0, y, v = 0.0;
+    int d, deg = 0, ntot = 0, njtot = 0, m, a, b;
+    for (d = 0; d < D; d++) {
+        double tau = xi[d] - xj[d];
+        double t = (tau == 0.0) ? 0.0 : tau / l[d];                 /* core.py:416 */
+        r2l2 += t * t;
+        ntot += ni[d] + nj[d];
+        njtot += nj[d];
+    }
+    y = 2.0 * nu * r2l2;                                             /* matern.py:347-348 */
+    if (ntot == 0) {                                                 /* matern.py:322-325 */
+        if (r2l2 == 0.0) return sigma * sigma;
+        return sigma * sigma * cnu * pow(y, 0.5 * nu) * orc_bessel_k(nu, sqrt(y));
+    }
+    if (ntot > ORC_MATERN_MAXORD) return NAN;
+    if (y == 0.0) {
+        /* every tau_d is zero: terms with singletons vanish or are NaN (see above); the all-pairs term survives */
+        int all_even = 1, mm = 0, bad = 0;
+        double fac = 1.0;
+        /* does any (j_1..j_D) with n1 > 0 have 2 (nu - m) + n1 <= 0?  n1 = ntot - 2 J, m = ntot - J with J = sum j_d
+         * pairs: the smallest value of 2 nu - 2 m + n1 = 2 nu - ntot over those is reached at every J alike */
+        for (d = 0; d < D; d++) if ((ni[d] + nj[d]) & 1) all_even = 0;
+        {
+            int Jmax = 0, J;
+            for (d = 0; d < D; d++) Jmax += (ni[d] + nj[d]) / 2;
+            for (J = 0; J <= Jmax; J++) {
+                const int n1 = ntot - 2 * J, mblk = ntot - J;
+                if (n1 > 0 && 2.0 * (nu - (double)mblk) + (double)n1 <= 0.0) bad = 1;
+            }
+        }
+        if (bad) return NAN;
+        if (!all_even) return sigma * sigma * (((njtot & 1) ? -1.0 : 1.0) * 0.0);
+        for (d = 0; d < D; d++) {
+            const int n = ni[d] + nj[d], j = n / 2;
+            double coef = 1.0;
+            int q;
+            for (q = 1; q <= j; q++) coef = coef * (double)((n - 2 * q + 2) * (n - 2 * q + 1)) / (2.0 * (double)q);
+            fac *= coef * pow(4.0 * nu / (l[d] * l[d]), (double)j);
+            mm += j;
+        }
+        v = cnu * yn2kn2der(nu, 0.0, mm) * fac;
+        return sigma * sigma * ((njtot & 1) ? -v : v);
+    }
+    c[0] = 1.0;
+    for (d = 0; d < D; d++) {
+        const int n = ni[d] + nj[d];
+        double tau, y1, y2, coef = 1.0;
+        int j;
+        if (n == 0) continue;
+        tau = xi[d] - xj[d];
+        y1 = 4.0 * nu * tau / (l[d] * l[d]);
+        y2 = 4.0 * nu / (l[d] * l[d]);
+        for (m = 0; m <= n; m++) pd[m] = 0.0;
+        for (j = 0; 2 * j <= n; j++) {
+            if (j > 0) coef = coef * (double)((n - 2 * j + 2) * (n - 2 * j + 1)) / (2.0 * (double)j);
+            pd[n - j] = coef * pow(y2, (double)j) * pow(y1, (double)(n - 2 * j));
+        }
+        for (m = 0; m <= deg + n; m++) cn[m] = 0.0;
+        for (a = 0; a <= deg; a++)
+            for (b = 0; b <= n; b++) cn[a + b] += c[a] * pd[b];
+        deg += n;
+        for (m = 0; m <= deg; m++) c[m] = cn[m];
+    }
+    for (m = 1; m <= deg; m++) {
+        if (c[m] == 0.0) continue;
+        v += c[m] * cnu * yn2kn2der(nu, y, m);
+    }
+    return sigma * sigma * ((njtot & 1) ? -v : v);
+}
+
 static int all_zero(const int32_t *n, int64_t count)
 {
     int64_t i;
@@ -277,7 +485,7 @@ static int check_args(int kernel_id, const double *params, int nparams, int D, i
     if (kernel_id == ORC_KERNEL_SE || kernel_id == ORC_KERNEL_M52) {
         if (nparams != D + 1) return ORC_EARG;
         if (hyper_deriv >= nparams) return ORC_EARG;
-    } else if (kernel_id == ORC_KERNEL_RQ) {
+    } else if (kernel_id == ORC_KERNEL_RQ || kernel_id == ORC_KERNEL_MATERN) {
         if (nparams != D + 2) return ORC_EARG;
         if (hyper_deriv >= 0) return ORC_ENOTIMPL;                   /* core.py:723-726 */
     } else if (kernel_id == ORC_KERNEL_DIAGNOISE || kernel_id == ORC_KERNEL_ZERO) {
@@ -301,6 +509,8 @@ static double any_pair(int kernel_id, const double *params, const double *var, i
         return params[0] * params[0] * m52_pair(xi, xj, ni, nj, D, var);   /* matern.py:555 */
     case ORC_KERNEL_RQ:
         return rq_pair(params, D, xi, xj, ni, nj);
+    case ORC_KERNEL_MATERN:
+        return matern_pair(params, D, xi, xj, ni, nj);
     case ORC_KERNEL_DIAGNOISE: {                                            /* noise.py:103-110 */
         double val;
         if (!symmetric) return 0.0;

@@ -20,7 +20,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SE, M52, DIAGNOISE, ZERO, RQ = 0, 1, 2, 3, 4
-KERNEL_IDS = {"se": SE, "m52": M52, "diagnoise": DIAGNOISE, "zero": ZERO, "rq": RQ}
+MATERN = 5
+KERNEL_IDS = {"se": SE, "m52": M52, "diagnoise": DIAGNOISE, "zero": ZERO, "rq": RQ, "matern": MATERN}
 
 _lib = None
 _ref = None

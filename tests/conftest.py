@@ -40,3 +40,18 @@ def assert_close(a, b, rtol=1e-12, atol_scale=1e-13, msg=""):
     fin = np.isfinite(b)
     scale = np.abs(b[fin]).max() if fin.any() else 1.0
     np.testing.assert_allclose(a[fin], b[fin], rtol=rtol, atol=atol_scale * scale, err_msg=msg)
+
+
+def assert_close_nan(a, b, rtol=1e-12, atol_scale=1e-13, msg=""):
+    """assert_close for results that may hold NaN / +-inf by design (MaternKernel at tau == 0): non-finite entries must
+    agree in kind and sign, finite ones within rtol / atol_scale."""
+    a = np.asarray(a, dtype=float)
+    b = np.asarray(b, dtype=float)
+    assert a.shape == b.shape, "%s shape %s vs %s" % (msg, a.shape, b.shape)
+    np.testing.assert_array_equal(np.isnan(a), np.isnan(b), err_msg=msg + " (NaN pattern)")
+    inf = np.isinf(b)
+    np.testing.assert_array_equal(np.isinf(a), inf, err_msg=msg + " (inf pattern)")
+    np.testing.assert_array_equal(np.sign(a[inf]), np.sign(b[inf]), err_msg=msg + " (inf sign)")
+    fin = np.isfinite(b)
+    scale = np.abs(b[fin]).max() if fin.any() else 1.0
+    np.testing.assert_allclose(a[fin], b[fin], rtol=rtol, atol=atol_scale * scale, err_msg=msg)

@@ -15,6 +15,7 @@ Fixture groups follow SURVEY.md section 8(c):
   G6 demo known-answer (config 1)              (demo/demo.py:133-253)
   G7 tests/test_matern.py scenario, seeded     (tests/test_matern.py:4-31)
   G8 RationalQuadraticKernel: pairs, Gram, fit, predict (kernel/rational_quadratic.py:30-164, kernel/core.py:691-816)
+  G10 MaternKernel (general nu): pairs, Gram, fit, predict (kernel/matern.py:251-465, utils.py:1369-1527)
   G9 ProductKernel (k1 * k2) with derivative orders: pairs, fit, predict (kernel/core.py:587-671)
 """
 import os
@@ -580,8 +581,95 @@ def gen_g9():
     save("g9_product", **out)
 
 
+# ----------------------------------------------------------------------------
+# G10: general-order MaternKernel, params [sigma_f, nu, l_1 .. l_D]
+# ----------------------------------------------------------------------------
+def matern_kernel(d, params):
+    return gptools.MaternKernel(num_dim=d, initial_params=list(params), param_bounds=[(0.0, 1e3)] * (d + 2))
+
+
+def gen_g10():
+    rs = np.random.RandomState(1010)
+    out = {}
+    # pair level: half-integer, integer and general orders; derivative orders 0..1 per point and dimension (what
+    # regression with gradient observations uses), tau == 0 rows, rows inside the reference's series region y <= 5e-4
+    for d in (1, 2, 3):
+        for tag, nu in (("a", 2.5), ("b", 1.5), ("c", 3.2), ("d", 2.0), ("e", 0.5), ("f", 4.7), ("g", 1.0)):
+            M = 120
+            Xi = rs.rand(M, d)
+            Xj = rs.rand(M, d)
+            Xj[:12] = Xi[:12]                                          # tau == 0: finite limits, zeros, NaN (nu <= 1)
+            Xj[12:24] = Xi[12:24] + 2e-3 * (rs.rand(12, d) - 0.5)      # 0 < y <= 5e-4: one-term series / nu -+ 0.001
+            ni = rs.randint(0, 2, size=(M, d))
+            nj = rs.randint(0, 2, size=(M, d))
+            ni[rs.rand(M) < 0.3] = 0
+            nj[rs.rand(M) < 0.3] = 0
+            params = np.concatenate(([1.3, nu], 0.2 + 0.5 * rs.rand(d)))
+            k = matern_kernel(d, params)
+            key = "pairs_d%d%s_" % (d, tag)
+            out[key + "Xi"], out[key + "Xj"] = Xi, Xj
+            out[key + "ni"], out[key + "nj"] = ni.astype(np.int32), nj.astype(np.int32)
+            out[key + "params"] = params
+            out[key + "k"] = np.asarray(k(Xi, Xj, ni, nj), dtype=float)
+    # second derivatives on one side (combined order up to 4): the reference's own sums are accurate to ~1e-9 here
+    for d in (1, 2):
+        M = 80
+        Xi, Xj = rs.rand(M, d), rs.rand(M, d)
+        ni = rs.randint(0, 3, size=(M, d))
+        nj = rs.randint(0, 3, size=(M, d))
+        for m in range(M):
+            while ni[m].sum() + nj[m].sum() > 4:
+                w = ni if rs.rand() < 0.5 else nj
+                c = rs.randint(d)
+                if w[m, c] > 0:
+                    w[m, c] -= 1
+        params = np.concatenate(([0.8, 3.7], 0.3 + 0.4 * rs.rand(d)))
+        key = "pairs2_d%d_" % d
+        out[key + "Xi"], out[key + "Xj"] = Xi, Xj
+        out[key + "ni"], out[key + "nj"] = ni.astype(np.int32), nj.astype(np.int32)
+        out[key + "params"] = params
+        out[key + "k"] = np.asarray(matern_kernel(d, params)(Xi, Xj, ni, nj), dtype=float)
+    # Gram matrices with value / first-derivative rows
+    for d in (1, 2, 3):
+        N, P = 40, 20
+        X = rs.rand(N, d)
+        Xs = rs.rand(P, d)
+        Xs[3] = X[7]
+        n = deriv_pattern(rs, N, d, 0.3, 1)
+        ns = deriv_pattern(rs, P, d, 0.5, 1)
+        params = np.concatenate(([0.9, 2.2], 0.2 + 0.4 * rs.rand(d)))
+        gp = gptools.GaussianProcess(matern_kernel(d, params))
+        key = "gram_d%d_" % d
+        out[key + "X"], out[key + "Xs"] = X, Xs
+        out[key + "n"], out[key + "ns"] = n.astype(np.int32), ns.astype(np.int32)
+        out[key + "params"] = params
+        out[key + "K"] = gp.compute_Kij(X, None, n, None)
+        out[key + "Ks"] = gp.compute_Kij(X, Xs, n, ns)
+    # fit + predict (value and first-derivative observations / predictions); nu = 5/2 must agree with Matern52Kernel
+    for N, d, nu in ((64, 2, 2.5), (160, 3, 1.8)):
+        key = "fit_N%d_d%d_" % (N, d)
+        n = deriv_pattern(rs, N, d, 0.25, 1)
+        X, y = synth(rs, N, d, n)
+        params = np.concatenate(([1.0, nu], 0.3 * np.ones(d)))
+        gp = gptools.GaussianProcess(matern_kernel(d, params))
+        gp.add_data(X, y, err_y=0.05, n=n)
+        record_fit(out, key, gp, with_L=False)
+        M = 24
+        Xs = rs.rand(M, d)
+        ns = np.zeros((M, d), dtype=int)
+        ns[M // 2:, 0] = 1
+        mean, std = gp.predict(Xs, n=ns)
+        out[key + "X"], out[key + "y"], out[key + "n"] = X, y, n.astype(np.int32)
+        out[key + "params"] = params
+        out[key + "Xs"], out[key + "ns"] = Xs, ns.astype(np.int32)
+        out[key + "mean"], out[key + "std"] = np.asarray(mean), np.asarray(std)
+    save("g10_matern", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g34", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g34", "g5", "g6", "g7", "g8", "g9", "g10"]
+    if "g10" in which:
+        gen_g10()
     if "g1" in which:
         gen_g1()
     if "g2" in which:

@@ -196,6 +196,80 @@ def test_g8_rational_quadratic_kernel_call(g, golden, oracle, d):
         k(Xi, Xj, 0 * ni, 0 * nj, hyper_deriv=1)
 
 
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_g10_matern_general_nu_pairs(g, golden, oracle, d):
+    """General-order MaternKernel on the device (kpair.hpp matern_pair: Temme's K_nu, closed-form derivatives, the
+    reference's behaviour at / near tau = 0) against fixtures generated by the reference (kernel/matern.py:251-465) and,
+    at derivative orders where the reference's own sums lose digits, against the CPU oracle."""
+    from conftest import assert_close_nan
+    G = golden("g10_matern")
+    for tag in "abcdefg":
+        key = "pairs_d%d%s_" % (d, tag)
+        p = G[key + "params"]
+        k = g.MaternKernel(num_dim=d, initial_params=list(p), param_bounds=[(0.0, 1e3)] * (d + 2))
+        got = k(G[key + "Xi"], G[key + "Xj"], G[key + "ni"], G[key + "nj"])
+        assert_close_nan(got, G[key + "k"], rtol=5e-11, atol_scale=1e-13, msg=key)
+        assert k.nu == p[1]
+    rs = np.random.RandomState(100 + d)
+    for nu in (0.8, 2.5, 3.0, 6.3):
+        M = 300
+        p = np.concatenate(([1.1, nu], 0.3 + 0.5 * rs.rand(d)))
+        k = g.MaternKernel(num_dim=d, initial_params=list(p), param_bounds=[(0.0, 1e3)] * (d + 2))
+        Xi, Xj = rs.rand(M, d), rs.rand(M, d)
+        Xj[:20] = Xi[:20]
+        Xj[20:40] = Xi[20:40] + 1e-3 * (rs.rand(20, d) - 0.5)
+        ni, nj = np.zeros((M, d), int), np.zeros((M, d), int)
+        for m in range(M):                       # combined order 0 .. 8, spread at random
+            # (rows 20..39 lie in the reference's series region 0 < y <= 5e-4, where its one-term series adds terms of
+            # size y^(nu - m) with alternating signs: beyond order 2 the sum is cancellation noise in ANY arithmetic)
+            for _ in range(rs.randint(0, 3 if 20 <= m < 40 else 9)):
+                (ni if rs.rand() < 0.5 else nj)[m, rs.randint(d)] += 1
+        yv = 2.0 * nu * (((Xi - Xj) / p[2:]) ** 2).sum(axis=1)
+        keep = (yv > 5e-4) | (yv == 0.0) | ((ni + nj).sum(axis=1) <= 2)      # (random rows can fall into that region too)
+        assert keep.sum() > 280
+        assert_close_nan(k(Xi, Xj, ni, nj)[keep], oracle.kpairs("matern", p, Xi, Xj, ni, nj)[keep], rtol=1e-9,
+                         atol_scale=1e-12, msg="nu %g, orders <= 8" % nu)
+    ni[0, 0] += 9
+    with pytest.raises(ValueError):          # beyond what the device builder carries
+        k(Xi, Xj, ni, nj)
+    with pytest.raises(NotImplementedError):  # ref: core.py:723-726
+        k(Xi, Xj, 0 * ni, 0 * nj, hyper_deriv=1)
+
+
+def test_g10_matern_general_nu_gram_fit_predict(g, golden, oracle):
+    G = golden("g10_matern")
+    for d in (1, 2, 3):
+        key = "gram_d%d_" % d
+        p, X, Xs, n, ns = (G[key + s] for s in ("params", "X", "Xs", "n", "ns"))
+        gp = g.GaussianProcess(g.MaternKernel(num_dim=d, initial_params=list(p), param_bounds=[(0.0, 1e3)] * (d + 2)))
+        assert_close(gp.compute_Kij(X, None, n, None), G[key + "K"], rtol=5e-11, atol_scale=1e-13, msg=key + "K")
+        assert_close(gp.compute_Kij(X, Xs, n, ns), G[key + "Ks"], rtol=5e-11, atol_scale=1e-13, msg=key + "Ks")
+    for N, d in ((64, 2), (160, 3)):
+        key = "fit_N%d_d%d_" % (N, d)
+        p, X, y, n = (G[key + s] for s in ("params", "X", "y", "n"))
+        k = g.MaternKernel(num_dim=d, initial_params=list(p), param_bounds=[(0.0, 1e3)] * (d + 2))
+        gp = g.GaussianProcess(k, X=X, y=y, err_y=0.05, n=n)
+        gp.compute_K_L_alpha_ll()
+        assert gp._fast_fit_possible()              # the fused device path, not the pair-list fallback
+        assert abs(gp.ll - G[key + "ll"]) <= 1e-9 * abs(G[key + "ll"])
+        assert abs(np.log(np.diag(gp.L)).sum() - G[key + "logdet_half"]) <= 1e-10 * abs(G[key + "logdet_half"])
+        mean, std = gp.predict(G[key + "Xs"], n=G[key + "ns"])
+        np.testing.assert_allclose(mean, G[key + "mean"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(std ** 2, G[key + "std"] ** 2, rtol=0, atol=1e-6)
+        # a new order nu through update_hyperparameters: same number as the CPU oracle
+        p2 = p * np.array([1.1, 1.3] + [1.05] * d)
+        negll = gp.update_hyperparameters(p2)
+        ref = oracle.fit("matern", p2, X, n, y, 0.05 * np.ones(N))
+        ll_ref = ref["ll_data"] + gp.hyperprior(gp.params)
+        assert abs(-negll - ll_ref) <= 1e-9 * abs(ll_ref)
+    # nu = 5/2: the same Gram matrix as the native Matern52Kernel
+    key = "fit_N64_d2_"
+    p, X, n = G[key + "params"], G[key + "X"], G[key + "n"]
+    gp52 = g.GaussianProcess(g.Matern52Kernel(num_dim=2, initial_params=[p[0], p[2], p[3]], param_bounds=[(0.0, 1e3)] * 3))
+    gpm = g.GaussianProcess(g.MaternKernel(num_dim=2, initial_params=list(p), param_bounds=[(0.0, 1e3)] * 4))
+    assert_close(gpm.compute_Kij(X, None, n, None), gp52.compute_Kij(X, None, n, None), rtol=1e-10, atol_scale=1e-13)
+
+
 def test_g8_rational_quadratic_gram_fit_predict(g, golden, oracle):
     G = golden("g8_rq")
     for d in (1, 2, 3):

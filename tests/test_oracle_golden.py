@@ -84,6 +84,67 @@ def test_g8_rational_quadratic_gram_fit_predict(oracle, golden):
         np.testing.assert_allclose(s, g[key + "std"], rtol=0, atol=1e-9)
 
 
+def test_bessel_k_restatement_matches_scipy(oracle):
+    """scipy.special.kv (AMOS) is what MaternKernel reaches through utils.Kn2Der / yn2Kn2Der; the oracle restates it by
+    Temme's method + the upward recurrence: 1e-13 relative over the orders and arguments a Matern kernel can ask for."""
+    import ctypes as C
+    import scipy.special as sp
+    f = oracle.lib().orc_bessel_k
+    f.restype = C.c_double
+    f.argtypes = [C.c_double, C.c_double]
+    for v in (0.0, 0.1, 0.3, 0.5, 0.7, 1.0, 1.3, 1.5, 2.0, 2.5, 3.499, 3.5, 4.2, 7.5, -1.5, -0.25):
+        for x in (1e-6, 1e-3, 0.02236, 0.1, 0.5, 1.0, 1.9999, 2.0, 2.0001, 3.0, 10.0, 50.0, 300.0):
+            ref = sp.kv(v, x)
+            if ref == 0.0 or not np.isfinite(ref):
+                continue
+            assert abs(f(v, x) - ref) <= 2e-13 * abs(ref), (v, x)
+
+
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_g10_matern_general_nu_pairs(oracle, golden, d):
+    """MaternKernel of general order (ref kernel/matern.py:251-465 via ChainRuleKernel, utils.py:1369-1527): half-integer,
+    integer and general nu; first-derivative orders on both sides; tau == 0 rows (finite limits, exact zeros, NaN for
+    nu <= 1) and rows inside the reference's series region y <= 5e-4 -- all as the reference itself returns them."""
+    from conftest import assert_close_nan
+    g = golden("g10_matern")
+    for tag in "abcdefg":
+        key = "pairs_d%d%s_" % (d, tag)
+        got = oracle.kpairs("matern", g[key + "params"], g[key + "Xi"], g[key + "Xj"], g[key + "ni"], g[key + "nj"])
+        assert_close_nan(got, g[key + "k"], rtol=2e-11, atol_scale=1e-13, msg=key)
+    if d <= 2:
+        # combined derivative order up to 4: here the reference's own Leibniz / Bell-polynomial sums lose digits (its
+        # result differs from the closed form of the same derivative, which mpmath confirms to 15 digits, by up to ~1e-8)
+        key = "pairs2_d%d_" % d
+        got = oracle.kpairs("matern", g[key + "params"], g[key + "Xi"], g[key + "Xj"], g[key + "ni"], g[key + "nj"])
+        assert_close_nan(got, g[key + "k"], rtol=1e-7, atol_scale=1e-9, msg=key)
+    with pytest.raises(NotImplementedError):
+        oracle.kpairs("matern", g[key + "params"], g[key + "Xi"], g[key + "Xj"], g[key + "ni"], g[key + "nj"], hyper_deriv=0)
+
+
+def test_g10_matern_general_nu_gram_fit_predict(oracle, golden):
+    g = golden("g10_matern")
+    for d in (1, 2, 3):
+        key = "gram_d%d_" % d
+        p, X, Xs, n, ns = (g[key + s] for s in ("params", "X", "Xs", "n", "ns"))
+        assert_close(oracle.kbuild("matern", p, X, n), g[key + "K"], rtol=2e-11, atol_scale=1e-13, msg=key + "K")
+        assert_close(oracle.kbuild("matern", p, X, n, Xs, ns), g[key + "Ks"], rtol=2e-11, atol_scale=1e-13, msg=key + "Ks")
+    for N, d in ((64, 2), (160, 3)):
+        key = "fit_N%d_d%d_" % (N, d)
+        r = oracle.fit("matern", g[key + "params"], g[key + "X"], g[key + "n"], g[key + "y"], 0.05 * np.ones(N))
+        ll = float(g[key + "ll"])
+        assert abs(r["ll_data"] + float(g[key + "prior"]) - ll) <= 1e-9 * abs(ll)
+        assert abs(r["logdet_half"] - float(g[key + "logdet_half"])) <= 1e-10 * abs(float(g[key + "logdet_half"]))
+        m, s, _ = oracle.predict("matern", g[key + "params"], g[key + "X"], g[key + "n"], r["L"], r["alpha"], g[key + "Xs"],
+                                 g[key + "ns"], want_cov=False)
+        np.testing.assert_allclose(m, g[key + "mean"], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(s, g[key + "std"], rtol=0, atol=1e-8)
+    # nu = 5/2 is the Matern52Kernel of the reference's C extension
+    key = "fit_N64_d2_"
+    p = g[key + "params"]
+    K52 = oracle.kbuild("m52", np.concatenate((p[:1], p[2:])), g[key + "X"], g[key + "n"])
+    assert_close(oracle.kbuild("matern", p, g[key + "X"], g[key + "n"]), K52, rtol=1e-11, atol_scale=1e-13, msg="nu=5/2")
+
+
 def test_m52_error_contract(oracle):
     X = np.zeros((2, 2))
     n2 = np.array([[2, 0], [0, 0]])
