@@ -134,6 +134,14 @@ __device__ __forceinline__ void mma_ktile(const double *tA, const double *tB, in
 // ------------------------------------------------------------------------------------------------
 // One output tile per workgroup (used with 64x64 tiles for small / latency-bound updates).
 // ------------------------------------------------------------------------------------------------
+// Per-workgroup wall-clock stamps (scratch/gemm_stamps.hip compiles this file with -DGPT_GEMM_STAMPS; absent from the library)
+#ifdef GPT_GEMM_STAMPS
+__device__ long long *g_gemm_stamps;
+#define GM_STAMP(i) do { if (threadIdx.x == 0) g_gemm_stamps[(long long)blockIdx.x * 8 + (i)] = (long long)wall_clock64(); } while (0)
+#else
+#define GM_STAMP(i) do { } while (0)
+#endif
+
 template <int BM, int BN, int WPS, int NSTAGE>
 __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     int64_t m, int64_t n, int64_t k, double alpha, const double *__restrict__ A, int64_t lda,
@@ -150,6 +158,15 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
 
     // tile of this workgroup: from the host-built, XCD-aware order table (see tile_order()) or, without one, the
     // closed-form enumeration
+    GM_STAMP(0);
+#ifndef GPT_GEMM_NOPRIO
+    // A new workgroup's waves are the YOUNGEST on their SIMDs and lose the issue arbitration to the three older
+    // workgroups' main loops: measured with per-workgroup stamps (scratch/gemm_stamps.hip) the prologue -- C tile and
+    // first operand tiles requested, then waited for -- took 20 us of a workgroup's 52 us at steady state against < 9 us
+    // when a launch starts on an empty chip, so only half of the resident workgroups were multiplying.  The prologue
+    // therefore runs at raised priority (its few dozen instructions go out at once; then the wave sleeps on memory).
+    __builtin_amdgcn_s_setprio(3);
+#endif
     int64_t ti, tj;
     if (order != nullptr) {
         const int2 t = order[blockIdx.x];
@@ -160,6 +177,7 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
         tile_decode(xcd_remap(blockIdx.x, nwg), tri, ntn, &ti, &tj);
     }
     const int64_t row0 = ti * BM, col0 = tj * BN;
+    GM_STAMP(6);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -183,6 +201,7 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
             stage_issue<BN>(srcB, (int64_t)t * GM_BK, ldsB + t * BBYTES, wave);
         }
 
+    GM_STAMP(7);
     f64x4 acc[RM][RN];
     const double cs = (beta != 0.0) ? beta / alpha : 0.0;
 #pragma unroll
@@ -196,11 +215,17 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
                 acc[i][j][r] = (beta != 0.0 && row < m && col < n) ? cs * C[row * ldc + col] : 0.0;
             }
         }
+    GM_STAMP(4);
     // k-tile 0 must have landed (the C loads above are older than nothing newer than the DMAs -> full drain is
     // correct here; in the loop the wait is counted)
     if (NSTAGE == 2 || nk < PRE) dma_wait();
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PRE - 1) * PERSTAGE) : "memory");
+    GM_STAMP(5);
     __syncthreads();
+#ifndef GPT_GEMM_NOPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    GM_STAMP(1);
 
     for (int64_t kt = 0; kt < nk; kt++) {
         const int cur = (int)(kt % NSTAGE);
@@ -215,6 +240,7 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PRE - 1) * PERSTAGE) : "memory");
         __syncthreads();
     }
+    GM_STAMP(2);
 
 #pragma unroll
     for (int i = 0; i < RM; i++)
@@ -227,6 +253,7 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
                 if (row < m && col < n) C[row * ldc + col] = alpha * acc[i][j][r];
             }
         }
+    GM_STAMP(3);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -23,7 +23,7 @@ try:
     bl = json.loads(bench[-1])
     lines.append("\n# dominant kernel, the launches bench.py's roofline times (gemm_nt_kernel on the main queue, Grid_Size >= %d): "
                  "%d dispatches in the trace (all %d evaluations of the run), average %.1f us;  bench.py (HIP events, the %d timed "
-                 "evaluations): roofline.avg_launch_us = %.1f" % (MIN_GRID_, len(bigd), len(bigd) // 28, sum(bigd) / len(bigd) * 1e-3,
+                 "evaluations): roofline.avg_launch_us = %.1f" % (MIN_GRID_, len(bigd), round(len(bigd) / bl['roofline']['launches_per_step']), sum(bigd) / len(bigd) * 1e-3,
                                                                  bl['steps'], bl['roofline']['avg_launch_us']))
 except Exception as e:
     lines.append("# (cross-check skipped: %r)" % (e,))
@@ -71,7 +71,7 @@ def big_launch_bytes(path, counter):
     return len(per), sum(per.values()) * 1024.0
 nf, fb = big_launch_bytes(src + '/pmc_fetch/t_counter_collection.csv', 'FETCH_SIZE')
 nw, wb = big_launch_bytes(src + '/pmc_write/t_counter_collection.csv', 'WRITE_SIZE')
-tj = {"round": 1, "kernel": "gemm_nt_kernel<64,64>",
+tj = {"round": int(sys.argv[4]) if len(sys.argv) > 4 else 2, "kernel": "gemm_nt_kernel<64,64>",
       "launch_filter": "main-stream queue, Grid_Size >= %d threads (the >= 1 GFLOP rank-%d trailing updates)" % (MIN_GRID, K_OUTER),
       "launches": nf, "fetch_bytes_per_launch_x2_corrected": 2 * fb / nf, "write_bytes_per_launch": wb / nw,
       "hbm_bytes_per_launch": 2 * fb / nf + wb / nw,
