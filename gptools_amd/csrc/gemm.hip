@@ -194,16 +194,11 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     const int64_t nk = k / GM_BK;
     constexpr int PRE = NSTAGE - 1;                         // k-tiles requested ahead of the one being multiplied
     constexpr int PERSTAGE = BM / 32 + BN / 32;             // DMA instructions per wave per k-tile
-#pragma unroll
-    for (int t = 0; t < PRE; t++)
-        if (t < nk) {
-            stage_issue<BM>(srcA, (int64_t)t * GM_BK, ldsA + t * ABYTES, wave);
-            stage_issue<BN>(srcB, (int64_t)t * GM_BK, ldsB + t * BBYTES, wave);
-        }
-
-    GM_STAMP(7);
     f64x4 acc[RM][RN];
     const double cs = (beta != 0.0) ? beta / alpha : 0.0;
+    // The C tile is requested first, as RAW values (all sixteen loads per lane go out before anything waits: with the
+    // scaling folded into the load expression the prologue measured 12 us per workgroup, 8.5 us this way), the first
+    // operand tiles behind it, the scaling last.
 #pragma unroll
     for (int i = 0; i < RM; i++)
 #pragma unroll
@@ -212,9 +207,20 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int64_t row = row0 + wm * WM + i * 16 + fk + 4 * r;
-                acc[i][j][r] = (beta != 0.0 && row < m && col < n) ? cs * C[row * ldc + col] : 0.0;
+                acc[i][j][r] = (beta != 0.0 && row < m && col < n) ? C[row * ldc + col] : 0.0;
             }
         }
+    GM_STAMP(7);
+#pragma unroll
+    for (int t = 0; t < PRE; t++)
+        if (t < nk) {
+            stage_issue<BM>(srcA, (int64_t)t * GM_BK, ldsA + t * ABYTES, wave);
+            stage_issue<BN>(srcB, (int64_t)t * GM_BK, ldsB + t * BBYTES, wave);
+        }
+#pragma unroll
+    for (int i = 0; i < RM; i++)
+#pragma unroll
+        for (int j = 0; j < RN; j++) acc[i][j] = acc[i][j] * cs;
     GM_STAMP(4);
     // k-tile 0 must have landed (the C loads above are older than nothing newer than the DMAs -> full drain is
     // correct here; in the loop the wait is counted)

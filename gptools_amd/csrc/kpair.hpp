@@ -93,7 +93,12 @@ __device__ __forceinline__ double m52_pair(const KParams &kp, const double *xi, 
         else if (ii >= 0 && ij >= 0 && ii == ij) v = GPT_FIVE_THIRDS * ivi;
         else v = 0.0;
     } else {
-        const double r = sqrt(r2);
+        // r = sqrt(r2) and 1/r2 from ONE v_rsq_f64 + a Newton step (1/sqrt(r2) to 1.5 * 2^-52): the correctly rounded
+        // sqrt and the IEEE division of the (e_a, e_b) class were ~50 of this kernel's instructions, and the Matern-5/2
+        // builder is bound by its arithmetic, not by the stores
+        const double y0 = __builtin_amdgcn_rsq(r2);
+        const double yr = fma(0.5 * y0, fma(-(r2 * y0), y0, 1.0), y0);
+        const double r = r2 * yr;
         const double s5r = GPT_SQRT5 * r;
         const double e = exp(-s5r);
         if (ii < 0 && ij < 0) {
@@ -108,7 +113,7 @@ __device__ __forceinline__ double m52_pair(const KParams &kp, const double *xi, 
             if (ii == ij) d2r -= r2 * ivi;
             const double dk_over_r = -GPT_FIVE_THIRDS * (1.0 + s5r) * e;
             const double d2k = GPT_FIVE_THIRDS * (5.0 * r2 - s5r - 1.0) * e;
-            v = (dk_over_r * d2r - d2k * cross) / r2;                  // term1 + term2, matern.c:143-146
+            v = (dk_over_r * d2r - d2k * cross) * (yr * yr);           // term1 + term2 over r^2, matern.c:143-146
         }
     }
     return kp.sigma * kp.sigma * v;

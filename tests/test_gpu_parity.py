@@ -687,6 +687,56 @@ def test_single_gpu_schedule_under_stream_jitter(ctx):
                 assert float(g_[1]) == ll and float(g_[2]) == ld, (N, g_, ll, ld)
 
 
+def test_schedule_options_agree_with_default(ctx, oracle):
+    """The schedule variants kept behind options (NOTES_r02.md) -- the 256-column leaf kernel
+    (potf2x2_trsm_kernel: two diagonal blocks, the block between them and the TRSM consumers in one launch), left-looking
+    panels, the deferred rest, the panel-stream urgent update on / off, variable panel widths -- factor the same matrix:
+    ll / log|K| within 1e-11 of the default schedule and of the CPU oracle, at a size with several panels and a ragged end."""
+    N, d = 3000, 3
+    X, n, y = c3_inputs(N, d)
+    p = np.array([1.0, 0.3, 0.3, 0.3])
+    err = 0.05 * np.ones(N)
+    ref = oracle.fit("m52", p, X, n, y, err, chol="scipy")
+    ctx.set_data(X, n)
+    base = ctx.fit(1, p, 0.0, y, err, 1e2 * EPS)
+    assert abs(base[0] - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"])
+    variants = ({"leaf256": 1}, {"leaf256": 1, "nb_outer": 256}, {"leaf256": 1, "nb_outer": 512}, {"inner": 1}, {"inner": 2},
+                {"defer_rows": 4608}, {"purg_rows": 0}, {"purg_rows": 1024}, {"nb_early": 512, "nb_switch_rows": 1500},
+                {"leaf256": 1, "purg_rows": 1024, "defer_rows": 4608})
+    defaults = {"leaf256": 0, "nb_outer": 0, "inner": 0, "defer_rows": 0, "purg_rows": 6144, "nb_early": 0, "nb_switch_rows": 4608}
+    try:
+        for v in variants:
+            for k_, d_ in defaults.items():
+                ctx.set_option(k_, d_)
+            for k_, v_ in v.items():
+                ctx.set_option(k_, v_)
+            for rep in range(2):                  # (twice: the flag word of the fused kernels carries over between launches)
+                got = ctx.fit(1, p, 0.0, y, err, 1e2 * EPS)
+                assert abs(got[0] - base[0]) <= 1e-11 * abs(base[0]), v
+                assert abs(got[1] - base[1]) <= 1e-12 * abs(base[1]), v
+    finally:
+        for k_, d_ in defaults.items():
+            ctx.set_option(k_, d_)
+    # the 256-column leaf kernel on dense matrices of awkward sizes against LAPACK
+    rs = np.random.RandomState(7)
+    try:
+        ctx.set_option("leaf256", 1)
+        for Nd in (255, 256, 300, 640, 1000):
+            for nb in (256, 384):
+                ctx.set_option("nb_outer", nb)
+                A = rs.randn(Nd, Nd)
+                A = A.dot(A.T) + Nd * np.eye(Nd)
+                np.testing.assert_allclose(np.tril(ctx.potrf_host(A)), np.linalg.cholesky(A), rtol=1e-11, atol=1e-11)
+        with pytest.raises(np.linalg.LinAlgError) as ei:      # not positive definite inside the second block of a 256-column leaf
+            A = np.eye(300)
+            A[200, 200] = -1.0
+            ctx.potrf_host(A)
+        assert "201-th leading minor" in str(ei.value)
+    finally:
+        ctx.set_option("leaf256", 0)
+        ctx.set_option("nb_outer", 0)
+
+
 def test_panel_inverse_and_gemm_solve_against_numpy():
     """gpt_dev_potrf_panel on the diagonal block, gpt_dev_trinv, then the rows below as ONE GEMM against the inverse --
     the tail chunks of the row-chunked multi-GPU schedule -- against numpy (L^-1 itself and X = B L^-T)."""
