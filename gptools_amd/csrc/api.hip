@@ -54,6 +54,9 @@ struct gpt_ctx {
     hipStream_t early_stream = nullptr;    // main stream of the update-bound head of a factorisation: fewer CUs reserved
     int64_t early_rows = 0;                // panels with more than this many rows left run their updates there (0 = off)
     int64_t nb_early = 0, nb_switch_rows = 4608;   // see potrf_enqueue (panel widths)
+    int pad_now = 0;                       // (set per panel by potrf_enqueue: LDS pad of the main stream's updates right now)
+    int late_pad = 0;                      // > 0: LDS pad of the main stream's updates once at most late_pad_rows rows remain -- fewer of its
+    int64_t late_pad_rows = 4608;          //      workgroups per CU, so that the panel stream's chain kernels share the CUs with less contention
     int64_t purg_rows = 6144;              // > 0: while more rows than this remain, the panel stream does the "urgent" update itself
                                            // (N=8192: 5.36 against 5.44 ms, bit-identical; no effect below ~7k rows or with the helper stream)
     int64_t defer_rows = 0;             // chain-bound end: with at most this many rows left, the main stream's "rest" update of
@@ -327,7 +330,7 @@ static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, 
         gp->flops = flops;
     }
     // trailing updates on the main stream leave room on every CU for the panel stream (see gemm.hip)
-    const int lds_pad = (on_main && c->lookahead) ? c->gemm_pad : 0;
+    const int lds_pad = (on_main && c->lookahead) ? (c->pad_now > 0 ? c->pad_now : c->gemm_pad) : 0;
     // `done` (a cross-stream edge) and the timing events ride on the dispatch packet itself where possible
     // (hipExtLaunchKernelGGL): a separate hipEventRecord is a barrier packet, ~6 us of command-processor time
     const bool ext = !c->use_graph && (c->tile == 0 || c->tile == 64);
@@ -630,6 +633,7 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
             GPT_HIP_CHECK(hipStreamWaitEvent(c->late_panel_stream, e_pl, 0));
             P = c->late_panel_stream;
         }
+        c->pad_now = (c->late_pad > 0 && n - c0 <= c->late_pad_rows) ? c->late_pad : 0;
         hipEvent_t e_first = pend.on ? get_event(c, 8 + 4 * widths.size() + k) : nullptr;
         if (pend.on && !e_first) return GPT_E_HIP;
         GPT_TRY(panel_ext(c, P, A, lda, n, c0, w, invd, info, e_cu_prev, e_panel, ext_k, e_first));
@@ -708,6 +712,7 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
         c0 += w;
     }
     if (pend.on) GPT_TRY(launch_rest(pend));
+    c->pad_now = 0;
     if (e_help_prev) GPT_HIP_CHECK(hipStreamWaitEvent(S, e_help_prev, 0));
     if (use_early && S_cur != S0) {
         hipEvent_t e_sw = get_event(c, 3 + 4 * widths.size());
@@ -915,6 +920,8 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "defer_rows")) c->defer_rows = value;
     else if (!strcmp(key, "late_rows")) c->late_rows = value;
     else if (!strcmp(key, "purg_rows")) c->purg_rows = value;
+    else if (!strcmp(key, "late_pad")) c->late_pad = (int)value;
+    else if (!strcmp(key, "late_pad_rows")) c->late_pad_rows = value;
     else if (!strcmp(key, "nb_early")) c->nb_early = value;
     else if (!strcmp(key, "nb_switch_rows")) c->nb_switch_rows = value;
     else if (!strcmp(key, "inner")) c->inner = (int)value;

@@ -13,6 +13,7 @@ int main(int argc, char **argv)
 {
     const int64_t m = argc > 1 ? atoll(argv[1]) : 7168, k = argc > 2 ? atoll(argv[2]) : 384;
     const int reserve = argc > 3 ? atoi(argv[3]) : 32;
+    const int64_t ncols = argc > 5 ? atoll(argv[5]) : m;          // narrow update: C is m x ncols (lower trapezoid)
     hipStream_t st;
     {
         hipDeviceProp_t prop;
@@ -40,7 +41,7 @@ int main(int argc, char **argv)
         hipMemsetAsync(dst, 0, nwg_max * 8 * 8, st);
         hipStreamSynchronize(st);
         hipEventRecord(e0, st);
-        launch_gemm_nt(st, m, m, k, -1.0, A, k, A, k, (argc > 4 ? atof(argv[4]) : 1.0), C, m, 1, 0, 1024, nullptr, nullptr);
+        launch_gemm_nt(st, m, ncols, k, -1.0, A, k, A, k, (argc > 4 ? atof(argv[4]) : 1.0), C, m, 1, 0, (argc > 6 ? atoi(argv[6]) : 1024), nullptr, nullptr);
         hipEventRecord(e1, st);
         hipStreamSynchronize(st);
         float ms = 0;
