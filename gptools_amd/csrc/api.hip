@@ -57,6 +57,7 @@ struct gpt_ctx {
     int pad_now = 0;                       // (set per panel by potrf_enqueue: LDS pad of the main stream's updates right now)
     int late_pad = 0;                      // > 0: LDS pad of the main stream's updates once at most late_pad_rows rows remain -- fewer of its
     int64_t late_pad_rows = 4608;          //      workgroups per CU, so that the panel stream's chain kernels share the CUs with less contention
+    int64_t panel_prio = 2;                // wave priority (0..3) of the panel stream's GEMM main loops
     int64_t purg_rows = 6144;              // > 0: while more rows than this remain, the panel stream does the "urgent" update itself
                                            // (N=8192: 5.36 against 5.44 ms, bit-identical; no effect below ~7k rows or with the helper stream)
     int64_t defer_rows = 0;             // chain-bound end: with at most this many rows left, the main stream's "rest" update of
@@ -343,7 +344,9 @@ static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, 
         gp->stop = gp->e1;
         GPT_HIP_CHECK(hipEventRecord(gp->e0, st));
     }
-    int rc = launch_gemm_nt(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, c->tile, lds_pad, e0, e1);
+    // the panel stream's updates keep a raised wave priority in their main loop (option panel_prio, see gemm.hip)
+    const int prio = (!on_main && c->lookahead) ? (int)c->panel_prio : 0;
+    int rc = launch_gemm_nt(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, c->tile, lds_pad, e0, e1, prio);
     if (!ext) {
         if (prof) GPT_HIP_CHECK(hipEventRecord(gp->e1, st));
         if (done) GPT_HIP_CHECK(hipEventRecord(done, st));
@@ -920,6 +923,7 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "defer_rows")) c->defer_rows = value;
     else if (!strcmp(key, "late_rows")) c->late_rows = value;
     else if (!strcmp(key, "purg_rows")) c->purg_rows = value;
+    else if (!strcmp(key, "panel_prio")) c->panel_prio = value;
     else if (!strcmp(key, "late_pad")) c->late_pad = (int)value;
     else if (!strcmp(key, "late_pad_rows")) c->late_pad_rows = value;
     else if (!strcmp(key, "nb_early")) c->nb_early = value;

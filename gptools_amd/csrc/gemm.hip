@@ -146,7 +146,7 @@ template <int BM, int BN, int WPS, int NSTAGE>
 __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     int64_t m, int64_t n, int64_t k, double alpha, const double *__restrict__ A, int64_t lda,
     const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
-    int tri, int64_t ntm, int64_t ntn, int64_t nwg, const int2 *__restrict__ order, int64_t seg_cols, int64_t bskip)
+    int tri, int64_t ntm, int64_t ntn, int64_t nwg, const int2 *__restrict__ order, int64_t seg_cols, int64_t bskip, int prio)
 {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int RM = WM / 16, RN = WN / 16;
@@ -229,7 +229,11 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     GM_STAMP(5);
     __syncthreads();
 #ifndef GPT_GEMM_NOPRIO
-    __builtin_amdgcn_s_setprio(0);
+    // (prio: launches of the latency-bound panel stream keep a raised wave priority in the main loop, so that on a CU they
+    // share with three workgroups of the main stream's trailing update their MFMAs issue first)
+    if (prio == 0) __builtin_amdgcn_s_setprio(0);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
 #endif
     GM_STAMP(1);
 
@@ -475,7 +479,7 @@ template <int BM, int BN, int WPS, int NSTAGE>
 static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A,
                          int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri,
                          int lds_pad, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int64_t seg_cols = 0,
-                         int64_t bskip = 0, int64_t row_step = 0)
+                         int64_t bskip = 0, int64_t row_step = 0, int prio = 0)
 {
     const int64_t ntm = (m + BM - 1) / BM, ntn = (n + BN - 1) / BN;
     int64_t nwg = (tri == 1) ? ntn * (ntn + 1) / 2 + (ntm - ntn) * ntn : ntm * ntn;
@@ -498,10 +502,10 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
     // would add two barrier packets per launch to the stream being measured
     if (ev0 || ev1)
         hipExtLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg), dim3(256), dyn, st, ev0, ev1, 0,
-                              m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip);
+                              m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip, prio);
     else
         hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg), dim3(256), dyn, st, m, n, k, alpha,
-                           A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip);
+                           A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip, prio);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
@@ -527,7 +531,7 @@ static int gemm_launch_persist(hipStream_t st, int64_t m, int64_t n, int64_t k, 
 
 int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A, int64_t lda,
                    const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile, int lds_pad,
-                   hipEvent_t ev0, hipEvent_t ev1)
+                   hipEvent_t ev0, hipEvent_t ev1, int prio)
 {
     gpt_jitter(st);
     if (m <= 0 || n <= 0) return GPT_OK;
@@ -555,7 +559,7 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
     // small panel updates (8064x128x128: 12 us either way): they are bound by launch + prologue latency, not by the
     // DMA wait, so everything uses the 2-stage kernel.
     if (force_tile == 65) return gemm_launch_t<64, 64, 1, 4>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0);
-    return gemm_launch_t<64, 64, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, lds_pad, ev0, ev1);
+    return gemm_launch_t<64, 64, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, lds_pad, ev0, ev1, 0, 0, 0, prio);
 }
 
 // Staircase update: C (m x nseg*seg_cols) += alpha * A B_q^T per column segment q, where segment q (seg_cols

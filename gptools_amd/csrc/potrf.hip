@@ -481,6 +481,8 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
         potf2_body<true>(A, lda, invd, info, info_col0, flag, flag_base);
         return;
     }
+    // (the chain's kernels share CUs with the main stream's trailing update: raised wave priority, as in gemm.hip)
+    __builtin_amdgcn_s_setprio(2);
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -882,6 +884,7 @@ __global__ __launch_bounds__(64 * TP_WAVES, 2) void trsm_panel_kernel(int64_t m,
 {
     __shared__ __attribute__((aligned(16))) double Lp[28][4][64];
     __shared__ __attribute__((aligned(16))) double Sc[TP_WAVES][16][TP_SP];
+    __builtin_amdgcn_s_setprio(2);        // (on the chain, sharing CUs with the main stream's update: see gemm.hip)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fk = lane >> 4;
