@@ -142,6 +142,17 @@ __device__ long long *g_gemm_stamps;
 #define GM_STAMP(i) do { } while (0)
 #endif
 
+// C accesses.  Streaming C past the L2 (nontemporal loads and stores, -DGPT_GEMM_C_NT) leaves the L2 to the operand panels
+// and cuts the fabric traffic of a 7168-row update from 503 + 207 MB to 395 + 207 MB (algorithmic 229 + 207), but the next
+// kernels of the factorisation read what this one wrote: measured 4.995 against 4.862 ms at N = 8192 (27.48 against 27.65 at
+// N = 16384), nontemporal loads alone 4.878, stores alone 4.900 -- so C stays cached.
+#ifdef GPT_GEMM_C_NT
+#define GM_LOADC(p) __builtin_nontemporal_load(p)
+#define GM_STOREC(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define GM_LOADC(p) (*(p))
+#define GM_STOREC(v, p) (*(p) = (v))
+#endif
 template <int BM, int BN, int WPS, int NSTAGE>
 __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     int64_t m, int64_t n, int64_t k, double alpha, const double *__restrict__ A, int64_t lda,
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int64_t row = row0 + wm * WM + i * 16 + fk + 4 * r;
-                acc[i][j][r] = (beta != 0.0 && row < m && col < n) ? C[row * ldc + col] : 0.0;
+                acc[i][j][r] = (beta != 0.0 && row < m && col < n) ? GM_LOADC(&C[row * ldc + col]) : 0.0;
             }
         }
     GM_STAMP(7);
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int64_t row = row0 + wm * WM + i * 16 + fk + 4 * r;
-                if (row < m && col < n) C[row * ldc + col] = alpha * acc[i][j][r];
+                if (row < m && col < n) GM_STOREC(alpha * acc[i][j][r], &C[row * ldc + col]);
             }
         }
     GM_STAMP(3);
@@ -386,12 +397,18 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_persist_kernel(
 }
 
 // ---- XCD-aware tile order ------------------------------------------------------------------------------------
-// Workgroup b runs on XCD b % 8 and the workgroups of one XCD start in the order of b / 8.  The table gives XCD x
-// the supertiles x, x+8, x+16, ... of the (lower part of the) tile grid, a supertile being an SG x SG square of
-// tiles walked row by row: the ~100 workgroups resident on an XCD at any time then share SG A-panels and SG
-// B-panels through that XCD's L2 instead of each streaming its own B panel (measured before: 337 MB of HBM/MALL
-// traffic per launch against ~130 MB algorithmic).  Tables are built once per (ntm, ntn, tri) and cached on the
-// device; slots past an XCD's list hold (-1, -1).
+// Workgroup b runs on XCD b % 8 and the workgroups of one XCD start in the order of b / 8.  The needed tiles are put
+// in ONE sequence -- supertiles of 64 x 8 tiles (rows x columns) in row-major order, each walked row by row -- and the
+// sequence is cut into eight contiguous pieces of equal length, one per XCD.  The ~110 workgroups resident on an XCD then
+// share 8 B-panels (kept in its L2 for 64 tile rows) and each A-panel eight times, and every XCD gets the same number of
+// tiles to within one.  Measured on a 7168-row rank-384 update (scratch/pmc_order.sh, scratch/gemm_time.py): 8 x 8
+// supertiles dealt round robin (round 1) 637 MB fetched / 412-417 us, the same cut evenly 674 MB / 402 us (the XCDs'
+// lists differed by up to one supertile = 8 % of a small launch: 4096 rows 157 -> 145 us), 64 x 8 cut evenly 503 MB /
+// 404 us, 16 x 16 846 MB (the streamed C tiles leave the panels well under the L2's 4 MB).  GPT_TILE_ORDER="rows,cols,mode"
+// overrides (mode 0 = round-robin deal).  Tables are built once per (ntm, ntn, tri) and cached on the device; slots past
+// an XCD's list hold (-1, -1).
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 struct TileOrder {
@@ -419,7 +436,14 @@ static inline bool tile_needed(int tri, int64_t i, int64_t j, int64_t seg_t, int
 static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64_t *grid, int64_t seg_t = 0,
                       int64_t rss_t = 0)
 {
-    constexpr int SG = 8;
+    static int sgm = 0, sgn = 0, mode = 0;
+    if (sgm == 0) {
+        sgm = 64, sgn = 8, mode = 1;
+        if (const char *e = getenv("GPT_TILE_ORDER")) {
+            int a = 0, b = 0, c = 0;
+            if (sscanf(e, "%d,%d,%d", &a, &b, &c) >= 2 && a > 0 && b > 0) sgm = a, sgn = b, mode = c;
+        }
+    }
     int dev = 0;
     GPT_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_orders_mu);
@@ -430,20 +454,30 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
             return GPT_OK;
         }
     std::vector<std::vector<int2>> per(8);
-    const int64_t sm = (ntm + SG - 1) / SG, sn = (ntn + SG - 1) / SG;
+    std::vector<int2> seq;
+    const int64_t sm = (ntm + sgm - 1) / sgm, sn = (ntn + sgn - 1) / sgn;
     int64_t sidx = 0;
     for (int64_t si = 0; si < sm; si++)
         for (int64_t sj = 0; sj < sn; sj++) {
-            std::vector<int2> &dst = per[sidx % 8];
+            std::vector<int2> &dst = mode ? seq : per[sidx % 8];
             bool any = false;
-            for (int64_t i = si * SG; i < (si + 1) * SG && i < ntm; i++)
-                for (int64_t j = sj * SG; j < (sj + 1) * SG && j < ntn; j++) {
+            for (int64_t i = si * sgm; i < (si + 1) * sgm && i < ntm; i++)
+                for (int64_t j = sj * sgn; j < (sj + 1) * sgn && j < ntn; j++) {
                     if (!tile_needed(tri, i, j, seg_t, rss_t)) continue;
                     dst.push_back(make_int2((int)i, (int)j));
                     any = true;
                 }
             if (any) sidx++;
         }
+    if (mode) {
+        const size_t T = seq.size(), q = T / 8, r = T % 8;
+        size_t at = 0;
+        for (int x = 0; x < 8; x++) {
+            const size_t len = q + ((size_t)x < r ? 1 : 0);
+            per[x].assign(seq.begin() + at, seq.begin() + at + len);
+            at += len;
+        }
+    }
     size_t mx = 0;
     for (auto &v : per) mx = v.size() > mx ? v.size() : mx;
     std::vector<int2> flat(mx * 8, make_int2(-1, -1));
