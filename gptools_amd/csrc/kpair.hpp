@@ -73,49 +73,109 @@ __device__ __forceinline__ double se_pair(const KParams &kp, const double *xi, c
     return k;
 }
 
+// exp(-x) for x >= 0: k = rint(-x log2 e), r = -x - k ln 2 in two fused steps (|r| <= ln2 / 2), then
+// exp(r) = 1 + r (1 + r q(r)) with q of degree 9 (Chebyshev interpolant of (e^r - 1 - r) / r^2, error 1.7e-17 relative;
+// scratch note in DESIGN.md section 4), scaled by 2^k with one v_ldexp.  x is clamped at 800 (exp(-800) = 0 in double
+// precision) so that k fits v_cvt_i32; the clamp (v_max) drops a NaN, which every caller multiplies back in through the
+// factors that carry r.  18 instructions against the ~35 of the library exp with its overflow / denormal handling,
+// within 1 ulp of it (the Matern-5/2 builder is bound by its arithmetic).
+__device__ __forceinline__ double exp_neg(double x)
+{
+    const double t = fmax(-x, -800.0);
+    const double k = __builtin_rint(t * 1.4426950408889634);
+    double r = fma(k, -6.93147180369123816490e-01, t);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double q = 2.5100274028176466e-08;
+    q = fma(q, r, 2.7620076086460433e-07);
+    q = fma(q, r, 2.7557268773616192e-06);
+    q = fma(q, r, 2.48015213222418e-05);
+    q = fma(q, r, 1.9841269862757975e-04);
+    q = fma(q, r, 1.3888888917196432e-03);
+    q = fma(q, r, 8.3333333333301673e-03);
+    q = fma(q, r, 4.1666666666624164e-02);
+    q = fma(q, r, 1.6666666666666669e-01);
+    q = fma(q, r, 5.0000000000000011e-01);
+    q = fma(q, r, 1.0);
+    q = fma(q, r, 1.0);
+    return __builtin_amdgcn_ldexp(q, (int)k);
+}
+
+// (keeps what depends on v inside the branch it is written in: hipcc otherwise speculates the cheap arithmetic of every
+// class above the class test and all pairs pay for it)
+__device__ __forceinline__ double pin_here(double v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 template <int D>
 __device__ __forceinline__ double m52_pair(const KParams &kp, const double *xi, const double *xj,
                                            const int *ni, const int *nj)
 {
-    double r2 = 0.0;
+    double r2 = 0.0, disp[D];
     int ii = -1, ij = -1;
-    double di = 0.0, dj = 0.0, ivi = 0.0, ivj = 0.0;   // displacement / inverse variance at the derivative dims
 #pragma unroll
     for (int d = D - 1; d >= 0; d--) {                  // descending so the FIRST index with n == 1 wins (matern.c:32-39)
-        const double disp = xi[d] - xj[d];
-        r2 = fma(disp * disp, kp.inv_var[d], r2);
-        if (ni[d] == 1) { ii = d; di = disp; ivi = kp.inv_var[d]; }
-        if (nj[d] == 1) { ij = d; dj = disp; ivj = kp.inv_var[d]; }
+        disp[d] = xi[d] - xj[d];
+        r2 = fma(disp[d] * disp[d], kp.inv_var[d], r2);
+        if (ni[d] == 1) ii = d;
+        if (nj[d] == 1) ij = d;
     }
-    double v;
-    if (r2 == 0.0) {                                    // matern.c:83-84, :100-101, :123-127
-        if (ii < 0 && ij < 0) v = 1.0;
-        else if (ii >= 0 && ij >= 0 && ii == ij) v = GPT_FIVE_THIRDS * ivi;
-        else v = 0.0;
+    // r = sqrt(r2) and 1/r2 from ONE v_rsq_f64 + a Newton step (1/sqrt(r2) to 1.5 * 2^-52): the correctly rounded
+    // sqrt and the IEEE division of the (e_a, e_b) class were ~50 of this kernel's instructions, and the Matern-5/2
+    // builder is bound by its arithmetic, not by the stores.  Coincident points (r2 == 0:
+    // matern.c:83-84, :100-101, :123-127) run the same arithmetic on r2 = 1 and take their constant at the end.
+    const bool zero = (r2 == 0.0);
+    const double r2s = zero ? 1.0 : r2;
+    const double y0 = __builtin_amdgcn_rsq(r2s);
+    const double yr = fma(0.5 * y0, fma(-(r2s * y0), y0, 1.0), y0);
+    const double s5r = GPT_SQRT5 * (r2s * yr);
+    const double e = exp_neg(s5r);
+    double v, v0;
+    // The class of a pair -- which side carries a derivative -- is the same for all 64 columns of a wave nearly
+    // everywhere (the rows are wave-uniform, the columns of one class are contiguous in any sensible ordering), so each
+    // class has its own branch and a wave executes one of them; the select-everything form of round 1 computed all four
+    // formulas for every pair (100 vector instructions per pair, 61 of them double precision).
+    if (__builtin_amdgcn_ballot_w64(ij >= 0) == 0) {
+        if (ii < 0) {
+            v = fma(GPT_FIVE_THIRDS, r2s, 1.0 + s5r) * e;
+            v0 = 1.0;
+        } else {
+            const double ep = pin_here(e);
+            double di = 0.0, ivi = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                const double dd = pin_here(disp[d]);
+                if (d == ii) { di = dd; ivi = kp.inv_var[d]; }
+            }
+            v = -(GPT_FIVE_THIRDS * (1.0 + s5r) * ep) * (di * ivi);
+            v0 = 0.0;
+        }
     } else {
-        // r = sqrt(r2) and 1/r2 from ONE v_rsq_f64 + a Newton step (1/sqrt(r2) to 1.5 * 2^-52): the correctly rounded
-        // sqrt and the IEEE division of the (e_a, e_b) class were ~50 of this kernel's instructions, and the Matern-5/2
-        // builder is bound by its arithmetic, not by the stores
-        const double y0 = __builtin_amdgcn_rsq(r2);
-        const double yr = fma(0.5 * y0, fma(-(r2 * y0), y0, 1.0), y0);
-        const double r = r2 * yr;
-        const double s5r = GPT_SQRT5 * r;
-        const double e = exp(-s5r);
-        if (ii < 0 && ij < 0) {
-            v = (1.0 + s5r + GPT_FIVE_THIRDS * r2) * e;
-        } else if (ij < 0) {
-            v = -GPT_FIVE_THIRDS * (1.0 + s5r) * e * (di * ivi);
-        } else if (ii < 0) {
-            v = GPT_FIVE_THIRDS * (1.0 + s5r) * e * (dj * ivj);       // arguments swapped => sign flips (matern.c:182-184)
+        const double ep = pin_here(e);
+        double di = 0.0, dj = 0.0, ivi = 0.0, ivj = 0.0;   // displacement / inverse variance at the derivative dims
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const double dd = pin_here(disp[d]);
+            if (d == ii) { di = dd; ivi = kp.inv_var[d]; }
+            if (d == ij) { dj = dd; ivj = kp.inv_var[d]; }
+        }
+        const double g = GPT_FIVE_THIRDS * (1.0 + s5r) * ep;              // -k'(r) / r
+        if (ii < 0) {
+            v = (ij >= 0) ? g * (dj * ivj)                                // arguments swapped => sign flips (matern.c:182-184)
+                          : fma(GPT_FIVE_THIRDS, r2s, 1.0 + s5r) * ep;
+            v0 = (ij >= 0) ? 0.0 : 1.0;
         } else {
             double d2r = (di * ivi) * (dj * ivj);
             const double cross = d2r;
-            if (ii == ij) d2r -= r2 * ivi;
-            const double dk_over_r = -GPT_FIVE_THIRDS * (1.0 + s5r) * e;
-            const double d2k = GPT_FIVE_THIRDS * (5.0 * r2 - s5r - 1.0) * e;
-            v = (dk_over_r * d2r - d2k * cross) * (yr * yr);           // term1 + term2 over r^2, matern.c:143-146
+            if (ii == ij) d2r -= r2s * ivi;
+            const double d2k = GPT_FIVE_THIRDS * (5.0 * r2s - s5r - 1.0) * ep;
+            const double both = (-g * d2r - d2k * cross) * (yr * yr);     // term1 + term2 over r^2, matern.c:143-146
+            v = (ij >= 0) ? both : -g * (di * ivi);
+            v0 = (ij >= 0 && ii == ij) ? GPT_FIVE_THIRDS * ivi : 0.0;
         }
     }
+    v = zero ? v0 : v;
     return kp.sigma * kp.sigma * v;
 }
 
