@@ -57,6 +57,8 @@ struct gpt_ctx {
     int pad_now = 0;                       // (set per panel by potrf_enqueue: LDS pad of the main stream's updates right now)
     int late_pad = 0;                      // > 0: LDS pad of the main stream's updates once at most late_pad_rows rows remain -- fewer of its
     int64_t late_pad_rows = 4608;          //      workgroups per CU, so that the panel stream's chain kernels share the CUs with less contention
+    bool defer_join = false;               // potrf_enqueue leaves the final panel -> main join to its caller (factor_and_ll)
+    hipStream_t tail_stream = nullptr;     // ... and reports the stream the factorisation ended on
     int64_t panel_prio = 2;                // wave priority (0..3) of the panel stream's GEMM main loops
     int64_t purg_rows = 6144;              // > 0: while more rows than this remain, the panel stream does the "urgent" update itself
                                            // (N=8192: 5.36 against 5.44 ms, bit-identical; no effect below ~7k rows or with the helper stream)
@@ -724,6 +726,11 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
         GPT_HIP_CHECK(hipStreamWaitEvent(S0, e_sw, 0));
     }
     S = S0;
+    if (c->defer_join && !c->use_graph) {
+        // (the caller continues on the panel stream -- the last leaf runs there -- and joins the streams itself)
+        c->tail_stream = P;
+        return GPT_OK;
+    }
     hipEvent_t e_end = get_event(c, 1);
     if (!e_end) return GPT_E_HIP;
     GPT_HIP_CHECK(hipEventRecord(e_end, P));
@@ -1135,11 +1142,27 @@ static int factor_and_ll(gpt_ctx *c, int64_t N, double *ll_data_out, double *log
         GPT_TRY(launch_fill_pad(st, c->dA, NP, N, NP, c->d_y, 1e300));
     }
     if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[2], st));
-    GPT_TRY(potrf_run(c, NP, c->dA, NP, c->d_invd, c->d_info));
-    if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[3], st));
-    GPT_TRY(launch_logdet_dot(st, c->dA, NP, N, c->d_info, c->d_scal));
-    GPT_HIP_CHECK(hipMemcpyAsync(c->h_scal, c->d_scal, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[4], st));
+    // The factorisation ends on the panel stream (its last leaf); the reduction over the diagonal and the augmented row
+    // and the 24-byte copy follow it THERE -- handing back to the main stream first cost an event edge (~20 us of a 5 ms
+    // evaluation) -- and the main stream is joined behind them, off the host's critical path.
+    c->defer_join = true;
+    c->tail_stream = nullptr;
+    int rc_f = potrf_run(c, NP, c->dA, NP, c->d_invd, c->d_info);
+    c->defer_join = false;
+    GPT_TRY(rc_f);
+    hipStream_t tl = c->tail_stream ? c->tail_stream : st;
+    c->tail_stream = nullptr;
+    if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[3], tl));
+    GPT_TRY(launch_logdet_dot(tl, c->dA, NP, N, c->d_info, c->d_scal));
+    GPT_HIP_CHECK(hipMemcpyAsync(c->h_scal, c->d_scal, 3 * sizeof(double), hipMemcpyDeviceToHost, tl));
+    if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[4], tl));
+    if (tl != st) {
+        hipEvent_t e_end = get_event(c, 1);
+        if (!e_end) return GPT_E_HIP;
+        GPT_HIP_CHECK(hipEventRecord(e_end, tl));
+        GPT_HIP_CHECK(hipStreamWaitEvent(st, e_end, 0));
+        GPT_HIP_CHECK(hipStreamSynchronize(tl));
+    }
     GPT_HIP_CHECK(hipStreamSynchronize(st));
     if (c->gprof_used) GPT_TRY(harvest_gemm_profile(c));
     if (c->timing) {
