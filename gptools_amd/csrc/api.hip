@@ -80,6 +80,7 @@ struct gpt_ctx {
     double *d_l10pk = nullptr;         // its scratch: the packed block between the two diagonal blocks (16384 doubles)
     unsigned *d_flag = nullptr;        // progress word of potf2_trsm_kernel (only ever raised)
     unsigned flag_epoch = 0;
+    int64_t helper_min_n = 12288;      // the helper stream takes part only above this matrix size
     int helper_tf = 35;                // assumed rate of the helper stream, in 0.1 TFLOP/s per 24 CUs (0 = no helper);
                                        // measured: 0 / 25 / 35 / 50 -> 212 / 209 / 206 / 214 ms at N=32768, 30.8 / 30.6 / 30.2 / 32.0 at N=16384
     int ramp = 0;                      // first panels 128, 256, ... wide (see potrf_enqueue); measured slower, off
@@ -581,7 +582,7 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
     // region lies inside the previous one, so H needs nothing but "panel k is final"; S waits for helper k before
     // it next touches columns >= s.
     // (only where the updates dominate: at n = 8192 the helper costs 0.5-1 %, at 16384 / 32768 it gains 2 / 3 %)
-    hipStream_t H = (c->helper_stream && !c->use_graph && c->helper_tf > 0 && n > 12288) ? c->helper_stream : nullptr;
+    hipStream_t H = (c->helper_stream && !c->use_graph && c->helper_tf > 0 && n > c->helper_min_n) ? c->helper_stream : nullptr;
     const double rate_s = 46e12, rate_h = 1e11 * (double)c->helper_tf * (double)c->helper_cus / 24.0;
     hipEvent_t e_cu_prev = nullptr, e_help_prev = nullptr, e_rest_prev = nullptr;
     int64_t c0 = 0, s_prev = 0;
@@ -938,6 +939,7 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "inner")) c->inner = (int)value;
     else if (!strcmp(key, "inner_rows")) c->inner_rows = value;
     else if (!strcmp(key, "helper_tf")) c->helper_tf = (int)value;
+    else if (!strcmp(key, "helper_min_n")) c->helper_min_n = value;
     else if (!strcmp(key, "fuse_trsm")) c->fuse_trsm = value;
     else if (!strcmp(key, "leaf256")) c->leaf256 = value ? 1 : 0;
     else if (!strcmp(key, "tile")) {
