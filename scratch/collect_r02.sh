@@ -10,6 +10,9 @@ python bench.py --steps 10 --warmup 3 --workload c2 --no-batched > $O/bench_c2_l
 python bench.py --steps 10 --warmup 3 --workload c5 --no-batched > $O/bench_c5_line.json 2> $O/bench_c5.err
 python bench.py --steps 5 --warmup 2 --workload c4 --no-batched > $O/bench_c4_line.json 2> $O/bench_c4.err
 python bench.py --gpus 1 --dist --workload c4 --steps 5 --warmup 2 > $O/bench_dist_c4_line.json 2> $O/bench_dist_c4.err
+# (the stamp programs compile the PRODUCT sources with -DGPT_*_STAMPS: rebuilt here so that they match the library)
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -DGPT_PD_STAMPS -Iinclude -o scratch/potf2_stamps scratch/potf2_stamps.hip
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -DGPT_GEMM_STAMPS -Iinclude -o scratch/gemm_stamps scratch/gemm_stamps.hip
 ./scratch/potf2_stamps > $O/potf2_stamps.txt 2>&1
 ./scratch/gemm_stamps 7168 384 32 > $O/gemm_stamps.txt 2>&1
 ROUND_TAG=r02c/prof bash scratch/prof_all.sh > $O/prof_all.log 2>&1
