@@ -278,7 +278,8 @@ def main():
         per_step = elapsed / args.steps
         value = flops_fit(N) / per_step * 1e-9
         out_ = {
-            "metric": METRIC, "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
+            # (BASELINE.json quotes the metric on N=8192 = the default workload; other workloads carry their own N in the name)
+            "metric": METRIC if N == 8192 else METRIC.replace("N=8192", "N=%d" % N), "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": per_step * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %s kernel, N=%d, d=%d%s, err_y=0.05, sigma_f=1, l=0.3 (BASELINE.json configs)"

@@ -81,7 +81,7 @@ struct gpt_ctx {
     unsigned *d_flag = nullptr;        // progress word of potf2_trsm_kernel (only ever raised)
     unsigned flag_epoch = 0;
     int64_t helper_min_n = 12288;      // the helper stream takes part only above this matrix size
-    int helper_tf = 35;                // assumed rate of the helper stream, in 0.1 TFLOP/s per 24 CUs (0 = no helper);
+    int helper_tf = 45;                // assumed rate of the helper stream, in 0.1 TFLOP/s per 24 CUs (0 = no helper);
                                        // measured: 0 / 25 / 35 / 50 -> 212 / 209 / 206 / 214 ms at N=32768, 30.8 / 30.6 / 30.2 / 32.0 at N=16384
     int ramp = 0;                      // first panels 128, 256, ... wide (see potrf_enqueue); measured slower, off
     int inner = 0;                     // look-ahead panel: 0 right-looking leaves, 1 left-looking (panel_ext_ll), 2 left-looking
@@ -364,7 +364,8 @@ static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, 
 static inline int64_t outer_width(const gpt_ctx *c, int64_t n)
 {
     if (c->nb_outer > 0) return c->nb_outer;
-    return (n <= 5120) ? 256 : (n <= 12288) ? 384 : 512;
+    // (round 2, with the helper stream at its measured rate: 640 against 512 gains 1 % at N = 16384, 0.5 % at 32768)
+    return (n <= 5120) ? 256 : (n <= 12288) ? 384 : 640;
 }
 
 // Two 128-column leaves at once (potf2x2_trsm_kernel): columns [lc, lc + 256) of the n x n matrix, m = n - lc - 256 rows
