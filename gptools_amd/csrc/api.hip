@@ -59,6 +59,7 @@ struct gpt_ctx {
     int64_t late_pad_rows = 4608;          //      workgroups per CU, so that the panel stream's chain kernels share the CUs with less contention
     bool defer_join = false;               // potrf_enqueue leaves the final panel -> main join to its caller (factor_and_ll)
     hipStream_t tail_stream = nullptr;     // ... and reports the stream the factorisation ended on
+    int64_t gemm_prio = -1;                // >= 0: wave priority of ALL GEMM main loops of this context
     int64_t panel_prio = 2;                // wave priority (0..3) of the panel stream's GEMM main loops
     int64_t purg_rows = 6144;              // > 0: while more rows than this remain, the panel stream does the "urgent" update itself
                                            // (N=8192: 5.36 against 5.44 ms, bit-identical; no effect below ~7k rows or with the helper stream)
@@ -348,7 +349,9 @@ static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, 
         GPT_HIP_CHECK(hipEventRecord(gp->e0, st));
     }
     // the panel stream's updates keep a raised wave priority in their main loop (option panel_prio, see gemm.hip)
-    const int prio = (!on_main && c->lookahead) ? (int)c->panel_prio : 0;
+    // (option gemm_prio >= 0: every GEMM of this context -- the panel-side context of the block-cyclic engine, whose
+    // launches all sit on the chain)
+    const int prio = (c->gemm_prio >= 0) ? (int)c->gemm_prio : (!on_main && c->lookahead) ? (int)c->panel_prio : 0;
     int rc = launch_gemm_nt(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, c->tile, lds_pad, e0, e1, prio);
     if (!ext) {
         if (prof) GPT_HIP_CHECK(hipEventRecord(gp->e1, st));
@@ -933,6 +936,7 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "late_rows")) c->late_rows = value;
     else if (!strcmp(key, "purg_rows")) c->purg_rows = value;
     else if (!strcmp(key, "panel_prio")) c->panel_prio = value;
+    else if (!strcmp(key, "gemm_prio")) c->gemm_prio = value;
     else if (!strcmp(key, "late_pad")) c->late_pad = (int)value;
     else if (!strcmp(key, "late_pad_rows")) c->late_pad_rows = value;
     else if (!strcmp(key, "nb_early")) c->nb_early = value;

@@ -151,6 +151,9 @@ class HipPanelOps(PanelOps):
         self._stream = {"main": self.main_stream, "panel": self.panel_stream, "recv": self.recv_stream}
         for c in self._ctx.values():
             c.set_option("lookahead", 0)
+        # everything the panel context launches sits on the chain and shares CUs with the main context's trailing update:
+        # its GEMM main loops keep a raised wave priority (gemm.hip; the TRSM / fused kernels carry theirs themselves)
+        self.ctx_panel.set_option("gemm_prio", int(os.environ.get("GPT_DIST_PANEL_PRIO", "2")))
 
     def queue(self, q):
         return torch.cuda.stream(self._stream[q])

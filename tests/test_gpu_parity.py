@@ -45,6 +45,66 @@ def make_kernel(g, kern, d, params, **kw):
     return cls(num_dim=d, initial_params=list(params), **kw)
 
 
+@pytest.mark.parametrize("d", [1, 3])
+def test_m52_pairs_over_the_whole_range_of_r(g, oracle, d):
+    """The Matern-5/2 builder carries its own exp(-x) and 1/sqrt (kpair.hpp: exp_neg, v_rsq + Newton): every derivative
+    class against the oracle from r = 1e-150 to the underflow of exp(-sqrt5 r) and beyond (the clamp at x = 800), with
+    coincident points, denormal distances and non-finite inputs mixed in.  Tolerance where the oracle's value is normal:
+    1e-13 + 1e-15 x relative, x = sqrt5 r -- exp(-x) turns the rounding of its own argument (a few ulp of x on either
+    side) into a relative error of that many ulp TIMES x, for the library exp as for this one (matern.c:61-186 restated
+    in oracle/gpt_oracle.c; the reference's own C code when oracle/_ref exists)."""
+    rs = np.random.RandomState(77 + d)
+    M = 6000
+    ell = np.array([0.7, 1.3, 0.4])[:d]
+    p = np.concatenate([[1.7], ell])
+    Xi = rs.rand(M, d)
+    # distances log-uniform over 1e-150 .. 1e4 length scales, random direction
+    u = rs.randn(M, d)
+    u /= np.sqrt((u * u).sum(1))[:, None]
+    r = 10.0 ** rs.uniform(-150, 4, M)
+    r[:200] = 10.0 ** rs.uniform(1.8, 2.8, 200)          # around the underflow of exp(-sqrt5 r): r = 330 .. 360
+    Xj = Xi + (r[:, None] * u) * ell
+    Xj[200:260] = Xi[200:260]                            # coincident points
+    ni = np.zeros((M, d), dtype=int)
+    nj = np.zeros((M, d), dtype=int)
+    cls = rs.randint(0, 4, M)
+    for m in range(M):
+        if cls[m] & 1:
+            ni[m, rs.randint(d)] = 1
+        if cls[m] & 2:
+            nj[m, rs.randint(d)] = 1
+    k = make_kernel(g, "m52", d, p)
+    got = k(Xi, Xj, ni, nj)
+    want = oracle.kpairs("m52", p, Xi, Xj, ni, nj)
+    assert np.all(np.isfinite(want))
+    normal = np.abs(want) > 1e-290
+    x = np.sqrt(5.0 * (((Xi - Xj) / ell) ** 2).sum(1))
+    tol = 1e-13 + 1e-15 * x
+    # derivative x derivative pairs in DIFFERENT dimensions: the reference's own expression (matern.c:143-146, term1 +
+    # term2) cancels to ~5 r^2 of its terms as r -> 0, so below r ~ 1e-7 its value IS rounding noise of size
+    # eps * (5/3) sigma^2 / l_i l_j -- compared absolutely there
+    atol = np.where(cls == 3, 4e-15 * p[0] ** 2 / ell.min() ** 2, 0.0)
+    bad = normal & (np.abs(got - want) > tol * np.abs(want) + atol)
+    assert not bad.any(), (np.where(bad)[0][:5], got[bad][:5], want[bad][:5], x[bad][:5])
+    assert np.all(np.abs(got[~normal]) <= 1e-289)        # underflow region: both (sub)normal-small or zero
+    if oracle.have_ref():
+        ref = p[0] ** 2 * oracle.ref_matern52(Xi, Xj, ni, nj, p[1:] ** 2)
+        nr = np.abs(ref) > 1e-290
+        assert not (nr & (np.abs(got - ref) > tol * np.abs(ref) + atol)).any()
+    # every lane of a wave in ONE class (the branch the K builder takes nearly everywhere) gives the same numbers
+    for c in range(4):
+        sel = np.where(cls == c)[0][:640]
+        np.testing.assert_array_equal(k(Xi[sel], Xj[sel], ni[sel], nj[sel]), got[sel])
+    # non-finite inputs propagate (the clamp of exp_neg must not hide a NaN)
+    Xn = Xi[:8].copy()
+    Xn[0, 0] = np.nan
+    Xn[1, 0] = np.inf
+    out = k(Xn, Xj[:8], ni[:8], nj[:8])
+    assert np.isnan(out[0]) and (np.isnan(out[1]) or out[1] == 0.0)
+    np.testing.assert_array_equal(out[2:], got[2:8])
+
+
+
 # ---------------------------------------------------------------- G1: Kernel.__call__ ---------
 @pytest.mark.parametrize("d", [1, 2, 3, 4])
 def test_g1_kernel_call_se(g, golden, d):
