@@ -68,17 +68,26 @@ const char *gpt_last_error(void);
 int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out);
 int gpt_ctx_destroy(gpt_ctx *ctx);
 /* Options (gpt_ctx_set_option):
- *   "nb_outer"     outer block width of the factorisation, multiple of 128; 0 = by size (384 up to n = 12288, 512 above)
+ *   "nb_outer"     outer block width of the factorisation, multiple of 128; 0 = by size (256 up to n = 5120, 384 up to
+ *                  12288, 640 above)
  *   "lookahead"    0/1: factor panel k+1 on the high-priority panel stream while the main stream applies panel k
- *   "helper_tf"    assumed rate of the helper stream (0.1 TFLOP/s per 24 CUs) that takes a slice of the large trailing
- *                  updates on the reserved CUs when n > 12288; 0 = off
- *   "ramp"         0/1: first panels 128, 256, ... wide (measured slower, off)
+ *   "purg_rows"    while more rows than this remain the panel stream applies panel k to the columns of panel k+1 itself
+ *                  (6144; 0 = the main stream always does)
+ *   "panel_prio"   wave priority (0..3) of the panel stream's GEMM main loops (2); "gemm_prio" >= 0 forces one priority
+ *                  for every GEMM of the context (the panel-side context of gptools_amd/dist.py)
+ *   "fuse_trsm"    panels with at most this many rows under a leaf use the fused diagonal-block + TRSM kernel (4096)
+ *   "helper_tf"    assumed rate of the helper stream (0.1 TFLOP/s per 24 CUs, 45) that takes a slice of the large trailing
+ *                  updates on the reserved CUs when n > "helper_min_n" (12288); 0 = off
  *   "gemm_pad"     bytes of dummy dynamic LDS of the main-stream GEMM (residency cap)
  *   "graph"        0/1: replay the factorisation from a captured hipGraph
  *   "timing"       0/1: record per-phase HIP events (gpt_last_timings)
  *   "profile_gemm" 0/1: HIP-event timing of each large GEMM launch (gpt_gemm_profile_read)
  *   "tile"         0 auto, 64, 65 (4-stage), 128 (persistent), 129: force the GEMM macro-tile
- * Environment: GPT_RESERVE_CUS (CUs the main stream leaves to the panel stream, default 32), GPT_GRAD_TIMING. */
+ *   measured and off by default: "ramp", "inner", "inner_rows", "leaf256", "defer_rows", "late_rows",
+ *   "early_rows", "nb_early", "nb_switch_rows", "late_pad", "late_pad_rows"
+ * Environment: GPT_RESERVE_CUS (CUs the main stream leaves to the panel stream, default 32), GPT_TILE_ORDER
+ * ("rows,cols,mode": supertile shape and deal of the GEMM's XCD-aware tile order, default 64,8,1), GPT_GRAD_TIMING,
+ * GPT_JITTER (test aid: random delay kernels in front of every dense launch). */
 int gpt_ctx_set_option(gpt_ctx *ctx, const char *key, int64_t value);
 int gpt_ctx_synchronize(gpt_ctx *ctx);
 void *gpt_ctx_stream(gpt_ctx *ctx);
