@@ -1532,10 +1532,16 @@ extern "C" int gpt_ll_grad(gpt_ctx *c, int nh, const int *term_idx, const int *l
     GPT_TRY(trtri_u(c, st, 0, NP, c->dA, NP, c->d_invd, U, NP));
     // (block rows of about NP/8: skinnier launches exploit more of U's zeros but run the GEMM far below its rate)
     if (gt) GPT_HIP_CHECK(hipEventRecord(ge[1], st));
-    const int64_t nb = (NP / 8 >= 512) ? (NP / 8) / 128 * 128 : 512;
+    int64_t nbdiv = 8;
+    if (const char *e = getenv("GPT_GRAD_ROWS_DIV")) nbdiv = atoi(e) > 0 ? atoi(e) : 8;
+    const int64_t nb = (NP / nbdiv >= 512) ? (NP / nbdiv) / 128 * 128 : 512;
     for (int64_t r0 = 0; r0 < NP; r0 += nb) {
         const int64_t rows = (NP - r0 < nb) ? NP - r0 : nb;
-        GPT_TRY(gemm_nt(c, st, rows, r0 + rows, NP - r0, 1.0, U + r0 * NP + r0, NP, U + r0, NP, 0.0, W + r0 * NP, NP, 0));
+        // the block row left of the diagonal block as a rectangle, the diagonal block itself as a lower trapezoid (the pair
+        // pass reads the lower triangle of W only)
+        if (r0 > 0)
+            GPT_TRY(gemm_nt(c, st, rows, r0, NP - r0, 1.0, U + r0 * NP + r0, NP, U + r0, NP, 0.0, W + r0 * NP, NP, 0));
+        GPT_TRY(gemm_nt(c, st, rows, rows, NP - r0, 1.0, U + r0 * NP + r0, NP, U + r0 * NP + r0, NP, 0.0, W + r0 * NP + r0, NP, 1));
     }
     if (gt) GPT_HIP_CHECK(hipEventRecord(ge[2], st));
     // sum_ab (alpha_a alpha_b - W_ab) dK_h[a][b], per kernel term, GPT_GRAD_MAXH parameters per launch
