@@ -586,7 +586,22 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
         return GPT_E_ARG;
     }
     int tile = force_tile;
-    if (tile == 0) tile = 64;   // measured on MI355X: 64x64 tiles at 4-5 workgroups per CU beat the 128x128 variants
+    if (tile == 0) {
+        tile = 64;   // measured on MI355X: 64x64 tiles at 4-5 workgroups per CU beat the 128x128 variants
+        // Launches of fewer than 512 64x64 tiles -- two per CU: the rank-128 updates of the chain (71 x 6 tiles at 4500 rows,
+        // 16 x 6 at 1000) -- are cut into 32x32 tiles instead: four times the workgroups, a quarter of the MFMAs per wave
+        // (128 -> 32 at k = 128), so a launch that is mostly latency gets off the chain sooner.  Same sums in the same
+        // order, bit-identical results.  Measured (scratch/env_ab.py, GPT_GEMM_SMALL = threshold): N = 8192 4.757 ->
+        // 4.625 ms at 512 (4.709 at 256, 4.648 at 1024, 4.692 at 2048), N = 4096 1.468 -> 1.386, N = 16384 27.28 -> 27.15.
+        static int small_below = -1;
+        if (small_below < 0) {
+            small_below = 512;
+            if (const char *e = getenv("GPT_GEMM_SMALL")) small_below = atoi(e);
+        }
+        const int64_t nt64 = ((m + 63) / 64) * ((n + 63) / 64);
+        if (nt64 < small_below && !ev0) tile = 32;
+    }
+    if (tile == 32) return gemm_launch_t<32, 32, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0, ev0, ev1, 0, 0, 0, prio);
     if (tile == 129) return gemm_launch_t<128, 128, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0);
     if (tile == 128) return gemm_launch_persist(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri);
     // A 4-stage variant (gemm_launch_t<64, 64, 1, 4>, DMA three k-tiles ahead, counted vmcnt) was measured on the
