@@ -57,6 +57,9 @@ struct gpt_ctx {
     int pad_now = 0;                       // (set per panel by potrf_enqueue: LDS pad of the main stream's updates right now)
     int late_pad = 0;                      // > 0: LDS pad of the main stream's updates once at most late_pad_rows rows remain -- fewer of its
     int64_t late_pad_rows = 4608;          //      workgroups per CU, so that the panel stream's chain kernels share the CUs with less contention
+    unsigned *d_edge = nullptr;            // edge-flag words (EdgeSig, common.hpp): [0,1] "panel k final", [16,17] "urgent update k done"
+    unsigned edge_seq = 0;                 // value of the last edge raised (monotonic over the context's life)
+    int64_t edge_flags = 1;                // 1: those two edges of the look-ahead are flags + hipStreamWaitValue32 instead of events
     bool defer_join = false;               // potrf_enqueue leaves the final panel -> main join to its caller (factor_and_ll)
     hipStream_t tail_stream = nullptr;     // ... and reports the stream the factorisation ended on
     int64_t gemm_prio = -1;                // >= 0: wave priority of ALL GEMM main loops of this context
@@ -311,7 +314,7 @@ static int check_rq_orders(const int32_t *ni, int64_t M, const int32_t *nj, int6
 // ------------------------------------------------------------------------------------------------
 static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A,
                    int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri,
-                   hipEvent_t done = nullptr)
+                   hipEvent_t done = nullptr, EdgeSig edge = EdgeSig(), EdgeSig wait = EdgeSig())
 {
     // algorithmic flop count: 2k per computed element of C (lower trapezoid when tri)
     const double elems = tri ? 0.5 * (double)n * (double)(n + 1) + (double)(m - n) * (double)n : (double)m * (double)n;
@@ -352,7 +355,7 @@ static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, 
     // (option gemm_prio >= 0: every GEMM of this context -- the panel-side context of the block-cyclic engine, whose
     // launches all sit on the chain)
     const int prio = (c->gemm_prio >= 0) ? (int)c->gemm_prio : (!on_main && c->lookahead) ? (int)c->panel_prio : 0;
-    int rc = launch_gemm_nt(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, c->tile, lds_pad, e0, e1, prio);
+    int rc = launch_gemm_nt(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, c->tile, lds_pad, e0, e1, prio, edge, wait);
     if (!ext) {
         if (prof) GPT_HIP_CHECK(hipEventRecord(gp->e1, st));
         if (done) GPT_HIP_CHECK(hipEventRecord(done, st));
@@ -478,8 +481,9 @@ static int panel_ext_ll(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int6
 // with a 256-column leaf: that kernel reads both of its leaves' columns when it starts).
 static int panel_ext(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64_t n, int64_t c0, int64_t w,
                      double *invd, int32_t *info, hipEvent_t wait_ev, hipEvent_t done_ev, int64_t ext = GPT_PANEL_EXT,
-                     hipEvent_t first_ev = nullptr)
+                     hipEvent_t first_ev = nullptr, EdgeSig wait_edge = EdgeSig(), EdgeSig done_edge = EdgeSig())
 {
+    // wait_edge / done_edge: the same two dependencies as wait_ev / done_ev carried by flag words (EdgeSig, common.hpp)
     // first_ev: recorded by the panel's FIRST update launch (see "deferred rest" in potrf_enqueue)
     if (c->inner == 1 || (c->inner == 2 && n - c0 <= c->inner_rows))
         return panel_ext_ll(c, st, A, lda, n, c0, w, invd, info, wait_ev, done_ev);
@@ -511,17 +515,30 @@ static int panel_ext(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64_t
                 c->flag_epoch = 0;
             }
             c->flag_epoch += 32;           // (the 256-column leaf kernel raises the word by up to 17 per launch)
-            GPT_TRY(launch_potf2_trsm(st, Ad, lda, ws, info, lc, m, c->d_flag, c->flag_epoch, last ? done_ev : nullptr));
+            GPT_TRY(launch_potf2_trsm(st, Ad, lda, ws, info, lc, m, c->d_flag, c->flag_epoch, last ? done_ev : nullptr,
+                                      (r1 == c0 + w) ? done_edge : EdgeSig()));
         } else {
             GPT_TRY(launch_potf2_diag(st, Ad, lda, ws, info, lc));
             // (a stop event on the launch is not recorded by stream capture: under a graph use a plain record)
-            GPT_TRY(launch_trsm_panel(st, m, Ad, lda, ws, Ad + 128 * lda, lda, (last && !c->use_graph) ? done_ev : nullptr));
+            GPT_TRY(launch_trsm_panel(st, m, Ad, lda, ws, Ad + 128 * lda, lda, (last && !c->use_graph) ? done_ev : nullptr,
+                                      (r1 == c0 + w) ? done_edge : EdgeSig()));
             if (last && c->use_graph) GPT_HIP_CHECK(hipEventRecord(done_ev, st));
         }
         if (lc == c0 && wait_ev) GPT_HIP_CHECK(hipStreamWaitEvent(st, wait_ev, 0));
         if (cend > r1) {
+            // (the first update of the panel is the first kernel of the chain that touches what the main stream's urgent
+            // update wrote: it waits for that edge itself, see gemm.hip)
+            // Its workgroups SPIN until the word is up, so the launch must not be able to fill the chip (the update they
+            // wait for needs room to run): in the kernel only while the launch stays under 1024 workgroups = half the wave
+            // slots, otherwise as a stream operation in front of it (a kernel of the runtime, ~5 us).
+            EdgeSig inwait;
+            if (lc == c0 && wait_edge.word) {
+                const int64_t wgs = ((n - r1 + 31) / 32) * ((cend - r1 + 31) / 32);
+                if (wgs <= 1024 && (c->tile == 0 || c->tile == 64)) inwait = wait_edge;
+                else GPT_HIP_CHECK(hipStreamWaitValue32(st, wait_edge.word, wait_edge.value, hipStreamWaitValueGte, 0xffffffffu));
+            }
             GPT_TRY(gemm_nt(c, st, n - r1, cend - r1, 128, -1.0, A + r1 * lda + lc, lda, A + r1 * lda + lc, lda, 1.0,
-                            A + r1 * lda + r1, lda, 1, first_ev));
+                            A + r1 * lda + r1, lda, 1, first_ev, EdgeSig(), inwait));
             first_ev = nullptr;
         }
     }
@@ -607,6 +624,20 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
     // ~17 (profiles/r01_timeline_c3_N8192.txt).  The rest of panel k is therefore held back until that leaf update is
     // done (one event), and is enqueued one loop iteration late so that the event is recorded before it is waited for.
     const bool use_late = c->late_panel_stream && c->late_rows > 0 && !c->use_graph;
+    // Flag edges (EdgeSig): "panel k is final" (panel stream -> main stream) and "the urgent update of panel k is done"
+    // (main -> panel stream) are raised by the last workgroup of the kernel that completes them and waited for with
+    // hipStreamWaitValue32 -- 1.5 us per edge against 8-9 for an event, and no stop event on the chain's kernels (4.5 us
+    // each).  In the chain-bound end both edges are on the critical path of every panel.
+    const bool use_flags = c->edge_flags && c->d_edge && !H && !c->use_graph && c->inner == 0 && !c->leaf256 && !use_early && !use_late
+                           && c->defer_rows == 0;
+    if (use_flags && c->edge_seq > 0xf0000000u) {           // (the words are only ever raised: start over long before a wrap)
+        GPT_HIP_CHECK(hipStreamSynchronize(S));
+        GPT_HIP_CHECK(hipStreamSynchronize(P));
+        GPT_HIP_CHECK(hipMemsetAsync(c->d_edge, 0, 256, S));
+        GPT_HIP_CHECK(hipStreamSynchronize(S));
+        c->edge_seq = 0;
+    }
+    EdgeSig cu_edge_prev;
     struct PendingRest { bool on; int64_t c0, w, u1, split; hipStream_t S; } pend = {false, 0, 0, 0, 0, nullptr};
     auto launch_rest = [&](const PendingRest &r) -> int {
         return gemm_nt(c, r.S, n - r.u1, r.split - r.u1, r.w, -1.0, A + r.u1 * lda + r.c0, lda, A + r.u1 * lda + r.c0, lda,
@@ -646,7 +677,14 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
         c->pad_now = (c->late_pad > 0 && n - c0 <= c->late_pad_rows) ? c->late_pad : 0;
         hipEvent_t e_first = pend.on ? get_event(c, 8 + 4 * widths.size() + k) : nullptr;
         if (pend.on && !e_first) return GPT_E_HIP;
-        GPT_TRY(panel_ext(c, P, A, lda, n, c0, w, invd, info, e_cu_prev, e_panel, ext_k, e_first));
+        EdgeSig panel_edge;
+        if (use_flags && c0 + w + ext_k < n) {
+            panel_edge.word = c->d_edge;
+            panel_edge.value = ++c->edge_seq;
+        }
+        GPT_TRY(panel_ext(c, P, A, lda, n, c0, w, invd, info, e_cu_prev, use_flags ? nullptr : e_panel, ext_k, e_first, cu_edge_prev,
+                          panel_edge));
+        cu_edge_prev = EdgeSig();
         if (pend.on) {
             GPT_HIP_CHECK(hipStreamWaitEvent(pend.S, e_first, 0));
             GPT_TRY(launch_rest(pend));
@@ -671,7 +709,8 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
                 GPT_HIP_CHECK(hipEventRecord(e_sdone, S));
                 GPT_HIP_CHECK(hipStreamWaitEvent(H, e_sdone, 0));
             }
-            GPT_HIP_CHECK(hipStreamWaitEvent(S, e_panel, 0));
+            if (use_flags) GPT_HIP_CHECK(hipStreamWaitValue32(S, panel_edge.word, panel_edge.value, hipStreamWaitValueGte, 0xffffffffu));
+            else GPT_HIP_CHECK(hipStreamWaitEvent(S, e_panel, 0));
             if (split < n) {
                 GPT_HIP_CHECK(hipStreamWaitEvent(H, e_panel, 0));
                 GPT_TRY(gemm_nt(c, H, n - split, n - split, w, -1.0, A + split * lda + c0, lda, A + split * lda + c0,
@@ -701,9 +740,18 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
                 continue;
             }
             e_rest_prev = nullptr;
-            GPT_TRY(gemm_nt(c, S, n - u0, u1 - u0, w, -1.0, A + u0 * lda + c0, lda, A + u0 * lda + c0, lda, 1.0,
-                            A + u0 * lda + u0, lda, 1, e_cu));
-            e_cu_prev = e_cu;
+            if (use_flags) {
+                EdgeSig cu_edge;
+                cu_edge.word = c->d_edge + 16;
+                cu_edge.value = ++c->edge_seq;
+                GPT_TRY(gemm_nt(c, S, n - u0, u1 - u0, w, -1.0, A + u0 * lda + c0, lda, A + u0 * lda + c0, lda, 1.0,
+                                A + u0 * lda + u0, lda, 1, nullptr, cu_edge));
+                cu_edge_prev = cu_edge;
+            } else {
+                GPT_TRY(gemm_nt(c, S, n - u0, u1 - u0, w, -1.0, A + u0 * lda + c0, lda, A + u0 * lda + c0, lda, 1.0,
+                                A + u0 * lda + u0, lda, 1, e_cu));
+                e_cu_prev = e_cu;
+            }
             if (u1 < n) {
                 if (e_help_prev && !waited) GPT_HIP_CHECK(hipStreamWaitEvent(S, e_help_prev, 0));
                 e_help_prev = nullptr;
@@ -860,10 +908,12 @@ extern "C" int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out)
     GPT_HIP_CHECK(hipMalloc(&c->d_info, sizeof(int32_t)));
     GPT_HIP_CHECK(hipMalloc((void **)&c->d_flag, 64));
     GPT_HIP_CHECK(hipMalloc((void **)&c->d_l10pk, 16384 * sizeof(double)));
+    GPT_HIP_CHECK(hipMalloc((void **)&c->d_edge, 256));
     // (hipMemsetAsync on the context's stream, never hipMemset: one call on the legacy null stream and from then on
     // every kernel of this process starts ~40 us late on every stream -- measured on the block-cyclic engine,
     // 31 -> 41 ms per rank at N=32768 over 8 ranks, potf2 26 -> 45..90 us in the trace)
     GPT_HIP_CHECK(hipMemsetAsync(c->d_flag, 0, 64, c->stream));
+    GPT_HIP_CHECK(hipMemsetAsync(c->d_edge, 0, 256, c->stream));
     GPT_HIP_CHECK(hipMalloc(&c->d_scal, 4 * sizeof(double)));
     GPT_HIP_CHECK(hipHostMalloc((void **)&c->h_scal, 4 * sizeof(double), hipHostMallocDefault));
     GPT_HIP_CHECK(hipHostMalloc((void **)&c->h_info, sizeof(int32_t), hipHostMallocDefault));
@@ -904,6 +954,7 @@ extern "C" int gpt_ctx_destroy(gpt_ctx *c)
     if (c->d_info) hipFree(c->d_info);
     if (c->d_flag) hipFree(c->d_flag);
     if (c->d_l10pk) hipFree(c->d_l10pk);
+    if (c->d_edge) hipFree(c->d_edge);
     if (c->d_scal) hipFree(c->d_scal);
     if (c->h_scal) hipHostFree(c->h_scal);
     if (c->h_info) hipHostFree(c->h_info);
@@ -936,6 +987,7 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "late_rows")) c->late_rows = value;
     else if (!strcmp(key, "purg_rows")) c->purg_rows = value;
     else if (!strcmp(key, "panel_prio")) c->panel_prio = value;
+    else if (!strcmp(key, "edge_flags")) c->edge_flags = value;
     else if (!strcmp(key, "gemm_prio")) c->gemm_prio = value;
     else if (!strcmp(key, "late_pad")) c->late_pad = (int)value;
     else if (!strcmp(key, "late_pad_rows")) c->late_pad_rows = value;

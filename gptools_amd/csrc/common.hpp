@@ -59,6 +59,31 @@ struct KParams {
     double m_g[2], m_gm[2], m_nus[2];             // Gamma(nu_s), Gamma(-nu_s), nu_s for the small-y series (nu_s = nu, or nu -+ 0.001)
 };
 
+// A cross-stream edge without an event: the kernel that completes a piece of work raises a 32-bit word in device
+// memory when its LAST workgroup is through (its results written with write-through stores and drained first) and the
+// waiting stream holds a hipStreamWaitValue32 on that word.  Measured (scratch/waitvalue_probe.hip): producer end ->
+// consumer start 1.5 us and nothing added to the producer's own stream, against 7.6-9.1 us and 1.7-4.5 us for a stop
+// event on the dispatch packet + hipStreamWaitEvent.  word[0] = the flag (only ever raised), word[1] = workgroup counter.
+struct EdgeSig {
+    unsigned *word = nullptr;
+    unsigned value = 0;
+};
+// device side: called by every workgroup that takes part, after its results are stored (all threads of the workgroup)
+#ifdef __HIPCC__
+__device__ __forceinline__ void edge_signal(unsigned *word, unsigned value, unsigned total)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's (write-through) stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned done = __hip_atomic_fetch_add(word + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (done == total) {
+            __hip_atomic_store(word + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+#endif
+
 // ---- launchers implemented in the .hip files (all asynchronous on `st`) -------------------
 int launch_kpairs(hipStream_t st, const KParams &kp, const double *dXi, const double *dXj,
                   const int32_t *dni, const int32_t *dnj, int64_t M, double *dout, int accumulate = 0);
@@ -69,18 +94,19 @@ int launch_kbuild(hipStream_t st, const KParams &kp, const double *dXi, const in
 int launch_check_orders(hipStream_t st, const int32_t *dn, int64_t M, int D, int32_t *d_flag);
 int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A, int64_t lda,
                    const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile, int lds_pad,
-                   hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int prio = 0);
+                   hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int prio = 0, EdgeSig edge = EdgeSig(),
+                   EdgeSig wait = EdgeSig());
 int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base);
 int launch_gemm_nt_stair(hipStream_t st, int64_t m, int64_t nseg, int64_t seg_cols, int64_t k, double alpha,
                          const double *A, int64_t lda, const double *B, int64_t ldb, int64_t b_stride, int64_t row_step,
                          double beta, double *C, int64_t ldc, int lds_pad, hipEvent_t ev0 = nullptr,
                          hipEvent_t ev1 = nullptr);
 int launch_potf2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
-                      unsigned *flag, unsigned flag_base, hipEvent_t done = nullptr);
+                      unsigned *flag, unsigned flag_base, hipEvent_t done = nullptr, EdgeSig edge = EdgeSig());
 int launch_potf2x2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
                         double *l10pk, unsigned *flag, unsigned flag_base, hipEvent_t done = nullptr);
 int launch_trsm_panel(hipStream_t st, int64_t m, const double *L, int64_t ldl, const double *invd,
-                      double *B, int64_t ldb, hipEvent_t done = nullptr);
+                      double *B, int64_t ldb, hipEvent_t done = nullptr, EdgeSig edge = EdgeSig());
 #define GPT_GRAD_MAXH 8
 int grad_reduce_blocks(int64_t N);
 int launch_grad_reduce(hipStream_t st, const KParams &kp, int nh, const int *hl, const double *dX, const int32_t *dn,

@@ -157,7 +157,8 @@ template <int BM, int BN, int WPS, int NSTAGE>
 __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     int64_t m, int64_t n, int64_t k, double alpha, const double *__restrict__ A, int64_t lda,
     const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
-    int tri, int64_t ntm, int64_t ntn, int64_t nwg, const int2 *__restrict__ order, int64_t seg_cols, int64_t bskip, int prio)
+    int tri, int64_t ntm, int64_t ntn, int64_t nwg, const int2 *__restrict__ order, int64_t seg_cols, int64_t bskip, int prio, unsigned *edge, unsigned edge_val,
+    unsigned edge_total, const unsigned *wait_word, unsigned wait_val)
 {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int RM = WM / 16, RN = WN / 16;
@@ -190,6 +191,17 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     const int64_t row0 = ti * BM, col0 = tj * BN;
     GM_STAMP(6);
     const int tid = threadIdx.x, lane = tid & 63;
+    // In-kernel side of a flag edge (EdgeSig): C of this launch is produced by a kernel of another stream that raises
+    // *wait_word to wait_val when it is through.  hipStreamWaitValue32 in front of this launch would be a kernel of its own
+    // (__amd_rocclr_streamOpsWait, ~5 us on the chain); here the common case -- the word is already up -- costs one load.
+    // C is then read past the L2 (the producer wrote it through to memory while this launch may already have been running).
+    if (wait_word != nullptr) {
+        if (tid == 0) {
+            while ((int)(__hip_atomic_load(wait_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - wait_val) < 0)
+                __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+    }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fk = lane >> 4;
@@ -218,7 +230,10 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int64_t row = row0 + wm * WM + i * 16 + fk + 4 * r;
-                acc[i][j][r] = (beta != 0.0 && row < m && col < n) ? GM_LOADC(&C[row * ldc + col]) : 0.0;
+                acc[i][j][r] = (beta != 0.0 && row < m && col < n)
+                                   ? (wait_word ? __hip_atomic_load(&C[row * ldc + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                : GM_LOADC(&C[row * ldc + col]))
+                                   : 0.0;
             }
         }
     GM_STAMP(7);
@@ -271,10 +286,16 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int64_t row = row0 + wm * WM + i * 16 + fk + 4 * r;
-                if (row < m && col < n) GM_STOREC(alpha * acc[i][j][r], &C[row * ldc + col]);
+                if (row < m && col < n) {
+                    // (a launch that raises an edge flag writes C through to memory: the waiting kernel starts before this
+                    // one's end-of-kernel cache write-back)
+                    if (edge) __hip_atomic_store(&C[row * ldc + col], alpha * acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else GM_STOREC(alpha * acc[i][j][r], &C[row * ldc + col]);
+                }
             }
         }
     GM_STAMP(3);
+    if (edge) edge_signal(edge, edge_val, edge_total);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -417,6 +438,7 @@ struct TileOrder {
     int64_t seg_t, rss_t;          // staircase tables: tiles per column segment, row-start step per segment (tiles)
     int2 *d_tab;
     int64_t grid;
+    int64_t ntiles;                // entries of the table that hold a tile (the rest are (-1, -1) padding)
 };
 static std::vector<TileOrder> g_orders;
 static std::mutex g_orders_mu;
@@ -434,7 +456,7 @@ static inline bool tile_needed(int tri, int64_t i, int64_t j, int64_t seg_t, int
 }
 
 static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64_t *grid, int64_t seg_t = 0,
-                      int64_t rss_t = 0)
+                      int64_t rss_t = 0, int64_t *ntiles = nullptr)
 {
     static int sgm = 0, sgn = 0, mode = 0;
     if (sgm == 0) {
@@ -451,6 +473,7 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
         if (o.ntm == ntm && o.ntn == ntn && o.tri == tri && o.dev == dev && o.seg_t == seg_t && o.rss_t == rss_t) {
             *tab = o.d_tab;
             *grid = o.grid;
+            if (ntiles) *ntiles = o.ntiles;
             return GPT_OK;
         }
     std::vector<std::vector<int2>> per(8);
@@ -491,6 +514,8 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
     o.seg_t = seg_t;
     o.rss_t = rss_t;
     o.grid = (int64_t)flat.size();
+    o.ntiles = 0;
+    for (auto &v : per) o.ntiles += (int64_t)v.size();
     o.d_tab = nullptr;
     GPT_HIP_CHECK(hipMalloc(&o.d_tab, flat.size() * sizeof(int2)));
     {   // upload on a private non-blocking stream: the caller may be inside a stream capture (hipGraph option), where
@@ -506,6 +531,7 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
     g_orders.push_back(o);
     *tab = o.d_tab;
     *grid = o.grid;
+    if (ntiles) *ntiles = o.ntiles;
     return GPT_OK;
 }
 
@@ -513,18 +539,20 @@ template <int BM, int BN, int WPS, int NSTAGE>
 static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A,
                          int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri,
                          int lds_pad, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int64_t seg_cols = 0,
-                         int64_t bskip = 0, int64_t row_step = 0, int prio = 0)
+                         int64_t bskip = 0, int64_t row_step = 0, int prio = 0, EdgeSig edge = EdgeSig(),
+                         EdgeSig wait = EdgeSig())
 {
     const int64_t ntm = (m + BM - 1) / BM, ntn = (n + BN - 1) / BN;
     int64_t nwg = (tri == 1) ? ntn * (ntn + 1) / 2 + (ntm - ntn) * ntn : ntm * ntn;
+    int64_t nreal = nwg;                   // workgroups that compute a tile (and count towards an edge flag)
     const int2 *order = nullptr;
     if (tri == 2) {                        // staircase: the tile list always comes from a table
         int64_t grid = 0;
-        GPT_TRY_RC(tile_order(ntm, ntn, 2, &order, &grid, seg_cols / BN, row_step / BM));
+        GPT_TRY_RC(tile_order(ntm, ntn, 2, &order, &grid, seg_cols / BN, row_step / BM, &nreal));
         nwg = grid;
     } else if (nwg >= 512) {               // large launches only: small ones live in L2 anyway
         int64_t grid = 0;
-        GPT_TRY_RC(tile_order(ntm, ntn, tri, &order, &grid));
+        GPT_TRY_RC(tile_order(ntm, ntn, tri, &order, &grid, 0, 0, &nreal));
         nwg = grid;
     }
     if (nwg <= 0) return GPT_OK;
@@ -536,10 +564,12 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
     // would add two barrier packets per launch to the stream being measured
     if (ev0 || ev1)
         hipExtLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg), dim3(256), dyn, st, ev0, ev1, 0,
-                              m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip, prio);
+                              m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip, prio, edge.word, edge.value, (unsigned)nreal,
+                              wait.word, wait.value);
     else
         hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg), dim3(256), dyn, st, m, n, k, alpha,
-                           A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip, prio);
+                           A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip, prio, edge.word, edge.value, (unsigned)nreal,
+                              wait.word, wait.value);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
@@ -565,10 +595,16 @@ static int gemm_launch_persist(hipStream_t st, int64_t m, int64_t n, int64_t k, 
 
 int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A, int64_t lda,
                    const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile, int lds_pad,
-                   hipEvent_t ev0, hipEvent_t ev1, int prio)
+                   hipEvent_t ev0, hipEvent_t ev1, int prio, EdgeSig edge, EdgeSig wait)
 {
     gpt_jitter(st);
-    if (m <= 0 || n <= 0) return GPT_OK;
+    if (m <= 0 || n <= 0) {
+        if (edge.word) {
+            gpt_set_error("gemm_nt: an empty launch cannot raise an edge flag");
+            return GPT_E_ARG;
+        }
+        return GPT_OK;
+    }
     if (alpha == 0.0) {
         gpt_set_error("gemm_nt: alpha must be non-zero");
         return GPT_E_ARG;
@@ -601,14 +637,18 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
         const int64_t nt64 = ((m + 63) / 64) * ((n + 63) / 64);
         if (nt64 < small_below && !ev0) tile = 32;
     }
-    if (tile == 32) return gemm_launch_t<32, 32, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0, ev0, ev1, 0, 0, 0, prio);
+    if (tile == 32) return gemm_launch_t<32, 32, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0, ev0, ev1, 0, 0, 0, prio, edge, wait);
+    if ((edge.word || wait.word) && tile != 64) {
+        gpt_set_error("gemm_nt: edge flags exist for the 64x64 / 32x32 kernels only");
+        return GPT_E_ARG;
+    }
     if (tile == 129) return gemm_launch_t<128, 128, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0);
     if (tile == 128) return gemm_launch_persist(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri);
     // A 4-stage variant (gemm_launch_t<64, 64, 1, 4>, DMA three k-tiles ahead, counted vmcnt) was measured on the
     // small panel updates (8064x128x128: 12 us either way): they are bound by launch + prologue latency, not by the
     // DMA wait, so everything uses the 2-stage kernel.
     if (force_tile == 65) return gemm_launch_t<64, 64, 1, 4>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0);
-    return gemm_launch_t<64, 64, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, lds_pad, ev0, ev1, 0, 0, 0, prio);
+    return gemm_launch_t<64, 64, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, lds_pad, ev0, ev1, 0, 0, 0, prio, edge, wait);
 }
 
 // Staircase update: C (m x nseg*seg_cols) += alpha * A B_q^T per column segment q, where segment q (seg_cols

@@ -475,10 +475,14 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restri
 __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restrict__ A, int64_t lda,
                                                                 double *__restrict__ invd, int32_t *info,
                                                                 int64_t info_col0, int64_t m, double *__restrict__ B,
-                                                                int64_t ldb, unsigned *flag, unsigned flag_base)
+                                                                int64_t ldb, unsigned *flag, unsigned flag_base,
+                                                                unsigned *edge, unsigned edge_val)
 {
     if (blockIdx.x == 0) {
         potf2_body<true>(A, lda, invd, info, info_col0, flag, flag_base);
+        // (edge flag: "the panel is final" -- what the waiting update reads are the consumers' rows; this workgroup only
+        // has to be counted)
+        if (edge) edge_signal(edge, edge_val, gridDim.x);
         return;
     }
     // (the chain's kernels share CUs with the main stream's trailing update: raised wave priority, as in gemm.hip)
@@ -529,7 +533,8 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
         for (int kk = 0; kk < 4; kk++) res = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], dv[kk], res, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            B[(row0 + fk + 4 * r) * ldb + j * 16 + fr] = res[r];
+            if (edge) __hip_atomic_store(&B[(row0 + fk + 4 * r) * ldb + j * 16 + fr], res[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else B[(row0 + fk + 4 * r) * ldb + j * 16 + fr] = res[r];
             X[fk + 4 * r][fr] = res[r];
         }
         if (j + 1 < NB16) {
@@ -548,6 +553,7 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
             }
         }
     }
+    if (edge) edge_signal(edge, edge_val, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -826,16 +832,16 @@ static int ensure_big_lds(const void *fn, int which, size_t shmem)
 // m rows below the 128x128 diagonal block at A (B = A + 128 * lda).  `flag` is a device word only ever raised;
 // flag_base must exceed every value written to it before (the caller counts: 16 per launch).
 int launch_potf2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
-                      unsigned *flag, unsigned flag_base, hipEvent_t done)
+                      unsigned *flag, unsigned flag_base, hipEvent_t done, EdgeSig edge)
 {
     gpt_jitter(st);
     const size_t shmem = (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
     { int rc_ = ensure_big_lds(reinterpret_cast<const void *>(potf2_trsm_kernel), 0, shmem); if (rc_ != GPT_OK) return rc_; }
     const unsigned grid = 1u + (unsigned)((m + 16 * PD_WAVES - 1) / (16 * PD_WAVES));
     if (done) hipExtLaunchKernelGGL(potf2_trsm_kernel, dim3(grid), dim3(PD_THREADS), shmem, st, nullptr, done, 0, A, lda, invd,
-                                    info, info_base, m, A + 128 * lda, lda, flag, flag_base);
+                                    info, info_base, m, A + 128 * lda, lda, flag, flag_base, edge.word, edge.value);
     else hipLaunchKernelGGL(potf2_trsm_kernel, dim3(grid), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base, m,
-                            A + 128 * lda, lda, flag, flag_base);
+                            A + 128 * lda, lda, flag, flag_base, edge.word, edge.value);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
@@ -880,7 +886,8 @@ int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int3
 #define TP_WAVES 4
 __global__ __launch_bounds__(64 * TP_WAVES, 2) void trsm_panel_kernel(int64_t m, const double *__restrict__ L,
                                                                       int64_t ldl, const double *__restrict__ invd,
-                                                                      double *__restrict__ B, int64_t ldb)
+                                                                      double *__restrict__ B, int64_t ldb, unsigned *edge,
+                                                                      unsigned edge_val)
 {
     __shared__ __attribute__((aligned(16))) double Lp[28][4][64];
     __shared__ __attribute__((aligned(16))) double Sc[TP_WAVES][16][TP_SP];
@@ -917,8 +924,8 @@ __global__ __launch_bounds__(64 * TP_WAVES, 2) void trsm_panel_kernel(int64_t m,
         for (int q = 0; q < NPK; q++) *reinterpret_cast<f64x2 *>(lflat + 2 * (tid + q * 64 * TP_WAVES)) = v[q];
     }
     __syncthreads();
-    if (!active) return;
     double (*X)[TP_SP] = Sc[wave];
+    if (active) {
 #pragma unroll
     for (int j = 0; j < NB16; j++) {
         f64x4 acc = bt[j];
@@ -939,7 +946,9 @@ __global__ __launch_bounds__(64 * TP_WAVES, 2) void trsm_panel_kernel(int64_t m,
         for (int kk = 0; kk < 4; kk++) res = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], dv[j][kk], res, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            B[(row0 + fk + 4 * r) * ldb + j * 16 + fr] = res[r];
+            // (a launch that raises an edge flag writes its rows through to memory, see EdgeSig)
+            if (edge) __hip_atomic_store(&B[(row0 + fk + 4 * r) * ldb + j * 16 + fr], res[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else B[(row0 + fk + 4 * r) * ldb + j * 16 + fr] = res[r];
             X[fk + 4 * r][fr] = res[r];
         }
         if (j + 1 < NB16) {
@@ -947,14 +956,20 @@ __global__ __launch_bounds__(64 * TP_WAVES, 2) void trsm_panel_kernel(int64_t m,
             for (int kk = 0; kk < 4; kk++) xa[j][kk] = -X[fr][fk + 4 * kk];
         }
     }
+    }
+    if (edge) edge_signal(edge, edge_val, gridDim.x);
 }
 
 int launch_trsm_panel(hipStream_t st, int64_t m, const double *L, int64_t ldl, const double *invd, double *B,
-                      int64_t ldb, hipEvent_t done)
+                      int64_t ldb, hipEvent_t done, EdgeSig edge)
 {
     gpt_jitter(st);
     if (m <= 0) {
         if (done) GPT_HIP_CHECK(hipEventRecord(done, st));
+        if (edge.word) {
+            gpt_set_error("trsm_panel: an empty launch cannot raise an edge flag");
+            return GPT_E_ARG;
+        }
         return GPT_OK;
     }
     if (m % 16) {
@@ -965,8 +980,9 @@ int launch_trsm_panel(hipStream_t st, int64_t m, const double *L, int64_t ldl, c
     const unsigned grid = (unsigned)((nwave + TP_WAVES - 1) / TP_WAVES);
     // `done` rides on the kernel's own completion signal (hipExtLaunchKernelGGL stop event): a separate
     // hipEventRecord would put a barrier packet -- ~6 us of command-processor time -- on the panel chain
-    if (done) hipExtLaunchKernelGGL(trsm_panel_kernel, dim3(grid), dim3(64 * TP_WAVES), 0, st, nullptr, done, 0, m, L, ldl, invd, B, ldb);
-    else hipLaunchKernelGGL(trsm_panel_kernel, dim3(grid), dim3(64 * TP_WAVES), 0, st, m, L, ldl, invd, B, ldb);
+    if (done) hipExtLaunchKernelGGL(trsm_panel_kernel, dim3(grid), dim3(64 * TP_WAVES), 0, st, nullptr, done, 0, m, L, ldl, invd, B, ldb,
+                                    edge.word, edge.value);
+    else hipLaunchKernelGGL(trsm_panel_kernel, dim3(grid), dim3(64 * TP_WAVES), 0, st, m, L, ldl, invd, B, ldb, edge.word, edge.value);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
