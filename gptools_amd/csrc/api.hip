@@ -637,7 +637,7 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
         GPT_HIP_CHECK(hipStreamSynchronize(S));
         c->edge_seq = 0;
     }
-    EdgeSig cu_edge_prev;
+    EdgeSig cu_edge_prev, rest_edge_prev;
     struct PendingRest { bool on; int64_t c0, w, u1, split; hipStream_t S; } pend = {false, 0, 0, 0, 0, nullptr};
     auto launch_rest = [&](const PendingRest &r) -> int {
         return gemm_nt(c, r.S, n - r.u1, r.split - r.u1, r.w, -1.0, A + r.u1 * lda + r.c0, lda, A + r.u1 * lda + r.c0, lda,
@@ -727,10 +727,32 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
             // columns (the main stream's rest of panel k-1 covers them too), so the panel stream waits for that rest.
             const bool p_urgent = !H && c->purg_rows > 0 && n - c0 > c->purg_rows && !c->use_graph && u1 < n;
             if (p_urgent) {
+                // (edge_flags >= 2: "the rest of panel k-1 is done" as a flag edge as well -- no stop event on the main
+                // stream's large launches, which set the pace here; the whole C of that launch is then written through)
+                const bool rest_flag = use_flags && c->edge_flags >= 2;
+                EdgeSig rwait;
                 if (e_rest_prev) GPT_HIP_CHECK(hipStreamWaitEvent(P, e_rest_prev, 0));
+                if (rest_edge_prev.word) {
+                    const int64_t nt64 = ((n - u0 + 63) / 64) * ((u1 - u0 + 63) / 64);
+                    const int64_t wgs = (nt64 < 512) ? ((n - u0 + 31) / 32) * ((u1 - u0 + 31) / 32) : nt64;
+                    if (wgs <= 1024 && (c->tile == 0 || c->tile == 64)) rwait = rest_edge_prev;
+                    else GPT_HIP_CHECK(hipStreamWaitValue32(P, rest_edge_prev.word, rest_edge_prev.value, hipStreamWaitValueGte, 0xffffffffu));
+                }
                 GPT_TRY(gemm_nt(c, P, n - u0, u1 - u0, w, -1.0, A + u0 * lda + c0, lda, A + u0 * lda + c0, lda, 1.0,
-                                A + u0 * lda + u0, lda, 1));
+                                A + u0 * lda + u0, lda, 1, nullptr, EdgeSig(), rwait));
                 e_cu_prev = nullptr;
+                rest_edge_prev = EdgeSig();
+                if (rest_flag) {
+                    EdgeSig re;
+                    re.word = c->d_edge + 32;
+                    re.value = ++c->edge_seq;
+                    GPT_TRY(gemm_nt(c, S, n - u1, n - u1, w, -1.0, A + u1 * lda + c0, lda, A + u1 * lda + c0, lda, 1.0,
+                                    A + u1 * lda + u1, lda, 1, nullptr, re));
+                    rest_edge_prev = re;
+                    e_rest_prev = nullptr;
+                    c0 += w;
+                    continue;
+                }
                 hipEvent_t e_rest = get_event(c, 10 + 5 * widths.size() + k);
                 if (!e_rest) return GPT_E_HIP;
                 GPT_TRY(gemm_nt(c, S, n - u1, n - u1, w, -1.0, A + u1 * lda + c0, lda, A + u1 * lda + c0, lda, 1.0,
@@ -740,6 +762,7 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
                 continue;
             }
             e_rest_prev = nullptr;
+            rest_edge_prev = EdgeSig();
             if (use_flags) {
                 EdgeSig cu_edge;
                 cu_edge.word = c->d_edge + 16;
