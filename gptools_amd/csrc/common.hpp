@@ -118,7 +118,8 @@ int launch_add_diag(hipStream_t st, double *A, int64_t lda, int64_t n, const dou
 void gpt_jitter(hipStream_t st);
 int launch_fill_pad(hipStream_t st, double *A, int64_t lda, int64_t n_valid, int64_t n_pad, const double *dy,
                     double big);
-int launch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_t n, const int32_t *d_info, double *d_out3);
+int launch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_t n, const int32_t *d_info, double *d_part,
+                      double *out3, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int launch_extract_lower(hipStream_t st, const double *A, int64_t lda, int64_t n, double *out, int64_t ldo);
 int launch_trsv_lt(hipStream_t st, int64_t n, const double *L, int64_t ldl, const double *invd, double *x);
 int launch_gemv_n(hipStream_t st, int64_t m, int64_t n, const double *A, int64_t lda, const double *x, double *y);

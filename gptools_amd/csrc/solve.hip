@@ -74,19 +74,32 @@ int launch_add_diag(hipStream_t st, double *A, int64_t lda, int64_t n, const dou
     return GPT_OK;
 }
 
-// out[0] = sum_{i<n} log A[i][i] ; out[1] = sum_{c<n} A[n][c]^2 (the augmented row z) ; out[2] = *info, so that one
-// small device-to-host copy returns everything an LML evaluation needs
-__global__ __launch_bounds__(1024) void logdet_dot_kernel(const double *__restrict__ A, int64_t lda, int64_t n,
-                                                          int has_z, const int32_t *__restrict__ info,
-                                                          double *__restrict__ out)
+// out[0] = sum_{i<n} log A[i][i] ; out[1] = sum_{c<n} A[n][c]^2 (the augmented row z) ; out[2] = *info -- everything an
+// LML evaluation returns.  LD_WGS workgroups take 256 entries at a time (the diagonal is one cache line per entry: a
+// single workgroup's address unit needed 4 us for the 8192 lines of n = 8192 and the kernel 15-17 us, on the tail of every
+// evaluation); each leaves a partial pair, the LAST one to finish adds them up in index order (deterministic) and writes
+// the three results to `out` -- which may be pinned host memory (system-scope stores): no copy kernel behind it.
+#define LD_WGS 32
+__global__ __launch_bounds__(256) void logdet_dot_kernel(const double *__restrict__ A, int64_t lda, int64_t n,
+                                                         int has_z, const int32_t *__restrict__ info,
+                                                         double *__restrict__ part, unsigned *__restrict__ count,
+                                                         double *__restrict__ out)
 {
-    __shared__ double s0[16], s1[16];
+    __shared__ double s0[4], s1[4];
+    __shared__ bool last;
     double a = 0.0, b = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
-        a += log(A[i * lda + i]);
-        if (has_z) {
-            const double z = A[n * lda + i];
-            b = fma(z, z, b);
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 4 * 256 * LD_WGS) {
+        double dg[4], zz[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int64_t i = i0 + (int64_t)q * 256 * LD_WGS;
+            dg[q] = (i < n) ? A[i * lda + i] : 1.0;
+            zz[q] = (has_z && i < n) ? A[n * lda + i] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            a += log(dg[q]);
+            b = fma(zz[q], zz[q], b);
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -100,20 +113,42 @@ __global__ __launch_bounds__(1024) void logdet_dot_kernel(const double *__restri
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double ta = 0.0, tb = 0.0;
-        for (int w = 0; w < 16; w++) {
-            ta += s0[w];
-            tb += s1[w];
+        const double ta = ((s0[0] + s0[1]) + s0[2]) + s0[3], tb = ((s1[0] + s1[1]) + s1[2]) + s1[3];
+        __hip_atomic_store(part + 2 * blockIdx.x, ta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(part + 2 * blockIdx.x + 1, tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned done = __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        last = (done == gridDim.x);
+        if (last) __hip_atomic_store(count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (last && threadIdx.x < 64) {
+        // the partial pairs in parallel (one per lane), then a fixed-shape tree: the same sum on every run
+        const unsigned w = threadIdx.x;
+        double ta = (w < gridDim.x) ? __hip_atomic_load(part + 2 * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        double tb = (w < gridDim.x) ? __hip_atomic_load(part + 2 * w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        for (int off = 32; off > 0; off >>= 1) {
+            ta += __shfl_down(ta, off);
+            tb += __shfl_down(tb, off);
         }
-        out[0] = ta;
-        out[1] = tb;
-        out[2] = info ? (double)*info : 0.0;
+        if (w == 0) {
+            __hip_atomic_store(out + 0, ta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(out + 1, tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(out + 2, info ? (double)*info : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
-int launch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_t n, const int32_t *d_info, double *d_out3)
+// d_part: 2 * LD_WGS doubles followed by one 32-bit counter (zero on entry, left zero); out3: device or pinned host memory.
+// ev0 / ev1 (optional): start / stop events on the dispatch packet itself.
+int launch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_t n, const int32_t *d_info, double *d_part,
+                      double *out3, hipEvent_t ev0, hipEvent_t ev1)
 {
-    hipLaunchKernelGGL(logdet_dot_kernel, dim3(1), dim3(1024), 0, st, A, lda, n, 1, d_info, d_out3);
+    unsigned *count = reinterpret_cast<unsigned *>(d_part + 2 * LD_WGS);
+    if (ev0 || ev1)
+        hipExtLaunchKernelGGL(logdet_dot_kernel, dim3(LD_WGS), dim3(256), 0, st, ev0, ev1, 0, A, lda, n, 1, d_info, d_part, count, out3);
+    else
+        hipLaunchKernelGGL(logdet_dot_kernel, dim3(LD_WGS), dim3(256), 0, st, A, lda, n, 1, d_info, d_part, count, out3);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
