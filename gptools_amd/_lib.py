@@ -32,6 +32,7 @@ SIGNATURES = {
     "gpt_ctx_set_option": (C.c_int, [_vp, C.c_char_p, _i64]),
     "gpt_ctx_synchronize": (C.c_int, [_vp]),
     "gpt_ctx_stream": (_vp, [_vp]),
+    "gpt_ctx_edge_count": (C.c_int64, [_vp]),
     "gpt_kpairs": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, _dp, _ip, _ip, _i64, C.c_int, C.c_int, C.c_int, _ip, _dp]),
     "gpt_kbuild": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, _ip, _i64, _dp, _ip, _i64, C.c_int, C.c_int, _ip, _dp]),
     "gpt_set_data": (C.c_int, [_vp, _dp, _ip, _i64, C.c_int]),
@@ -178,6 +179,12 @@ class Context(object):
     @property
     def stream(self):
         return self._lib.gpt_ctx_stream(self.handle)
+
+    @property
+    def edge_count(self):
+        """Flag edges raised so far (0 while the look-ahead runs on events: more than two live contexts, a profiler's
+        counter collection, GPT_EDGE_FLAGS=0, n > 12288)."""
+        return int(self._lib.gpt_ctx_edge_count(self.handle))
 
     # ---- Kernel.__call__ / compute_Kij -------------------------------------------------------
     def kpairs(self, kernel_id, params, Xi, Xj, ni, nj, hyper_deriv=None, symmetric=False, noise_n=None):

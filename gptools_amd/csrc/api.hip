@@ -393,6 +393,9 @@ static int leaf256_factor(gpt_ctx *c, hipStream_t st, double *Ad, int64_t lda, i
 }
 
 // Factor the block column Ap (m x w, diag block on top): recursive halving down to 128 columns.
+#include <atomic>
+static std::atomic<int> g_live_ctx{0};      // contexts alive in this process (see use_flags in potrf_enqueue)
+
 static int panel_rec(gpt_ctx *c, hipStream_t st, double *Ap, int64_t lda, int64_t m, int64_t w, double *invd,
                      int32_t *info, int64_t base)
 {
@@ -628,7 +631,17 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
     // (main -> panel stream) are raised by the last workgroup of the kernel that completes them and waited for with
     // hipStreamWaitValue32 -- 1.5 us per edge against 8-9 for an event, and no stop event on the chain's kernels (4.5 us
     // each).  In the chain-bound end both edges are on the critical path of every panel.
-    const bool use_flags = c->edge_flags && c->d_edge && !H && !c->use_graph && c->inner == 0 && !c->leaf256 && !use_early && !use_late
+    // NOT under a tool that runs one kernel at a time (rocprofv3 counter collection: ROCPROF_COUNTER_COLLECTION): a kernel
+    // that waits for another kernel's flag -- the runtime's own stream-wait kernel included -- then never ends
+    // (measured the hard way: a --pmc pass hung until the box's time limit).  GPT_EDGE_FLAGS=0 switches them off as well.
+    static int flags_ok = -1;
+    if (flags_ok < 0) {
+        const char *e = getenv("GPT_EDGE_FLAGS"), *r = getenv("ROCPROF_COUNTER_COLLECTION");
+        flags_ok = !((e && atoi(e) == 0) || (r && r[0] && r[0] != '0' && r[0] != 'F' && r[0] != 'f'));
+    }
+    // ... and not with more than two contexts alive in the process: beyond that the runtime multiplexes their streams onto
+    // shared hardware queues, where a kernel that waits for a flag can sit in front of the kernel that raises it.
+    const bool use_flags = flags_ok && g_live_ctx.load() <= 2 && c->edge_flags && c->d_edge && !H && !c->use_graph && c->inner == 0 && !c->leaf256 && !use_early && !use_late
                            && c->defer_rows == 0;
     if (use_flags && c->edge_seq > 0xf0000000u) {           // (the words are only ever raised: start over long before a wrap)
         GPT_HIP_CHECK(hipStreamSynchronize(S));
@@ -941,6 +954,7 @@ extern "C" int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out)
     GPT_HIP_CHECK(hipMemsetAsync(c->d_scal, 0, 80 * sizeof(double), c->stream));
     GPT_HIP_CHECK(hipHostMalloc((void **)&c->h_scal, 4 * sizeof(double), hipHostMallocDefault));
     GPT_HIP_CHECK(hipHostMalloc((void **)&c->h_info, sizeof(int32_t), hipHostMallocDefault));
+    g_live_ctx.fetch_add(1);
     *out = c;
     return GPT_OK;
 }
@@ -962,6 +976,7 @@ static void free_factor(gpt_ctx *c)
 extern "C" int gpt_ctx_destroy(gpt_ctx *c)
 {
     if (!c) return GPT_OK;
+    g_live_ctx.fetch_sub(1);
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     hipStreamSynchronize(c->panel_stream);
@@ -1044,6 +1059,7 @@ extern "C" int gpt_ctx_synchronize(gpt_ctx *c)
 }
 
 extern "C" void *gpt_ctx_stream(gpt_ctx *c) { return c ? (void *)c->stream : nullptr; }
+extern "C" int64_t gpt_ctx_edge_count(gpt_ctx *c) { return c ? (int64_t)c->edge_seq : -1; }
 
 #define CTX_ENTER(c)                          \
     do {                                      \

@@ -91,6 +91,9 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
 int gpt_ctx_set_option(gpt_ctx *ctx, const char *key, int64_t value);
 int gpt_ctx_synchronize(gpt_ctx *ctx);
 void *gpt_ctx_stream(gpt_ctx *ctx);
+/* Number of flag edges (common.hpp: EdgeSig -- cross-stream dependencies carried by a word in device memory instead of an
+ * event) the context has raised so far; diagnostics / tests. */
+int64_t gpt_ctx_edge_count(gpt_ctx *ctx);
 
 /* ---- Kernel.__call__ ---------------------------------------------------------------------- */
 /* Replaces  Kernel.__call__(Xi, Xj, ni, nj, hyper_deriv=None, symmetric=False) -> (M,) float64

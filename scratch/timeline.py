@@ -6,6 +6,10 @@ ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?"
 ks.sort()
 # the last kbuild marks the start of the last fit
 idx = max(i for i, k in enumerate(ks) if "kbuild_kernel" in k[3])
+# ... of which the K build is launched in two parts (head columns first), after the upload of y and the padding kernel
+while idx > 0 and ("kbuild_kernel" in ks[idx - 1][3] or "fill_pad" in ks[idx - 1][3] or "copyBuffer" in ks[idx - 1][3] or "fillBuffer" in ks[idx - 1][3]) \
+        and ks[idx][0] - ks[idx - 1][1] < 100000:
+    idx -= 1
 t0 = ks[idx][0]
 lo = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
 hi = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9

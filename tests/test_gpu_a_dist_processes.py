@@ -218,3 +218,46 @@ def test_bench_partitioned_line_is_complete_two_ranks():
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["t_kbuild_cpu_s"] > 0 and cb["t_potrf_cpu_s"] > 0
     par = line["parity"]
     assert par["ok"] and par["ll_rel_err_vs_cpu"] <= 1e-8 and par["logdet_rel_err_vs_cpu"] <= 1e-8
+
+
+def test_flag_edges_single_context_bitwise_and_under_jitter():
+    """The look-ahead's per-panel dependencies as flag words (EdgeSig: last-workgroup flag + hipStreamWaitValue32 / in-kernel
+    wait, api.hip potrf_enqueue) give bit-identical results to the event edges, also with random delays in front of every
+    dense launch.  Fresh process: the flags are used only while at most two contexts are alive."""
+    code = (
+        "import faulthandler; faulthandler.dump_traceback_later(300, exit=True)\n"
+        "import os, sys, json, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "from gptools_amd import _lib\n"
+        "from test_gpu_parity import c3_inputs\n"
+        "out = {}\n"
+        "for N, kid, d in ((2900, _lib.KERNEL_M52, 3), (8192, _lib.KERNEL_M52, 3), (5000, _lib.KERNEL_SE, 2)):\n"
+        "    X, n, y = c3_inputs(N, d)\n"
+        "    err = np.full(N, 0.05)\n"
+        "    p = np.array([1.0] + [0.3] * d)\n"
+        "    ctx = _lib.Context(0)\n"
+        "    ctx.set_data(X, n)\n"
+        "    res = []\n"
+        "    for flags in (1, 0, 1, 1):\n"
+        "        ctx.set_option('edge_flags', flags)\n"
+        "        e0 = ctx.edge_count\n"
+        "        ll, ld = ctx.fit(kid, p, 0.0, y, err, 2.2e-14)\n"
+        "        L = ctx.get_L(N)\n"
+        "        res.append((ll, ld, float(np.abs(L).sum()), ctx.edge_count - e0))\n"
+        "    out[str(N)] = res\n"
+        "    del ctx\n"
+        "print('RESULT', json.dumps(out))\n") % (ROOT, ROOT)
+    for jitter in (None, "40"):
+        env = dict(os.environ)
+        env.pop("GPT_EDGE_FLAGS", None)
+        if jitter:
+            env["GPT_JITTER"] = jitter
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        import json
+        out = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT")][0][7:])
+        for N, res in out.items():
+            assert res[0][3] > 0 and res[2][3] > 0, "flag edges were not in use at N=%s: %r" % (N, res)
+            assert res[1][3] == 0
+            for r in res[1:]:
+                assert r[:3] == res[0][:3], (N, jitter, res)
