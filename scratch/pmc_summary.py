@@ -19,7 +19,8 @@ try:
     kt = list(csv.DictReader(open(src + '/trace/t_kernel_trace.csv')))
     mq = [r['Queue_Id'] for r in kt if 'kbuild_kernel' in r['Kernel_Name']][0]
     bigd = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in kt
-            if 'gemm_nt_kernel' in r['Kernel_Name'] and r['Queue_Id'] == mq and int(r['Grid_Size_X']) >= MIN_GRID_]
+            if 'gemm_nt_kernel' in r['Kernel_Name'] and '64, 64' in r['Kernel_Name'] and r['Queue_Id'] == mq
+            and int(r['Grid_Size_X']) >= MIN_GRID_]
     bl = json.loads(bench[-1])
     lines.append("\n# dominant kernel, the launches bench.py's roofline times (gemm_nt_kernel on the main queue, Grid_Size >= %d): "
                  "%d dispatches in the trace (all %d evaluations of the run), average %.1f us;  bench.py (HIP events, the %d timed "
@@ -65,8 +66,9 @@ def big_launch_bytes(path, counter):
     mainq = [r['Queue_Id'] for r in rows if 'kbuild_kernel' in r['Kernel_Name']][0]
     per = collections.defaultdict(float)
     for r in rows:
-        if r['Counter_Name'] == counter and 'gemm_nt_kernel' in r['Kernel_Name'] and r['Queue_Id'] == mainq \
-                and int(r['Grid_Size']) >= MIN_GRID:
+        # (the 64x64-tile kernel only: the 32x32 variant of the small launches has four times the threads per tile)
+        if r['Counter_Name'] == counter and 'gemm_nt_kernel' in r['Kernel_Name'] and '64, 64' in r['Kernel_Name'] \
+                and r['Queue_Id'] == mainq and int(r['Grid_Size']) >= MIN_GRID:
             per[r['Dispatch_Id']] += float(r['Counter_Value'])
     return len(per), sum(per.values()) * 1024.0
 nf, fb = big_launch_bytes(src + '/pmc_fetch/t_counter_collection.csv', 'FETCH_SIZE')
