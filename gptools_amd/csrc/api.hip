@@ -945,6 +945,14 @@ extern "C" int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out)
     GPT_HIP_CHECK(hipMalloc((void **)&c->d_flag, 64));
     GPT_HIP_CHECK(hipMalloc((void **)&c->d_l10pk, 16384 * sizeof(double)));
     GPT_HIP_CHECK(hipMalloc((void **)&c->d_edge, 256));
+    {   // flag edges need hipStreamWaitValue32 (potrf_enqueue); without it the look-ahead stays on events
+        int can = 0;
+        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device_id) != hipSuccess) {
+            (void)hipGetLastError();
+            can = 0;
+        }
+        if (!can) c->edge_flags = 0;
+    }
     // (hipMemsetAsync on the context's stream, never hipMemset: one call on the legacy null stream and from then on
     // every kernel of this process starts ~40 us late on every stream -- measured on the block-cyclic engine,
     // 31 -> 41 ms per rank at N=32768 over 8 ranks, potf2 26 -> 45..90 us in the trace)
