@@ -1372,10 +1372,14 @@ static int fit_terms(gpt_ctx *c, const std::vector<KParams> &terms, double noise
     if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[0], st));
     memcpy(c->h_yerr, y, (size_t)N * sizeof(double));
     memcpy(c->h_yerr + c->NP, err_y, (size_t)N * sizeof(double));
-    GPT_HIP_CHECK(hipMemcpyAsync(c->d_y, c->h_yerr, (size_t)(c->NP + N) * sizeof(double), hipMemcpyHostToDevice, st));
-    if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[1], st));
     const int64_t NP = c->NP;
-    GPT_HIP_CHECK(hipMemsetAsync(c->d_info, 0, sizeof(int32_t), st));
+    // (kernel path without T: upload, info = 0 and the padding rows are one launch, see upload_pad_kernel)
+    const bool one_launch = (c->dT == nullptr) && NP > N;
+    if (!one_launch) {
+        GPT_HIP_CHECK(hipMemcpyAsync(c->d_y, c->h_yerr, (size_t)(c->NP + N) * sizeof(double), hipMemcpyHostToDevice, st));
+        if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[1], st));
+        GPT_HIP_CHECK(hipMemsetAsync(c->d_info, 0, sizeof(int32_t), st));
+    }
     c->terms = terms;
     c->kp = terms[0];
     if (c->dT) {
@@ -1399,7 +1403,12 @@ static int fit_terms(gpt_ctx *c, const std::vector<KParams> &terms, double noise
         return factor_and_ll(c, N, ll_data_out, logdet_half_out, true);
     }
     // The columns the first panel touches are built first so that its pivot chain overlaps the rest of the build.
-    GPT_TRY(launch_fill_pad(st, c->dA, NP, N, NP, c->d_y, 1e300));
+    if (one_launch) {
+        GPT_TRY(launch_upload_pad(st, c->h_yerr, c->d_y, NP + N, c->d_info, c->dA, NP, N, NP, 1e300));
+        if (c->timing) GPT_HIP_CHECK(hipEventRecord(c->tev[1], st));
+    } else {
+        GPT_TRY(launch_fill_pad(st, c->dA, NP, N, NP, c->d_y, 1e300));
+    }
     const int64_t w0 = (c->nb_early > outer_width(c, NP)) ? c->nb_early : outer_width(c, NP);
     int64_t head = round_up((c->ramp ? 128 : w0) + (c->leaf256 ? 256 : GPT_PANEL_EXT), 256);   // what panel 0 touches
     hipEvent_t e_head = nullptr;

@@ -116,6 +116,8 @@ int launch_add_diag(hipStream_t st, double *A, int64_t lda, int64_t n, const dou
 // every dense launch.  The schedules express every dependency as an event, so results must not move with the relative
 // timing of the streams; a missing edge shows up as a wrong number (tests/test_gpu_parity.py).  Off: one branch.
 void gpt_jitter(hipStream_t st);
+int launch_upload_pad(hipStream_t st, const double *h_src, double *d_dst, int64_t ncopy, int32_t *info, double *A,
+                      int64_t lda, int64_t n_valid, int64_t n_pad, double big);
 int launch_fill_pad(hipStream_t st, double *A, int64_t lda, int64_t n_valid, int64_t n_pad, const double *dy,
                     double big);
 int launch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_t n, const int32_t *d_info, double *d_part,

@@ -46,6 +46,46 @@ void gpt_jitter(hipStream_t st)
     hipLaunchKernelGGL(jitter_kernel, dim3(1), dim3(1), 0, st, ticks);
 }
 
+// The start of an LML evaluation in ONE launch: upload y | err_y from the pinned staging buffer (the kernel reads host memory
+// directly: ncopy doubles, coalesced), zero the info word, write the padding rows with y in the augmented row.  Replaces a
+// host-to-device copy, a memset and fill_pad: while the GPU is idle at the start of an evaluation every launch costs what
+// the HOST needs to issue it (5-13 us each in the trace).
+__global__ void upload_pad_kernel(const double *__restrict__ h_src, double *__restrict__ d_dst, int64_t ncopy,
+                                  int32_t *__restrict__ info, double *__restrict__ A, int64_t lda, int64_t n_valid,
+                                  int64_t n_pad, double big)
+{
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.y == 0) {
+        if (col == 0 && info) *info = 0;
+        // (the grid's x extent covers max(ncopy, n_pad) entries)
+        if (col < ncopy) d_dst[col] = h_src[col];
+    }
+    const int64_t row = n_valid + blockIdx.y;
+    if (row >= n_pad || col >= n_pad) return;
+    double v = 0.0;
+    if (row == n_valid) {
+        if (col < n_valid) v = h_src[col];
+        else if (col == row) v = big;
+    } else if (col == row) {
+        v = 1.0;
+    }
+    A[row * lda + col] = v;
+}
+
+int launch_upload_pad(hipStream_t st, const double *h_src, double *d_dst, int64_t ncopy, int32_t *info, double *A,
+                      int64_t lda, int64_t n_valid, int64_t n_pad, double big)
+{
+    if (n_pad <= n_valid) {
+        gpt_set_error("upload_pad: the padded order must exceed the order (augmented row)");
+        return GPT_E_ARG;
+    }
+    const int64_t w = ncopy > n_pad ? ncopy : n_pad;
+    dim3 grid((unsigned)((w + 255) / 256), (unsigned)(n_pad - n_valid));
+    hipLaunchKernelGGL(upload_pad_kernel, grid, dim3(256), 0, st, h_src, d_dst, ncopy, info, A, lda, n_valid, n_pad, big);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
 int launch_fill_pad(hipStream_t st, double *A, int64_t lda, int64_t n_valid, int64_t n_pad, const double *dy,
                     double big)
 {
