@@ -58,6 +58,8 @@ struct gpt_ctx {
     int late_pad = 0;                      // > 0: LDS pad of the main stream's updates once at most late_pad_rows rows remain -- fewer of its
     int64_t late_pad_rows = 4608;          //      workgroups per CU, so that the panel stream's chain kernels share the CUs with less contention
     unsigned *d_edge = nullptr;            // edge-flag words (EdgeSig, common.hpp): [0,1] "panel k final", [16,17] "urgent update k done"
+    EdgeSig first_wait;                    // ... handed by potrf_enqueue to the first leaf launch (panel_ext)
+    EdgeSig head_wait;                     // set by fit_terms: the first leaf of the next factorisation waits for this word (K-build head)
     unsigned edge_seq = 0;                 // value of the last edge raised (monotonic over the context's life)
     int64_t edge_flags = 1;                // 1: those two edges of the look-ahead are flags + hipStreamWaitValue32 instead of events
     bool defer_join = false;               // potrf_enqueue leaves the final panel -> main join to its caller (factor_and_ll)
@@ -396,6 +398,21 @@ static int leaf256_factor(gpt_ctx *c, hipStream_t st, double *Ad, int64_t lda, i
 #include <atomic>
 static std::atomic<int> g_live_ctx{0};      // contexts alive in this process (see use_flags in potrf_enqueue)
 
+// Flag edges (EdgeSig) are usable at all: not under a tool that runs one kernel at a time (rocprofv3 counter collection,
+// ROCPROF_COUNTER_COLLECTION) -- a kernel that waits for another kernel's flag, the runtime's own stream-wait kernel
+// included, then never ends (measured the hard way: a --pmc pass hung until the box's time limit) --, not with
+// GPT_EDGE_FLAGS=0, and not with more than two contexts alive in the process: beyond that the runtime multiplexes their
+// streams onto shared hardware queues, where a kernel that waits for a flag can sit in front of the kernel that raises it.
+static bool edge_flags_usable(const gpt_ctx *c)
+{
+    static int flags_ok = -1;
+    if (flags_ok < 0) {
+        const char *e = getenv("GPT_EDGE_FLAGS"), *r = getenv("ROCPROF_COUNTER_COLLECTION");
+        flags_ok = !((e && atoi(e) == 0) || (r && r[0] && r[0] != '0' && r[0] != 'F' && r[0] != 'f'));
+    }
+    return flags_ok && g_live_ctx.load() <= 2 && c->edge_flags && c->d_edge && !c->use_graph;
+}
+
 static int panel_rec(gpt_ctx *c, hipStream_t st, double *Ap, int64_t lda, int64_t m, int64_t w, double *invd,
                      int32_t *info, int64_t base)
 {
@@ -511,6 +528,11 @@ static int panel_ext(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64_t
         const int64_t r1 = lc + 128;
         const bool last = (r1 == c0 + w) && done_ev;
         const int64_t m = n - r1;
+        EdgeSig fw;                                   // the first leaf of a factorisation may have to wait for the K build's head
+        if (lc == 0) {
+            fw = c->first_wait;
+            c->first_wait = EdgeSig();
+        }
         if (c->fuse_trsm > 0 && m >= 128 && m <= c->fuse_trsm && !c->use_graph) {
             // short panel: diagonal block and TRSM in one launch, the substitution trailing the pivots (potrf.hip)
             if (c->flag_epoch > 0x3fffff00u) {
@@ -519,9 +541,9 @@ static int panel_ext(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64_t
             }
             c->flag_epoch += 32;           // (the 256-column leaf kernel raises the word by up to 17 per launch)
             GPT_TRY(launch_potf2_trsm(st, Ad, lda, ws, info, lc, m, c->d_flag, c->flag_epoch, last ? done_ev : nullptr,
-                                      (r1 == c0 + w) ? done_edge : EdgeSig()));
+                                      (r1 == c0 + w) ? done_edge : EdgeSig(), fw));
         } else {
-            GPT_TRY(launch_potf2_diag(st, Ad, lda, ws, info, lc));
+            GPT_TRY(launch_potf2_diag(st, Ad, lda, ws, info, lc, fw));
             // (a stop event on the launch is not recorded by stream capture: under a graph use a plain record)
             GPT_TRY(launch_trsm_panel(st, m, Ad, lda, ws, Ad + 128 * lda, lda, (last && !c->use_graph) ? done_ev : nullptr,
                                       (r1 == c0 + w) ? done_edge : EdgeSig()));
@@ -560,6 +582,9 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
     const bool la = c->lookahead && nblk > 1;
     hipEvent_t head = c->head_event;
     c->head_event = nullptr;
+    const EdgeSig head_wait = c->head_wait;                   // (the K build's head columns as a flag word, see fit_terms)
+    c->head_wait = EdgeSig();
+    c->first_wait = EdgeSig();
     if (!la) {
         for (int64_t k = 0; k < nblk; k++) {
             const int64_t c0 = k * nbo, w = (n - c0 < nbo) ? n - c0 : nbo, m = n - c0;
@@ -576,12 +601,17 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
     // u0 = c0 + nbo + EXT in two launches: the nbo columns panel k+1 is going to touch first ("urgent", event e_cu),
     // then the rest.  P never waits for a large update: its only dependency is e_cu(k) before the first update of
     // panel k+1, and S has the whole first pivot block + TRSM of that panel to get there.
-    if (!head) {
-        head = get_event(c, 0);
-        if (!head) return GPT_E_HIP;
-        GPT_HIP_CHECK(hipEventRecord(head, S));
+    if (head_wait.word && c->inner == 0 && !c->leaf256) {
+        // the first leaf's kernel waits for the word itself (potrf.hip: edge_wait): no event edge in front of the chain
+        c->first_wait = head_wait;
+    } else {
+        if (!head) {
+            head = get_event(c, 0);
+            if (!head) return GPT_E_HIP;
+            GPT_HIP_CHECK(hipEventRecord(head, S));
+        }
+        GPT_HIP_CHECK(hipStreamWaitEvent(P, head, 0));
     }
-    GPT_HIP_CHECK(hipStreamWaitEvent(P, head, 0));
     // Panel widths: nbo; optionally ("ramp") 128, 256, ... at the start so that the main stream gets its first update
     // after one leaf instead of after a whole panel -- measured slightly slower (N=8192: 5.95 against 5.90 ms,
     // N=16384: 31.4 against 31.2: the rank-128/256 updates it adds are inefficient), so it is off by default.
@@ -631,19 +661,9 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
     // (main -> panel stream) are raised by the last workgroup of the kernel that completes them and waited for with
     // hipStreamWaitValue32 -- 1.5 us per edge against 8-9 for an event, and no stop event on the chain's kernels (4.5 us
     // each).  In the chain-bound end both edges are on the critical path of every panel.
-    // NOT under a tool that runs one kernel at a time (rocprofv3 counter collection: ROCPROF_COUNTER_COLLECTION): a kernel
-    // that waits for another kernel's flag -- the runtime's own stream-wait kernel included -- then never ends
-    // (measured the hard way: a --pmc pass hung until the box's time limit).  GPT_EDGE_FLAGS=0 switches them off as well.
-    static int flags_ok = -1;
-    if (flags_ok < 0) {
-        const char *e = getenv("GPT_EDGE_FLAGS"), *r = getenv("ROCPROF_COUNTER_COLLECTION");
-        flags_ok = !((e && atoi(e) == 0) || (r && r[0] && r[0] != '0' && r[0] != 'F' && r[0] != 'f'));
-    }
-    // ... and not with more than two contexts alive in the process: beyond that the runtime multiplexes their streams onto
-    // shared hardware queues, where a kernel that waits for a flag can sit in front of the kernel that raises it.
-    const bool use_flags = flags_ok && g_live_ctx.load() <= 2 && c->edge_flags && c->d_edge && !H && !c->use_graph && c->inner == 0 && !c->leaf256 && !use_early && !use_late
+    const bool use_flags = edge_flags_usable(c) && !H && c->inner == 0 && !c->leaf256 && !use_early && !use_late
                            && c->defer_rows == 0;
-    if (use_flags && c->edge_seq > 0xf0000000u) {           // (the words are only ever raised: start over long before a wrap)
+    if (use_flags && c->edge_seq > 0xf0000000u && !head_wait.word) {           // (the words are only ever raised: start over long before a wrap)
         GPT_HIP_CHECK(hipStreamSynchronize(S));
         GPT_HIP_CHECK(hipStreamSynchronize(P));
         GPT_HIP_CHECK(hipMemsetAsync(c->d_edge, 0, 256, S));
@@ -1412,10 +1432,20 @@ static int fit_terms(gpt_ctx *c, const std::vector<KParams> &terms, double noise
     const int64_t w0 = (c->nb_early > outer_width(c, NP)) ? c->nb_early : outer_width(c, NP);
     int64_t head = round_up((c->ramp ? 128 : w0) + (c->leaf256 ? 256 : GPT_PANEL_EXT), 256);   // what panel 0 touches
     hipEvent_t e_head = nullptr;
-    if (c->lookahead && !c->use_graph && head < N && (e_head = get_event(c, 0)) != nullptr) {
+    c->head_wait = EdgeSig();
+    const bool head_flag = edge_flags_usable(c) && c->edge_seq < 0xf0000000u;
+    if (c->lookahead && !c->use_graph && head < N && (head_flag || (e_head = get_event(c, 0)) != nullptr)) {
         GPT_TRY(kbuild_terms(c, st, terms, 1, c->dX, c->dn, N, c->dX, c->dn, head, 1, 0, 0, c->d_erry, noise_var, diag_add,
                              c->dA, NP));
-        GPT_HIP_CHECK(hipEventRecord(e_head, st));
+        if (head_flag) {
+            // "the head columns are built" as a flag word raised from this stream (a one-thread kernel behind the build);
+            // the first diagonal-block kernel of the panel stream polls it itself: no event record here, no event wait there
+            c->head_wait.word = c->d_edge + 48;
+            c->head_wait.value = ++c->edge_seq;
+            GPT_TRY(launch_set_flag(st, c->head_wait.word, c->head_wait.value));
+        } else {
+            GPT_HIP_CHECK(hipEventRecord(e_head, st));
+        }
         GPT_TRY(kbuild_terms(c, st, terms, 1, c->dX + head * c->D, c->dn + head * c->D, N - head, c->dX + head * c->D,
                              c->dn + head * c->D, N - head, 1, head, head, c->d_erry, noise_var, diag_add,
                              c->dA + head * NP + head, NP));

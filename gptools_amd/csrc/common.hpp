@@ -96,13 +96,15 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
                    const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile, int lds_pad,
                    hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int prio = 0, EdgeSig edge = EdgeSig(),
                    EdgeSig wait = EdgeSig());
-int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base);
+int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base,
+                      EdgeSig wait = EdgeSig());
 int launch_gemm_nt_stair(hipStream_t st, int64_t m, int64_t nseg, int64_t seg_cols, int64_t k, double alpha,
                          const double *A, int64_t lda, const double *B, int64_t ldb, int64_t b_stride, int64_t row_step,
                          double beta, double *C, int64_t ldc, int lds_pad, hipEvent_t ev0 = nullptr,
                          hipEvent_t ev1 = nullptr);
 int launch_potf2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
-                      unsigned *flag, unsigned flag_base, hipEvent_t done = nullptr, EdgeSig edge = EdgeSig());
+                      unsigned *flag, unsigned flag_base, hipEvent_t done = nullptr, EdgeSig edge = EdgeSig(),
+                      EdgeSig wait = EdgeSig());
 int launch_potf2x2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
                         double *l10pk, unsigned *flag, unsigned flag_base, hipEvent_t done = nullptr);
 int launch_trsm_panel(hipStream_t st, int64_t m, const double *L, int64_t ldl, const double *invd,
@@ -116,6 +118,7 @@ int launch_add_diag(hipStream_t st, double *A, int64_t lda, int64_t n, const dou
 // every dense launch.  The schedules express every dependency as an event, so results must not move with the relative
 // timing of the streams; a missing edge shows up as a wrong number (tests/test_gpu_parity.py).  Off: one branch.
 void gpt_jitter(hipStream_t st);
+int launch_set_flag(hipStream_t st, unsigned *word, unsigned value);
 int launch_upload_pad(hipStream_t st, const double *h_src, double *d_dst, int64_t ncopy, int32_t *info, double *A,
                       int64_t lda, int64_t n_valid, int64_t n_pad, double big);
 int launch_fill_pad(hipStream_t st, double *A, int64_t lda, int64_t n_valid, int64_t n_pad, const double *dy,

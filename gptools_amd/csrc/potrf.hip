@@ -253,6 +253,21 @@ __device__ __forceinline__ void pivot_block_16(double (*S)[PD_PITCH], double (*T
 }
 
 #define PD_THREADS 512
+
+// In-kernel side of a flag edge (EdgeSig, common.hpp) for the FIRST kernel of a factorisation: the block it factors is being
+// written by a kernel of the main stream (the head columns of the K build); one thread polls the word, the workgroup
+// follows.  These launches are one workgroup (or at most 33 on the CUs reserved for the panel stream): they cannot fill
+// the chip in front of the kernel they wait for.
+__device__ __forceinline__ void edge_wait(const unsigned *word, unsigned value)
+{
+    if (word != nullptr) {
+        if (threadIdx.x == 0) {
+            while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0)
+                __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+    }
+}
 #define TP_SP 18              // pitch of the per-wave 16x16 re-layout scratch of the TRSM kernels
 #define PD_WAVES (PD_THREADS / 64)
 
@@ -455,8 +470,10 @@ __device__ __forceinline__ void potf2_body(double *__restrict__ A, int64_t lda, 
 
 __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restrict__ A, int64_t lda,
                                                                 double *__restrict__ invd, int32_t *info,
-                                                                int64_t info_col0)
+                                                                int64_t info_col0, const unsigned *wait_word,
+                                                                unsigned wait_val)
 {
+    edge_wait(wait_word, wait_val);
     potf2_body<false>(A, lda, invd, info, info_col0, nullptr, 0u);
 }
 
@@ -476,8 +493,10 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
                                                                 double *__restrict__ invd, int32_t *info,
                                                                 int64_t info_col0, int64_t m, double *__restrict__ B,
                                                                 int64_t ldb, unsigned *flag, unsigned flag_base,
-                                                                unsigned *edge, unsigned edge_val)
+                                                                unsigned *edge, unsigned edge_val,
+                                                                const unsigned *wait_word, unsigned wait_val)
 {
+    edge_wait(wait_word, wait_val);
     if (blockIdx.x == 0) {
         potf2_body<true>(A, lda, invd, info, info_col0, flag, flag_base);
         // (edge flag: "the panel is final" -- what the waiting update reads are the consumers' rows; this workgroup only
@@ -832,16 +851,17 @@ static int ensure_big_lds(const void *fn, int which, size_t shmem)
 // m rows below the 128x128 diagonal block at A (B = A + 128 * lda).  `flag` is a device word only ever raised;
 // flag_base must exceed every value written to it before (the caller counts: 16 per launch).
 int launch_potf2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
-                      unsigned *flag, unsigned flag_base, hipEvent_t done, EdgeSig edge)
+                      unsigned *flag, unsigned flag_base, hipEvent_t done, EdgeSig edge, EdgeSig wait)
 {
     gpt_jitter(st);
     const size_t shmem = (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
     { int rc_ = ensure_big_lds(reinterpret_cast<const void *>(potf2_trsm_kernel), 0, shmem); if (rc_ != GPT_OK) return rc_; }
     const unsigned grid = 1u + (unsigned)((m + 16 * PD_WAVES - 1) / (16 * PD_WAVES));
     if (done) hipExtLaunchKernelGGL(potf2_trsm_kernel, dim3(grid), dim3(PD_THREADS), shmem, st, nullptr, done, 0, A, lda, invd,
-                                    info, info_base, m, A + 128 * lda, lda, flag, flag_base, edge.word, edge.value);
+                                    info, info_base, m, A + 128 * lda, lda, flag, flag_base, edge.word, edge.value,
+                                    wait.word, wait.value);
     else hipLaunchKernelGGL(potf2_trsm_kernel, dim3(grid), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base, m,
-                            A + 128 * lda, lda, flag, flag_base, edge.word, edge.value);
+                            A + 128 * lda, lda, flag, flag_base, edge.word, edge.value, wait.word, wait.value);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
@@ -865,12 +885,12 @@ int launch_potf2x2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, in
     return GPT_OK;
 }
 
-int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base)
+int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, EdgeSig wait)
 {
     gpt_jitter(st);
     const size_t shmem = (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
     { int rc_ = ensure_big_lds(reinterpret_cast<const void *>(potf2_diag_kernel), 1, shmem); if (rc_ != GPT_OK) return rc_; }
-    hipLaunchKernelGGL(potf2_diag_kernel, dim3(1), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base);
+    hipLaunchKernelGGL(potf2_diag_kernel, dim3(1), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base, wait.word, wait.value);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }

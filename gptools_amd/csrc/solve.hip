@@ -25,6 +25,20 @@ __global__ void fill_pad_kernel(double *__restrict__ A, int64_t lda, int64_t n_v
     A[row * lda + col] = v;
 }
 
+// Raises an edge-flag word (EdgeSig) from the stream it is launched on: everything in front of it on that stream is complete
+// and visible (kernel boundary) when it runs.
+__global__ void set_flag_kernel(unsigned *word, unsigned value)
+{
+    __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int launch_set_flag(hipStream_t st, unsigned *word, unsigned value)
+{
+    hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(1), 0, st, word, value);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
 __global__ void jitter_kernel(long long ticks)
 {
     const long long t0 = wall_clock64();

@@ -7,7 +7,7 @@ ks.sort()
 # the last kbuild marks the start of the last fit
 idx = max(i for i, k in enumerate(ks) if "kbuild_kernel" in k[3])
 # ... of which the K build is launched in two parts (head columns first), after the upload of y and the padding kernel
-while idx > 0 and ("kbuild_kernel" in ks[idx - 1][3] or "fill_pad" in ks[idx - 1][3] or "copyBuffer" in ks[idx - 1][3] or "fillBuffer" in ks[idx - 1][3]) \
+while idx > 0 and ("kbuild_kernel" in ks[idx - 1][3] or "fill_pad" in ks[idx - 1][3] or "copyBuffer" in ks[idx - 1][3] or "fillBuffer" in ks[idx - 1][3] or "set_flag" in ks[idx - 1][3] or "upload_pad" in ks[idx - 1][3]) \
         and ks[idx][0] - ks[idx - 1][1] < 100000:
     idx -= 1
 t0 = ks[idx][0]
