@@ -76,6 +76,9 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
  *   "panel_prio"   wave priority (0..3) of the panel stream's GEMM main loops (2); "gemm_prio" >= 0 forces one priority
  *                  for every GEMM of the context (the panel-side context of gptools_amd/dist.py)
  *   "fuse_trsm"    panels with at most this many rows under a leaf use the fused diagonal-block + TRSM kernel (4096)
+ *   "edge_flags"   1 (default): the per-panel dependencies of the look-ahead are flag words in device memory (last workgroup
+ *                  of the producer raises it; hipStreamWaitValue32 / an in-kernel wait on the consumer side) instead of events;
+ *                  0: events.  Off by itself under rocprofv3 counter collection, with more than two live contexts, n > 12288
  *   "helper_tf"    assumed rate of the helper stream (0.1 TFLOP/s per 24 CUs, 45) that takes a slice of the large trailing
  *                  updates on the reserved CUs when n > "helper_min_n" (12288); 0 = off
  *   "gemm_pad"     bytes of dummy dynamic LDS of the main-stream GEMM (residency cap)
@@ -87,6 +90,7 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
  *   "early_rows", "nb_early", "nb_switch_rows", "late_pad", "late_pad_rows"
  * Environment: GPT_RESERVE_CUS (CUs the main stream leaves to the panel stream, default 32), GPT_TILE_ORDER
  * ("rows,cols,mode": supertile shape and deal of the GEMM's XCD-aware tile order, default 64,8,1), GPT_GRAD_TIMING,
+ * GPT_EDGE_FLAGS=0 (event edges only), GPT_GEMM_SMALL (64x64-tile count under which a GEMM launch uses 32x32 tiles, 512),
  * GPT_JITTER (test aid: random delay kernels in front of every dense launch). */
 int gpt_ctx_set_option(gpt_ctx *ctx, const char *key, int64_t value);
 int gpt_ctx_synchronize(gpt_ctx *ctx);
