@@ -765,6 +765,16 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
                 const bool rest_flag = use_flags && c->edge_flags >= 2;
                 EdgeSig rwait;
                 if (e_rest_prev) GPT_HIP_CHECK(hipStreamWaitEvent(P, e_rest_prev, 0));
+                if (!e_rest_prev && !rest_edge_prev.word) {
+                    // First update the PANEL stream applies beyond the head columns: whatever the main stream still has in
+                    // flight on those columns -- the rest of the K build of this evaluation -- must be through.  (Found with the
+                    // `ramp` option, whose 128-wide first panel is done before the K build is: "8064-th leading minor not
+                    // positive definite"; with 384-wide panels the build happened to finish first.)
+                    hipEvent_t e_k = get_event(c, 9 + 5 * widths.size());
+                    if (!e_k) return GPT_E_HIP;
+                    GPT_HIP_CHECK(hipEventRecord(e_k, S));
+                    GPT_HIP_CHECK(hipStreamWaitEvent(P, e_k, 0));
+                }
                 if (rest_edge_prev.word) {
                     const int64_t nt64 = ((n - u0 + 63) / 64) * ((u1 - u0 + 63) / 64);
                     const int64_t wgs = (nt64 < 512) ? ((n - u0 + 31) / 32) * ((u1 - u0 + 31) / 32) : nt64;

@@ -762,8 +762,12 @@ def test_schedule_options_agree_with_default(ctx, oracle):
     assert abs(base[0] - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"])
     variants = ({"leaf256": 1}, {"leaf256": 1, "nb_outer": 256}, {"leaf256": 1, "nb_outer": 512}, {"inner": 1}, {"inner": 2},
                 {"defer_rows": 4608}, {"purg_rows": 0}, {"purg_rows": 1024}, {"nb_early": 512, "nb_switch_rows": 1500},
-                {"leaf256": 1, "purg_rows": 1024, "defer_rows": 4608})
-    defaults = {"leaf256": 0, "nb_outer": 0, "inner": 0, "defer_rows": 0, "purg_rows": 6144, "nb_early": 0, "nb_switch_rows": 4608}
+                {"leaf256": 1, "purg_rows": 1024, "defer_rows": 4608},
+                # a 128-wide first panel is factored before the rest of K is built: the panel stream's first update beyond
+                # the head columns has to wait for the build (it once did not: "8064-th leading minor ...")
+                {"ramp": 1, "purg_rows": 1024}, {"ramp": 1, "purg_rows": 0}, {"edge_flags": 0}, {"edge_flags": 0, "ramp": 1, "purg_rows": 512})
+    defaults = {"leaf256": 0, "nb_outer": 0, "inner": 0, "defer_rows": 0, "purg_rows": 6144, "nb_early": 0, "nb_switch_rows": 4608,
+                "ramp": 0, "edge_flags": 1}
     try:
         for v in variants:
             for k_, d_ in defaults.items():
@@ -1295,3 +1299,24 @@ def test_device_ll_gradient_against_host_path_and_finite_differences(g):
                 tm[i] -= h
                 fd[i] = (-gp3.update_hyperparameters(tp) + gp3.update_hyperparameters(tm)) / (2 * h)
             np.testing.assert_allclose(-grad, fd, rtol=2e-5, atol=1e-4 * np.abs(fd).max())
+
+
+def test_panel_stream_update_waits_for_a_slow_k_build(g, oracle):
+    """Look-ahead with the panel stream applying the first update itself (purg_rows) while the K build is SLOW (general-order
+    Matern: Temme's K_nu per pair) and the first panel quick (ramp: 128 columns): the update must not touch columns the
+    build has not written yet.  ll against the CPU oracle."""
+    from gptools_amd import _lib
+    N, d = 6800, 2
+    X, n, y = c3_inputs(N, d)
+    n[:] = 0
+    p = np.array([1.0, 1.3, 0.35, 0.3])           # sigma_f, nu, l_1, l_2
+    err = 0.05 * np.ones(N)
+    ref = oracle.fit("matern", p, X, n, y, err, chol="scipy")
+    c = _lib.Context(0)
+    c.set_data(X, n)
+    for opts in ({}, {"ramp": 1, "purg_rows": 1024}, {"ramp": 1, "purg_rows": 1024, "edge_flags": 0}):
+        for k_, v_ in opts.items():
+            c.set_option(k_, v_)
+        for rep in range(2):
+            got = c.fit(_lib.KERNEL_MATERN, p, 0.0, y, err, 1e2 * EPS)
+            assert abs(got[0] - ref["ll_data"]) <= 1e-8 * abs(ref["ll_data"]), (opts, got, ref["ll_data"])
