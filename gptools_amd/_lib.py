@@ -182,7 +182,7 @@ class Context(object):
 
     @property
     def edge_count(self):
-        """Flag edges raised so far (0 while the look-ahead runs on events: more than two live contexts, a profiler's
+        """Flag edges raised so far (0 while the look-ahead runs on events: a second live context, a profiler's
         counter collection, GPT_EDGE_FLAGS=0, n > 12288)."""
         return int(self._lib.gpt_ctx_edge_count(self.handle))
 

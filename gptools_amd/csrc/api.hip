@@ -401,8 +401,17 @@ static std::atomic<int> g_live_ctx{0};      // contexts alive in this process (s
 // Flag edges (EdgeSig) are usable at all: not under a tool that runs one kernel at a time (rocprofv3 counter collection,
 // ROCPROF_COUNTER_COLLECTION) -- a kernel that waits for another kernel's flag, the runtime's own stream-wait kernel
 // included, then never ends (measured the hard way: a --pmc pass hung until the box's time limit) --, not with
-// GPT_EDGE_FLAGS=0, and not with more than two contexts alive in the process: beyond that the runtime multiplexes their
-// streams onto shared hardware queues, where a kernel that waits for a flag can sit in front of the kernel that raises it.
+// GPT_EDGE_FLAGS=0, and ONLY WHILE THIS IS THE ONLY CONTEXT ALIVE IN THE PROCESS.  With two contexts evaluating in two
+// threads (the `batched` leg of bench.py, GaussianProcess.ll_batch) the six streams plus the runtime's own can exceed the
+// hardware queues the firmware keeps resident; a waiting kernel then holds its queue's slot while the queue of the kernel
+// it waits for is scheduled out, and every hand-over costs a scheduling quantum: measured 0.8 s per evaluation instead
+// of 1.3 ms at N = 4096, intermittently (scratch/stress_flags.py).  Event edges do not spin and are immune.
+static bool edge_flags_usable(const gpt_ctx *c);
+
+// Workgroups a launch may have and still wait for its flag INSIDE the kernel: its spinning workgroups must leave at least
+// half of the chip's 8192 wave slots to the kernel they wait for (1024 workgroups of four waves).
+static int64_t inkernel_wait_budget() { return 1024; }
+
 static bool edge_flags_usable(const gpt_ctx *c)
 {
     static int flags_ok = -1;
@@ -410,7 +419,7 @@ static bool edge_flags_usable(const gpt_ctx *c)
         const char *e = getenv("GPT_EDGE_FLAGS"), *r = getenv("ROCPROF_COUNTER_COLLECTION");
         flags_ok = !((e && atoi(e) == 0) || (r && r[0] && r[0] != '0' && r[0] != 'F' && r[0] != 'f'));
     }
-    return flags_ok && g_live_ctx.load() <= 2 && c->edge_flags && c->d_edge && !c->use_graph;
+    return flags_ok && g_live_ctx.load() <= 1 && c->edge_flags && c->d_edge && !c->use_graph;
 }
 
 static int panel_rec(gpt_ctx *c, hipStream_t st, double *Ap, int64_t lda, int64_t m, int64_t w, double *invd,
@@ -559,7 +568,7 @@ static int panel_ext(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64_t
             EdgeSig inwait;
             if (lc == c0 && wait_edge.word) {
                 const int64_t wgs = ((n - r1 + 31) / 32) * ((cend - r1 + 31) / 32);
-                if (wgs <= 1024 && (c->tile == 0 || c->tile == 64)) inwait = wait_edge;
+                if (wgs <= inkernel_wait_budget() && (c->tile == 0 || c->tile == 64)) inwait = wait_edge;
                 else GPT_HIP_CHECK(hipStreamWaitValue32(st, wait_edge.word, wait_edge.value, hipStreamWaitValueGte, 0xffffffffu));
             }
             GPT_TRY(gemm_nt(c, st, n - r1, cend - r1, 128, -1.0, A + r1 * lda + lc, lda, A + r1 * lda + lc, lda, 1.0,
@@ -778,7 +787,7 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
                 if (rest_edge_prev.word) {
                     const int64_t nt64 = ((n - u0 + 63) / 64) * ((u1 - u0 + 63) / 64);
                     const int64_t wgs = (nt64 < 512) ? ((n - u0 + 31) / 32) * ((u1 - u0 + 31) / 32) : nt64;
-                    if (wgs <= 1024 && (c->tile == 0 || c->tile == 64)) rwait = rest_edge_prev;
+                    if (wgs <= inkernel_wait_budget() && (c->tile == 0 || c->tile == 64)) rwait = rest_edge_prev;
                     else GPT_HIP_CHECK(hipStreamWaitValue32(P, rest_edge_prev.word, rest_edge_prev.value, hipStreamWaitValueGte, 0xffffffffu));
                 }
                 GPT_TRY(gemm_nt(c, P, n - u0, u1 - u0, w, -1.0, A + u0 * lda + c0, lda, A + u0 * lda + c0, lda, 1.0,

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     if (wait_word != nullptr) {
         if (tid == 0) {
             while ((int)(__hip_atomic_load(wait_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - wait_val) < 0)
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(16);          // (~1000 cycles between polls: the waiting waves must not eat issue slots)
         }
         __syncthreads();
     }

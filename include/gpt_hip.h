@@ -78,7 +78,7 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
  *   "fuse_trsm"    panels with at most this many rows under a leaf use the fused diagonal-block + TRSM kernel (4096)
  *   "edge_flags"   1 (default): the per-panel dependencies of the look-ahead are flag words in device memory (last workgroup
  *                  of the producer raises it; hipStreamWaitValue32 / an in-kernel wait on the consumer side) instead of events;
- *                  0: events.  Off by itself under rocprofv3 counter collection, with more than two live contexts, n > 12288
+ *                  0: events.  Off by itself under rocprofv3 counter collection, with a second live context, n > 12288
  *   "helper_tf"    assumed rate of the helper stream (0.1 TFLOP/s per 24 CUs, 45) that takes a slice of the large trailing
  *                  updates on the reserved CUs when n > "helper_min_n" (12288); 0 = off
  *   "gemm_pad"     bytes of dummy dynamic LDS of the main-stream GEMM (residency cap)

@@ -223,7 +223,7 @@ def test_bench_partitioned_line_is_complete_two_ranks():
 def test_flag_edges_single_context_bitwise_and_under_jitter():
     """The look-ahead's per-panel dependencies as flag words (EdgeSig: last-workgroup flag + hipStreamWaitValue32 / in-kernel
     wait, api.hip potrf_enqueue) give bit-identical results to the event edges, also with random delays in front of every
-    dense launch.  Fresh process: the flags are used only while at most two contexts are alive."""
+    dense launch.  Fresh process: the flags are used only while the context is the only one alive."""
     code = (
         "import faulthandler; faulthandler.dump_traceback_later(300, exit=True)\n"
         "import os, sys, json, numpy as np\n"
