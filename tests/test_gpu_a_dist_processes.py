@@ -244,6 +244,16 @@ def test_flag_edges_single_context_bitwise_and_under_jitter():
         "        ll, ld = ctx.fit(kid, p, 0.0, y, err, 2.2e-14)\n"
         "        L = ctx.get_L(N)\n"
         "        res.append((ll, ld, float(np.abs(L).sum()), ctx.edge_count - e0))\n"
+        "    # a factorisation that fails (not positive definite) with the flag edges in use: error, no hang, and the next\n"
+        "    # evaluation on the same context is unaffected\n"
+        "    ctx.set_option('edge_flags', 1)\n"
+        "    try:\n"
+        "        ctx.fit(kid, p, 0.0, y, 0.0 * err, -5.0)\n"
+        "        failed = False\n"
+        "    except np.linalg.LinAlgError:\n"
+        "        failed = True\n"
+        "    again = ctx.fit(kid, p, 0.0, y, err, 2.2e-14)\n"
+        "    res.append((again[0], again[1], res[0][2], 1 if failed else -1))\n"
         "    out[str(N)] = res\n"
         "    del ctx\n"
         "print('RESULT', json.dumps(out))\n") % (ROOT, ROOT)
@@ -259,5 +269,6 @@ def test_flag_edges_single_context_bitwise_and_under_jitter():
         for N, res in out.items():
             assert res[0][3] > 0 and res[2][3] > 0, "flag edges were not in use at N=%s: %r" % (N, res)
             assert res[1][3] == 0
+            assert res[-1][3] == 1, "the indefinite matrix did not raise LinAlgError"
             for r in res[1:]:
                 assert r[:3] == res[0][:3], (N, jitter, res)
