@@ -145,10 +145,15 @@ __device__ long long *g_gemm_stamps;
 // C accesses.  Streaming C past the L2 (nontemporal loads and stores, -DGPT_GEMM_C_NT) leaves the L2 to the operand panels
 // and cuts the fabric traffic of a 7168-row update from 503 + 207 MB to 395 + 207 MB (algorithmic 229 + 207), but the next
 // kernels of the factorisation read what this one wrote: measured 4.995 against 4.862 ms at N = 8192 (27.48 against 27.65 at
-// N = 16384), nontemporal loads alone 4.878, stores alone 4.900 -- so C stays cached.
+// N = 16384), nontemporal loads alone 4.878, stores alone 4.900 -- so C stays cached.  Re-measured at the end of round 2
+// (-DGPT_GEMM_C_NTLOAD, loads only): fetch 501 -> 421 MB per 7168-row launch (1.62x -> 1.44x the algorithmic bytes), N = 8192
+// 4.563 -> 4.611 ms, N = 16384 27.83 -> 27.65 ms: the traffic is not the bound, the evaluation time decides.
 #ifdef GPT_GEMM_C_NT
 #define GM_LOADC(p) __builtin_nontemporal_load(p)
 #define GM_STOREC(v, p) __builtin_nontemporal_store((v), (p))
+#elif defined(GPT_GEMM_C_NTLOAD)
+#define GM_LOADC(p) __builtin_nontemporal_load(p)
+#define GM_STOREC(v, p) (*(p) = (v))
 #else
 #define GM_LOADC(p) (*(p))
 #define GM_STOREC(v, p) (*(p) = (v))
