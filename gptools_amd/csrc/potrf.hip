@@ -398,33 +398,9 @@ __device__ __forceinline__ void potf2_body(double *__restrict__ A, int64_t lda, 
                 const unsigned long long m = __ballot(!(dg > 0.0)) & 0xffffull;
                 if (m != 0ull && lane == 0) atomicCAS(info, 0, (int32_t)(info_col0 + jb * 16 + __ffsll((long long)m)));
             }
-            // column block jb of L, row-major: lane -> (row = lane / 8 of a group of eight rows, two columns)
-            {
-                const int c2 = jb * 16 + (lane & 7) * 2, rr = lane >> 3;
-                const int ngrp = (PD_NB - jb * 16) / 8;
-                const bool vec = (((uintptr_t)A & 15) == 0) && ((lda & 1) == 0);
-                for (int g0 = 0; g0 < ngrp; g0 += 4) {
-                    f64x2 w[4];
-#pragma unroll
-                    for (int g = 0; g < 4; g++)
-                        if (g0 + g < ngrp) w[g] = *reinterpret_cast<const f64x2 *>(&S[jb * 16 + (g0 + g) * 8 + rr][c2]);
-#pragma unroll
-                    for (int g = 0; g < 4; g++)
-                        if (g0 + g < ngrp) {
-                            const int r = jb * 16 + (g0 + g) * 8 + rr;
-                            double *dst = A + (int64_t)r * lda + c2;
-                            if (c2 + 1 <= r) {
-                                if (vec) *reinterpret_cast<f64x2 *>(dst) = w[g];
-                                else {
-                                    dst[0] = w[g][0];
-                                    dst[1] = w[g][1];
-                                }
-                            } else if (c2 == r) {
-                                dst[0] = w[g][0];
-                            }
-                        }
-                }
-            }
+            // (the row-major copy of L is written after the last step, by all eight waves: nobody reads it before the kernel
+            // ends -- the TRSM consumers take the packed workspace -- and in the first steps it was this wave, not the pivot
+            // chain, that the end-of-step barrier waited for: 1800-2400 cycles against 250, profiles/r02_potf2_stamps.txt)
         } else if (jb + 1 < NB16) {
             const int rem = NB16 - 1 - jb;
             const int ntile = rem * (rem + 1) / 2;
@@ -463,6 +439,26 @@ __device__ __forceinline__ void potf2_body(double *__restrict__ A, int64_t lda, 
         if (jb == 0) PD_STAMPW(86 + wave);
         __syncthreads();
         PD_STAMP(8 + jb * 8 + 5);
+    }
+    // L (lower triangle of S), row-major, 16 bytes per thread and store
+    {
+        const bool vec = (((uintptr_t)A & 15) == 0) && ((lda & 1) == 0);
+        constexpr int NCH2 = PD_NB * PD_NB / 2;
+        for (int idx = tid; idx < NCH2; idx += PD_THREADS) {
+            const int r = idx / (PD_NB / 2), c2 = (idx % (PD_NB / 2)) * 2;
+            if (c2 > r) continue;
+            const f64x2 w = *reinterpret_cast<const f64x2 *>(&S[r][c2]);
+            double *dst = A + (int64_t)r * lda + c2;
+            if (c2 + 1 <= r) {
+                if (vec) *reinterpret_cast<f64x2 *>(dst) = w;
+                else {
+                    dst[0] = w[0];
+                    dst[1] = w[1];
+                }
+            } else {
+                dst[0] = w[0];
+            }
+        }
     }
     PD_STAMP(2);
     PD_STAMP_DUMP();

@@ -90,6 +90,41 @@ int main()
                    h[77] - h[76], h[78] - h[77], h[79] - h[78]);
         }
     }
+    {   // ---- the fused diagonal-block + TRSM kernel (workgroup 0 publishes, PUBLISH = true) on a (128 + m) x 128 panel
+        for (int m : {1024, 3072}) {
+            const int n2 = 128 + m, ld = 128;
+            std::vector<double> P((size_t)n2 * ld);
+            for (int i = 0; i < n2; i++)
+                for (int j = 0; j < 128; j++) P[(size_t)i * ld + j] = (i == j ? 300.0 : 0) + 0.5 * cos(i * 0.37 + j * 0.11) * cos(j * 0.37 + i * 0.11);
+            double *dP, *dws2;
+            unsigned *dflag;
+            hipMalloc(&dP, P.size() * 8);
+            hipMalloc(&dws2, GPT_WS_BLOCK * 8);
+            hipMalloc(&dflag, 64);
+            hipMemsetAsync(dflag, 0, 64, st);
+            for (int rep = 0; rep < 3; rep++) {
+                hipMemcpyAsync(dP, P.data(), P.size() * 8, hipMemcpyHostToDevice, st);
+                hipMemsetAsync(dst, 0, 128 * 8, st);
+                hipEventRecord(e0, st);
+                launch_potf2_trsm(st, dP, ld, dws2, dinfo, 0, m, dflag, 32u * (rep + 1));
+                hipEventRecord(e1, st);
+                hipStreamSynchronize(st);
+                float ms = 0;
+                hipEventElapsedTime(&ms, e0, e1);
+                long long h[128];
+                hipMemcpy(h, dst, sizeof(h), hipMemcpyDeviceToHost);
+                if (rep < 2) continue;
+                printf("potf2_trsm m=%d: event %.1f us; workgroup 0: stage+pivot0 -> barrier %lld, loop total %lld cycles\n", m, ms * 1e3,
+                       h[1] - h[0], h[2] - h[1]);
+                printf("  jb: strip  barrier  tile-upd  pivot  barrier   (sum)\n");
+                for (int jb = 0; jb < 8; jb++) {
+                    const long long *q = h + 8 + jb * 8;
+                    if (jb < 7) printf("  %d: %6lld %6lld %6lld %6lld %6lld   %6lld\n", jb, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[5] - q[0]);
+                    else printf("  %d: %6lld %6lld (last: stores only) %6lld\n", jb, q[1] - q[0], q[2] - q[1], q[5] - q[2]);
+                }
+            }
+        }
+    }
     int info = -1;
     hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost);
     std::vector<double> L(n * n);
