@@ -61,6 +61,8 @@ struct gpt_ctx {
     EdgeSig first_wait;                    // ... handed by potrf_enqueue to the first leaf launch (panel_ext)
     EdgeSig head_wait;                     // set by fit_terms: the first leaf of the next factorisation waits for this word (K-build head)
     unsigned edge_seq = 0;                 // value of the last edge raised (monotonic over the context's life)
+    int64_t merge_min_tiles = 1024;        // ... while the merged launch has at least this many 64x64 tiles (>= 512: it needs an order table)
+    int64_t merge_urgent = 1;              // 1: with flag edges, urgent + rest of a panel are ONE launch (urgent tiles first, partial flag)
     int64_t edge_flags = 1;                // 1: those two edges of the look-ahead are flags + hipStreamWaitValue32 instead of events
     bool defer_join = false;               // potrf_enqueue leaves the final panel -> main join to its caller (factor_and_ll)
     hipStream_t tail_stream = nullptr;     // ... and reports the stream the factorisation ended on
@@ -316,7 +318,7 @@ static int check_rq_orders(const int32_t *ni, int64_t M, const int32_t *nj, int6
 // ------------------------------------------------------------------------------------------------
 static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A,
                    int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri,
-                   hipEvent_t done = nullptr, EdgeSig edge = EdgeSig(), EdgeSig wait = EdgeSig())
+                   hipEvent_t done = nullptr, EdgeSig edge = EdgeSig(), EdgeSig wait = EdgeSig(), int64_t edge_cols = 0)
 {
     // algorithmic flop count: 2k per computed element of C (lower trapezoid when tri)
     const double elems = tri ? 0.5 * (double)n * (double)(n + 1) + (double)(m - n) * (double)n : (double)m * (double)n;
@@ -357,7 +359,7 @@ static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, 
     // (option gemm_prio >= 0: every GEMM of this context -- the panel-side context of the block-cyclic engine, whose
     // launches all sit on the chain)
     const int prio = (c->gemm_prio >= 0) ? (int)c->gemm_prio : (!on_main && c->lookahead) ? (int)c->panel_prio : 0;
-    int rc = launch_gemm_nt(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, c->tile, lds_pad, e0, e1, prio, edge, wait);
+    int rc = launch_gemm_nt(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, c->tile, lds_pad, e0, e1, prio, edge, wait, edge_cols);
     if (!ext) {
         if (prof) GPT_HIP_CHECK(hipEventRecord(gp->e1, st));
         if (done) GPT_HIP_CHECK(hipEventRecord(done, st));
@@ -819,6 +821,18 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
                 EdgeSig cu_edge;
                 cu_edge.word = c->d_edge + 16;
                 cu_edge.value = ++c->edge_seq;
+                // Urgent + rest as ONE launch (option merge_urgent) while the update is large enough for an order table: the
+                // tiles of the urgent columns come first on every XCD, write through and raise the flag when THEY are done;
+                // the rest follows in the same launch -- one drain and one ramp-up less per panel on the main stream, and
+                // the small urgent launch (30 TFLOP/s on its own) runs at the large launch's rate.
+                const int64_t nt64m = ((n - u0 + 63) / 64) * ((n - u0 + 63) / 64 + 1) / 2;
+                if (c->merge_urgent && u1 < n && split == n && nt64m >= c->merge_min_tiles && (c->tile == 0 || c->tile == 64) && (u1 - u0) % 64 == 0) {
+                    GPT_TRY(gemm_nt(c, S, n - u0, n - u0, w, -1.0, A + u0 * lda + c0, lda, A + u0 * lda + c0, lda, 1.0,
+                                    A + u0 * lda + u0, lda, 1, nullptr, cu_edge, EdgeSig(), u1 - u0));
+                    cu_edge_prev = cu_edge;
+                    c0 += w;
+                    continue;
+                }
                 GPT_TRY(gemm_nt(c, S, n - u0, u1 - u0, w, -1.0, A + u0 * lda + c0, lda, A + u0 * lda + c0, lda, 1.0,
                                 A + u0 * lda + u0, lda, 1, nullptr, cu_edge));
                 cu_edge_prev = cu_edge;
@@ -1074,6 +1088,8 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "purg_rows")) c->purg_rows = value;
     else if (!strcmp(key, "panel_prio")) c->panel_prio = value;
     else if (!strcmp(key, "edge_flags")) c->edge_flags = value;
+    else if (!strcmp(key, "merge_urgent")) c->merge_urgent = value;
+    else if (!strcmp(key, "merge_min_tiles")) c->merge_min_tiles = value < 512 ? 512 : value;
     else if (!strcmp(key, "gemm_prio")) c->gemm_prio = value;
     else if (!strcmp(key, "late_pad")) c->late_pad = (int)value;
     else if (!strcmp(key, "late_pad_rows")) c->late_pad_rows = value;

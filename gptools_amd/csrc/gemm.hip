@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     int64_t m, int64_t n, int64_t k, double alpha, const double *__restrict__ A, int64_t lda,
     const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
     int tri, int64_t ntm, int64_t ntn, int64_t nwg, const int2 *__restrict__ order, int64_t seg_cols, int64_t bskip, int prio, unsigned *edge, unsigned edge_val,
-    unsigned edge_total, const unsigned *wait_word, unsigned wait_val)
+    unsigned edge_total, const unsigned *wait_word, unsigned wait_val, int edge_cols)
 {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int RM = WM / 16, RN = WN / 16;
@@ -196,6 +196,9 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     const int64_t row0 = ti * BM, col0 = tj * BN;
     GM_STAMP(6);
     const int tid = threadIdx.x, lane = tid & 63;
+    // (edge_cols > 0: only the workgroups of the first edge_cols tile columns -- first in the order table -- write through
+    // and count towards the edge flag: the "urgent" part of a merged trailing update, see launch_gemm_nt)
+    if (edge_cols > 0 && tj >= edge_cols) edge = nullptr;
     // In-kernel side of a flag edge (EdgeSig): C of this launch is produced by a kernel of another stream that raises
     // *wait_word to wait_val when it is through.  hipStreamWaitValue32 in front of this launch would be a kernel of its own
     // (__amd_rocclr_streamOpsWait, ~5 us on the chain); here the common case -- the word is already up -- costs one load.
@@ -444,6 +447,7 @@ struct TileOrder {
     int2 *d_tab;
     int64_t grid;
     int64_t ntiles;                // entries of the table that hold a tile (the rest are (-1, -1) padding)
+    int64_t edge_cols, nedge;      // partial edge flag: the tiles of the first edge_cols columns come first; their number
 };
 static std::vector<TileOrder> g_orders;
 static std::mutex g_orders_mu;
@@ -461,7 +465,7 @@ static inline bool tile_needed(int tri, int64_t i, int64_t j, int64_t seg_t, int
 }
 
 static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64_t *grid, int64_t seg_t = 0,
-                      int64_t rss_t = 0, int64_t *ntiles = nullptr)
+                      int64_t rss_t = 0, int64_t *ntiles = nullptr, int64_t edge_cols = 0, int64_t *nedge = nullptr)
 {
     static int sgm = 0, sgn = 0, mode = 0;
     if (sgm == 0) {
@@ -475,35 +479,38 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
     GPT_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_orders_mu);
     for (const auto &o : g_orders)
-        if (o.ntm == ntm && o.ntn == ntn && o.tri == tri && o.dev == dev && o.seg_t == seg_t && o.rss_t == rss_t) {
+        if (o.ntm == ntm && o.ntn == ntn && o.tri == tri && o.dev == dev && o.seg_t == seg_t && o.rss_t == rss_t && o.edge_cols == edge_cols) {
             *tab = o.d_tab;
             *grid = o.grid;
             if (ntiles) *ntiles = o.ntiles;
+            if (nedge) *nedge = o.nedge;
             return GPT_OK;
         }
     std::vector<std::vector<int2>> per(8);
-    std::vector<int2> seq;
+    std::vector<int2> seq, sequ;          // sequ: the tiles of the first edge_cols columns (they go first on every XCD)
     const int64_t sm = (ntm + sgm - 1) / sgm, sn = (ntn + sgn - 1) / sgn;
     int64_t sidx = 0;
     for (int64_t si = 0; si < sm; si++)
         for (int64_t sj = 0; sj < sn; sj++) {
-            std::vector<int2> &dst = mode ? seq : per[sidx % 8];
+            std::vector<int2> &dst = (mode || edge_cols > 0) ? seq : per[sidx % 8];
             bool any = false;
             for (int64_t i = si * sgm; i < (si + 1) * sgm && i < ntm; i++)
                 for (int64_t j = sj * sgn; j < (sj + 1) * sgn && j < ntn; j++) {
                     if (!tile_needed(tri, i, j, seg_t, rss_t)) continue;
-                    dst.push_back(make_int2((int)i, (int)j));
+                    (j < edge_cols ? sequ : dst).push_back(make_int2((int)i, (int)j));
                     any = true;
                 }
             if (any) sidx++;
         }
-    if (mode) {
-        const size_t T = seq.size(), q = T / 8, r = T % 8;
-        size_t at = 0;
-        for (int x = 0; x < 8; x++) {
-            const size_t len = q + ((size_t)x < r ? 1 : 0);
-            per[x].assign(seq.begin() + at, seq.begin() + at + len);
-            at += len;
+    if (mode || edge_cols > 0) {
+        for (const std::vector<int2> *sq : {&sequ, &seq}) {
+            const size_t T = sq->size(), q = T / 8, r = T % 8;
+            size_t at = 0;
+            for (int x = 0; x < 8; x++) {
+                const size_t len = q + ((size_t)x < r ? 1 : 0);
+                per[x].insert(per[x].end(), sq->begin() + at, sq->begin() + at + len);
+                at += len;
+            }
         }
     }
     size_t mx = 0;
@@ -518,6 +525,8 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
     o.dev = dev;
     o.seg_t = seg_t;
     o.rss_t = rss_t;
+    o.edge_cols = edge_cols;
+    o.nedge = (int64_t)sequ.size();
     o.grid = (int64_t)flat.size();
     o.ntiles = 0;
     for (auto &v : per) o.ntiles += (int64_t)v.size();
@@ -537,6 +546,7 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
     *tab = o.d_tab;
     *grid = o.grid;
     if (ntiles) *ntiles = o.ntiles;
+    if (nedge) *nedge = o.nedge;
     return GPT_OK;
 }
 
@@ -545,11 +555,12 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
                          int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri,
                          int lds_pad, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int64_t seg_cols = 0,
                          int64_t bskip = 0, int64_t row_step = 0, int prio = 0, EdgeSig edge = EdgeSig(),
-                         EdgeSig wait = EdgeSig())
+                         EdgeSig wait = EdgeSig(), int64_t edge_cols_elems = 0)
 {
     const int64_t ntm = (m + BM - 1) / BM, ntn = (n + BN - 1) / BN;
     int64_t nwg = (tri == 1) ? ntn * (ntn + 1) / 2 + (ntm - ntn) * ntn : ntm * ntn;
     int64_t nreal = nwg;                   // workgroups that compute a tile (and count towards an edge flag)
+    int64_t nedge = 0;                     // ... of which in the first edge_cols columns (partial edge flag)
     const int2 *order = nullptr;
     if (tri == 2) {                        // staircase: the tile list always comes from a table
         int64_t grid = 0;
@@ -557,8 +568,12 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
         nwg = grid;
     } else if (nwg >= 512) {               // large launches only: small ones live in L2 anyway
         int64_t grid = 0;
-        GPT_TRY_RC(tile_order(ntm, ntn, tri, &order, &grid, 0, 0, &nreal));
+        GPT_TRY_RC(tile_order(ntm, ntn, tri, &order, &grid, 0, 0, &nreal, edge_cols_elems / BN, &nedge));
         nwg = grid;
+    }
+    if (edge_cols_elems > 0 && (order == nullptr || !edge.word || nedge <= 0)) {
+        gpt_set_error("gemm_nt: a partial edge flag needs a launch large enough for an order table");
+        return GPT_E_ARG;
     }
     if (nwg <= 0) return GPT_OK;
     // lds_pad bytes of unused dynamic LDS cap the residency of the 64x64 kernel (32 KiB static): the trailing
@@ -569,12 +584,12 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
     // would add two barrier packets per launch to the stream being measured
     if (ev0 || ev1)
         hipExtLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg), dim3(256), dyn, st, ev0, ev1, 0,
-                              m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip, prio, edge.word, edge.value, (unsigned)nreal,
-                              wait.word, wait.value);
+                              m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip, prio, edge.word, edge.value,
+                              (unsigned)(edge_cols_elems > 0 ? nedge : nreal), wait.word, wait.value, (int)(edge_cols_elems / BN));
     else
         hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg), dim3(256), dyn, st, m, n, k, alpha,
-                           A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip, prio, edge.word, edge.value, (unsigned)nreal,
-                              wait.word, wait.value);
+                           A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip, prio, edge.word, edge.value,
+                              (unsigned)(edge_cols_elems > 0 ? nedge : nreal), wait.word, wait.value, (int)(edge_cols_elems / BN));
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
@@ -600,7 +615,7 @@ static int gemm_launch_persist(hipStream_t st, int64_t m, int64_t n, int64_t k, 
 
 int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A, int64_t lda,
                    const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile, int lds_pad,
-                   hipEvent_t ev0, hipEvent_t ev1, int prio, EdgeSig edge, EdgeSig wait)
+                   hipEvent_t ev0, hipEvent_t ev1, int prio, EdgeSig edge, EdgeSig wait, int64_t edge_cols)
 {
     gpt_jitter(st);
     if (m <= 0 || n <= 0) {
@@ -640,10 +655,10 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
             if (const char *e = getenv("GPT_GEMM_SMALL")) small_below = atoi(e);
         }
         const int64_t nt64 = ((m + 63) / 64) * ((n + 63) / 64);
-        if (nt64 < small_below && !ev0) tile = 32;
+        if (nt64 < small_below && !ev0 && edge_cols == 0) tile = 32;
     }
     if (tile == 32) return gemm_launch_t<32, 32, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0, ev0, ev1, 0, 0, 0, prio, edge, wait);
-    if ((edge.word || wait.word) && tile != 64) {
+    if ((edge.word || wait.word || edge_cols) && tile != 64) {
         gpt_set_error("gemm_nt: edge flags exist for the 64x64 / 32x32 kernels only");
         return GPT_E_ARG;
     }
@@ -653,7 +668,7 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
     // small panel updates (8064x128x128: 12 us either way): they are bound by launch + prologue latency, not by the
     // DMA wait, so everything uses the 2-stage kernel.
     if (force_tile == 65) return gemm_launch_t<64, 64, 1, 4>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0);
-    return gemm_launch_t<64, 64, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, lds_pad, ev0, ev1, 0, 0, 0, prio, edge, wait);
+    return gemm_launch_t<64, 64, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, lds_pad, ev0, ev1, 0, 0, 0, prio, edge, wait, edge_cols);
 }
 
 // Staircase update: C (m x nseg*seg_cols) += alpha * A B_q^T per column segment q, where segment q (seg_cols
