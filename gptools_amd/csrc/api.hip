@@ -62,6 +62,7 @@ struct gpt_ctx {
     EdgeSig head_wait;                     // set by fit_terms: the first leaf of the next factorisation waits for this word (K-build head)
     unsigned edge_seq = 0;                 // value of the last edge raised (monotonic over the context's life)
     int64_t merge_min_tiles = 1024;        // ... while the merged launch has at least this many 64x64 tiles (>= 512: it needs an order table)
+    int64_t purg_rows_flags = 0;           // purg_rows while flag edges + merged launches are in use
     int64_t merge_urgent = 1;              // 1: with flag edges, urgent + rest of a panel are ONE launch (urgent tiles first, partial flag)
     int64_t edge_flags = 1;                // 1: those two edges of the look-ahead are flags + hipStreamWaitValue32 instead of events
     bool defer_join = false;               // potrf_enqueue leaves the final panel -> main join to its caller (factor_and_ll)
@@ -769,7 +770,10 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
             // ("urgent") itself, right behind the panel -- no event round trip panel -> main -> panel on the chain and
             // one launch less on the main stream, which sets the pace there.  Both streams read-modify-write those
             // columns (the main stream's rest of panel k-1 covers them too), so the panel stream waits for that rest.
-            const bool p_urgent = !H && c->purg_rows > 0 && n - c0 > c->purg_rows && !c->use_graph && u1 < n;
+            // (with flag edges and merged launches the main stream has one launch per panel anyway and the urgent tiles run at
+            // the large launch's rate: the panel stream's own urgent update no longer pays -- 4.444 against 4.492 ms at N = 8192)
+            const int64_t purg_eff = (use_flags && c->merge_urgent) ? c->purg_rows_flags : c->purg_rows;
+            const bool p_urgent = !H && purg_eff > 0 && n - c0 > purg_eff && !c->use_graph && u1 < n;
             if (p_urgent) {
                 // (edge_flags >= 2: "the rest of panel k-1 is done" as a flag edge as well -- no stop event on the main
                 // stream's large launches, which set the pace here; the whole C of that launch is then written through)
@@ -1089,6 +1093,7 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "panel_prio")) c->panel_prio = value;
     else if (!strcmp(key, "edge_flags")) c->edge_flags = value;
     else if (!strcmp(key, "merge_urgent")) c->merge_urgent = value;
+    else if (!strcmp(key, "purg_rows_flags")) c->purg_rows_flags = value;
     else if (!strcmp(key, "merge_min_tiles")) c->merge_min_tiles = value < 512 ? 512 : value;
     else if (!strcmp(key, "gemm_prio")) c->gemm_prio = value;
     else if (!strcmp(key, "late_pad")) c->late_pad = (int)value;
