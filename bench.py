@@ -364,14 +364,17 @@ def main():
         ctx.set_option("profile_gemm", 0)
         if gcount:
             ach = gflops_alg / (gms * 1e-3) * 1e-12
+            traffic_note = None
             traffic = None        # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
             import glob            # FETCH doubled per the gfx950 note), committed under profiles/ per round
             tjs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_traffic.json")))
             if wl == "c3" and tjs:
-                traffic = json.load(open(tjs[-1])).get("hbm_bytes_per_launch")
+                tj_ = json.load(open(tjs[-1]))
+                traffic = tj_.get("hbm_bytes_per_launch")
+                traffic_note = tj_.get("note")
             roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<64,64> (trailing SYRK/GEMM updates >= 1 GFLOP)",
                     "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
-                    "traffic": traffic, "traffic_unit": "bytes/launch", "launches_per_step": gcount / args.steps,
+                    "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_note": traffic_note, "launches_per_step": gcount / args.steps,
                     "avg_launch_us": gms * 1e3 / gcount, "flops_per_launch": gflops_alg / gcount}
         # predict leg (SURVEY 8d "Predict (if timed): N^2 M + N M^2"; ref gaussian_process.py:965-1006) on the factor of
         # the last timed step: K* build, mean = K*^T alpha, v = L^-1 K*, then the row norms (std) or the SYRK (cov).
