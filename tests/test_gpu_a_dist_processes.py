@@ -254,6 +254,13 @@ def test_flag_edges_single_context_bitwise_and_under_jitter():
         "        failed = True\n"
         "    again = ctx.fit(kid, p, 0.0, y, err, 2.2e-14)\n"
         "    res.append((again[0], again[1], res[0][2], 1 if failed else -1))\n"
+        "    # the plain factorisation entry (gpt_potrf on a host matrix) through the same look-ahead, flags in use\n"
+        "    rs = np.random.RandomState(N)\n"
+        "    Ad = rs.randn(1700, 1700); Ad = Ad.dot(Ad.T) + 1700 * np.eye(1700)\n"
+        "    e1 = ctx.edge_count\n"
+        "    Ld = np.tril(ctx.potrf_host(Ad))\n"
+        "    assert ctx.edge_count > e1, 'potrf_host did not use the flag edges'\n"
+        "    np.testing.assert_allclose(Ld, np.linalg.cholesky(Ad), rtol=1e-11, atol=1e-11)\n"
         "    out[str(N)] = res\n"
         "    del ctx\n"
         "print('RESULT', json.dumps(out))\n") % (ROOT, ROOT)
