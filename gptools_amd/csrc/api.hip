@@ -84,7 +84,7 @@ struct gpt_ctx {
     int timing = 0;
     int tile = 0;
     int gemm_pad = 1024;
-    int64_t fuse_trsm = 4096;          // panels with at most this many rows below the leaf use potf2_trsm_kernel (0 = never)
+    int64_t fuse_trsm = 8192;          // panels with at most this many rows below the leaf use potf2_trsm_kernel (0 = never)
     int leaf256 = 0;                   // 256-column leaves (potf2x2_trsm_kernel) where two 128-column leaves of a short panel follow each other
     double *d_l10pk = nullptr;         // its scratch: the packed block between the two diagonal blocks (16384 doubles)
     unsigned *d_flag = nullptr;        // progress word of potf2_trsm_kernel (only ever raised)

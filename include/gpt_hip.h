@@ -75,7 +75,7 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
  *                  (6144; 0 = the main stream always does)
  *   "panel_prio"   wave priority (0..3) of the panel stream's GEMM main loops (2); "gemm_prio" >= 0 forces one priority
  *                  for every GEMM of the context (the panel-side context of gptools_amd/dist.py)
- *   "fuse_trsm"    panels with at most this many rows under a leaf use the fused diagonal-block + TRSM kernel (4096)
+ *   "fuse_trsm"    panels with at most this many rows under a leaf use the fused diagonal-block + TRSM kernel (8192)
  *   "merge_urgent" 1 (default, with edge_flags): the two trailing updates per panel are one launch with a partial edge flag
  *   "edge_flags"   1 (default): the per-panel dependencies of the look-ahead are flag words in device memory (last workgroup
  *                  of the producer raises it; hipStreamWaitValue32 / an in-kernel wait on the consumer side) instead of events;
