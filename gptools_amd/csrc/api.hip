@@ -61,7 +61,7 @@ struct gpt_ctx {
     EdgeSig first_wait;                    // ... handed by potrf_enqueue to the first leaf launch (panel_ext)
     EdgeSig head_wait;                     // set by fit_terms: the first leaf of the next factorisation waits for this word (K-build head)
     unsigned edge_seq = 0;                 // value of the last edge raised (monotonic over the context's life)
-    int64_t merge_min_tiles = 1024;        // ... while the merged launch has at least this many 64x64 tiles (>= 512: it needs an order table)
+    int64_t merge_min_tiles = 512;         // ... while the merged launch has at least this many 64x64 tiles (>= 512: it needs an order table)
     int64_t purg_rows_flags = 0;           // purg_rows while flag edges + merged launches are in use
     int64_t merge_urgent = 1;              // 1: with flag edges, urgent + rest of a panel are ONE launch (urgent tiles first, partial flag)
     int64_t edge_flags = 1;                // 1: those two edges of the look-ahead are flags + hipStreamWaitValue32 instead of events
