@@ -9,9 +9,11 @@ X, n are resident in HBM before the timed region; per step only the hyperparamet
 y / err_y vectors) cross the boundary.
 
   python bench.py --gpus 1 --steps K --warmup W          # 1 GPU: config C3 (Matern52, N=8192, d=3, derivative rows)
+  python bench.py --gpus N ...                            # N>1: config C4 (SE, N=32768, d=4) block-cyclic panel
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
-                                                          # N>1: config C4 (SE, N=32768, d=4) block-cyclic panel
-                                                          # Cholesky partitioned over the N ranks, RCCL broadcasts
+                                                          # Cholesky partitioned over the N ranks, RCCL broadcasts; without a
+                                                          # launcher (no RANK in the environment) bench.py starts its N ranks
+                                                          # itself as child processes (self_launch)
 value  = algorithmic flops of the steps / wall time, in GFLOP/s, with the LAPACK potrf+potrs count
          (N^3/3 + N^2/2 + N/6 + 2 N^2) -- K-build time is in the denominator but adds no flops.
 roofline  : the trailing-update SYRK/GEMM kernel (fp64 MFMA bound), achieved = sum of algorithmic flops of the
@@ -221,6 +223,65 @@ class Watchdog(object):
         return True
 
 
+def self_launch(ngpus):
+    """`python bench.py --gpus N` without a launcher: this process starts the N ranks itself -- fresh child processes of
+    this same script, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment (what
+    torch.distributed.run would set) -- relays rank 0's JSON line and exits with the worst child status.  The parent
+    never imports torch or touches HIP (a process that has initialised the GPU must not be the one that forks / execs the
+    ranks), and nothing is re-exec'ed: the children are ordinary subprocesses."""
+    import signal
+    import socket
+    import subprocess
+    import threading
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(ngpus), LOCAL_WORLD_SIZE=str(ngpus), MASTER_ADDR="127.0.0.1",
+                MASTER_PORT=os.environ.get("MASTER_PORT", str(port)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one_gpu = bool(os.environ.get("GPT_BENCH_ONE_GPU"))        # (test hook: every rank on cuda:0, with GPT_BENCH_BACKEND=gloo)
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(ngpus):
+        env = dict(base, RANK=str(r), LOCAL_RANK="0" if one_gpu else str(r), GROUP_RANK="0")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1))
+
+    def relay(p, r):
+        for line in p.stdout:
+            # rank 0's stdout is the bench line; whatever another rank prints goes to stderr, tagged
+            if r == 0:
+                sys.stdout.write(line)
+                sys.stdout.flush()
+            else:
+                sys.stderr.write("[rank %d] %s" % (r, line))
+    threads = [threading.Thread(target=relay, args=(p, r), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+    # a rank that dies leaves the others waiting in a collective: give them a grace period, then end them (exact PIDs)
+    grace, first_bad = float(os.environ.get("GPT_BENCH_GRACE_S", "60")), None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if first_bad is None and any(c not in (None, 0) for c in codes):
+            first_bad = time.time()
+        if first_bad is not None and time.time() - first_bad > grace:
+            for p in procs:
+                if p.poll() is None:
+                    p.send_signal(signal.SIGTERM)
+            time.sleep(5)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.2)
+    for t in threads:
+        t.join(timeout=5)
+    worst = 0
+    for c in codes:
+        c = 128 - c if c < 0 else c
+        worst = max(worst, c)
+    sys.exit(worst)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -237,15 +298,15 @@ def main():
     ap.add_argument("--no-probe", action="store_true", help="N>1: skip the step trace and the link probes after the timed region")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        self_launch(args.gpus)          # plain `python bench.py --gpus N`: start the N ranks (never returns)
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
-                             % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")

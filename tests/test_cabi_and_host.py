@@ -237,3 +237,38 @@ def test_bench_parity_gate_reports_and_gates():
     assert not bench.parity_report(-1234.5 * (1 + 1e-6), 987.0, ref)[1]
     assert not bench.parity_report(-1234.5, 987.0 * (1 - 1e-7), ref)[1]
     assert not bench.parity_report(-1234.5, 987.0, ref, (m, 0.1 + m), (m + 1e-4, 0.1 + m))[1]
+
+
+def test_bench_self_launch_starts_the_ranks_and_relays_their_status():
+    """`python bench.py --gpus N` with no launcher in the environment starts its N ranks itself (bench.self_launch): fresh
+    children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, the parent never imports torch, and a failing rank's
+    status comes back.  Without a GPU every rank stops at "needs an MI355X" -- which is exactly what is relayed here."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(GPT_BENCH_GRACE_S="2", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu"], capture_output=True,
+                         text=True, timeout=300, env=env)
+    assert out.returncode == 1, (out.returncode, out.stderr[-500:])
+    assert out.stderr.count("needs an MI355X") == 2 and out.stdout.strip() == ""
+    # the rank environment a child sees (the hook prints it instead of running)
+    code = ("import os, sys; sys.argv = ['bench.py', '--gpus', '3']; sys.path.insert(0, %r)\n"
+            "import bench, subprocess\n"
+            "seen = []\n"
+            "class P(object):\n"
+            "    def __init__(self, cmd, env=None, **kw):\n"
+            "        seen.append((env['RANK'], env['LOCAL_RANK'], env['WORLD_SIZE'], env['MASTER_ADDR'], cmd[1]))\n"
+            "        self.stdout = []\n"
+            "    def poll(self): return 0\n"
+            "subprocess.Popen = P\n"
+            "try: bench.self_launch(3)\n"
+            "except SystemExit as e: print('exit', e.code)\n"
+            "print(seen); print('torch' in sys.modules)\n" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stderr[-500:]
+    lines = out.stdout.splitlines()
+    assert lines[0] == "exit 0" and lines[2] == "False"
+    seen = eval(lines[1])
+    assert [s[:4] for s in seen] == [(str(r), str(r), "3", "127.0.0.1") for r in range(3)]
+    assert all(s[4].endswith("bench.py") for s in seen)

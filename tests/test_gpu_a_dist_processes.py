@@ -279,3 +279,20 @@ def test_flag_edges_single_context_bitwise_and_under_jitter():
             assert res[-1][3] == 1, "the indefinite matrix did not raise LinAlgError"
             for r in res[1:]:
                 assert r[:3] == res[0][:3], (N, jitter, res)
+
+
+def test_bench_plain_python_gpus_2_self_launches():
+    """`python bench.py --gpus 2` with NO launcher (no RANK / WORLD_SIZE in the environment): bench.py starts the two ranks
+    itself (bench.self_launch), relays rank 0's one JSON line and exits 0.  Both ranks on cuda:0 over gloo (test hooks
+    GPT_BENCH_ONE_GPU / GPT_BENCH_BACKEND), the C2 workload."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(GPT_BENCH_BACKEND="gloo", GPT_BENCH_ONE_GPU="1", GPT_BENCH_WATCHDOG_S="500")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c2", "--steps", "3", "--warmup", "1",
+           "--schedule", "bcast+bcast", "--no-probe", "--no-ref"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["N"] == 4096 and line["parity"]["ok"] and line["roofline"]["achieved"] > 0
