@@ -293,6 +293,7 @@ def main():
     ap.add_argument("--dist", action="store_true", help="use the block-cyclic DistributedLML path even with one rank")
     ap.add_argument("--no-batched", action="store_true", help="N=1: skip the two-evaluations-in-flight throughput leg")
     ap.add_argument("--no-predict", action="store_true", help="N=1: skip the predict leg")
+    ap.add_argument("--no-gp-api", action="store_true", help="N=1: skip the GaussianProcess.update_hyperparameters leg")
     ap.add_argument("--no-ref", action="store_true", help="N>1: skip the single-GPU run of the same workload on rank 0")
     ap.add_argument("--schedule", default=None, help="N>1: fix the schedule+exchange (e.g. pipelined+bcast) instead of tuning")
     ap.add_argument("--no-probe", action="store_true", help="N>1: skip the step trace and the link probes after the timed region")
@@ -369,10 +370,11 @@ def main():
             return ctx.fit(KID[kernel], params, 0.0, y, err, diag_add)
         for _ in range(args.warmup):
             ll, ld = step()
-        # The throughput leg (two contexts, two host threads) runs FIRST and its second context is destroyed before the timed
-        # loop: with more than one context alive the library keeps the look-ahead's cross-stream edges on events (its flag
-        # edges make a kernel wait for a kernel of another stream, which is only safe while the process's queues all stay
-        # resident: gptools_amd/csrc/api.hip, edge_flags_usable) -- the metric is the single-chain evaluation.
+        # The throughput leg (two contexts, two host threads) runs first, inside _lib.concurrent_evaluations(): while several
+        # chains are in flight the library keeps every look-ahead on event edges (a kernel spinning on a flag word must not
+        # share the hardware queues with a second chain: gptools_amd/csrc/api.hip, EvalScope).  The second context then
+        # STAYS ALIVE through the timed loop -- as GaussianProcess's pooled context does -- because what decides the schedule
+        # is the number of evaluations in flight, not of contexts alive; `flag_schedule` / `live_contexts` below say what ran.
         if not args.no_batched:
             # Throughput mode (reported beside `value`, never in it): two INDEPENDENT evaluations (different theta, same
             # data) in flight on the GPU, one context + host thread each -- how GaussianProcess.ll_batch /
@@ -390,21 +392,20 @@ def main():
                 for _ in range(args.steps):
                     c_.fit(KID[kernel], p_, 0.0, y, err, diag_add)
             th = [threading.Thread(target=run, args=cp) for cp in pair]
-            barrier()
-            tb = time.perf_counter()
-            for t_ in th:
-                t_.start()
-            for t_ in th:
-                t_.join()
-            barrier()
-            tb = time.perf_counter() - tb
+            with _lib.concurrent_evaluations():
+                barrier()
+                tb = time.perf_counter()
+                for t_ in th:
+                    t_.start()
+                for t_ in th:
+                    t_.join()
+                barrier()
+                tb = time.perf_counter() - tb
             extra["batched"] = {"in_flight": 2, "lml_evals_per_s": 2 * args.steps / tb,
                                 "value": 2 * args.steps * flops_fit(N) / tb * 1e-9, "unit": "GFLOP/s",
                                 "note": "two independent LML evaluations (different hyperparameters) concurrently on one "
                                         "GPU; throughput of multi-start MAP / likelihood grids, not of one MAP chain"}
-            del ctx2, pair, th, c_, p_, t_
-            import gc
-            gc.collect()          # (the second context must be GONE before the timed single-context loop: see the note above)
+            del pair, th, c_, p_, t_
             ctx.set_option("timing", 1)
             for _ in range(2):   # (untimed: the first evaluations after the mode change)
                 ll, ld = step()
@@ -437,6 +438,41 @@ def main():
                     "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                     "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_note": traffic_note, "launches_per_step": gcount / args.steps,
                     "avg_launch_us": gms * 1e3 / gcount, "flops_per_launch": gflops_alg / gcount}
+        extra["flag_edges_per_step"] = (ctx.edge_count - edges0_) / float(args.steps)   # 0: the look-ahead ran on events
+        extra["flag_schedule"] = extra["flag_edges_per_step"] > 0
+        extra["live_contexts"] = 1 if ctx2 is None else 2
+        # The same step through the plugin API (north_star's unit: GaussianProcess.update_hyperparameters, ref
+        # gaussian_process.py:1332-1416): a GaussianProcess over the same data whose main / pooled contexts ARE the two of this
+        # bench -- the same streams and hardware queues as the timed loop above, so the difference is what the Python layer
+        # costs (parameter bookkeeping, the log-prior, ctypes) and which schedule the library picks for it.
+        if not args.no_gp_api:
+            import warnings
+            import gptools_amd as g
+            kcls_ = {"se": g.SquaredExponentialKernel, "m52": g.Matern52Kernel}[kernel]
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                gp_ = g.GaussianProcess(kcls_(num_dim=d, initial_params=params, param_bounds=[(1e-3, 10.0)] * (d + 1)),
+                                        X=X, y=y, err_y=err, n=n)
+            gp_._ctx_obj, gp_._ctx_pool, gp_._data_on_device = ctx, ([[ctx2, -1]] if ctx2 is not None else []), True
+            ctx.set_option("profile_gemm", 1)      # (the per-launch events of the roofline line, as in the timed loop above)
+            for _ in range(2):
+                v_ = gp_.update_hyperparameters(params)
+            eg_ = ctx.edge_count
+            barrier()
+            tg_ = time.perf_counter()
+            for _ in range(args.steps):
+                v_ = gp_.update_hyperparameters(params)
+            barrier()
+            tg_ = (time.perf_counter() - tg_) / args.steps
+            extra["via_gp_api"] = {"call": "GaussianProcess.update_hyperparameters", "ms_per_step": tg_ * 1e3,
+                                   "ratio_to_ms_per_step": tg_ / (elapsed / args.steps),
+                                   "flag_edges_per_step": (ctx.edge_count - eg_) / float(args.steps),
+                                   "ll_identical_to_c_abi": bool(-v_ - gp_.hyperprior(gp_.params) == ll
+                                                                 or abs((-v_ - gp_.hyperprior(gp_.params)) - ll) <= 1e-12 * abs(ll))}
+            gp_._ctx_obj = gp_._ctx_pool = None
+            del gp_
+            ctx.gemm_profile_read()
+            ctx.set_option("profile_gemm", 0)
         # predict leg (SURVEY 8d "Predict (if timed): N^2 M + N M^2"; ref gaussian_process.py:965-1006) on the factor of
         # the last timed step: K* build, mean = K*^T alpha, v = L^-1 K*, then the row norms (std) or the SYRK (cov).
         # Host buffers in and out (Xstar up, mean / std / cov down) are inside the wall time.
@@ -460,7 +496,6 @@ def main():
             pl["note"] = ("wall time of gpt_predict incl. host->device Xstar and device->host results (cov: M^2 doubles = "
                           "134 MB over PCIe at M=4096); flops = N^2 M (triangular solve) + N M^2 (cov) or 2 N M (std)")
             extra["predict"] = pl
-        extra["flag_edges_per_step"] = (ctx.edge_count - edges0_) / float(args.steps)   # 0: the look-ahead ran on events
         extra["kbuild_ms"] = tk / args.steps
         extra["potrf_ms"] = tp / args.steps
         extra["kbuild_GBps_written"] = (8.0 * N * (N + 1) / 2.0) / (tk / args.steps * 1e-3) * 1e-9

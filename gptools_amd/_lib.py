@@ -33,6 +33,7 @@ SIGNATURES = {
     "gpt_ctx_synchronize": (C.c_int, [_vp]),
     "gpt_ctx_stream": (_vp, [_vp]),
     "gpt_ctx_edge_count": (C.c_int64, [_vp]),
+    "gpt_concurrency_hint": (C.c_int, [C.c_int]),
     "gpt_kpairs": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, _dp, _ip, _ip, _i64, C.c_int, C.c_int, C.c_int, _ip, _dp]),
     "gpt_kbuild": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, _ip, _i64, _dp, _ip, _i64, C.c_int, C.c_int, _ip, _dp]),
     "gpt_set_data": (C.c_int, [_vp, _dp, _ip, _i64, C.c_int]),
@@ -142,6 +143,19 @@ def iptr(a):
     return None if a is None else a.ctypes.data_as(_ip)
 
 
+class concurrent_evaluations(object):
+    """``with concurrent_evaluations():`` brackets a section in which several contexts of this process evaluate at the same
+    time (one host thread each): the library then keeps every look-ahead on event edges (gpt_concurrency_hint)."""
+
+    def __enter__(self):
+        load().gpt_concurrency_hint(1)
+        return self
+
+    def __exit__(self, *exc):
+        load().gpt_concurrency_hint(-1)
+        return False
+
+
 class Context(object):
     """One GPU + stream; owns the device-resident X, n, K_tot/L, invd, alpha."""
 
@@ -182,8 +196,8 @@ class Context(object):
 
     @property
     def edge_count(self):
-        """Flag edges raised so far (0 while the look-ahead runs on events: a second live context, a profiler's
-        counter collection, GPT_EDGE_FLAGS=0, n > 12288)."""
+        """Flag edges raised so far (does not grow while the look-ahead runs on events: another evaluation in flight in the
+        process, a profiler's counter collection, GPT_EDGE_FLAGS=0, n > 12288, after a flag timeout)."""
         return int(self._lib.gpt_ctx_edge_count(self.handle))
 
     # ---- Kernel.__call__ / compute_Kij -------------------------------------------------------

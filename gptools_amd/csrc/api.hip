@@ -64,7 +64,10 @@ struct gpt_ctx {
     int64_t merge_min_tiles = 512;         // ... while the merged launch has at least this many 64x64 tiles (>= 512: it needs an order table)
     int64_t purg_rows_flags = 0;           // purg_rows while flag edges + merged launches are in use
     int64_t merge_urgent = 1;              // 1: with flag edges, urgent + rest of a panel are ONE launch (urgent tiles first, partial flag)
-    int64_t edge_flags = 1;                // 1: those two edges of the look-ahead are flags + hipStreamWaitValue32 instead of events
+    int64_t edge_flags = 1;                // 1: those two edges of the look-ahead may be flag words instead of events (see EvalScope)
+    bool flags_now = false;                // ... and ARE, in the evaluation in progress (set by EvalScope)
+    int reserve_cus = 0;                   // CUs the main stream's mask leaves to the panel stream (0: unmasked)
+    int64_t head_wait_wgs = 33;            // first leaf: in-kernel wait for the K build's head while its launch has at most this many workgroups
     bool defer_join = false;               // potrf_enqueue leaves the final panel -> main join to its caller (factor_and_ll)
     hipStream_t tail_stream = nullptr;     // ... and reports the stream the factorisation ended on
     int64_t gemm_prio = -1;                // >= 0: wave priority of ALL GEMM main loops of this context
@@ -397,32 +400,109 @@ static int leaf256_factor(gpt_ctx *c, hipStream_t st, double *Ad, int64_t lda, i
     return launch_potf2x2_trsm(st, Ad, lda, ws, info, info_base, rows_below, c->d_l10pk, c->d_flag, c->flag_epoch, done_ev);
 }
 
-// Factor the block column Ap (m x w, diag block on top): recursive halving down to 128 columns.
+// ------------------------------------------------------------------------------------------------
+// When may an evaluation run its look-ahead on flag edges (EdgeSig, common.hpp)?
+// ------------------------------------------------------------------------------------------------
+// A kernel that waits for a flag holds its hardware queue's slot.  With two evaluations in flight in one process (two
+// contexts in two host threads: GaussianProcess.ll_batch, the `batched` leg of bench.py) the streams of both plus the
+// runtime's own can exceed the hardware queues the firmware keeps resident; the queue of the kernel that would raise the
+// flag is then scheduled out behind the waiter and every hand-over costs a scheduling quantum: measured 0.8 s per evaluation
+// instead of 1.3 ms at N = 4096, intermittently (scratch/stress_flags.py).  Event edges do not spin and are immune.
+// What decides is therefore not how many contexts EXIST (an idle context's streams cost nothing: GaussianProcess keeps a
+// pooled second context for ll_batch, Kernel.__call__ a process-wide one) but how many evaluations are IN FLIGHT:
+//   * an evaluation (EvalScope, below) takes the flag edges only if it is the only one in flight in the process when it
+//     starts, nobody has announced concurrent evaluations (gpt_concurrency_hint: ll_batch and bench.py bracket their
+//     threaded sections with it), the context owns its streams, and the process has not tripped a flag timeout;
+//   * an evaluation that starts while a flag-mode evaluation is in flight first waits for that one to end (one evaluation's
+//     time, once: from then on each of the two finds the other in flight and both stay on events);
+//   * every wait is bounded (common.hpp); a timeout -- queues oversubscribed by ANOTHER process on the same GPU, a tool that
+//     serialises kernels and is not recognised below -- ends the evaluation with an internal status, the process goes to
+//     event edges for good (g_flags_tripped) and the evaluation is repeated (fit_terms / gpt_fit_matrix).
+// Not usable at all: under rocprofv3 counter collection (ROCPROF_COUNTER_COLLECTION: one kernel at a time -- a --pmc pass
+// once hung until the box's limit; with bounded waits it would crawl instead), with GPT_EDGE_FLAGS=0 (the documented switch
+// for jobs that share a GPU between processes), under graph capture, on a caller-supplied stream (its other work is
+// invisible to the accounting above).
 #include <atomic>
-static std::atomic<int> g_live_ctx{0};      // contexts alive in this process (see use_flags in potrf_enqueue)
+#include <condition_variable>
+#include <mutex>
+static std::mutex g_eval_mu;
+static std::condition_variable g_eval_cv;
+static int g_evals = 0;                 // evaluations in flight in this process
+static int g_flag_evals = 0;            // ... of which on flag edges (0 or 1)
+static int g_announced = 0;             // gpt_concurrency_hint depth
+static std::atomic<bool> g_flags_tripped{false};
+#define GPT_I_EDGE_TIMEOUT (-100)       // internal status of an evaluation whose flag wait timed out (never leaves the library)
 
-// Flag edges (EdgeSig) are usable at all: not under a tool that runs one kernel at a time (rocprofv3 counter collection,
-// ROCPROF_COUNTER_COLLECTION) -- a kernel that waits for another kernel's flag, the runtime's own stream-wait kernel
-// included, then never ends (measured the hard way: a --pmc pass hung until the box's time limit) --, not with
-// GPT_EDGE_FLAGS=0, and ONLY WHILE THIS IS THE ONLY CONTEXT ALIVE IN THE PROCESS.  With two contexts evaluating in two
-// threads (the `batched` leg of bench.py, GaussianProcess.ll_batch) the six streams plus the runtime's own can exceed the
-// hardware queues the firmware keeps resident; a waiting kernel then holds its queue's slot while the queue of the kernel
-// it waits for is scheduled out, and every hand-over costs a scheduling quantum: measured 0.8 s per evaluation instead
-// of 1.3 ms at N = 4096, intermittently (scratch/stress_flags.py).  Event edges do not spin and are immune.
-static bool edge_flags_usable(const gpt_ctx *c);
-
-// Workgroups a launch may have and still wait for its flag INSIDE the kernel: its spinning workgroups must leave at least
-// half of the chip's 8192 wave slots to the kernel they wait for (1024 workgroups of four waves).
-static int64_t inkernel_wait_budget() { return 1024; }
-
-static bool edge_flags_usable(const gpt_ctx *c)
+static bool edge_flags_env_ok()
 {
     static int flags_ok = -1;
     if (flags_ok < 0) {
         const char *e = getenv("GPT_EDGE_FLAGS"), *r = getenv("ROCPROF_COUNTER_COLLECTION");
         flags_ok = !((e && atoi(e) == 0) || (r && r[0] && r[0] != '0' && r[0] != 'F' && r[0] != 'f'));
     }
-    return flags_ok && g_live_ctx.load() <= 1 && c->edge_flags && c->d_edge && !c->use_graph;
+    return flags_ok != 0;
+}
+
+// One synchronous evaluation (K build + factorisation + reduction, ends with the streams drained): decides c->flags_now.
+struct EvalScope {
+    gpt_ctx *c;
+    bool flags;
+    explicit EvalScope(gpt_ctx *c_) : c(c_), flags(false)
+    {
+        std::unique_lock<std::mutex> lk(g_eval_mu);
+        g_eval_cv.wait(lk, [] { return g_flag_evals == 0; });
+        flags = edge_flags_env_ok() && !g_flags_tripped.load() && g_evals == 0 && g_announced == 0 && c->edge_flags &&
+                c->own_stream && c->d_edge && !c->use_graph;
+        g_evals++;
+        if (flags) g_flag_evals++;
+        c->flags_now = flags;
+    }
+    ~EvalScope()
+    {
+        std::lock_guard<std::mutex> lk(g_eval_mu);
+        g_evals--;
+        if (flags) g_flag_evals--;
+        c->flags_now = false;
+        g_eval_cv.notify_all();
+    }
+};
+
+extern "C" int gpt_concurrency_hint(int delta)
+{
+    std::lock_guard<std::mutex> lk(g_eval_mu);
+    g_announced += delta;
+    if (g_announced < 0) g_announced = 0;
+    return g_announced;
+}
+
+// May a rank-k update of an m x n block wait for its flag INSIDE the kernel?  Its workgroups spin until the word is up, so
+// the launch must not be able to fill the chip in front of the update it waits for: only launches that launch_gemm_nt cuts
+// into 32x32 tiles (fewer than gemm_small_threshold() 64x64 tiles: 8 KB of LDS and 256 threads per workgroup, many fit
+// beside a trailing update) and only up to 1024 of those workgroups (half the chip's wave slots).  A launch of 64x64 tiles
+// never does: measured at N = 8192 with 750 such workgroups waiting in the kernel, 4.84 against 4.45 ms per evaluation.
+// Everything else waits on the stream, in front of the launch (stream_wait_flag).
+static bool gemm_may_wait_in_kernel(const gpt_ctx *c, int64_t m, int64_t n)
+{
+    if (!(c->tile == 0 || c->tile == 64)) return false;
+    const int64_t nt64 = ((m + 63) / 64) * ((n + 63) / 64);
+    return nt64 < gemm_small_threshold() && ((m + 31) / 32) * ((n + 31) / 32) <= 1024;
+}
+// the error word of the context's bounded flag waits
+static inline EdgeSig with_err(gpt_ctx *c, EdgeSig e)
+{
+    static const bool unbounded = getenv("GPT_EDGE_UNBOUNDED") != nullptr;      // (measurement aid)
+    e.err = unbounded ? nullptr : c->d_edge + 60;
+    return e;
+}
+// stream-side wait: own bounded kernel, or (GPT_EDGE_WAITVALUE, measurement aid) the runtime's hipStreamWaitValue32
+static int stream_wait_flag(hipStream_t st, EdgeSig w)
+{
+    static const bool rt = getenv("GPT_EDGE_WAITVALUE") != nullptr;
+    if (rt) {
+        GPT_HIP_CHECK(hipStreamWaitValue32(st, w.word, w.value, hipStreamWaitValueGte, 0xffffffffu));
+        return GPT_OK;
+    }
+    return launch_wait_flag(st, w);
 }
 
 static int panel_rec(gpt_ctx *c, hipStream_t st, double *Ap, int64_t lda, int64_t m, int64_t w, double *invd,
@@ -541,9 +621,18 @@ static int panel_ext(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64_t
         const bool last = (r1 == c0 + w) && done_ev;
         const int64_t m = n - r1;
         EdgeSig fw;                                   // the first leaf of a factorisation may have to wait for the K build's head
-        if (lc == 0) {
+        if (lc == 0 && c->first_wait.word) {
             fw = c->first_wait;
             c->first_wait = EdgeSig();
+            // Inside the leaf's kernel only while that launch fits the CUs reserved for the panel stream: every workgroup of
+            // the fused kernel holds a whole CU (135 KB of LDS) while it spins, and beyond the reserved CUs they would be
+            // taken from the K build the launch is waiting for.  Otherwise a one-wave wait kernel in front of it.
+            const bool fused = c->fuse_trsm > 0 && m >= 128 && m <= c->fuse_trsm && !c->use_graph;
+            const int64_t wgs = fused ? 1 + (m + 127) / 128 : 1;
+            if (wgs > c->head_wait_wgs) {
+                GPT_TRY(stream_wait_flag(st, fw));
+                fw = EdgeSig();
+            }
         }
         if (c->fuse_trsm > 0 && m >= 128 && m <= c->fuse_trsm && !c->use_graph) {
             // short panel: diagonal block and TRSM in one launch, the substitution trailing the pivots (potrf.hip)
@@ -570,9 +659,8 @@ static int panel_ext(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64_t
             // slots, otherwise as a stream operation in front of it (a kernel of the runtime, ~5 us).
             EdgeSig inwait;
             if (lc == c0 && wait_edge.word) {
-                const int64_t wgs = ((n - r1 + 31) / 32) * ((cend - r1 + 31) / 32);
-                if (wgs <= inkernel_wait_budget() && (c->tile == 0 || c->tile == 64)) inwait = wait_edge;
-                else GPT_HIP_CHECK(hipStreamWaitValue32(st, wait_edge.word, wait_edge.value, hipStreamWaitValueGte, 0xffffffffu));
+                if (gemm_may_wait_in_kernel(c, n - r1, cend - r1)) inwait = wait_edge;
+                else GPT_TRY(stream_wait_flag(st, wait_edge));
             }
             GPT_TRY(gemm_nt(c, st, n - r1, cend - r1, 128, -1.0, A + r1 * lda + lc, lda, A + r1 * lda + lc, lda, 1.0,
                             A + r1 * lda + r1, lda, 1, first_ev, EdgeSig(), inwait));
@@ -673,8 +761,9 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
     // (main -> panel stream) are raised by the last workgroup of the kernel that completes them and waited for with
     // hipStreamWaitValue32 -- 1.5 us per edge against 8-9 for an event, and no stop event on the chain's kernels (4.5 us
     // each).  In the chain-bound end both edges are on the critical path of every panel.
-    const bool use_flags = edge_flags_usable(c) && !H && c->inner == 0 && !c->leaf256 && !use_early && !use_late
-                           && c->defer_rows == 0;
+    // (tile: the edge flags live in the 64x64 / 32x32 GEMM kernels only)
+    const bool use_flags = c->flags_now && !H && c->inner == 0 && !c->leaf256 && !use_early && !use_late
+                           && c->defer_rows == 0 && (c->tile == 0 || c->tile == 64);
     if (use_flags && c->edge_seq > 0xf0000000u && !head_wait.word) {           // (the words are only ever raised: start over long before a wrap)
         GPT_HIP_CHECK(hipStreamSynchronize(S));
         GPT_HIP_CHECK(hipStreamSynchronize(P));
@@ -726,6 +815,7 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
         if (use_flags && c0 + w + ext_k < n) {
             panel_edge.word = c->d_edge;
             panel_edge.value = ++c->edge_seq;
+            panel_edge = with_err(c, panel_edge);
         }
         GPT_TRY(panel_ext(c, P, A, lda, n, c0, w, invd, info, e_cu_prev, use_flags ? nullptr : e_panel, ext_k, e_first, cu_edge_prev,
                           panel_edge));
@@ -754,7 +844,7 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
                 GPT_HIP_CHECK(hipEventRecord(e_sdone, S));
                 GPT_HIP_CHECK(hipStreamWaitEvent(H, e_sdone, 0));
             }
-            if (use_flags) GPT_HIP_CHECK(hipStreamWaitValue32(S, panel_edge.word, panel_edge.value, hipStreamWaitValueGte, 0xffffffffu));
+            if (use_flags) GPT_TRY(stream_wait_flag(S, panel_edge));
             else GPT_HIP_CHECK(hipStreamWaitEvent(S, e_panel, 0));
             if (split < n) {
                 GPT_HIP_CHECK(hipStreamWaitEvent(H, e_panel, 0));
@@ -791,10 +881,8 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
                     GPT_HIP_CHECK(hipStreamWaitEvent(P, e_k, 0));
                 }
                 if (rest_edge_prev.word) {
-                    const int64_t nt64 = ((n - u0 + 63) / 64) * ((u1 - u0 + 63) / 64);
-                    const int64_t wgs = (nt64 < 512) ? ((n - u0 + 31) / 32) * ((u1 - u0 + 31) / 32) : nt64;
-                    if (wgs <= inkernel_wait_budget() && (c->tile == 0 || c->tile == 64)) rwait = rest_edge_prev;
-                    else GPT_HIP_CHECK(hipStreamWaitValue32(P, rest_edge_prev.word, rest_edge_prev.value, hipStreamWaitValueGte, 0xffffffffu));
+                    if (gemm_may_wait_in_kernel(c, n - u0, u1 - u0)) rwait = rest_edge_prev;
+                    else GPT_TRY(stream_wait_flag(P, rest_edge_prev));
                 }
                 GPT_TRY(gemm_nt(c, P, n - u0, u1 - u0, w, -1.0, A + u0 * lda + c0, lda, A + u0 * lda + c0, lda, 1.0,
                                 A + u0 * lda + u0, lda, 1, nullptr, EdgeSig(), rwait));
@@ -804,6 +892,7 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
                     EdgeSig re;
                     re.word = c->d_edge + 32;
                     re.value = ++c->edge_seq;
+                    re = with_err(c, re);
                     GPT_TRY(gemm_nt(c, S, n - u1, n - u1, w, -1.0, A + u1 * lda + c0, lda, A + u1 * lda + c0, lda, 1.0,
                                     A + u1 * lda + u1, lda, 1, nullptr, re));
                     rest_edge_prev = re;
@@ -825,6 +914,7 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
                 EdgeSig cu_edge;
                 cu_edge.word = c->d_edge + 16;
                 cu_edge.value = ++c->edge_seq;
+                cu_edge = with_err(c, cu_edge);
                 // Urgent + rest as ONE launch (option merge_urgent) while the update is large enough for an order table: the
                 // tiles of the urgent columns come first on every XCD, write through and raise the flag when THEY are done;
                 // the rest follows in the same launch -- one drain and one ramp-up less per panel on the main stream, and
@@ -958,6 +1048,7 @@ extern "C" int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out)
             for (int i = reserve; i < ncu; i++) mask[i / 32] |= (1u << (i % 32));
             masked = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()) == hipSuccess;
             if (!masked) (void)hipGetLastError();
+            else c->reserve_cus = reserve;
             // helper stream: the reserved CUs except the first 8 (those stay free for the diagonal-block kernel, which
             // needs a whole CU's LDS).  While the trailing updates dominate, the panel stream leaves the reserved CUs
             // idle most of the time; a slice of every update runs there (potrf_enqueue).
@@ -1002,14 +1093,6 @@ extern "C" int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out)
     GPT_HIP_CHECK(hipMalloc((void **)&c->d_flag, 64));
     GPT_HIP_CHECK(hipMalloc((void **)&c->d_l10pk, 16384 * sizeof(double)));
     GPT_HIP_CHECK(hipMalloc((void **)&c->d_edge, 256));
-    {   // flag edges need hipStreamWaitValue32 (potrf_enqueue); without it the look-ahead stays on events
-        int can = 0;
-        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device_id) != hipSuccess) {
-            (void)hipGetLastError();
-            can = 0;
-        }
-        if (!can) c->edge_flags = 0;
-    }
     // (hipMemsetAsync on the context's stream, never hipMemset: one call on the legacy null stream and from then on
     // every kernel of this process starts ~40 us late on every stream -- measured on the block-cyclic engine,
     // 31 -> 41 ms per rank at N=32768 over 8 ranks, potf2 26 -> 45..90 us in the trace)
@@ -1019,7 +1102,6 @@ extern "C" int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out)
     GPT_HIP_CHECK(hipMemsetAsync(c->d_scal, 0, 80 * sizeof(double), c->stream));
     GPT_HIP_CHECK(hipHostMalloc((void **)&c->h_scal, 4 * sizeof(double), hipHostMallocDefault));
     GPT_HIP_CHECK(hipHostMalloc((void **)&c->h_info, sizeof(int32_t), hipHostMallocDefault));
-    g_live_ctx.fetch_add(1);
     *out = c;
     return GPT_OK;
 }
@@ -1041,7 +1123,6 @@ static void free_factor(gpt_ctx *c)
 extern "C" int gpt_ctx_destroy(gpt_ctx *c)
 {
     if (!c) return GPT_OK;
-    g_live_ctx.fetch_sub(1);
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     hipStreamSynchronize(c->panel_stream);
@@ -1092,6 +1173,7 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "purg_rows")) c->purg_rows = value;
     else if (!strcmp(key, "panel_prio")) c->panel_prio = value;
     else if (!strcmp(key, "edge_flags")) c->edge_flags = value;
+    else if (!strcmp(key, "head_wait_wgs")) c->head_wait_wgs = value;
     else if (!strcmp(key, "merge_urgent")) c->merge_urgent = value;
     else if (!strcmp(key, "purg_rows_flags")) c->purg_rows_flags = value;
     else if (!strcmp(key, "merge_min_tiles")) c->merge_min_tiles = value < 512 ? 512 : value;
@@ -1322,7 +1404,8 @@ static int factor_and_ll(gpt_ctx *c, int64_t N, double *ll_data_out, double *log
     // (the three results go straight to pinned host memory, and the two timing events ride on the kernel's dispatch packet:
     // a copy kernel and two barrier packets less on the tail of every evaluation, ~15 us)
     // (only a STOP event: a start event on the packet holds the kernel back ~7 us like a barrier packet would)
-    GPT_TRY(launch_logdet_dot(tl, c->dA, NP, N, c->d_info, c->d_scal, c->h_scal, nullptr, c->timing ? c->tev[4] : nullptr));
+    GPT_TRY(launch_logdet_dot(tl, c->dA, NP, N, c->d_info, c->d_scal, c->h_scal, nullptr, c->timing ? c->tev[4] : nullptr,
+                              c->flags_now ? c->d_edge + 60 : nullptr));
     if (tl != st) {
         hipEvent_t e_end = get_event(c, 1);
         if (!e_end) return GPT_E_HIP;
@@ -1345,6 +1428,11 @@ static int factor_and_ll(gpt_ctx *c, int64_t N, double *ll_data_out, double *log
         c->timings[4] = ms;
     }
     c->alpha_valid = c->binv_valid = false;
+    if (c->flags_now && c->h_scal[3] != 0.0) {
+        // a flag wait of this evaluation timed out (common.hpp): its numbers mean nothing; the caller repeats it on events
+        c->factored = false;
+        return GPT_I_EDGE_TIMEOUT;
+    }
     const int32_t info = (int32_t)c->h_scal[2];
     if (info != 0) {
         c->factored = false;
@@ -1420,8 +1508,42 @@ extern "C" int gpt_fit_sum(gpt_ctx *c, int nterms, const int *kernel_ids, const 
     return fit_terms(c, terms, noise_var, y, err_y, diag_add, ll_data_out, logdet_half_out);
 }
 
+static int fit_terms_once(gpt_ctx *c, const std::vector<KParams> &terms, double noise_var, const double *y,
+                          const double *err_y, double diag_add, double *ll_data_out, double *logdet_half_out);
+
+// An evaluation whose flag wait timed out: the process goes to event edges for good and the evaluation runs again.
+static int edge_timeout_fallback(gpt_ctx *c)
+{
+    g_flags_tripped.store(true);
+    hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->panel_stream);
+    static bool told = false;
+    if (!told) {
+        told = true;
+        fprintf(stderr, "libgpt_hip: a flag-edge wait timed out (GPU shared with other work, or kernels serialised by a tool); "
+                        "this process uses event edges from now on (GPT_EDGE_FLAGS=0 avoids the attempt)\n");
+    }
+    return GPT_OK;
+}
+
 static int fit_terms(gpt_ctx *c, const std::vector<KParams> &terms, double noise_var, const double *y,
                      const double *err_y, double diag_add, double *ll_data_out, double *logdet_half_out)
+{
+    int rc;
+    {
+        EvalScope scope(c);
+        rc = fit_terms_once(c, terms, noise_var, y, err_y, diag_add, ll_data_out, logdet_half_out);
+    }
+    if (rc == GPT_I_EDGE_TIMEOUT) {
+        edge_timeout_fallback(c);
+        EvalScope scope(c);
+        rc = fit_terms_once(c, terms, noise_var, y, err_y, diag_add, ll_data_out, logdet_half_out);
+    }
+    return rc;
+}
+
+static int fit_terms_once(gpt_ctx *c, const std::vector<KParams> &terms, double noise_var, const double *y,
+                          const double *err_y, double diag_add, double *ll_data_out, double *logdet_half_out)
 {
     const int64_t Nx = c->Nx;
     const int64_t N = c->dT ? c->Ny : Nx;          // order of K_tot
@@ -1473,7 +1595,7 @@ static int fit_terms(gpt_ctx *c, const std::vector<KParams> &terms, double noise
     int64_t head = round_up((c->ramp ? 128 : w0) + (c->leaf256 ? 256 : GPT_PANEL_EXT), 256);   // what panel 0 touches
     hipEvent_t e_head = nullptr;
     c->head_wait = EdgeSig();
-    const bool head_flag = edge_flags_usable(c) && c->edge_seq < 0xf0000000u;
+    const bool head_flag = c->flags_now && c->edge_seq < 0xf0000000u;
     if (c->lookahead && !c->use_graph && head < N && (head_flag || (e_head = get_event(c, 0)) != nullptr)) {
         GPT_TRY(kbuild_terms(c, st, terms, 1, c->dX, c->dn, N, c->dX, c->dn, head, 1, 0, 0, c->d_erry, noise_var, diag_add,
                              c->dA, NP));
@@ -1482,7 +1604,12 @@ static int fit_terms(gpt_ctx *c, const std::vector<KParams> &terms, double noise
             // the first diagonal-block kernel of the panel stream polls it itself: no event record here, no event wait there
             c->head_wait.word = c->d_edge + 48;
             c->head_wait.value = ++c->edge_seq;
-            GPT_TRY(launch_set_flag(st, c->head_wait.word, c->head_wait.value));
+            c->head_wait = with_err(c, c->head_wait);
+            // (GPT_EDGE_TEST_STALL=1, test aid: the flag is NOT raised, once -- the waiter must time out, the evaluation be
+            // repeated on events and give the right numbers: tests/test_gpu_a_dist_processes.py)
+            static bool stall_once = getenv("GPT_EDGE_TEST_STALL") != nullptr;
+            if (stall_once) stall_once = false;
+            else GPT_TRY(launch_set_flag(st, c->head_wait.word, c->head_wait.value));
         } else {
             GPT_HIP_CHECK(hipEventRecord(e_head, st));
         }
@@ -1498,11 +1625,30 @@ static int fit_terms(gpt_ctx *c, const std::vector<KParams> &terms, double noise
     return factor_and_ll(c, N, ll_data_out, logdet_half_out, true);
 }
 
+static int fit_matrix_once(gpt_ctx *c, const double *K_tot, int64_t N, const double *y, double *ll_data_out,
+                           double *logdet_half_out);
+
 extern "C" int gpt_fit_matrix(gpt_ctx *c, const double *K_tot, int64_t N, const double *y, double *ll_data_out,
                               double *logdet_half_out)
 {
     CTX_ENTER(c);
     if (!K_tot || !y || N <= 0) return GPT_E_ARG;
+    int rc;
+    {
+        EvalScope scope(c);
+        rc = fit_matrix_once(c, K_tot, N, y, ll_data_out, logdet_half_out);
+    }
+    if (rc == GPT_I_EDGE_TIMEOUT) {
+        edge_timeout_fallback(c);
+        EvalScope scope(c);
+        rc = fit_matrix_once(c, K_tot, N, y, ll_data_out, logdet_half_out);
+    }
+    return rc;
+}
+
+static int fit_matrix_once(gpt_ctx *c, const double *K_tot, int64_t N, const double *y, double *ll_data_out,
+                           double *logdet_half_out)
+{
     GPT_TRY(ensure_factor_storage(c, N));
     hipStream_t st = c->stream;
     c->factored = false;

@@ -61,13 +61,36 @@ struct KParams {
 
 // A cross-stream edge without an event: the kernel that completes a piece of work raises a 32-bit word in device
 // memory when its LAST workgroup is through (its results written with write-through stores and drained first) and the
-// waiting stream holds a hipStreamWaitValue32 on that word.  Measured (scratch/waitvalue_probe.hip): producer end ->
-// consumer start 1.5 us and nothing added to the producer's own stream, against 7.6-9.1 us and 1.7-4.5 us for a stop
-// event on the dispatch packet + hipStreamWaitEvent.  word[0] = the flag (only ever raised), word[1] = workgroup counter.
+// consumer polls that word -- inside its first kernel, or in a one-wave wait kernel in front of it (launch_wait_flag).
+// Measured (scratch/waitvalue_probe.hip): producer end -> consumer start 1.5 us and nothing added to the producer's own
+// stream, against 7.6-9.1 us and 1.7-4.5 us for a stop event on the dispatch packet + hipStreamWaitEvent.
+// word[0] = the flag (only ever raised), word[1] = workgroup counter.
+//
+// Memory ordering.  Producer: the payload is written with agent-scope (write-through, sc1) stores, every wave drains its
+// own (s_waitcnt vmcnt(0)) before the barrier, then ONE thread raises the word -- no release fence: on gfx950 that is
+// buffer_wbl2, a write-back of every dirty line of the XCD's L2 (1.7-6 us per hand-over, measured) for data that is
+// already in memory.  Consumer: whatever it reads of the payload BEHIND the flag inside the same kernel must not come from
+// a line cached before the producer wrote it.  Two forms: (a) the payload is read with agent-scope (sc1, cache-bypassing)
+// loads -- the GEMM waiter's C tile, the TRSM consumers' packed blocks -- and nothing else is needed; (b) the payload is read
+// with plain loads (the first diagonal-block kernel of a factorisation: its 128 x 128 block and rows) and the polling
+// thread issues an agent-scope ACQUIRE fence (buffer_inv sc1) after it has seen the value and before the workgroup
+// barrier (edge_poll<.., true>).  The fence is NOT free for the rest of the chip -- it drops the non-coherent lines of the
+// whole XCD's L2, i.e. the operand panels of a trailing update running there: issued by every workgroup of the panel
+// stream's waiting GEMM launches it cost 10 % of an evaluation at N = 8192 (4.96 against 4.50 ms, same-box A/B) -- so it is
+// used only in form (b), once per evaluation and workgroup.  A stream-side wait (wait_flag_kernel) needs neither: the
+// kernel behind it starts with the dispatch packet's own acquire.
+//
+// Every wait is BOUNDED: a kernel that waits for another kernel never ends if the other one cannot run -- a tool that runs
+// one kernel at a time, queues oversubscribed by other processes on the GPU, a lost launch.  After GPT_EDGE_TIMEOUT_TICKS of
+// the 100 MHz wall clock the waiter raises `*err`, stops waiting and carries on (on data that may be incomplete); the host
+// finds the error word at the end of the evaluation, switches the process to event edges for good and runs the
+// evaluation again (api.hip: EvalScope / fit_terms).
 struct EdgeSig {
     unsigned *word = nullptr;
     unsigned value = 0;
+    unsigned *err = nullptr;      // waits only: raised when the wait timed out
 };
+#define GPT_EDGE_TIMEOUT_TICKS 25000000ll      // 250 ms
 // device side: called by every workgroup that takes part, after its results are stored (all threads of the workgroup)
 #ifdef __HIPCC__
 __device__ __forceinline__ void edge_signal(unsigned *word, unsigned value, unsigned total)
@@ -81,6 +104,23 @@ __device__ __forceinline__ void edge_signal(unsigned *word, unsigned value, unsi
             __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+// Consumer side, ONE thread of the workgroup (the caller follows with __syncthreads()): poll until *word >= value (signed
+// difference: the words only ever go up), SLEEP = s_sleep argument between polls; bounded; ACQUIRE: see above.
+template <int SLEEP, bool ACQUIRE>
+__device__ __forceinline__ void edge_poll(const unsigned *word, unsigned value, unsigned *err)
+{
+    if ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) {
+        const long long t0 = wall_clock64();
+        while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) {
+            __builtin_amdgcn_s_sleep(SLEEP);
+            if (err && wall_clock64() - t0 > GPT_EDGE_TIMEOUT_TICKS) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    if (ACQUIRE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 #endif
 
@@ -119,12 +159,15 @@ int launch_add_diag(hipStream_t st, double *A, int64_t lda, int64_t n, const dou
 // timing of the streams; a missing edge shows up as a wrong number (tests/test_gpu_parity.py).  Off: one branch.
 void gpt_jitter(hipStream_t st);
 int launch_set_flag(hipStream_t st, unsigned *word, unsigned value);
+// One-wave kernel on `st` that waits (bounded, see EdgeSig) until *w.word >= w.value: the stream-side end of a flag edge.
+int launch_wait_flag(hipStream_t st, EdgeSig w);
+int gemm_small_threshold();      // 64x64-tile count under which launch_gemm_nt cuts a launch into 32x32 tiles (gemm.hip)
 int launch_upload_pad(hipStream_t st, const double *h_src, double *d_dst, int64_t ncopy, int32_t *info, double *A,
                       int64_t lda, int64_t n_valid, int64_t n_pad, double big);
 int launch_fill_pad(hipStream_t st, double *A, int64_t lda, int64_t n_valid, int64_t n_pad, const double *dy,
                     double big);
 int launch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_t n, const int32_t *d_info, double *d_part,
-                      double *out3, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+                      double *out4, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, unsigned *edge_err = nullptr);
 int launch_extract_lower(hipStream_t st, const double *A, int64_t lda, int64_t n, double *out, int64_t ldo);
 int launch_trsv_lt(hipStream_t st, int64_t n, const double *L, int64_t ldl, const double *invd, double *x);
 int launch_gemv_n(hipStream_t st, int64_t m, int64_t n, const double *A, int64_t lda, const double *x, double *y);

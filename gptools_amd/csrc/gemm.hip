@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     int64_t m, int64_t n, int64_t k, double alpha, const double *__restrict__ A, int64_t lda,
     const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
     int tri, int64_t ntm, int64_t ntn, int64_t nwg, const int2 *__restrict__ order, int64_t seg_cols, int64_t bskip, int prio, unsigned *edge, unsigned edge_val,
-    unsigned edge_total, const unsigned *wait_word, unsigned wait_val, int edge_cols)
+    unsigned edge_total, const unsigned *wait_word, unsigned wait_val, unsigned *wait_err, int edge_cols)
 {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int RM = WM / 16, RN = WN / 16;
@@ -204,10 +204,9 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     // (__amd_rocclr_streamOpsWait, ~5 us on the chain); here the common case -- the word is already up -- costs one load.
     // C is then read past the L2 (the producer wrote it through to memory while this launch may already have been running).
     if (wait_word != nullptr) {
-        if (tid == 0) {
-            while ((int)(__hip_atomic_load(wait_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - wait_val) < 0)
-                __builtin_amdgcn_s_sleep(16);          // (~1000 cycles between polls: the waiting waves must not eat issue slots)
-        }
+        // (~1000 cycles between polls: the waiting waves must not eat issue slots; bounded: common.hpp edge_poll; no acquire
+        // fence: what the producer wrote -- this launch's C -- is read with agent-scope loads below)
+        if (tid == 0) edge_poll<16, false>(wait_word, wait_val, wait_err);
         __syncthreads();
     }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -585,11 +584,11 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
     if (ev0 || ev1)
         hipExtLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg), dim3(256), dyn, st, ev0, ev1, 0,
                               m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip, prio, edge.word, edge.value,
-                              (unsigned)(edge_cols_elems > 0 ? nedge : nreal), wait.word, wait.value, (int)(edge_cols_elems / BN));
+                              (unsigned)(edge_cols_elems > 0 ? nedge : nreal), wait.word, wait.value, wait.err, (int)(edge_cols_elems / BN));
     else
         hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg), dim3(256), dyn, st, m, n, k, alpha,
                            A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip, prio, edge.word, edge.value,
-                              (unsigned)(edge_cols_elems > 0 ? nedge : nreal), wait.word, wait.value, (int)(edge_cols_elems / BN));
+                              (unsigned)(edge_cols_elems > 0 ? nedge : nreal), wait.word, wait.value, wait.err, (int)(edge_cols_elems / BN));
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
@@ -611,6 +610,18 @@ static int gemm_launch_persist(hipStream_t st, int64_t m, int64_t n, int64_t k, 
                        C, ldc, tri, ntn, ntiles);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
+}
+
+// Launches of fewer than this many 64x64 tiles are cut into 32x32 tiles (see launch_gemm_nt); api.hip sizes the in-kernel
+// wait budget of the panel stream's updates with the same number.
+int gemm_small_threshold()
+{
+    static int small_below = -1;
+    if (small_below < 0) {
+        small_below = 512;
+        if (const char *e = getenv("GPT_GEMM_SMALL")) small_below = atoi(e);
+    }
+    return small_below;
 }
 
 int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A, int64_t lda,
@@ -649,11 +660,7 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
         // (128 -> 32 at k = 128), so a launch that is mostly latency gets off the chain sooner.  Same sums in the same
         // order, bit-identical results.  Measured (scratch/env_ab.py, GPT_GEMM_SMALL = threshold): N = 8192 4.757 ->
         // 4.625 ms at 512 (4.709 at 256, 4.648 at 1024, 4.692 at 2048), N = 4096 1.468 -> 1.386, N = 16384 27.28 -> 27.15.
-        static int small_below = -1;
-        if (small_below < 0) {
-            small_below = 512;
-            if (const char *e = getenv("GPT_GEMM_SMALL")) small_below = atoi(e);
-        }
+        const int small_below = gemm_small_threshold();
         const int64_t nt64 = ((m + 63) / 64) * ((n + 63) / 64);
         if (nt64 < small_below && !ev0 && edge_cols == 0) tile = 32;
     }

@@ -301,6 +301,17 @@ __device__ __forceinline__ void bessk_temme(const KParams &kp, double mu, double
 {
     const double PI = 3.14159265358979323846, EPS = 1.0e-16;
     const double mu2 = mu * mu;
+    // NaN in, NaN out at once (scipy.special.kv does the same): with a NaN the convergence tests below are never true and
+    // every affected pair would walk the full 500 / 10000 iterations -- a K build with one NaN coordinate went from
+    // microseconds to minutes.  x = +inf: K_mu(inf) = 0.
+    if (!(x == x)) {
+        kmu = kmu1 = x;
+        return;
+    }
+    if (x > 1.0e300) {
+        kmu = kmu1 = 0.0;
+        return;
+    }
     if (x <= 2.0) {
         // negmu: the same constants serve -mu (1/Gamma(1 +- mu) swap, gam1 and gam2 are even in mu)
         const double gampl = negmu ? kp.m_gammi : kp.m_gampl, gammi = negmu ? kp.m_gampl : kp.m_gammi;

@@ -255,16 +255,13 @@ __device__ __forceinline__ void pivot_block_16(double (*S)[PD_PITCH], double (*T
 #define PD_THREADS 512
 
 // In-kernel side of a flag edge (EdgeSig, common.hpp) for the FIRST kernel of a factorisation: the block it factors is being
-// written by a kernel of the main stream (the head columns of the K build); one thread polls the word, the workgroup
-// follows.  These launches are one workgroup (or at most 33 on the CUs reserved for the panel stream): they cannot fill
-// the chip in front of the kernel they wait for.
-__device__ __forceinline__ void edge_wait(const unsigned *word, unsigned value)
+// written by a kernel of the main stream (the head columns of the K build); one thread polls the word (bounded, then an
+// agent-scope acquire: common.hpp edge_poll), the workgroup follows.  The host uses this form only while the launch fits the
+// CUs reserved for the panel stream (api.hip, panel_ext): every workgroup of the fused kernel holds a whole CU while it spins.
+__device__ __forceinline__ void edge_wait(const unsigned *word, unsigned value, unsigned *err)
 {
     if (word != nullptr) {
-        if (threadIdx.x == 0) {
-            while ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0)
-                __builtin_amdgcn_s_sleep(2);
-        }
+        if (threadIdx.x == 0) edge_poll<2, true>(word, value, err);
         __syncthreads();
     }
 }
@@ -467,9 +464,9 @@ __device__ __forceinline__ void potf2_body(double *__restrict__ A, int64_t lda, 
 __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restrict__ A, int64_t lda,
                                                                 double *__restrict__ invd, int32_t *info,
                                                                 int64_t info_col0, const unsigned *wait_word,
-                                                                unsigned wait_val)
+                                                                unsigned wait_val, unsigned *wait_err)
 {
-    edge_wait(wait_word, wait_val);
+    edge_wait(wait_word, wait_val, wait_err);
     potf2_body<false>(A, lda, invd, info, info_col0, nullptr, 0u);
 }
 
@@ -490,9 +487,10 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
                                                                 int64_t info_col0, int64_t m, double *__restrict__ B,
                                                                 int64_t ldb, unsigned *flag, unsigned flag_base,
                                                                 unsigned *edge, unsigned edge_val,
-                                                                const unsigned *wait_word, unsigned wait_val)
+                                                                const unsigned *wait_word, unsigned wait_val,
+                                                                unsigned *wait_err)
 {
-    edge_wait(wait_word, wait_val);
+    edge_wait(wait_word, wait_val, wait_err);
     if (blockIdx.x == 0) {
         potf2_body<true>(A, lda, invd, info, info_col0, flag, flag_base);
         // (edge flag: "the panel is final" -- what the waiting update reads are the consumers' rows; this workgroup only
@@ -855,9 +853,9 @@ int launch_potf2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int3
     const unsigned grid = 1u + (unsigned)((m + 16 * PD_WAVES - 1) / (16 * PD_WAVES));
     if (done) hipExtLaunchKernelGGL(potf2_trsm_kernel, dim3(grid), dim3(PD_THREADS), shmem, st, nullptr, done, 0, A, lda, invd,
                                     info, info_base, m, A + 128 * lda, lda, flag, flag_base, edge.word, edge.value,
-                                    wait.word, wait.value);
+                                    wait.word, wait.value, wait.err);
     else hipLaunchKernelGGL(potf2_trsm_kernel, dim3(grid), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base, m,
-                            A + 128 * lda, lda, flag, flag_base, edge.word, edge.value, wait.word, wait.value);
+                            A + 128 * lda, lda, flag, flag_base, edge.word, edge.value, wait.word, wait.value, wait.err);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
@@ -886,7 +884,7 @@ int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int3
     gpt_jitter(st);
     const size_t shmem = (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
     { int rc_ = ensure_big_lds(reinterpret_cast<const void *>(potf2_diag_kernel), 1, shmem); if (rc_ != GPT_OK) return rc_; }
-    hipLaunchKernelGGL(potf2_diag_kernel, dim3(1), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base, wait.word, wait.value);
+    hipLaunchKernelGGL(potf2_diag_kernel, dim3(1), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base, wait.word, wait.value, wait.err);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }

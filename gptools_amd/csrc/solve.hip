@@ -29,7 +29,24 @@ __global__ void fill_pad_kernel(double *__restrict__ A, int64_t lda, int64_t n_v
 // and visible (kernel boundary) when it runs.
 __global__ void set_flag_kernel(unsigned *word, unsigned value)
 {
-    __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (release: this kernel has no payload of its own -- what it publishes was written by the kernels in front of it on the
+    // stream, whose end-of-kernel write-back has happened -- so the fence finds nothing dirty and costs nothing)
+    __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Stream-side end of a flag edge: a one-wave kernel that polls the word (bounded, then acquire; common.hpp edge_poll).  In
+// place of hipStreamWaitValue32, which is a kernel of the runtime of the same cost (~5 us, measured) but with no bound.
+__global__ void wait_flag_kernel(const unsigned *word, unsigned value, unsigned *err)
+{
+    if (threadIdx.x == 0) edge_poll<4, false>(word, value, err);
+}
+
+int launch_wait_flag(hipStream_t st, EdgeSig w)
+{
+    if (!w.word) return GPT_OK;
+    hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, st, w.word, w.value, w.err);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
 }
 
 int launch_set_flag(hipStream_t st, unsigned *word, unsigned value)
@@ -137,7 +154,7 @@ int launch_add_diag(hipStream_t st, double *A, int64_t lda, int64_t n, const dou
 __global__ __launch_bounds__(256) void logdet_dot_kernel(const double *__restrict__ A, int64_t lda, int64_t n,
                                                          int has_z, const int32_t *__restrict__ info,
                                                          double *__restrict__ part, unsigned *__restrict__ count,
-                                                         double *__restrict__ out)
+                                                         double *__restrict__ out, unsigned *__restrict__ edge_err)
 {
     __shared__ double s0[4], s1[4];
     __shared__ bool last;
@@ -189,20 +206,27 @@ __global__ __launch_bounds__(256) void logdet_dot_kernel(const double *__restric
             __hip_atomic_store(out + 0, ta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(out + 1, tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(out + 2, info ? (double)*info : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // out[3]: a flag-edge wait of this evaluation timed out (EdgeSig, common.hpp); read and cleared
+            double ee = 0.0;
+            if (edge_err) {
+                ee = (double)__hip_atomic_load(edge_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(edge_err, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            __hip_atomic_store(out + 3, ee, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
 
-// d_part: 2 * LD_WGS doubles followed by one 32-bit counter (zero on entry, left zero); out3: device or pinned host memory.
-// ev0 / ev1 (optional): start / stop events on the dispatch packet itself.
+// d_part: 2 * LD_WGS doubles followed by one 32-bit counter (zero on entry, left zero); out3: FOUR doubles of device or
+// pinned host memory.  ev0 / ev1 (optional): start / stop events on the dispatch packet itself.
 int launch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_t n, const int32_t *d_info, double *d_part,
-                      double *out3, hipEvent_t ev0, hipEvent_t ev1)
+                      double *out3, hipEvent_t ev0, hipEvent_t ev1, unsigned *edge_err)
 {
     unsigned *count = reinterpret_cast<unsigned *>(d_part + 2 * LD_WGS);
     if (ev0 || ev1)
-        hipExtLaunchKernelGGL(logdet_dot_kernel, dim3(LD_WGS), dim3(256), 0, st, ev0, ev1, 0, A, lda, n, 1, d_info, d_part, count, out3);
+        hipExtLaunchKernelGGL(logdet_dot_kernel, dim3(LD_WGS), dim3(256), 0, st, ev0, ev1, 0, A, lda, n, 1, d_info, d_part, count, out3, edge_err);
     else
-        hipLaunchKernelGGL(logdet_dot_kernel, dim3(LD_WGS), dim3(256), 0, st, A, lda, n, 1, d_info, d_part, count, out3);
+        hipLaunchKernelGGL(logdet_dot_kernel, dim3(LD_WGS), dim3(256), 0, st, A, lda, n, 1, d_info, d_part, count, out3, edge_err);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }

@@ -635,10 +635,11 @@ class GaussianProcess(object):
                 except (np.linalg.LinAlgError, ValueError, ArithmeticError):
                     pass                                            # the +inf policy of update_hyperparameters
         threads = [threading.Thread(target=worker, args=(c[0],)) for c in ctxs[:B]]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        with _lib.concurrent_evaluations():          # several chains at once: event edges (include/gpt_hip.h)
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
         return out
 
     def _batched_fd(self, eps, bounds):

@@ -51,7 +51,10 @@ extern "C" {
                                   * (GPT_E_VALUE beyond; the reference has no limit); no hyper-parameter derivatives */
 #define GPT_RQ_MAXORD 8
 #define GPT_KERNEL_MATERN 5      /* MaternKernel (general order nu), params [sigma_f, nu, l_1 .. l_D] (ref: kernel/matern.py:251-465
-                                  * through ChainRuleKernel.__call__); same limit on the derivative orders of a pair */
+                                  * through ChainRuleKernel.__call__); same limit on the derivative orders of a pair; nu must
+                                  * lie in (0, 60) (GPT_E_VALUE otherwise: beyond it the closed form the device evaluates,
+                                  * 2^(1-nu)/Gamma(nu) y^((nu-m)/2) K_(nu-m)(sqrt y), overflows in its factors before the
+                                  * product is formed; the reference accepts any nu) */
 
 #define GPT_MAX_DIM 16      /* largest supported num_dim */
 #define GPT_WS_BLOCK 9216    /* doubles of factorisation workspace per 128 columns (d_invd arguments) */
@@ -78,8 +81,11 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
  *   "fuse_trsm"    panels with at most this many rows under a leaf use the fused diagonal-block + TRSM kernel (8192)
  *   "merge_urgent" 1 (default, with edge_flags): the two trailing updates per panel are one launch with a partial edge flag
  *   "edge_flags"   1 (default): the per-panel dependencies of the look-ahead are flag words in device memory (last workgroup
- *                  of the producer raises it; hipStreamWaitValue32 / an in-kernel wait on the consumer side) instead of events;
- *                  0: events.  Off by itself under rocprofv3 counter collection, with a second live context, n > 12288
+ *                  of the producer raises it; a bounded in-kernel wait or a one-wave wait kernel on the consumer side)
+ *                  instead of events; 0: events.  Used by an evaluation only while it is the only one in flight in the
+ *                  process (idle contexts do not count; see gpt_concurrency_hint) on a context that owns its streams; off by
+ *                  itself under rocprofv3 counter collection, for n > 12288, and for the rest of the process once a wait has
+ *                  timed out (250 ms: the evaluation is then repeated on events)
  *   "helper_tf"    assumed rate of the helper stream (0.1 TFLOP/s per 24 CUs, 45) that takes a slice of the large trailing
  *                  updates on the reserved CUs when n > "helper_min_n" (12288); 0 = off
  *   "gemm_pad"     bytes of dummy dynamic LDS of the main-stream GEMM (residency cap)
@@ -91,7 +97,7 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
  *   "early_rows", "nb_early", "nb_switch_rows", "late_pad", "late_pad_rows"
  * Environment: GPT_RESERVE_CUS (CUs the main stream leaves to the panel stream, default 32), GPT_TILE_ORDER
  * ("rows,cols,mode": supertile shape and deal of the GEMM's XCD-aware tile order, default 64,8,1), GPT_GRAD_TIMING,
- * GPT_EDGE_FLAGS=0 (event edges only), GPT_GEMM_SMALL (64x64-tile count under which a GEMM launch uses 32x32 tiles, 512),
+ * GPT_EDGE_FLAGS=0 (event edges only: set it for jobs that share one GPU between several processes), GPT_GEMM_SMALL (64x64-tile count under which a GEMM launch uses 32x32 tiles, 512),
  * GPT_JITTER (test aid: random delay kernels in front of every dense launch). */
 int gpt_ctx_set_option(gpt_ctx *ctx, const char *key, int64_t value);
 int gpt_ctx_synchronize(gpt_ctx *ctx);
@@ -99,6 +105,12 @@ void *gpt_ctx_stream(gpt_ctx *ctx);
 /* Number of flag edges (common.hpp: EdgeSig -- cross-stream dependencies carried by a word in device memory instead of an
  * event) the context has raised so far; diagnostics / tests. */
 int64_t gpt_ctx_edge_count(gpt_ctx *ctx);
+/* Announce (delta = +1) / retract (delta = -1) that the caller is about to run evaluations on several contexts of this
+ * process concurrently (GaussianProcess.ll_batch: one host thread per context; ref gaussian_process.py:723-735, 1607-1692
+ * are the reference's pool.map sites this replaces).  While the count is positive every evaluation keeps its look-ahead on
+ * event edges (a kernel spinning on a flag must not share the hardware queues with a second chain).  Optional: without it
+ * the library notices the overlap itself at the cost of serialising the first two evaluations.  Returns the new count. */
+int gpt_concurrency_hint(int delta);
 
 /* ---- Kernel.__call__ ---------------------------------------------------------------------- */
 /* Replaces  Kernel.__call__(Xi, Xj, ni, nj, hyper_deriv=None, symmetric=False) -> (M,) float64

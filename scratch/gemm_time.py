@@ -9,6 +9,8 @@ ctx.set_option("lookahead", 1)
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 7168
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 384
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+if len(sys.argv) > 4:
+    ctx.set_option("tile", int(sys.argv[4]))
 with torch.cuda.stream(st):
     A = torch.randn(m, k, dtype=torch.float64, device="cuda")
     C = torch.randn(m, m, dtype=torch.float64, device="cuda")
@@ -21,4 +23,4 @@ with torch.cuda.stream(st):
         st.synchronize()
         best = min(best, e0.elapsed_time(e1))
 fl = k * (m * (m + 1.0))
-print("gemm tri m=%d k=%d: best %.1f us -> %.1f TF/s" % (m, k, best * 1e3, fl / best * 1e-9))
+print("gemm tri m=%d k=%d tile=%s: best %.1f us -> %.1f TF/s" % (m, k, sys.argv[4] if len(sys.argv) > 4 else "0", best * 1e3, fl / best * 1e-9))

@@ -296,3 +296,130 @@ def test_bench_plain_python_gpus_2_self_launches():
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["N"] == 4096 and line["parity"]["ok"] and line["roofline"]["achieved"] > 0
+
+
+def _run_fresh(code, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    env.pop("GPT_EDGE_FLAGS", None)
+    env.update(env_extra or {})
+    head = ("import faulthandler; faulthandler.dump_traceback_later(%d, exit=True)\n"
+            "import os, sys, json, warnings, numpy as np\n"
+            "warnings.simplefilter('ignore')\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n" % (timeout - 30, ROOT, ROOT))
+    p = subprocess.run([sys.executable, "-c", head + code], capture_output=True, text=True, timeout=timeout, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    import json
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT")][0][7:]), p.stderr
+
+
+def test_gaussian_process_reaches_the_flag_schedule_by_default():
+    """north_star's unit is GaussianProcess.update_hyperparameters: with default settings -- the pooled second context of
+    ll_batch alive, the process-wide context of Kernel.__call__ alive -- the evaluation must run the flag-edge schedule the
+    bench times (idle contexts do not count, api.hip EvalScope), at the metric's N = 8192; ll_batch (two chains in flight)
+    must run on events and leave the flag schedule usable afterwards."""
+    code = (
+        "import gptools_amd as g\n"
+        "from gptools_amd import _lib\n"
+        "from test_gpu_parity import c3_inputs\n"
+        "X, n, y = c3_inputs(8192, 3)\n"
+        "k = g.Matern52Kernel(num_dim=3, initial_params=[1.0, 0.3, 0.3, 0.3], param_bounds=[(1e-3, 10.0)] * 4)\n"
+        "k(X[:4], X[:4], n[:4], n[:4])                      # Kernel.__call__: creates the process-wide default context\n"
+        "gp = g.GaussianProcess(k, X=X, y=y, err_y=0.05, n=n)\n"
+        "v0 = gp.update_hyperparameters([1.0, 0.3, 0.3, 0.3])\n"
+        "assert gp._ctx_pool and len(gp._ctx_pool) == 1     # the pooled context exists (batch_concurrency = 2)\n"
+        "e0 = gp._ctx.edge_count\n"
+        "v1 = gp.update_hyperparameters([1.0, 0.3, 0.3, 0.3])\n"
+        "e1 = gp._ctx.edge_count\n"
+        "b = gp.ll_batch([[1.0, 0.3, 0.3, 0.3], [1.1, 0.3, 0.3, 0.3], [1.0, 0.33, 0.3, 0.3], [1.0, 0.3, 0.3, 0.27]])\n"
+        "e2 = gp._ctx.edge_count\n"
+        "v2 = gp.update_hyperparameters([1.0, 0.3, 0.3, 0.3])\n"
+        "e3 = gp._ctx.edge_count\n"
+        "gp._ctx.set_option('edge_flags', 0)\n"
+        "v3 = gp.update_hyperparameters([1.0, 0.3, 0.3, 0.3])\n"
+        "print('RESULT', json.dumps({'v': [v0, v1, v2, v3], 'b0': float(b[0]), 'e': [e0, e1, e2, e3, gp._ctx.edge_count]}))\n")
+    out, _ = _run_fresh(code)
+    e = out["e"]
+    assert e[1] - e[0] >= 20, "update_hyperparameters did not run on flag edges: %r" % (e,)
+    assert e[2] == e[1], "ll_batch (two chains in flight) must stay on event edges: %r" % (e,)
+    assert e[3] - e[2] >= 20 and e[4] == e[3], e
+    assert out["v"][0] == out["v"][1] == out["v"][2] == out["v"][3]          # flag and event schedules: bit-identical
+    assert -out["b0"] == out["v"][0]
+
+
+def test_flag_wait_times_out_and_the_evaluation_is_repeated_on_events():
+    """Every flag wait is bounded (common.hpp edge_poll): with the head flag withheld once (test aid GPT_EDGE_TEST_STALL) the
+    first leaf times out after 250 ms instead of hanging, the evaluation is repeated on event edges and returns the right
+    numbers, and the process stays on events from then on."""
+    code = (
+        "import time\n"
+        "from gptools_amd import _lib\n"
+        "from test_gpu_parity import c3_inputs\n"
+        "X, n, y = c3_inputs(3000, 3)\n"
+        "err, p = np.full(3000, 0.05), np.array([1.0, 0.3, 0.3, 0.3])\n"
+        "ctx = _lib.Context(0); ctx.set_data(X, n)\n"
+        "t0 = time.time(); r0 = ctx.fit(1, p, 0.0, y, err, 2.2e-14); t0 = time.time() - t0\n"
+        "e0 = ctx.edge_count\n"
+        "t1 = time.time(); r1 = ctx.fit(1, p, 0.0, y, err, 2.2e-14); t1 = time.time() - t1\n"
+        "e1 = ctx.edge_count\n"
+        "ctx.set_option('edge_flags', 0); r2 = ctx.fit(1, p, 0.0, y, err, 2.2e-14)\n"
+        "print('RESULT', json.dumps({'r': [r0, r1, r2], 't': [t0, t1], 'e': [e0, e1]}))\n")
+    out, err = _run_fresh(code, {"GPT_EDGE_TEST_STALL": "1"})
+    assert out["r"][0] == out["r"][1] == out["r"][2], out
+    assert 0.2 < out["t"][0] < 20.0 and out["t"][1] < 0.2, out["t"]
+    assert out["e"][1] == out["e"][0], "after a timeout the process must stay on event edges"
+    assert "flag-edge wait timed out" in err
+
+
+def test_fit_with_every_gemm_tile_option_in_a_single_context_process():
+    """with `tile` = 65 / 128 / 129 (GEMM kernels without edge flags) a look-ahead factorisation in a single-context
+    process must fall back to event edges, not fail with 'edge flags exist for the 64x64 / 32x32 kernels only'."""
+    code = (
+        "from gptools_amd import _lib\n"
+        "from test_gpu_parity import c3_inputs\n"
+        "X, n, y = c3_inputs(2900, 3)\n"
+        "err, p = np.full(2900, 0.05), np.array([1.0, 0.3, 0.3, 0.3])\n"
+        "ctx = _lib.Context(0); ctx.set_data(X, n)\n"
+        "res = {}\n"
+        "for tile in (0, 64, 65, 128, 129, 0):\n"
+        "    ctx.set_option('tile', tile)\n"
+        "    e0 = ctx.edge_count\n"
+        "    ll, ld = ctx.fit(1, p, 0.0, y, err, 2.2e-14)\n"
+        "    res[str(tile)] = (ll, ld, ctx.edge_count - e0)\n"
+        "print('RESULT', json.dumps(res))\n")
+    out, _ = _run_fresh(code)
+    ref = out["0"]
+    assert ref[2] > 0 and out["64"][2] > 0
+    for tile in ("65", "128", "129"):
+        assert out[tile][2] <= 1, out          # (at most the K build's head flag, which the diagonal-block kernel waits for)
+        assert abs(out[tile][0] - ref[0]) <= 1e-10 * abs(ref[0]) and abs(out[tile][1] - ref[1]) <= 1e-11 * abs(ref[1]), out
+    assert out["64"][:2] == ref[:2]
+
+
+def test_two_threads_without_the_concurrency_hint_do_not_crawl():
+    """Two contexts evaluated from two host threads WITHOUT gpt_concurrency_hint: the library notices the overlap itself (an
+    evaluation that starts while a flag-mode one is in flight waits for it, then both run on events): right numbers, and
+    nothing near the 0.8 s per evaluation of the queue-oversubscription crawl."""
+    code = (
+        "import threading, time\n"
+        "from gptools_amd import _lib\n"
+        "from test_gpu_parity import c3_inputs\n"
+        "X, n, y = c3_inputs(4096, 2)\n"
+        "n[:] = 0\n"
+        "err, p = np.full(4096, 0.05), np.array([1.0, 0.3, 0.3])\n"
+        "cs = [_lib.Context(0), _lib.Context(0)]\n"
+        "for c in cs: c.set_data(X, n)\n"
+        "ref = cs[0].fit(0, p, 0.0, y, err, 2.2e-14)\n"
+        "cs[1].fit(0, p, 0.0, y, err, 2.2e-14)\n"
+        "res = [[], []]\n"
+        "def run(i):\n"
+        "    for _ in range(60): res[i].append(cs[i].fit(0, p, 0.0, y, err, 2.2e-14))\n"
+        "th = [threading.Thread(target=run, args=(i,)) for i in range(2)]\n"
+        "t = time.time()\n"
+        "for x in th: x.start()\n"
+        "for x in th: x.join()\n"
+        "t = time.time() - t\n"
+        "ok = all(r == ref for rr in res for r in rr)\n"
+        "print('RESULT', json.dumps({'ok': ok, 't': t}))\n")
+    out, _ = _run_fresh(code)
+    assert out["ok"]
+    assert out["t"] < 3.0, "120 evaluations at N=4096 took %.2f s" % out["t"]
