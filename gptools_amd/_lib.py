@@ -45,6 +45,8 @@ SIGNATURES = {
     "gpt_get_alpha": (C.c_int, [_vp, _dp]),
     "gpt_ll_grad": (C.c_int, [_vp, C.c_int, _ip, _ip, _dp]),
     "gpt_predict": (C.c_int, [_vp, _dp, _ip, _i64, C.c_int, _dp, _ip, _dp, _dp, _dp]),
+    "gpt_host_alloc": (C.c_int, [_i64, C.POINTER(_vp)]),
+    "gpt_host_free": (C.c_int, [_vp]),
     "gpt_solve_L": (C.c_int, [_vp, _dp, _i64]),
     "gpt_cho_solve": (C.c_int, [_vp, _dp, _i64]),
     "gpt_last_timings": (C.c_int, [_vp, _dp, C.c_int]),
@@ -141,6 +143,59 @@ def dptr(a):
 
 def iptr(a):
     return None if a is None else a.ctypes.data_as(_ip)
+
+
+class _PinnedOwner(object):
+    """Returns a gpt_host_alloc block to the pool (or frees it) when the numpy array built over it is collected."""
+
+    def __init__(self, lib, ptr, nbytes):
+        self._lib, self._ptr, self._nbytes = lib, ptr, nbytes
+
+    def __del__(self):
+        try:
+            if self._ptr:
+                _pinned_release(self._lib, self._ptr, self._nbytes)
+                self._ptr = None
+        except Exception:
+            pass
+
+
+# Page-locking memory costs about as much as moving it once through the pageable path (~0.1 ms per MB), so blocks are kept
+# for the next result of the same size -- the usual pattern is predict after predict at the same number of points -- up
+# to PINNED_POOL_BYTES in total.
+PINNED_POOL_BYTES = 2 << 30
+_pinned_free = {}
+_pinned_held = [0]
+
+
+def _pinned_release(lib, ptr, nbytes):
+    with _lock:
+        if _pinned_held[0] + nbytes <= PINNED_POOL_BYTES:
+            _pinned_free.setdefault(nbytes, []).append(ptr)
+            _pinned_held[0] += nbytes
+            return
+    lib.gpt_host_free(ptr)
+
+
+def pinned_empty(shape, min_bytes=1 << 20):
+    """``numpy.empty(shape)`` of float64 in page-locked host memory (gpt_host_alloc) when it is at least ``min_bytes`` large
+    -- the device writes such an array by asynchronous DMA (the (M, M) covariance of predict) -- else a plain array."""
+    n = int(np.prod(shape))
+    if n * 8 < min_bytes:
+        return np.empty(shape, dtype=np.float64)
+    lib = load()
+    p = None
+    with _lock:
+        blocks = _pinned_free.get(n * 8)
+        if blocks:
+            p = blocks.pop()
+            _pinned_held[0] -= n * 8
+    if p is None:
+        p = _vp()
+        check(lib.gpt_host_alloc(n * 8, C.byref(p)))
+    buf = (C.c_double * n).from_address(p.value)
+    buf._owner = _PinnedOwner(lib, p, n * 8)     # lives as long as the array (numpy keeps `buf` as the array's base)
+    return np.ctypeslib.as_array(buf).reshape(shape)
 
 
 class concurrent_evaluations(object):
@@ -292,7 +347,7 @@ class Context(object):
         M = Xstar.shape[0]
         mean = np.empty(M)
         std = np.empty(M) if want >= 1 else None
-        cov = np.empty((M, M)) if want == 2 else None
+        cov = pinned_empty((M, M)) if want == 2 else None
         npar = None if noise_params is None else f64(noise_params)
         nn = None if noise_n is None else i32(noise_n)
         check(self._lib.gpt_predict(self.handle, dptr(Xstar), iptr(nstar), M, int(want), dptr(npar), iptr(nn),

@@ -175,6 +175,9 @@ int launch_rowsumsq_sub(hipStream_t st, int64_t m, int64_t n, const double *V, i
                         double *var_out);
 int launch_add_noise_sym(hipStream_t st, const KParams &kp, const double *dX, const int32_t *dn, int64_t M,
                          double *C, int64_t ldc);
+int launch_mirror_rows(hipStream_t st, double *A, int64_t lda, int64_t c0, int64_t w, int64_t n);
+int launch_alpha_trace(hipStream_t st, const double *alpha, const double *W, int64_t ldw, int64_t n, double *out);
+int launch_diag_gather(hipStream_t st, const double *A, int64_t lda, int64_t n, double *out);
 int launch_copy2d(hipStream_t st, int64_t rows, int64_t cols, const double *src, int64_t lds, double *dst, int64_t ldd);
 int launch_zero2d(hipStream_t st, int64_t rows, int64_t cols, double *dst, int64_t ldd);
 int launch_pad_block(hipStream_t st, double *A, int64_t lda, int64_t c0, int64_t nb, int64_t n_valid, int64_t n_pad,

@@ -664,7 +664,22 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
         const int64_t nt64 = ((m + 63) / 64) * ((n + 63) / 64);
         if (nt64 < small_below && !ev0 && edge_cols == 0) tile = 32;
     }
-    if (tile == 32) return gemm_launch_t<32, 32, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0, ev0, ev1, 0, 0, 0, prio, edge, wait);
+    if (tile == 32) {
+        // Small launches with a LONG k loop (the leaf / update GEMMs of a triangular solve with few right-hand sides: predict
+        // at a handful of points, k = 512) run one workgroup per CU, so nobody hides the DMA latency of the 2-stage pipeline:
+        // 0.65 us per 16-wide k-tile for 4 MFMAs per wave.  Four LDS stages (DMA three k-tiles ahead, counted vmcnt) bring it
+        // to ~0.3 us: predict with std at 64 points, N = 8192: 0.91 -> 0.62 ms.  The rank-128 updates of the factorisation's
+        // chain (8 k-tiles, mostly prologue) do not gain (N = 4096: 1.242 / 1.250 / 1.261 ms with 2 / 3 / 4 stages), hence
+        // the k threshold.  GPT_GEMM_SMALL_STAGES=2|4 forces one variant.
+        static int stages = -1;
+        if (stages < 0) {
+            stages = 0;
+            if (const char *e = getenv("GPT_GEMM_SMALL_STAGES")) stages = atoi(e);
+        }
+        if ((stages == 4 && k >= 64) || (stages == 0 && k >= 256))
+            return gemm_launch_t<32, 32, 2, 4>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0, ev0, ev1, 0, 0, 0, prio, edge, wait);
+        return gemm_launch_t<32, 32, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0, ev0, ev1, 0, 0, 0, prio, edge, wait);
+    }
     if ((edge.word || wait.word || edge_cols) && tile != 64) {
         gpt_set_error("gemm_nt: edge flags exist for the 64x64 / 32x32 kernels only");
         return GPT_E_ARG;

@@ -366,49 +366,126 @@ int launch_trsv_lt(hipStream_t st, int64_t n, const double *L, int64_t ldl, cons
     return GPT_OK;
 }
 
-// y (m) = A (m x n, row-major) * x (n): one wave per row
-__global__ __launch_bounds__(256) void gemv_n_kernel(int64_t m, int64_t n, const double *__restrict__ A, int64_t lda,
+// y (m) = A (m x n, row-major) * x (n), and var[i] = kdiag[i] - sum_c V[i][c]^2 (the diagonal of Kss - V V^T without forming
+// the M x M product).  One wave per row while there are many rows; with few rows (predict at a handful of points: 64 rows of
+// 8192 entries) a whole workgroup per row, four loads in flight per thread -- one wave per row walked 128 dependent
+// iterations, 42 us for either kernel at M = 64, N = 8192.  Fixed summation order for a given shape in both forms.
+template <int WAVES, bool SQ>
+__global__ __launch_bounds__(256) void rowred_kernel(int64_t m, int64_t n, const double *__restrict__ A, int64_t lda,
                                                      const double *__restrict__ x, double *__restrict__ y)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= m) return;
-    double acc = 0.0;
-    for (int64_t c = lane; c < n; c += 64) acc = fma(A[row * lda + c], x[c], acc);
+    // SQ: y[row] = x[row] - sum_c A[row][c]^2 ; else y[row] = sum_c A[row][c] x[c].  WAVES waves share a row.
+    __shared__ double part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (WAVES == 4) ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wave;
+    const bool live = row < m;
+    const int t = (WAVES == 4) ? (int)threadIdx.x : lane, T = WAVES * 64;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (live) {
+        const double *r = A + row * lda;
+        int64_t c = t;
+        for (; c + 3 * T < n; c += 4 * T) {
+            const double v0 = r[c], v1 = r[c + T], v2 = r[c + 2 * T], v3 = r[c + 3 * T];
+            a0 = fma(v0, SQ ? v0 : x[c], a0);
+            a1 = fma(v1, SQ ? v1 : x[c + T], a1);
+            a2 = fma(v2, SQ ? v2 : x[c + 2 * T], a2);
+            a3 = fma(v3, SQ ? v3 : x[c + 3 * T], a3);
+        }
+        for (; c < n; c += T) {
+            const double v0 = r[c];
+            a0 = fma(v0, SQ ? v0 : x[c], a0);
+        }
+    }
+    double acc = (a0 + a1) + (a2 + a3);
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    if (lane == 0) y[row] = acc;
+    if (WAVES == 4) {
+        if (lane == 0) part[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0 && live) {
+            const double tot = (part[0] + part[1]) + (part[2] + part[3]);
+            y[row] = SQ ? x[row] - tot : tot;
+        }
+    } else if (lane == 0 && live) {
+        y[row] = SQ ? x[row] - acc : acc;
+    }
 }
 
 int launch_gemv_n(hipStream_t st, int64_t m, int64_t n, const double *A, int64_t lda, const double *x, double *y)
 {
     if (m <= 0) return GPT_OK;
-    hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, m, n, A, lda, x, y);
+    if (m < 2048) hipLaunchKernelGGL((rowred_kernel<4, false>), dim3((unsigned)m), dim3(256), 0, st, m, n, A, lda, x, y);
+    else hipLaunchKernelGGL((rowred_kernel<1, false>), dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, m, n, A, lda, x, y);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
-}
-
-// var[i] = kdiag[i] - sum_c V[i][c]^2  (diagonal of Kss - V V^T without forming the M x M product)
-__global__ __launch_bounds__(256) void rowsumsq_sub_kernel(int64_t m, int64_t n, const double *__restrict__ V,
-                                                           int64_t ldv, const double *__restrict__ kdiag,
-                                                           double *__restrict__ var_out)
-{
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= m) return;
-    double acc = 0.0;
-    for (int64_t c = lane; c < n; c += 64) {
-        const double v = V[row * ldv + c];
-        acc = fma(v, v, acc);
-    }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    if (lane == 0) var_out[row] = kdiag[row] - acc;
 }
 
 int launch_rowsumsq_sub(hipStream_t st, int64_t m, int64_t n, const double *V, int64_t ldv, const double *kdiag,
                         double *var_out)
 {
     if (m <= 0) return GPT_OK;
-    hipLaunchKernelGGL(rowsumsq_sub_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, m, n, V, ldv, kdiag, var_out);
+    if (m < 2048) hipLaunchKernelGGL((rowred_kernel<4, true>), dim3((unsigned)m), dim3(256), 0, st, m, n, V, ldv, kdiag, var_out);
+    else hipLaunchKernelGGL((rowred_kernel<1, true>), dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, m, n, V, ldv, kdiag, var_out);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
+// Completes block row [c0, c0 + w) of a symmetric matrix whose lower triangle holds the values: A[a][b] = A[b][a] for a in
+// the block row and b > a (32 x 32 tiles through LDS).  Used by gpt_predict behind each block column of the covariance SYRK.
+__global__ __launch_bounds__(256) void mirror_rows_kernel(double *__restrict__ A, int64_t lda, int64_t c0, int64_t w, int64_t n)
+{
+    __shared__ double t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t a0 = c0 + (int64_t)blockIdx.y * 32;            // rows of the block row (destination rows)
+    const int64_t b0 = a0 + (int64_t)blockIdx.x * 32;            // destination columns: from the diagonal tile on
+    if (b0 >= n) return;
+    for (int i = ty; i < 32; i += 8)                             // source tile: rows b0.., columns a0..
+        if (b0 + i < n && a0 + tx < c0 + w) t[i][tx] = A[(b0 + i) * lda + a0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int64_t a = a0 + i, b = b0 + tx;
+        if (a < c0 + w && b < n && b > a) A[a * lda + b] = t[tx][i];
+    }
+}
+
+int launch_mirror_rows(hipStream_t st, double *A, int64_t lda, int64_t c0, int64_t w, int64_t n)
+{
+    if (w <= 0 || c0 >= n) return GPT_OK;
+    dim3 grid((unsigned)((n - c0 + 31) / 32), (unsigned)((w + 31) / 32));
+    hipLaunchKernelGGL(mirror_rows_kernel, grid, dim3(256), 0, st, A, lda, c0, w, n);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
+// out[0] = sum_{i<n} (alpha_i^2 - W_ii): the noise term of the LML gradient over the observations (one workgroup, fixed order)
+__global__ __launch_bounds__(256) void alpha_trace_kernel(const double *__restrict__ alpha, const double *__restrict__ W,
+                                                          int64_t ldw, int64_t n, double *__restrict__ out)
+{
+    __shared__ double s0[4];
+    double a = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) a += alpha[i] * alpha[i] - W[i * ldw + i];
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+    if ((threadIdx.x & 63) == 0) s0[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = ((s0[0] + s0[1]) + s0[2]) + s0[3];
+}
+
+int launch_alpha_trace(hipStream_t st, const double *alpha, const double *W, int64_t ldw, int64_t n, double *out)
+{
+    hipLaunchKernelGGL(alpha_trace_kernel, dim3(1), dim3(256), 0, st, alpha, W, ldw, n, out);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
+__global__ void diag_gather_kernel(const double *__restrict__ A, int64_t lda, int64_t n, double *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = A[i * lda + i];
+}
+
+int launch_diag_gather(hipStream_t st, const double *A, int64_t lda, int64_t n, double *out)
+{
+    if (n <= 0) return GPT_OK;
+    hipLaunchKernelGGL(diag_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, lda, n, out);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }

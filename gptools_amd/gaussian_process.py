@@ -447,23 +447,29 @@ class GaussianProcess(object):
         alpha = ctx.get_alpha(Ny)
         self._cache["alpha"] = alpha.reshape(-1, 1)
 
-        def term(dK):
-            if self.T is not None:
+        def term(dK, transform=True):
+            if self.T is not None and transform:
                 dK = self.T.dot(dK).dot(self.T.T)
             W = ctx.solve_L(dK)                     # L^-1 dK
             W2 = ctx.solve_L(np.ascontiguousarray(W.T))    # L^-1 (L^-1 dK)^T -> trace equals tr(K^-1 dK)
             return 0.5 * (alpha.dot(dK.dot(alpha)) - np.trace(W2))
 
         ll_deriv = np.zeros(len(self.free_params))
-        terms = self._native_terms() if (self._fit_mode == "kernel" and self.T is None) else None
-        if terms is not None and all(t[0] == _lib.KERNEL_SE for t in terms):
-            # device path (gpt_ll_grad): K_tot^-1 once (~N^3 flop on the MFMA GEMM, whatever the number of
-            # parameters), then one fused pass over the pairs per group of parameters; dK never exists
-            knk = self.k
-            free_idx = np.arange(0, len(knk.params), dtype=int)[~np.asarray(knk.fixed_params, dtype=bool)]
+        terms = self._native_terms() if self._fit_mode == "kernel" else None
+        knk = self.k
+        free_idx = np.arange(0, len(knk.params), dtype=int)[~np.asarray(knk.fixed_params, dtype=bool)]
+        tix = lix = None
+        if terms is not None:
+            # which kernel term each free parameter belongs to; the device path needs every FREE parameter in a
+            # squared-exponential term (terms of other kernels may take part in the sum with all their parameters fixed:
+            # they have no hyperparameter derivatives in the reference either, kernel/core.py:723-726)
             bounds = np.cumsum([0] + [len(t[1]) for t in terms])
             tix = [int(np.searchsorted(bounds, pi, side="right") - 1) for pi in free_idx]
             lix = [int(pi - bounds[t]) for pi, t in zip(free_idx, tix)]
+        if terms is not None and all(terms[t][0] == _lib.KERNEL_SE for t in tix):
+            # device path (gpt_ll_grad): K_tot^-1 once (2 N^3 / 3 flop on the MFMA GEMM, whatever the number of
+            # parameters), then one fused pass over the pairs per group of parameters; dK never exists.  With a linear
+            # transform T the pass runs over the latent points against T^T K_tot^-1 T (two more GEMMs on the device).
             g_dev = ctx.ll_grad(tix, lix)
             ll_deriv[:len(free_idx)] = g_dev[:-1]
             if isinstance(self.noise_k, DiagonalNoiseKernel) and not isinstance(self.noise_k, ZeroKernel) \
@@ -475,7 +481,8 @@ class GaussianProcess(object):
             elif isinstance(self.noise_k, DiagonalNoiseKernel):
                 knk = self.k
                 if not self.noise_k.fixed_params[0]:
-                    ll_deriv[len(self.k.free_params)] = term(2.0 * self.noise_k.params[0] * np.eye(Ny))
+                    # (the reference does not transform this term: 2 sigma_n eye(len(y)), ref :1482-1488)
+                    ll_deriv[len(self.k.free_params)] = term(2.0 * self.noise_k.params[0] * np.eye(Ny), transform=False)
             else:
                 knk = self.k + self.noise_k
             free_idx = np.arange(0, len(knk.params), dtype=int)[~np.asarray(knk.fixed_params, dtype=bool)]

@@ -198,7 +198,11 @@ int gpt_ll_grad(gpt_ctx *ctx, int nh, const int *term_idx, const int *local_idx,
  * noise_params != NULL adds the DiagonalNoiseKernel term to K(Xstar, Xstar) (ref :985-986,
  * kernel/noise.py:103-104; the X-vs-Xstar term of ref :967-968 is identically zero because that
  * call is not `symmetric`, kernel/noise.py:109-110).
- * Uses the kernel / params of the last gpt_fit. */
+ * Uses the kernel / params of the last gpt_fit.
+ * cov_out may be pageable or pinned host memory (gpt_host_alloc): into pinned memory the block rows of the covariance are
+ * written by asynchronous DMA while the next block column of the SYRK is computed; pageable memory is reached through a
+ * pinned staging ring.  want == 2 with cov_out == NULL leaves the covariance on the device (nothing of size M^2 crosses
+ * PCIe; mean and, if std_out != NULL, std are still returned). */
 int gpt_predict(gpt_ctx *ctx, const double *Xstar, const int32_t *nstar, int64_t M, int want,
                 const double *noise_params, const int32_t *noise_n,
                 double *mean_out, double *std_out, double *cov_out);
@@ -206,6 +210,11 @@ int gpt_predict(gpt_ctx *ctx, const double *Xstar, const int32_t *nstar, int64_t
 /* Generic right-hand sides against the resident factor (host in/out, row-major):
  *   gpt_solve_L   : B (N, nrhs) <- L^-1 B          (ref: gaussian_process.py:983 solve_triangular)
  *   gpt_cho_solve : B (N, nrhs) <- K_tot^-1 B      (ref: gaussian_process.py:1462,1487,1503 cho_solve) */
+/* Pinned (page-locked) host memory for large results: hipHostMalloc / hipHostFree behind a C ABI, so that a binding can hand
+ * gpt_predict a destination the DMA engine writes directly. */
+int gpt_host_alloc(int64_t bytes, void **out);
+int gpt_host_free(void *p);
+
 int gpt_solve_L(gpt_ctx *ctx, double *B, int64_t nrhs);
 int gpt_cho_solve(gpt_ctx *ctx, double *B, int64_t nrhs);
 

@@ -5,6 +5,8 @@ import bench
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
 Ms = [int(v) for v in sys.argv[2:]] or [64, 1024, 4096]
 ctx = _lib.Context(0)
+import os
+if os.environ.get('GPT_TILE'): ctx.set_option('tile', int(os.environ['GPT_TILE']))
 kernel, N, d, deriv = bench.WORKLOADS[wl]
 X, n, y, err, params = bench.synth(kernel, N, d, deriv)
 ctx.set_data(X, n)
