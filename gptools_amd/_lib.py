@@ -40,6 +40,7 @@ SIGNATURES = {
     "gpt_set_T": (C.c_int, [_vp, _dp, _i64]),
     "gpt_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, C.c_double, _dp, _dp]),
     "gpt_fit_sum": (C.c_int, [_vp, C.c_int, _ip, _dp, _ip, C.c_double, _dp, _dp, C.c_double, _dp, _dp]),
+    "gpt_fit_batch": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, _dp, C.c_double, _dp, _dp, _ip]),
     "gpt_fit_matrix": (C.c_int, [_vp, _dp, _i64, _dp, _dp, _dp]),
     "gpt_get_L": (C.c_int, [_vp, _dp]),
     "gpt_get_alpha": (C.c_int, [_vp, _dp]),
@@ -317,6 +318,18 @@ class Context(object):
         check(self._lib.gpt_fit_sum(self.handle, len(ids), iptr(ids), dptr(flat), iptr(npar), float(noise_var), dptr(y),
                                     dptr(err_y), float(diag_add), C.byref(ll), C.byref(ld)))
         return ll.value, ld.value
+
+    def fit_batch(self, kernel_id, params, noise_var, y, err_y, diag_add):
+        """gpt_fit_batch: ``params`` (B, nparams), ``noise_var`` (B,), ``y`` (B, N), shared ``err_y`` (N,) ->
+        ``(ll_data (B,), logdet_half (B,), info (B,) int32)``; ``info[b] > 0``: element b is not positive definite."""
+        params, noise_var, y, err_y = f64(np.atleast_2d(params)), f64(noise_var), f64(np.atleast_2d(y)), f64(err_y)
+        B = params.shape[0]
+        if noise_var.shape != (B,) or y.shape[0] != B or y.shape[1] != err_y.shape[0]:
+            raise ValueError("fit_batch: params (B, p), noise_var (B,), y (B, N), err_y (N,) expected")
+        ll, ld, info = np.empty(B), np.empty(B), np.zeros(B, dtype=np.int32)
+        check(self._lib.gpt_fit_batch(self.handle, B, kernel_id, dptr(params), params.shape[1], dptr(noise_var), dptr(y),
+                                      dptr(err_y), float(diag_add), dptr(ll), dptr(ld), iptr(info)))
+        return ll, ld, info
 
     def ll_grad(self, term_idx, local_idx):
         """Data-term gradient for the listed (term, parameter) pairs plus the noise trace term (last entry)."""

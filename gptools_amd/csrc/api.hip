@@ -41,7 +41,7 @@ struct DevBuf {
 
 enum { SLOT_XI = 0, SLOT_XJ, SLOT_NI, SLOT_NJ, SLOT_OUT, SLOT_KST, SLOT_KSS, SLOT_XS, SLOT_NS, SLOT_VEC, SLOT_VEC2,
        SLOT_RHS, SLOT_LOW, SLOT_KFULL, SLOT_TK, SLOT_ZERO, SLOT_UINV, SLOT_WINV, SLOT_GPART, SLOT_BINV, SLOT_BTMP,
-       SLOT_BINV2, SLOT_COUNT };
+       SLOT_BINV2, SLOT_BATCH_A, SLOT_BATCH_WS, SLOT_BATCH_MISC, SLOT_COUNT };
 
 struct gpt_ctx {
     int device = 0;
@@ -122,6 +122,8 @@ struct gpt_ctx {
     double *h_stage = nullptr;         // pinned staging ring for results that go to pageable host memory (2 x GPT_STAGE_BYTES)
     hipStream_t copy_stream = nullptr; // device-to-host copies that overlap the next block's compute (created on first use)
     hipEvent_t cev[4] = {nullptr, nullptr, nullptr, nullptr};
+    double *h_batch = nullptr;         // pinned staging of gpt_fit_batch (y, KParams, noise variances, err_y in; results out)
+    size_t h_batch_cap = 0;
     int64_t cov_M = 0;                 // > 0: SLOT_KSS holds the lower triangle of the predictive covariance of the last gpt_predict(want = 2, cov_out = NULL)
     KParams kp;                      // first term (single-kernel paths)
     std::vector<KParams> terms;      // the model kernel as a sum of native kernels (gpt_fit_sum)
@@ -1148,6 +1150,7 @@ extern "C" int gpt_ctx_destroy(gpt_ctx *c)
     if (c->d_scal) hipFree(c->d_scal);
     if (c->h_scal) hipHostFree(c->h_scal);
     if (c->h_stage) hipHostFree(c->h_stage);
+    if (c->h_batch) hipHostFree(c->h_batch);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     for (auto &e : c->cev)
         if (e) hipEventDestroy(e);
@@ -1671,6 +1674,114 @@ static int fit_matrix_once(gpt_ctx *c, const double *K_tot, int64_t N, const dou
     GPT_HIP_CHECK(hipMemcpy2DAsync(c->dA, (size_t)c->NP * sizeof(double), K_tot, (size_t)N * sizeof(double),
                                    (size_t)N * sizeof(double), (size_t)N, hipMemcpyHostToDevice, st));
     return factor_and_ll(c, N, ll_data_out, logdet_half_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// batched small fits
+// ------------------------------------------------------------------------------------------------
+// nbatch independent LML evaluations of the resident data set -- the reference's likelihood grids and random starts
+// (ref: gaussian_process.py:1607-1692, :723-735; gp_utils.py:98-115) live at N of a few hundred to a few thousand, where ONE
+// evaluation cannot fill the GPU: its chain of 128-column leaves (diagonal block 20 us on one CU, TRSM, rank-128 update) is
+// pure latency and the host's launch rate bounds it (0.37 ms at N = 1024).  Here every kernel of that chain carries the
+// whole batch in a grid dimension: element b works on its own matrix A + b NP^2 with its own hyperparameters, the
+// diagonal-block kernel runs nbatch workgroups on nbatch CUs at once, and the launch sequence (3 launches per leaf) is paid
+// once per batch.  No look-ahead, one stream: the parallelism is across the batch.  Same kernels, same tile choice and the
+// same summation orders as gpt_fit, so an element's ll / log-determinant carry the very bits gpt_fit returns for it alone
+// (tests/test_gpu_parity.py::test_fit_batch_*).  N <= GPT_BATCH_MAX_N; one native kernel, no transform.
+#define GPT_BATCH_MAX_N 2048
+extern "C" int gpt_fit_batch(gpt_ctx *c, int nbatch, int kernel_id, const double *params, int nparams,
+                             const double *noise_var, const double *y, const double *err_y, double diag_add,
+                             double *ll_data_out, double *logdet_half_out, int32_t *info_out)
+{
+    CTX_ENTER(c);
+    if (!c->dX) {
+        gpt_set_error("gpt_fit_batch: call gpt_set_data first");
+        return GPT_E_STATE;
+    }
+    if (nbatch < 1 || nbatch > 65535 || !params || !noise_var || !y || !err_y || !ll_data_out || !info_out) return GPT_E_ARG;
+    if (c->dT || c->Nx > GPT_BATCH_MAX_N) {
+        gpt_set_error("gpt_fit_batch: needs N <= %d and no linear transform (N = %lld)", GPT_BATCH_MAX_N, (long long)c->Nx);
+        return GPT_E_ARG;
+    }
+    if (kernel_id != GPT_KERNEL_SE && kernel_id != GPT_KERNEL_M52 && kernel_id != GPT_KERNEL_RQ && kernel_id != GPT_KERNEL_MATERN) {
+        gpt_set_error("gpt_fit_batch: kernel_id must be SE, Matern52, RationalQuadratic or Matern");
+        return GPT_E_ARG;
+    }
+    if ((kernel_id == GPT_KERNEL_RQ || kernel_id == GPT_KERNEL_MATERN) && 2 * c->n_maxsum > GPT_RQ_MAXORD) {
+        gpt_set_error("RationalQuadratic / Matern kernel: derivative orders of a pair sum to %ld, the device builder supports %d",
+                      2 * c->n_maxsum, GPT_RQ_MAXORD);
+        return GPT_E_VALUE;
+    }
+    const int64_t N = c->Nx, NP = round_up(N + 1, 128), nleaf = NP / 128, bs = NP * NP, bws = nleaf * GPT_WS_BLOCK;
+    // pinned staging: [y: nbatch N | err: N | noise: nbatch | KParams: nbatch | results: 4 nbatch]; err .. KParams go to the
+    // device in one copy
+    static_assert(sizeof(KParams) % 8 == 0, "KParams is copied as an array of doubles");
+    const size_t kp_doubles = sizeof(KParams) / 8;
+    const size_t off_err = (size_t)nbatch * N, off_nv = off_err + (size_t)N, off_kp = off_nv + (size_t)nbatch,
+                 off_res = off_kp + (size_t)nbatch * kp_doubles;
+    const size_t need = (off_res + 4 * (size_t)nbatch) * sizeof(double);
+    if (c->h_batch_cap < need) {
+        if (c->h_batch) GPT_HIP_CHECK(hipHostFree(c->h_batch));
+        c->h_batch = nullptr;
+        c->h_batch_cap = 0;
+        GPT_HIP_CHECK(hipHostMalloc((void **)&c->h_batch, need + need / 4, hipHostMallocDefault));
+        c->h_batch_cap = need + need / 4;
+    }
+    double *h = c->h_batch;
+    memcpy(h, y, (size_t)nbatch * N * sizeof(double));
+    memcpy(h + off_err, err_y, (size_t)N * sizeof(double));
+    memcpy(h + off_nv, noise_var, (size_t)nbatch * sizeof(double));
+    for (int b = 0; b < nbatch; b++) {
+        KParams kp;
+        GPT_TRY(make_kparams(kernel_id, params + (size_t)b * nparams, nparams, c->D, -1, 1, nullptr, &kp));
+        memcpy(reinterpret_cast<char *>(h + off_kp) + (size_t)b * kp_doubles * 8, &kp, sizeof(KParams));
+    }
+    double *dA, *dws, *dmisc;
+    GPT_TRY(ensure(c, SLOT_BATCH_A, (size_t)nbatch * bs * sizeof(double), (void **)&dA));
+    GPT_TRY(ensure(c, SLOT_BATCH_WS, (size_t)nbatch * bws * sizeof(double), (void **)&dws));
+    // device side of the small inputs: [err: N | noise: nbatch | KParams: nbatch | info: nbatch]
+    const size_t d_off_nv = (size_t)N, d_off_kp = d_off_nv + (size_t)nbatch, d_off_info = d_off_kp + (size_t)nbatch * kp_doubles;
+    GPT_TRY(ensure(c, SLOT_BATCH_MISC, (d_off_info + (size_t)nbatch) * sizeof(double), (void **)&dmisc));
+    int32_t *dinfo = reinterpret_cast<int32_t *>(dmisc + d_off_info);
+    EvalScope scope(c);                      // (an evaluation in flight like any other for the flag-edge accounting; uses none)
+    // everything on the panel stream: unmasked (all 256 CUs), the main stream is idle here
+    hipStream_t st = c->panel_stream;
+    {
+        hipEvent_t e = get_event(c, 0);
+        if (!e) return GPT_E_HIP;
+        GPT_HIP_CHECK(hipEventRecord(e, c->stream));
+        GPT_HIP_CHECK(hipStreamWaitEvent(st, e, 0));
+    }
+    GPT_HIP_CHECK(hipMemcpyAsync(dmisc, h + off_err, ((size_t)N + (size_t)nbatch + (size_t)nbatch * kp_doubles) * sizeof(double),
+                                 hipMemcpyHostToDevice, st));
+    GPT_TRY(launch_batch_pad(st, h, nbatch, dA, NP, bs, N, NP, 1e300, dinfo));
+    GPT_TRY(launch_kbuild_batch(st, kernel_id, c->D, reinterpret_cast<const KParams *>(dmisc + d_off_kp), dmisc + d_off_nv, nbatch,
+                                c->dX, c->dn, N, dmisc, diag_add, dA, NP, bs));
+    for (int64_t lc = 0; lc < NP; lc += 128) {
+        GPT_TRY(launch_potf2_diag(st, dA + lc * NP + lc, NP, dws + (lc / 128) * GPT_WS_BLOCK, dinfo, lc, EdgeSig(), nbatch, bs, bws));
+        const int64_t r1 = lc + 128, m = NP - r1;
+        if (m <= 0) break;
+        GPT_TRY(launch_trsm_panel(st, m, dA + lc * NP + lc, NP, dws + (lc / 128) * GPT_WS_BLOCK, dA + r1 * NP + lc, NP, nullptr,
+                                  EdgeSig(), nbatch, bs, bws));
+        GPT_TRY(launch_gemm_nt(st, m, m, 128, -1.0, dA + r1 * NP + lc, NP, dA + r1 * NP + lc, NP, 1.0, dA + r1 * NP + r1, NP, 1, 0, 0,
+                               nullptr, nullptr, 0, EdgeSig(), EdgeSig(), 0, nbatch, bs));
+    }
+    GPT_TRY(launch_batch_logdet_dot(st, dA, NP, bs, N, nbatch, dinfo, h + off_res));
+    GPT_HIP_CHECK(hipStreamSynchronize(st));
+    int bad = 0;
+    for (int b = 0; b < nbatch; b++) {
+        const double logdet_half = h[off_res + 4 * b], zz = h[off_res + 4 * b + 1];
+        int32_t info = (int32_t)h[off_res + 4 * b + 2];
+        if (info > N) info = (int32_t)N;                       // only the augmented pivot failed (non-finite data)
+        const double ll = -0.5 * zz - logdet_half - 0.5 * (double)N * log(2.0 * M_PI);
+        if (info == 0 && !(ll == ll)) info = (int32_t)N;
+        info_out[b] = info;
+        ll_data_out[b] = ll;
+        if (logdet_half_out) logdet_half_out[b] = logdet_half;
+        bad += info != 0;
+    }
+    (void)bad;
+    return GPT_OK;
 }
 
 extern "C" int gpt_last_timings(gpt_ctx *c, double *out_ms, int n)

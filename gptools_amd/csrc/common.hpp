@@ -135,9 +135,9 @@ int launch_check_orders(hipStream_t st, const int32_t *dn, int64_t M, int D, int
 int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A, int64_t lda,
                    const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile, int lds_pad,
                    hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int prio = 0, EdgeSig edge = EdgeSig(),
-                   EdgeSig wait = EdgeSig(), int64_t edge_cols = 0);
+                   EdgeSig wait = EdgeSig(), int64_t edge_cols = 0, int64_t nbatch = 1, int64_t bstride = 0);
 int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base,
-                      EdgeSig wait = EdgeSig());
+                      EdgeSig wait = EdgeSig(), int64_t nbatch = 1, int64_t bstride_a = 0, int64_t bstride_ws = 0);
 int launch_gemm_nt_stair(hipStream_t st, int64_t m, int64_t nseg, int64_t seg_cols, int64_t k, double alpha,
                          const double *A, int64_t lda, const double *B, int64_t ldb, int64_t b_stride, int64_t row_step,
                          double beta, double *C, int64_t ldc, int lds_pad, hipEvent_t ev0 = nullptr,
@@ -148,7 +148,16 @@ int launch_potf2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int3
 int launch_potf2x2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
                         double *l10pk, unsigned *flag, unsigned flag_base, hipEvent_t done = nullptr);
 int launch_trsm_panel(hipStream_t st, int64_t m, const double *L, int64_t ldl, const double *invd,
-                      double *B, int64_t ldb, hipEvent_t done = nullptr, EdgeSig edge = EdgeSig());
+                      double *B, int64_t ldb, hipEvent_t done = nullptr, EdgeSig edge = EdgeSig(), int64_t nbatch = 1,
+                      int64_t bstride_a = 0, int64_t bstride_ws = 0);
+// batched small fits (gpt_fit_batch)
+int launch_kbuild_batch(hipStream_t st, int kernel_id, int D, const KParams *d_kps, const double *d_noise_var, int64_t nbatch,
+                        const double *dX, const int32_t *dn, int64_t N, const double *d_err_y, double diag_add, double *dK,
+                        int64_t ldk, int64_t bstride);
+int launch_batch_pad(hipStream_t st, const double *h_y, int64_t nbatch, double *A, int64_t lda, int64_t bstride, int64_t n_valid,
+                     int64_t n_pad, double big, int32_t *info);
+int launch_batch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_t bstride, int64_t n, int64_t nbatch,
+                            const int32_t *d_info, double *out3);
 #define GPT_GRAD_MAXH 8
 int grad_reduce_blocks(int64_t N);
 int launch_grad_reduce(hipStream_t st, const KParams &kp, int nh, const int *hl, const double *dX, const int32_t *dn,

@@ -163,8 +163,13 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     int64_t m, int64_t n, int64_t k, double alpha, const double *__restrict__ A, int64_t lda,
     const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
     int tri, int64_t ntm, int64_t ntn, int64_t nwg, const int2 *__restrict__ order, int64_t seg_cols, int64_t bskip, int prio, unsigned *edge, unsigned edge_val,
-    unsigned edge_total, const unsigned *wait_word, unsigned wait_val, unsigned *wait_err, int edge_cols)
+    unsigned edge_total, const unsigned *wait_word, unsigned wait_val, unsigned *wait_err, int edge_cols, int64_t bstride)
 {
+    // batched launches (gpt_fit_batch: independent small matrices, blockIdx.y = batch element): A, B and C all lie inside
+    // the element's own matrix, bstride elements apart
+    A += (int64_t)blockIdx.y * bstride;
+    B += (int64_t)blockIdx.y * bstride;
+    C += (int64_t)blockIdx.y * bstride;
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int RM = WM / 16, RN = WN / 16;
     // NSTAGE LDS buffers per operand: 2 for the large launches (four workgroups per CU hide the DMA latency for each
@@ -554,7 +559,7 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
                          int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri,
                          int lds_pad, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int64_t seg_cols = 0,
                          int64_t bskip = 0, int64_t row_step = 0, int prio = 0, EdgeSig edge = EdgeSig(),
-                         EdgeSig wait = EdgeSig(), int64_t edge_cols_elems = 0)
+                         EdgeSig wait = EdgeSig(), int64_t edge_cols_elems = 0, int64_t nbatch = 1, int64_t bstride = 0)
 {
     const int64_t ntm = (m + BM - 1) / BM, ntn = (n + BN - 1) / BN;
     int64_t nwg = (tri == 1) ? ntn * (ntn + 1) / 2 + (ntm - ntn) * ntn : ntm * ntn;
@@ -582,13 +587,13 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
     // timing events (roofline line of bench.py) ride on the dispatch packet itself: separate hipEventRecord calls
     // would add two barrier packets per launch to the stream being measured
     if (ev0 || ev1)
-        hipExtLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg), dim3(256), dyn, st, ev0, ev1, 0,
+        hipExtLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg, (unsigned)nbatch), dim3(256), dyn, st, ev0, ev1, 0,
                               m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip, prio, edge.word, edge.value,
-                              (unsigned)(edge_cols_elems > 0 ? nedge : nreal), wait.word, wait.value, wait.err, (int)(edge_cols_elems / BN));
+                              (unsigned)(edge_cols_elems > 0 ? nedge : nreal), wait.word, wait.value, wait.err, (int)(edge_cols_elems / BN), bstride);
     else
-        hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg), dim3(256), dyn, st, m, n, k, alpha,
+        hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg, (unsigned)nbatch), dim3(256), dyn, st, m, n, k, alpha,
                            A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip, prio, edge.word, edge.value,
-                              (unsigned)(edge_cols_elems > 0 ? nedge : nreal), wait.word, wait.value, wait.err, (int)(edge_cols_elems / BN));
+                              (unsigned)(edge_cols_elems > 0 ? nedge : nreal), wait.word, wait.value, wait.err, (int)(edge_cols_elems / BN), bstride);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
@@ -626,7 +631,8 @@ int gemm_small_threshold()
 
 int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A, int64_t lda,
                    const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile, int lds_pad,
-                   hipEvent_t ev0, hipEvent_t ev1, int prio, EdgeSig edge, EdgeSig wait, int64_t edge_cols)
+                   hipEvent_t ev0, hipEvent_t ev1, int prio, EdgeSig edge, EdgeSig wait, int64_t edge_cols, int64_t nbatch,
+                   int64_t bstride)
 {
     gpt_jitter(st);
     if (m <= 0 || n <= 0) {
@@ -652,6 +658,10 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
         gpt_set_error("gemm_nt: tri requires m >= n");
         return GPT_E_ARG;
     }
+    if (nbatch > 1 && (force_tile != 0 || edge.word || wait.word || edge_cols || ev0 || ev1)) {
+        gpt_set_error("gemm_nt: batched launches take the default tiles, no edges and no events");
+        return GPT_E_ARG;
+    }
     int tile = force_tile;
     if (tile == 0) {
         tile = 64;   // measured on MI355X: 64x64 tiles at 4-5 workgroups per CU beat the 128x128 variants
@@ -661,6 +671,7 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
         // order, bit-identical results.  Measured (scratch/env_ab.py, GPT_GEMM_SMALL = threshold): N = 8192 4.757 ->
         // 4.625 ms at 512 (4.709 at 256, 4.648 at 1024, 4.692 at 2048), N = 4096 1.468 -> 1.386, N = 16384 27.28 -> 27.15.
         const int small_below = gemm_small_threshold();
+        // (batched: the tile choice follows the SINGLE matrix, so that an element of a batch is computed exactly as alone)
         const int64_t nt64 = ((m + 63) / 64) * ((n + 63) / 64);
         if (nt64 < small_below && !ev0 && edge_cols == 0) tile = 32;
     }
@@ -677,8 +688,8 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
             if (const char *e = getenv("GPT_GEMM_SMALL_STAGES")) stages = atoi(e);
         }
         if ((stages == 4 && k >= 64) || (stages == 0 && k >= 256))
-            return gemm_launch_t<32, 32, 2, 4>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0, ev0, ev1, 0, 0, 0, prio, edge, wait);
-        return gemm_launch_t<32, 32, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0, ev0, ev1, 0, 0, 0, prio, edge, wait);
+            return gemm_launch_t<32, 32, 2, 4>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0, ev0, ev1, 0, 0, 0, prio, edge, wait, 0, nbatch, bstride);
+        return gemm_launch_t<32, 32, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0, ev0, ev1, 0, 0, 0, prio, edge, wait, 0, nbatch, bstride);
     }
     if ((edge.word || wait.word || edge_cols) && tile != 64) {
         gpt_set_error("gemm_nt: edge flags exist for the 64x64 / 32x32 kernels only");
@@ -690,7 +701,8 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
     // small panel updates (8064x128x128: 12 us either way): they are bound by launch + prologue latency, not by the
     // DMA wait, so everything uses the 2-stage kernel.
     if (force_tile == 65) return gemm_launch_t<64, 64, 1, 4>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0);
-    return gemm_launch_t<64, 64, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, lds_pad, ev0, ev1, 0, 0, 0, prio, edge, wait, edge_cols);
+    return gemm_launch_t<64, 64, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, lds_pad, ev0, ev1, 0, 0, 0, prio, edge, wait, edge_cols,
+                                       nbatch, bstride);
 }
 
 // Staircase update: C (m x nseg*seg_cols) += alpha * A B_q^T per column segment q, where segment q (seg_cols

@@ -8,89 +8,7 @@
 // (pure write pattern, 4.6-5.0 TB/s): SE runs at that ceiling (4.65-4.7 TB/s), Matern-5/2 is bound by its
 // sqrt + exp + divide arithmetic (2.7-3.1 TB/s).  For the fit only the tiles of the lower triangle are launched.
 // Fused epilogue: the diagonal loading of ref :1447-1451 ((K + noise_var) + err_y^2) + diag_add.
-#include "kpair.hpp"
-
-#define KB_THREADS 256
-#define KB_CPT 1                        // columns per lane.  2 (16-byte stores) lifts the pure write pattern from 4.6 to
-                                        // 5.4 TB/s but the pair arithmetic then runs with half the waves: SE 4.65 -> 4.44
-                                        // TB/s, Matern-5/2 with derivative rows 0.18 -> 0.21 ms at N=8192 (measured)
-#define KB_COLS (KB_THREADS * KB_CPT)
-#define KB_ROWS 32
-#define KB_RATIO (KB_COLS / KB_ROWS)
-
-template <int KID, int D>
-__global__ __launch_bounds__(KB_THREADS) void kbuild_kernel(
-    KParams kp, const double *__restrict__ Xi, const int32_t *__restrict__ ni, int64_t M,
-    const double *__restrict__ Xj, const int32_t *__restrict__ nj, int64_t P,
-    int lower_only, int64_t i0, int64_t j0, const double *__restrict__ err_y, double noise_var,
-    double diag_add, double *__restrict__ K, int64_t ldk, int accumulate)
-{
-    int64_t rt, ct;
-    if (lower_only == 2) {
-        // Triangular launch (i0 == j0, M == P): only the tiles that touch the lower triangle exist.  Row tile rt
-        // (KB_ROWS rows) needs column tiles 0 .. rt / R (R = KB_COLS / KB_ROWS); groups of R row tiles share a count,
-        // so with g = rt / R the tiles before group g number R g (g + 1) / 2 and the linear index inverts in closed
-        // form.
-        constexpr int64_t R = KB_RATIO;
-        const int64_t b = blockIdx.x;
-        int64_t g = (int64_t)((sqrt(1.0 + 8.0 * (double)b / (double)R) - 1.0) * 0.5);
-        while (g > 0 && R * g * (g + 1) / 2 > b) g--;
-        while (R * (g + 1) * (g + 2) / 2 <= b) g++;
-        const int64_t rem = b - R * g * (g + 1) / 2;
-        rt = R * g + rem / (g + 1);
-        ct = rem % (g + 1);
-        if (rt * KB_ROWS >= M) return;
-    } else {
-        rt = blockIdx.y;
-        ct = blockIdx.x;
-    }
-    const int64_t rbase = rt * KB_ROWS;
-    const int64_t cbase = ct * KB_COLS;
-    if (lower_only && (cbase + j0 > rbase + KB_ROWS - 1 + i0)) return;     // tile strictly above the diagonal
-    const int64_t jfirst = cbase + (int64_t)threadIdx.x * KB_CPT;
-    double xj[KB_CPT][D];
-    int njr[KB_CPT][D];
-#pragma unroll
-    for (int c = 0; c < KB_CPT; c++) {
-        const int64_t jc = (jfirst + c < P) ? jfirst + c : (P - 1);
-#pragma unroll
-        for (int d = 0; d < D; d++) {
-            xj[c][d] = Xj[jc * D + d];
-            njr[c][d] = nj[jc * D + d];
-        }
-    }
-    // both columns in range and the pair 16-byte aligned -> one dwordx4 store per row
-    const bool vec = (jfirst + KB_CPT <= P) && ((ldk & 1) == 0) && ((((uintptr_t)K >> 3) + (uint64_t)jfirst) & 1) == 0;
-    const int64_t rend = (rbase + KB_ROWS < M) ? rbase + KB_ROWS : M;
-    for (int64_t i = rbase; i < rend; i++) {
-        double xi[D];
-        int nir[D];
-#pragma unroll
-        for (int d = 0; d < D; d++) {          // wave-uniform addresses -> scalar loads
-            xi[d] = Xi[i * D + d];
-            nir[d] = ni[i * D + d];
-        }
-        double v[KB_CPT];
-#pragma unroll
-        for (int c = 0; c < KB_CPT; c++) {
-            v[c] = any_pair<KID, D>(kp, xi, xj[c], nir, njr[c]);
-            // SumKernel (ref: gptools/kernel/core.py:549-584): later terms add to what the earlier passes stored
-            if (accumulate && jfirst + c < P) v[c] += K[i * ldk + jfirst + c];
-            if (err_y != nullptr && (i + i0 == jfirst + c + j0)) {
-                const double e = err_y[i + i0];
-                v[c] = ((v[c] + noise_var) + e * e) + diag_add;
-            }
-        }
-        if (KB_CPT == 2 && vec) {
-            f64x2 w = {v[0], v[KB_CPT - 1]};
-            *reinterpret_cast<f64x2 *>(K + i * ldk + jfirst) = w;
-        } else {
-#pragma unroll
-            for (int c = 0; c < KB_CPT; c++)
-                if (jfirst + c < P) K[i * ldk + jfirst + c] = v[c];
-        }
-    }
-}
+#include "kbuild_kernel.hpp"
 
 template <int KID, int D>
 __global__ __launch_bounds__(256) void kpairs_kernel(KParams kp, const double *__restrict__ Xi,
@@ -153,8 +71,9 @@ static int kbuild_dispatch_d(hipStream_t st, const KParams &kp, const double *dX
     }
 #define KB_CASE(DD)                                                                                     \
     case DD:                                                                                            \
-        hipLaunchKernelGGL((kbuild_kernel<KID, DD>), grid, block, 0, st, kp, dXi, dni, M, dXj, dnj, P,   \
-                           lower_only, i0, j0, d_err_y, noise_var, diag_add, dK, ldk, accumulate);      \
+        hipLaunchKernelGGL((kbuild_kernel<KID, DD, false>), grid, block, 0, st, kp, dXi, dni, M, dXj, dnj, P,   \
+                           lower_only, i0, j0, d_err_y, noise_var, diag_add, dK, ldk, accumulate,               \
+                           (const KParams *)nullptr, (const double *)nullptr, (int64_t)0);                       \
         break;
     switch (kp.D) {
         KB_CASE(1) KB_CASE(2) KB_CASE(3) KB_CASE(4) KB_CASE(5) KB_CASE(6) KB_CASE(7) KB_CASE(8)

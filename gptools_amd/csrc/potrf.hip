@@ -464,9 +464,14 @@ __device__ __forceinline__ void potf2_body(double *__restrict__ A, int64_t lda, 
 __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restrict__ A, int64_t lda,
                                                                 double *__restrict__ invd, int32_t *info,
                                                                 int64_t info_col0, const unsigned *wait_word,
-                                                                unsigned wait_val, unsigned *wait_err)
+                                                                unsigned wait_val, unsigned *wait_err, int64_t bs_a,
+                                                                int64_t bs_ws)
 {
     edge_wait(wait_word, wait_val, wait_err);
+    // (batched: blockIdx.y = element of a batch of independent matrices, gpt_fit_batch)
+    A += (int64_t)blockIdx.y * bs_a;
+    invd += (int64_t)blockIdx.y * bs_ws;
+    info += blockIdx.y;
     potf2_body<false>(A, lda, invd, info, info_col0, nullptr, 0u);
 }
 
@@ -879,12 +884,14 @@ int launch_potf2x2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, in
     return GPT_OK;
 }
 
-int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, EdgeSig wait)
+int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, EdgeSig wait,
+                      int64_t nbatch, int64_t bstride_a, int64_t bstride_ws)
 {
     gpt_jitter(st);
     const size_t shmem = (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
     { int rc_ = ensure_big_lds(reinterpret_cast<const void *>(potf2_diag_kernel), 1, shmem); if (rc_ != GPT_OK) return rc_; }
-    hipLaunchKernelGGL(potf2_diag_kernel, dim3(1), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base, wait.word, wait.value, wait.err);
+    hipLaunchKernelGGL(potf2_diag_kernel, dim3(1, (unsigned)nbatch), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base, wait.word,
+                       wait.value, wait.err, bstride_a, bstride_ws);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
@@ -901,8 +908,10 @@ int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int3
 __global__ __launch_bounds__(64 * TP_WAVES, 2) void trsm_panel_kernel(int64_t m, const double *__restrict__ L,
                                                                       int64_t ldl, const double *__restrict__ invd,
                                                                       double *__restrict__ B, int64_t ldb, unsigned *edge,
-                                                                      unsigned edge_val)
+                                                                      unsigned edge_val, int64_t bs_a, int64_t bs_ws)
 {
+    invd += (int64_t)blockIdx.y * bs_ws;          // (batched: blockIdx.y = element, see potf2_diag_kernel)
+    B += (int64_t)blockIdx.y * bs_a;
     __shared__ __attribute__((aligned(16))) double Lp[28][4][64];
     __shared__ __attribute__((aligned(16))) double Sc[TP_WAVES][16][TP_SP];
     __builtin_amdgcn_s_setprio(2);        // (on the chain, sharing CUs with the main stream's update: see gemm.hip)
@@ -975,7 +984,7 @@ __global__ __launch_bounds__(64 * TP_WAVES, 2) void trsm_panel_kernel(int64_t m,
 }
 
 int launch_trsm_panel(hipStream_t st, int64_t m, const double *L, int64_t ldl, const double *invd, double *B,
-                      int64_t ldb, hipEvent_t done, EdgeSig edge)
+                      int64_t ldb, hipEvent_t done, EdgeSig edge, int64_t nbatch, int64_t bstride_a, int64_t bstride_ws)
 {
     gpt_jitter(st);
     if (m <= 0) {
@@ -994,9 +1003,10 @@ int launch_trsm_panel(hipStream_t st, int64_t m, const double *L, int64_t ldl, c
     const unsigned grid = (unsigned)((nwave + TP_WAVES - 1) / TP_WAVES);
     // `done` rides on the kernel's own completion signal (hipExtLaunchKernelGGL stop event): a separate
     // hipEventRecord would put a barrier packet -- ~6 us of command-processor time -- on the panel chain
-    if (done) hipExtLaunchKernelGGL(trsm_panel_kernel, dim3(grid), dim3(64 * TP_WAVES), 0, st, nullptr, done, 0, m, L, ldl, invd, B, ldb,
-                                    edge.word, edge.value);
-    else hipLaunchKernelGGL(trsm_panel_kernel, dim3(grid), dim3(64 * TP_WAVES), 0, st, m, L, ldl, invd, B, ldb, edge.word, edge.value);
+    if (done) hipExtLaunchKernelGGL(trsm_panel_kernel, dim3(grid, (unsigned)nbatch), dim3(64 * TP_WAVES), 0, st, nullptr, done, 0, m, L, ldl,
+                                    invd, B, ldb, edge.word, edge.value, bstride_a, bstride_ws);
+    else hipLaunchKernelGGL(trsm_panel_kernel, dim3(grid, (unsigned)nbatch), dim3(64 * TP_WAVES), 0, st, m, L, ldl, invd, B, ldb, edge.word,
+                            edge.value, bstride_a, bstride_ws);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }

@@ -231,6 +231,103 @@ int launch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_t n, c
     return GPT_OK;
 }
 
+// ---- batched small fits (gpt_fit_batch): one matrix per batch element, bstride elements apart -------------------------------
+// Padding rows + augmented row of every element (as fill_pad_kernel), y read from the pinned host buffer h_y (nbatch x n_valid),
+// and the elements' info words cleared.  blockIdx.z = element.
+__global__ void batch_pad_kernel(const double *__restrict__ h_y, double *__restrict__ A, int64_t lda, int64_t bstride,
+                                 int64_t n_valid, int64_t n_pad, double big, int32_t *__restrict__ info)
+{
+    const int64_t b = blockIdx.z;
+    const int64_t row = n_valid + blockIdx.y;
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) info[b] = 0;
+    if (row >= n_pad || col >= n_pad) return;
+    double v = 0.0;
+    if (row == n_valid) {
+        if (col < n_valid) v = h_y[b * n_valid + col];
+        else if (col == row) v = big;
+    } else if (col == row) {
+        v = 1.0;
+    }
+    A[b * bstride + row * lda + col] = v;
+}
+
+int launch_batch_pad(hipStream_t st, const double *h_y, int64_t nbatch, double *A, int64_t lda, int64_t bstride, int64_t n_valid,
+                     int64_t n_pad, double big, int32_t *info)
+{
+    if (n_pad <= n_valid || nbatch <= 0) return GPT_OK;
+    dim3 grid((unsigned)((n_pad + 255) / 256), (unsigned)(n_pad - n_valid), (unsigned)nbatch);
+    hipLaunchKernelGGL(batch_pad_kernel, grid, dim3(256), 0, st, h_y, A, lda, bstride, n_valid, n_pad, big, info);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
+// The two ll scalars + info of every element: out[4 b + {0, 1, 2}].  One workgroup per element walks the LD_WGS partial sums
+// of logdet_dot_kernel one after another, each formed by the same threads in the same order and reduced by the same tree, so
+// an element's scalars carry the very bits a single gpt_fit of it returns.
+__global__ __launch_bounds__(256) void batch_logdet_dot_kernel(const double *__restrict__ A, int64_t lda, int64_t bstride,
+                                                               int64_t n, const int32_t *__restrict__ info,
+                                                               double *__restrict__ out)
+{
+    __shared__ double s0[4], s1[4], p0[LD_WGS], p1[LD_WGS];
+    const double *Ab = A + (int64_t)blockIdx.x * bstride;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int vw = 0; vw < LD_WGS; vw++) {
+        double a = 0.0, b = 0.0;
+        for (int64_t i0 = (int64_t)vw * 256 + threadIdx.x; i0 < n; i0 += 4 * 256 * LD_WGS) {
+            double dg[4], zz[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int64_t i = i0 + (int64_t)q * 256 * LD_WGS;
+                dg[q] = (i < n) ? Ab[i * lda + i] : 1.0;
+                zz[q] = (i < n) ? Ab[n * lda + i] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                a += log(dg[q]);
+                b = fma(zz[q], zz[q], b);
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_down(a, off);
+            b += __shfl_down(b, off);
+        }
+        if (lane == 0) {
+            s0[wave] = a;
+            s1[wave] = b;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            p0[vw] = ((s0[0] + s0[1]) + s0[2]) + s0[3];
+            p1[vw] = ((s1[0] + s1[1]) + s1[2]) + s1[3];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 64) {
+        const unsigned w = threadIdx.x;
+        double ta = (w < LD_WGS) ? p0[w] : 0.0, tb = (w < LD_WGS) ? p1[w] : 0.0;
+        for (int off = 32; off > 0; off >>= 1) {
+            ta += __shfl_down(ta, off);
+            tb += __shfl_down(tb, off);
+        }
+        if (w == 0) {
+            double *o = out + 4 * (int64_t)blockIdx.x;
+            __hip_atomic_store(o + 0, ta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(o + 1, tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(o + 2, (double)info[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+int launch_batch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_t bstride, int64_t n, int64_t nbatch,
+                            const int32_t *d_info, double *out3)
+{
+    if (nbatch <= 0) return GPT_OK;
+    hipLaunchKernelGGL(batch_logdet_dot_kernel, dim3((unsigned)nbatch), dim3(256), 0, st, A, lda, bstride, n, d_info, out3);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
 __global__ void extract_lower_kernel(const double *__restrict__ A, int64_t lda, int64_t n,
                                      double *__restrict__ out, int64_t ldo)
 {

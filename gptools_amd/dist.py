@@ -287,7 +287,7 @@ class DistributedLML(object):
         # (N=32768, 8 ranks replayed on one GPU: 3.0 ms from first to last chunk of an early panel, against
         # ~0.8 ms when it has the chip).  Pointless with one or two ranks (the owner is always the same / every
         # other step), on by default from three.
-        self.owner_first = (self.world > 2) if owner_first is None else bool(owner_first)
+        self.owner_first = (self.world > 2) if owner_first is None else (owner_first if owner_first == "head" else bool(owner_first))
         # inv_trsm: the rows of a panel below its head chunk (pipelined) / diagonal block (bcast) are solved as ONE GEMM against the
         # explicit inverse of the factored diagonal block (computed once per panel, off the chain) instead of by
         # substitution in four 128-column leaves: twice the flops at several times the rate for tall chunks.
@@ -708,7 +708,11 @@ class DistributedLML(object):
                 produce(k + 1)
             with ops.queue("main"):
                 if self.owner_first and k + 1 < nblk and owner(k + 1):
-                    arrivals[k + 1][-1].ev.wait()          # own panel first (see __init__)
+                    # own panel first (see __init__): all of it, or ("head") only the chunks on the chain -- the head and
+                    # block 2, which the next owner's head needs; the bulk below them is then produced beside this rank's
+                    # own trailing update (it is needed by the main queues, which lag the chain while updates dominate)
+                    own = arrivals[k + 1]
+                    own[min(1, len(own) - 1) if self.owner_first == "head" else -1].ev.wait()
                 for a in arrivals.pop(k):
                     a.wait()
                 self._mark(k, "arrived")

@@ -546,6 +546,11 @@ class GaussianProcess(object):
     #: 211 evaluations/s against 164 at N=8192 and 811 against 476 at N=4096; more than 2 lose again (the
     #: diagonal-block kernels compete for the CUs reserved for them).
     batch_concurrency = 2
+    #: at most this many points: ll_batch (hence compute_ll_matrix, the finite-difference gradients of
+    #: optimize_hyperparameters) evaluates ``batch_grid`` hyperparameter vectors per launch sequence (gpt_fit_batch) instead
+    #: of one per context and host thread; measured on MI355X at N = 1024: see DESIGN.md section 7.2
+    batch_grid_max_n = 2048
+    batch_grid = 64
 
     def _batch_contexts(self, count):
         self._ctx                                            # creates the pool together with the main context
@@ -618,6 +623,33 @@ class GaussianProcess(object):
             self._upload_data(self._ctx)
             self._data_on_device = True
         version = getattr(self, "_data_version", 0)
+        if (self.T is None and len(self.y) <= self.batch_grid_max_n and int(self.batch_grid) > 1 and jobs
+                and all(len(j[1]) == 1 for j in jobs)):
+            # small N: the whole batch in ONE launch sequence (gpt_fit_batch: every kernel of the factorisation carries the
+            # batch in a grid dimension), batch_grid evaluations at a time; bit-identical to one gpt_fit per vector
+            kid = jobs[0][1][0][0]
+            err_y = np.asarray(self.err_y, dtype=float)
+            self._cache = {}
+            G = int(self.batch_grid)
+            for s0 in range(0, len(jobs), G):
+                chunk = jobs[s0:s0 + G]
+                try:
+                    ll, _, info = self._ctx.fit_batch(kid, np.array([j[1][0][1] for j in chunk]),
+                                                      np.array([j[3] for j in chunk]), np.array([j[4] for j in chunk]),
+                                                      err_y, diag_add)
+                except (ValueError, ArithmeticError):
+                    # an argument the library rejects for one element (e.g. a kernel parameter out of its domain) fails the
+                    # whole call: that chunk one vector at a time, with the +inf policy of update_hyperparameters
+                    ll, info = np.zeros(len(chunk)), np.ones(len(chunk), dtype=int)
+                    for q, j in enumerate(chunk):
+                        try:
+                            ll[q], info[q] = self._device_fit(self._ctx, j[1], j[3], j[4], diag_add)[0], 0
+                        except (np.linalg.LinAlgError, ValueError, ArithmeticError):
+                            pass
+                for j, l, bad in zip(chunk, ll, info):
+                    if bad == 0:
+                        out[j[0]] = l + j[5]
+            return out
         ctxs = [[self._ctx, version]] + self._batch_contexts(B)
         for c in ctxs[1:]:
             if c[1] != version:                                      # data added since this context last saw it

@@ -170,6 +170,18 @@ int gpt_fit_sum(gpt_ctx *ctx, int nterms, const int *kernel_ids, const double *p
                 double noise_var, const double *y, const double *err_y, double diag_add, double *ll_data_out,
                 double *logdet_half_out);
 
+/* nbatch INDEPENDENT evaluations of the resident data set in one launch sequence: element b uses params[b * nparams ..],
+ * noise_var[b] and the target y[b * N ..] (the mean function may depend on the hyperparameters); err_y (N) is shared.
+ * Replaces the loops over hyperparameter vectors of the reference's likelihood grid and random starts
+ * (ref: gaussian_process.py:1607-1692, :723-735, gp_utils.py:98-115) at the sizes those run at: N <= 2048 resident
+ * points, one native kernel, no transform (GPT_E_ARG otherwise: the caller falls back to one gpt_fit per vector).
+ * Every kernel of the factorisation carries the batch in a grid dimension; an element's results are bit-identical to
+ * gpt_fit's for the same inputs.  info_out[b] = 0, or the LAPACK index of the leading minor that is not positive
+ * definite (ll_data_out[b] is then meaningless); the call itself returns GPT_OK in both cases. */
+int gpt_fit_batch(gpt_ctx *ctx, int nbatch, int kernel_id, const double *params, int nparams,
+                  const double *noise_var, const double *y, const double *err_y, double diag_add,
+                  double *ll_data_out, double *logdet_half_out, int32_t *info_out);
+
 /* Same as gpt_fit but for an explicit, caller-assembled symmetric K_tot (host, (N, N) row-major;
  * only the lower triangle is read): used for the `T` (linear transform) branch,
  * ref: gaussian_process.py:1443-1446, where K_tot = T (K + noise_K) T^T + ... is (N_y, N_y). */

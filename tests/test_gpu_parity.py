@@ -1424,3 +1424,37 @@ def test_device_ll_gradient_with_transform_mixed_sum_and_block_inverses(g, case)
             # WITHOUT the transform (ref :1482-1488) although K_tot holds T (sigma_n^2 I) T^T -- reproduced (drop-in), so that
             # entry follows the reference's formula (checked against the host path above), not the function's slope
             np.testing.assert_allclose(-grad[:3], fd[:3], rtol=5e-5, atol=1e-4 * np.abs(fd[:3]).max())
+
+
+@pytest.mark.parametrize("kern,N,d,deriv", [("m52", 700, 3, True), ("se", 1100, 2, False), ("se", 130, 1, False)])
+def test_fit_batch_is_bit_identical_to_single_fits(kern, N, d, deriv):
+    """gpt_fit_batch (every kernel of the small-N factorisation carries the batch in a grid dimension; SURVEY 8f-2, ref
+    gaussian_process.py:1607-1692 / :723-735) against one gpt_fit per hyperparameter vector: ll and log-determinant
+    bit for bit (same kernels, same tile choice, same summation orders), per-element targets and noise variances, an element
+    that is not positive definite reported through info without disturbing the others."""
+    from gptools_amd import _lib
+    X, n, y = c3_inputs(N, d)
+    if not deriv:
+        n[:] = 0
+    err = np.full(N, 0.05)
+    rs = np.random.RandomState(N)
+    B = 23
+    P = np.column_stack([0.5 + rs.rand(B)] + [0.1 + 0.6 * rs.rand(B) for _ in range(d)])
+    nv = 0.01 * rs.rand(B)
+    Y = y[None, :] + 0.01 * rs.randn(B, N)
+    nv[5] = -10.0                                     # K + noise_var I is not positive definite
+    c = _lib.Context(0)
+    c.set_data(X, n)
+    ll, ld, info = c.fit_batch(KID[kern], P, nv, Y, err, 1e2 * EPS)
+    assert info[5] > 0 and (np.delete(info, 5) == 0).all()
+    for b in range(B):
+        if b == 5:
+            with pytest.raises(np.linalg.LinAlgError):
+                c.fit(KID[kern], P[b], nv[b], Y[b], err, 1e2 * EPS)
+            continue
+        l1, d1 = c.fit(KID[kern], P[b], nv[b], Y[b], err, 1e2 * EPS)
+        assert (l1, d1) == (ll[b], ld[b]), (b, l1 - ll[b], d1 - ld[b])
+    # a second batch of another size on the same context, after single fits
+    ll2, ld2, info2 = c.fit_batch(KID[kern], P[:3], nv[:3], Y[:3], err, 1e2 * EPS)
+    assert np.array_equal(ll2, ll[:3]) and np.array_equal(ld2, ld[:3]) and not info2.any()
+    c.close()
