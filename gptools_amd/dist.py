@@ -594,6 +594,7 @@ class DistributedLML(object):
                     self._accumulate_scalars()
         return self._finish(t_host0)
 
+
     # ------------------------------------------------------------------------------------------
     def _chunk_bounds(self, k):
         """Panel-local block rows at which panel k is cut: [0, 2, 8, 32, ..., blocks of panel k] (``chunk_blocks``);

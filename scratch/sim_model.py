@@ -145,6 +145,15 @@ for it in range(iters):
         it, " ".join("%.1f" % e for e in ends), max(ends), delta), flush=True)
     if it >= 2 and delta < 0.15:
         break
+if os.environ.get("SIM_DUMP"):
+    # the converged chain: per panel, when each chunk was produced by its owner and when it arrived (ms from the start)
+    allprod = {}
+    for r, p in enumerate(plans):
+        for key, (e, nb_) in p.produced.items():
+            allprod[key] = (p.t0_ev.elapsed_time(e), nb_)
+    for k in range(0, nblk, int(os.environ.get("SIM_DUMP"))):
+        row = sorted((lo, tp, arrive[(kk, lo)], nb_) for (kk, lo), (tp, nb_) in allprod.items() if kk == k)
+        print("panel %2d (owner %d): " % (k, k % W) + "  ".join("[%d: prod %.2f arr %.2f %dMB]" % (lo // NB, tp, ta, nb_ >> 20) for lo, tp, ta, nb_ in row))
 T = hist[-1][0]
 print("MODEL %s N=%d W=%d schedule=%s exchange=%s latency=%.0fus bw=%.0fGB/s chunks=%s owner_first=%s nb=%d: %.1f ms -> %.1f TFLOP/s = %.1f %% of %d x 78.6" % (
     wl, N, W, sched, exch, lat * 1e3, BW * 1e-9, ",".join(map(str, chunks)), ofirst, NB, T, bench.flops_fit(N) / T * 1e-9,

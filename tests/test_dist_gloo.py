@@ -139,6 +139,7 @@ _WHOLE_SAG = {"schedule": "bcast", "exchange": "scatter_gather", "sag_min_bytes"
 _PIPE = {"schedule": "pipelined"}                                                  # chunks cut at 2, 8, 32 blocks
 _PIPE_SUBST = {"schedule": "pipelined", "inv_trsm": False}                         # tail chunks by substitution
 _PIPE_FINE = {"schedule": "pipelined", "chunk_blocks": (2, 3, 5), "exchange": "scatter_gather", "sag_min_bytes": 0}
+_PIPE_HEAD = {"schedule": "pipelined", "chunk_blocks": (2, 3), "owner_first": "head"}    # owner waits for its head only
 
 
 @pytest.mark.parametrize("world,N,d,nb,kid,lookahead,plan_kw", [
@@ -156,6 +157,7 @@ _PIPE_FINE = {"schedule": "pipelined", "chunk_blocks": (2, 3, 5), "exchange": "s
     (4, 900, 2, 128, 0, True, _PIPE_FINE),  # more ranks than panel buffers minus one
     (8, 1900, 2, 128, 0, True, _PIPE),      # the world size of the 8-GPU node: 15 block columns, owner_first on
     (8, 1900, 2, 128, 0, True, _WHOLE_INV),
+    (3, 1500, 2, 128, 0, True, _PIPE_HEAD),
 ])
 def test_distributed_fit_matches_single_process_oracle(world, N, d, nb, kid, lookahead, plan_kw):
     from oracle import oracle as O
