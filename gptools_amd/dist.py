@@ -165,9 +165,8 @@ class HipPanelOps(PanelOps):
         return _StreamEvent(timing=True)
 
     def synchronize(self):
-        self.main_stream.synchronize()
-        self.panel_stream.synchronize()
-        self.recv_stream.synchronize()
+        for st in self._stream.values():
+            st.synchronize()
 
     def kbuild_block(self, kernel_id, params, X, n, r0, r1, c0, c1, err_y, noise_var, diag_add, out, ld):
         """out[(i - r0) * ld + (j - c0)] = K_tot[i][j] for i in [r0, r1), j in [c0, c1) (global indices)."""
@@ -184,13 +183,13 @@ class HipPanelOps(PanelOps):
         _lib.check(self.lib.gpt_dev_potrf_panel(self.ctx_panel.handle, m, nb, A, lda, invd.data_ptr(),
                                                 info.data_ptr(), info_base))
 
-    def trsm_rlt(self, m, nb, L, ldl, invd, B, ldb):
-        """B (m x nb) <- B L^-T on the panel queue, L the factored diagonal block of the same panel."""
-        _lib.check(self.lib.gpt_dev_trsm_rlt(self.ctx_panel.handle, m, nb, L, ldl, invd.data_ptr(), B, ldb))
+    def trsm_rlt(self, m, nb, L, ldl, invd, B, ldb, q="panel"):
+        """B (m x nb) <- B L^-T on queue ``q``, L the factored diagonal block of the same panel."""
+        _lib.check(self.lib.gpt_dev_trsm_rlt(self._ctx[q].handle, m, nb, L, ldl, invd.data_ptr(), B, ldb))
 
-    def trinv(self, nb, L, ldl, invd, W, ldw):
-        """W (nb x nb) <- L^-1 on the panel queue (gpt_dev_trinv): the TRSM of a tall chunk then is one GEMM."""
-        _lib.check(self.lib.gpt_dev_trinv(self.ctx_panel.handle, nb, L, ldl, invd.data_ptr(), W, ldw))
+    def trinv(self, nb, L, ldl, invd, W, ldw, q="panel"):
+        """W (nb x nb) <- L^-1 on queue ``q`` (gpt_dev_trinv): the TRSM of a tall chunk then is one GEMM."""
+        _lib.check(self.lib.gpt_dev_trinv(self._ctx[q].handle, nb, L, ldl, invd.data_ptr(), W, ldw))
 
     def gemm_nt(self, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, q="main"):
         _lib.check(self.lib.gpt_dev_gemm_nt(self._ctx[q].handle, m, n, k, float(alpha), A, lda, B, ldb, float(beta),

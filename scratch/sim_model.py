@@ -145,6 +145,22 @@ for it in range(iters):
         it, " ".join("%.1f" % e for e in ends), max(ends), delta), flush=True)
     if it >= 2 and delta < 0.15:
         break
+if os.environ.get("SIM_TRACE"):
+    # one more replay of one rank with its main-queue marks: when panel i had arrived on the main queue, when its update was done
+    r = int(os.environ["SIM_TRACE"])
+    p = plans[r]
+    p.trace = True
+    p.arrive, p.produced = arrive, {}
+    p.fit(kid, params, y, err)
+    torch.cuda.synchronize()
+    st = p.timings.get("steps_ms", [])
+    arr_ = {k: t for k, tag, t in st if tag == "arrived"}
+    app_ = {k: t for k, tag, t in st if tag == "applied"}
+    off = p._t0.elapsed_ms(_StreamEvent.__new__(_StreamEvent)) if False else 0.0
+    heads = {k: min(t for (kk, lo), t in arrive.items() if kk == k) for k in range(nblk)}
+    print("rank %d main queue: step: head arrival (model) | all chunks arrived on main | update done   (ms)" % r)
+    for k in sorted(arr_):
+        print("  %2d%s: %7.2f | %7.2f | %7.2f" % (k, "*" if k % W == r else " ", heads.get(k, 0.0), arr_[k], app_.get(k, 0.0)))
 if os.environ.get("SIM_DUMP"):
     # the converged chain: per panel, when each chunk was produced by its owner and when it arrived (ms from the start)
     allprod = {}

@@ -63,12 +63,12 @@ class _NumpyDense(object):
         if m > nb:
             P[nb:] = scipy.linalg.solve_triangular(L, P[nb:].T, lower=True).T
 
-    def trsm_rlt(self, m, nb, L, ldl, invd, B, ldb):
+    def trsm_rlt(self, m, nb, L, ldl, invd, B, ldb, q="panel"):
         import scipy.linalg
         Lv, Bv = np.tril(_view(L, nb, nb, ldl)), _view(B, m, nb, ldb)
         Bv[:, :] = scipy.linalg.solve_triangular(Lv, Bv.T.copy(), lower=True).T
 
-    def trinv(self, nb, L, ldl, invd, W, ldw):
+    def trinv(self, nb, L, ldl, invd, W, ldw, q="panel"):
         import scipy.linalg
         _view(W, nb, nb, ldw)[:, :] = scipy.linalg.solve_triangular(np.tril(_view(L, nb, nb, ldl)), np.eye(nb), lower=True)
 
