@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libgpt_hip.so")
 
 GPT_OK = 0
 GPT_E_ARG, GPT_E_VALUE, GPT_E_NOTIMPL, GPT_E_HIP, GPT_E_NOMEM, GPT_E_STATE = -1, -2, -3, -4, -5, -6
-KERNEL_SE, KERNEL_M52, KERNEL_DIAGNOISE, KERNEL_ZERO, KERNEL_RQ, KERNEL_MATERN = 0, 1, 2, 3, 4, 5
+KERNEL_SE, KERNEL_M52, KERNEL_DIAGNOISE, KERNEL_ZERO, KERNEL_RQ, KERNEL_MATERN, KERNEL_PRODUCT = 0, 1, 2, 3, 4, 5, 6
 MAX_DIM = 16
 
 _dp = C.POINTER(C.c_double)
@@ -36,6 +36,9 @@ SIGNATURES = {
     "gpt_concurrency_hint": (C.c_int, [C.c_int]),
     "gpt_kpairs": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, _dp, _ip, _ip, _i64, C.c_int, C.c_int, C.c_int, _ip, _dp]),
     "gpt_kbuild": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, _ip, _i64, _dp, _ip, _i64, C.c_int, C.c_int, _ip, _dp]),
+    "gpt_kpairs2": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, _ip, _ip, _i64, C.c_int, _dp]),
+    "gpt_kbuild2": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_int, _dp, C.c_int, _dp, _ip, _i64, _dp, _ip, _i64, C.c_int, _dp]),
+    "gpt_fit_terms": (C.c_int, [_vp, C.c_int, _ip, _ip, _dp, _ip, _ip, C.c_double, _dp, _dp, C.c_double, _dp, _dp]),
     "gpt_set_data": (C.c_int, [_vp, _dp, _ip, _i64, C.c_int]),
     "gpt_set_T": (C.c_int, [_vp, _dp, _i64]),
     "gpt_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, C.c_double, _dp, _dp]),
@@ -283,6 +286,47 @@ class Context(object):
                                    dptr(Xj_), iptr(nj_), P, D, -1 if hyper_deriv is None else int(hyper_deriv),
                                    iptr(nn), dptr(out)))
         return out
+
+    def kpairs2(self, kid1, params1, kid2, params2, Xi, Xj, ni, nj):
+        """Pair list of the product of two native kernels (gpt_kpairs2)."""
+        p1, p2, Xi, Xj, ni, nj = f64(params1), f64(params2), f64(Xi), f64(Xj), i32(ni), i32(nj)
+        if Xi.ndim != 2 or Xi.shape != Xj.shape or ni.shape != Xi.shape or nj.shape != Xi.shape:
+            raise ValueError("Lengths/widths of Xi, Xj, ni, nj don't match")
+        M, D = Xi.shape
+        out = np.empty(M, dtype=np.float64)
+        check(self._lib.gpt_kpairs2(self.handle, kid1, dptr(p1), len(p1), kid2, dptr(p2), len(p2), dptr(Xi), dptr(Xj),
+                                    iptr(ni), iptr(nj), M, D, dptr(out)))
+        return out
+
+    def kbuild2(self, kid1, params1, kid2, params2, Xi, ni, Xj=None, nj=None):
+        """Covariance matrix of the product of two native kernels (gpt_kbuild2)."""
+        p1, p2, Xi, ni = f64(params1), f64(params2), f64(Xi), i32(ni)
+        M, D = Xi.shape
+        if Xj is None:
+            Xj_, nj_, P = None, None, M
+        else:
+            Xj_, nj_ = f64(Xj), i32(nj)
+            P = Xj_.shape[0]
+        out = np.empty((M, P), dtype=np.float64)
+        check(self._lib.gpt_kbuild2(self.handle, kid1, dptr(p1), len(p1), kid2, dptr(p2), len(p2), dptr(Xi), iptr(ni), M,
+                                    dptr(Xj_), iptr(nj_), P, D, dptr(out)))
+        return out
+
+    def fit_terms(self, terms, noise_var, y, err_y, diag_add):
+        """gpt_fit_terms: ``terms`` is a list of ``(kernel_id, params)`` or ``(kernel_id1, params1, kernel_id2, params2)``
+        (a product term)."""
+        ids = i32(np.asarray([t[0] for t in terms]))
+        ids2 = i32(np.asarray([t[2] if len(t) == 4 else -1 for t in terms]))
+        npar1 = i32(np.asarray([len(t[1]) for t in terms]))
+        npar = i32(np.asarray([len(t[1]) + (len(t[3]) if len(t) == 4 else 0) for t in terms]))
+        flat = f64(np.concatenate([np.concatenate([np.asarray(t[1], dtype=float)] +
+                                                  ([np.asarray(t[3], dtype=float)] if len(t) == 4 else [])) for t in terms]))
+        y, err_y = f64(y), f64(err_y)
+        ll = C.c_double()
+        ld = C.c_double()
+        check(self._lib.gpt_fit_terms(self.handle, len(ids), iptr(ids), iptr(ids2), dptr(flat), iptr(npar), iptr(npar1),
+                                      float(noise_var), dptr(y), dptr(err_y), float(diag_add), C.byref(ll), C.byref(ld)))
+        return ll.value, ld.value
 
     # ---- fit / state ---------------------------------------------------------------------------
     def set_data(self, X, n):

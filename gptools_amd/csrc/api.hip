@@ -127,6 +127,7 @@ struct gpt_ctx {
     int64_t cov_M = 0;                 // > 0: SLOT_KSS holds the lower triangle of the predictive covariance of the last gpt_predict(want = 2, cov_out = NULL)
     KParams kp;                      // first term (single-kernel paths)
     std::vector<KParams> terms;      // the model kernel as a sum of native kernels (gpt_fit_sum)
+    std::vector<KParams> terms2;     // ... term t is the PRODUCT terms[t] * terms2[t] where terms2[t].kernel_id >= 0 (gpt_fit_terms)
     double timings[5] = {0, 0, 0, 0, 0};
     // per-launch HIP-event timing of the dominant (large) GEMM/SYRK launches, for the roofline line
     int prof_gemm = 0;
@@ -1308,6 +1309,91 @@ extern "C" int gpt_kbuild(gpt_ctx *c, int kernel_id, const double *params, int n
     return GPT_OK;
 }
 
+// Kernel.__call__ / compute_Kij of the product of two native kernels (ProductKernel, ref: kernel/core.py:587-671)
+static int make_product(int kid1, const double *p1, int n1, int kid2, const double *p2, int n2, int D, KParams *k1, KParams *k2)
+{
+    if (!p1 || !p2) return GPT_E_ARG;
+    for (int kid : {kid1, kid2})
+        if (kid != GPT_KERNEL_SE && kid != GPT_KERNEL_M52 && kid != GPT_KERNEL_RQ && kid != GPT_KERNEL_MATERN) {
+            gpt_set_error("product factors must be SE, Matern52, RationalQuadratic or Matern kernels");
+            return GPT_E_ARG;
+        }
+    GPT_TRY(make_kparams(kid1, p1, n1, D, -1, 0, nullptr, k1));
+    GPT_TRY(make_kparams(kid2, p2, n2, D, -1, 0, nullptr, k2));
+    return GPT_OK;
+}
+
+extern "C" int gpt_kpairs2(gpt_ctx *c, int kernel_id1, const double *params1, int nparams1, int kernel_id2,
+                           const double *params2, int nparams2, const double *Xi, const double *Xj, const int32_t *ni,
+                           const int32_t *nj, int64_t M, int D, double *out)
+{
+    CTX_ENTER(c);
+    if (M < 0 || (M > 0 && (!Xi || !Xj || !ni || !nj || !out))) return GPT_E_ARG;
+    KParams k1, k2;
+    GPT_TRY(make_product(kernel_id1, params1, nparams1, kernel_id2, params2, nparams2, D, &k1, &k2));
+    if (kernel_id1 == GPT_KERNEL_M52 || kernel_id2 == GPT_KERNEL_M52) {
+        GPT_TRY(check_m52_orders(ni, M, D));
+        GPT_TRY(check_m52_orders(nj, M, D));
+    }
+    if (M > 0) GPT_TRY(check_rq_orders(ni, M, nj, M, D, true));       // combined order of a pair <= GPT_RQ_MAXORD
+    if (M == 0) return GPT_OK;
+    double *dXi, *dXj, *dout;
+    int32_t *dni, *dnj;
+    const size_t xb = (size_t)M * D * sizeof(double), nb = (size_t)M * D * sizeof(int32_t);
+    GPT_TRY(ensure(c, SLOT_XI, xb, (void **)&dXi));
+    GPT_TRY(ensure(c, SLOT_XJ, xb, (void **)&dXj));
+    GPT_TRY(ensure(c, SLOT_NI, nb, (void **)&dni));
+    GPT_TRY(ensure(c, SLOT_NJ, nb, (void **)&dnj));
+    GPT_TRY(ensure(c, SLOT_OUT, (size_t)M * sizeof(double), (void **)&dout));
+    hipStream_t st = c->stream;
+    GPT_HIP_CHECK(hipMemcpyAsync(dXi, Xi, xb, hipMemcpyHostToDevice, st));
+    GPT_HIP_CHECK(hipMemcpyAsync(dXj, Xj, xb, hipMemcpyHostToDevice, st));
+    GPT_HIP_CHECK(hipMemcpyAsync(dni, ni, nb, hipMemcpyHostToDevice, st));
+    GPT_HIP_CHECK(hipMemcpyAsync(dnj, nj, nb, hipMemcpyHostToDevice, st));
+    GPT_TRY(launch_kpairs(st, k1, dXi, dXj, dni, dnj, M, dout, 0, &k2));
+    GPT_HIP_CHECK(hipMemcpyAsync(out, dout, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, st));
+    GPT_HIP_CHECK(hipStreamSynchronize(st));
+    return GPT_OK;
+}
+
+extern "C" int gpt_kbuild2(gpt_ctx *c, int kernel_id1, const double *params1, int nparams1, int kernel_id2,
+                           const double *params2, int nparams2, const double *Xi, const int32_t *ni, int64_t M,
+                           const double *Xj, const int32_t *nj, int64_t P, int D, double *K_out)
+{
+    CTX_ENTER(c);
+    if (!Xj) {
+        Xj = Xi;
+        nj = ni;
+        P = M;
+    }
+    if (M < 0 || P < 0) return GPT_E_ARG;
+    KParams k1, k2;
+    GPT_TRY(make_product(kernel_id1, params1, nparams1, kernel_id2, params2, nparams2, D, &k1, &k2));
+    if (M == 0 || P == 0) return GPT_OK;
+    if (!Xi || !ni || !Xj || !nj || !K_out) return GPT_E_ARG;
+    if (kernel_id1 == GPT_KERNEL_M52 || kernel_id2 == GPT_KERNEL_M52) {
+        GPT_TRY(check_m52_orders(ni, M, D));
+        GPT_TRY(check_m52_orders(nj, P, D));
+    }
+    GPT_TRY(check_rq_orders(ni, M, nj, P, D, false));
+    double *dXi, *dXj, *dK;
+    int32_t *dni, *dnj;
+    GPT_TRY(ensure(c, SLOT_XI, (size_t)M * D * sizeof(double), (void **)&dXi));
+    GPT_TRY(ensure(c, SLOT_NI, (size_t)M * D * sizeof(int32_t), (void **)&dni));
+    GPT_TRY(ensure(c, SLOT_XJ, (size_t)P * D * sizeof(double), (void **)&dXj));
+    GPT_TRY(ensure(c, SLOT_NJ, (size_t)P * D * sizeof(int32_t), (void **)&dnj));
+    GPT_TRY(ensure(c, SLOT_OUT, (size_t)M * P * sizeof(double), (void **)&dK));
+    hipStream_t st = c->stream;
+    GPT_HIP_CHECK(hipMemcpyAsync(dXi, Xi, (size_t)M * D * sizeof(double), hipMemcpyHostToDevice, st));
+    GPT_HIP_CHECK(hipMemcpyAsync(dni, ni, (size_t)M * D * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    GPT_HIP_CHECK(hipMemcpyAsync(dXj, Xj, (size_t)P * D * sizeof(double), hipMemcpyHostToDevice, st));
+    GPT_HIP_CHECK(hipMemcpyAsync(dnj, nj, (size_t)P * D * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    GPT_TRY(launch_kbuild(st, k1, dXi, dni, M, dXj, dnj, P, 0, 0, 0, nullptr, 0.0, 0.0, dK, P, 0, &k2));
+    GPT_HIP_CHECK(hipMemcpyAsync(K_out, dK, (size_t)M * P * sizeof(double), hipMemcpyDeviceToHost, st));
+    GPT_HIP_CHECK(hipStreamSynchronize(st));
+    return GPT_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // data residency + fit
 // ------------------------------------------------------------------------------------------------
@@ -1469,14 +1555,15 @@ static int kbuild_terms(gpt_ctx *c, hipStream_t st, const std::vector<KParams> &
                         int64_t i0, int64_t j0, const double *d_err, double noise_var, double diag_add, double *dK,
                         int64_t ldk)
 {
-    (void)c;
     for (size_t t = 0; t < terms.size(); t++) {
         KParams kp = terms[t];
         kp.symmetric = symmetric;
         kp.hyper_deriv = -1;
         const bool last = t + 1 == terms.size();
+        // (a product term brings its second factor: c->terms2 runs parallel to c->terms whenever `terms` IS c->terms)
+        const KParams *kp2 = (&terms == &c->terms && t < c->terms2.size() && c->terms2[t].kernel_id >= 0) ? &c->terms2[t] : nullptr;
         GPT_TRY(launch_kbuild(st, kp, dXi, dni, M, dXj, dnj, P, lower_only, i0, j0, last ? d_err : nullptr, noise_var,
-                              diag_add, dK, ldk, t > 0 ? 1 : 0));
+                              diag_add, dK, ldk, t > 0 ? 1 : 0, kp2));
     }
     return GPT_OK;
 }
@@ -1517,6 +1604,52 @@ extern "C" int gpt_fit_sum(gpt_ctx *c, int nterms, const int *kernel_ids, const 
         GPT_TRY(make_kparams(kernel_ids[t], p, nparams[t], c->D, -1, 1, nullptr, &terms[(size_t)t]));
         p += nparams[t];
     }
+    c->terms2.assign(terms.size(), KParams());
+    for (auto &k2 : c->terms2) k2.kernel_id = -1;
+    return fit_terms(c, terms, noise_var, y, err_y, diag_add, ll_data_out, logdet_half_out);
+}
+
+// The same with product terms (include/gpt_hip.h)
+static bool native_fit_kernel(int kid)
+{
+    return kid == GPT_KERNEL_SE || kid == GPT_KERNEL_M52 || kid == GPT_KERNEL_RQ || kid == GPT_KERNEL_MATERN;
+}
+
+extern "C" int gpt_fit_terms(gpt_ctx *c, int nterms, const int *kernel_ids, const int *kernel_ids2, const double *params,
+                             const int *nparams, const int *nparams1, double noise_var, const double *y, const double *err_y,
+                             double diag_add, double *ll_data_out, double *logdet_half_out)
+{
+    CTX_ENTER(c);
+    if (!c->dX) {
+        gpt_set_error("gpt_fit_terms: call gpt_set_data first");
+        return GPT_E_STATE;
+    }
+    if (nterms < 1 || nterms > 8 || !kernel_ids || !kernel_ids2 || !params || !nparams || !nparams1 || !y || !err_y) return GPT_E_ARG;
+    std::vector<KParams> terms((size_t)nterms), terms2((size_t)nterms);
+    const double *p = params;
+    for (int t = 0; t < nterms; t++) {
+        const bool prod = kernel_ids2[t] >= 0;
+        if (!native_fit_kernel(kernel_ids[t]) || (prod && !native_fit_kernel(kernel_ids2[t]))) {
+            gpt_set_error("gpt_fit_terms: kernel ids must be SE, Matern52, RationalQuadratic or Matern");
+            return GPT_E_ARG;
+        }
+        const int n1 = prod ? nparams1[t] : nparams[t];
+        if (n1 < 1 || n1 > nparams[t]) return GPT_E_ARG;
+        // derivative orders: a product meets the SUM of both points' orders in either factor
+        const bool any_chain = kernel_ids[t] == GPT_KERNEL_RQ || kernel_ids[t] == GPT_KERNEL_MATERN ||
+                               (prod && (kernel_ids2[t] == GPT_KERNEL_RQ || kernel_ids2[t] == GPT_KERNEL_MATERN));
+        if ((any_chain || prod) && 2 * c->n_maxsum > GPT_RQ_MAXORD) {
+            gpt_set_error("derivative orders of a pair sum to %ld, the device builder supports %d for products and the "
+                          "RationalQuadratic / Matern kernels", 2 * c->n_maxsum, GPT_RQ_MAXORD);
+            return GPT_E_VALUE;
+        }
+        GPT_TRY(make_kparams(kernel_ids[t], p, n1, c->D, -1, 1, nullptr, &terms[(size_t)t]));
+        terms2[(size_t)t] = KParams();
+        terms2[(size_t)t].kernel_id = -1;
+        if (prod) GPT_TRY(make_kparams(kernel_ids2[t], p + n1, nparams[t] - n1, c->D, -1, 1, nullptr, &terms2[(size_t)t]));
+        p += nparams[t];
+    }
+    c->terms2 = terms2;
     return fit_terms(c, terms, noise_var, y, err_y, diag_add, ll_data_out, logdet_half_out);
 }
 
@@ -1587,7 +1720,7 @@ static int fit_terms_once(gpt_ctx *c, const std::vector<KParams> &terms, double 
         GPT_HIP_CHECK(hipMemsetAsync(dzero, 0, (size_t)Nx * sizeof(double), st));
         if (NxP > Nx) GPT_HIP_CHECK(hipMemsetAsync(dK, 0, (size_t)NxP * NxP * sizeof(double), st));   // zero padding of k
         // (K + noise_K): the builder's diagonal epilogue with err = 0, diag_add = 0 adds exactly noise_var
-        GPT_TRY(kbuild_terms(c, st, terms, 1, c->dX, c->dn, Nx, c->dX, c->dn, Nx, 0, 0, 0, dzero, noise_var, 0.0, dK, NxP));
+        GPT_TRY(kbuild_terms(c, st, c->terms, 1, c->dX, c->dn, Nx, c->dX, c->dn, Nx, 0, 0, 0, dzero, noise_var, 0.0, dK, NxP));
         GPT_TRY(gemm_nt(c, st, NyP, NxP, NxP, 1.0, c->dT, NxP, dK, NxP, 0.0, dTK, NxP, 0));          // T K  (K = K^T)
         GPT_TRY(gemm_nt(c, st, NyP, NyP, NxP, 1.0, dTK, NxP, c->dT, NxP, 0.0, c->dA, NP, 1));        // (T K) T^T, lower
         GPT_TRY(launch_add_diag(st, c->dA, NP, N, c->d_erry, diag_add));
@@ -1609,7 +1742,7 @@ static int fit_terms_once(gpt_ctx *c, const std::vector<KParams> &terms, double 
     c->head_wait = EdgeSig();
     const bool head_flag = c->flags_now && c->edge_seq < 0xf0000000u;
     if (c->lookahead && !c->use_graph && head < N && (head_flag || (e_head = get_event(c, 0)) != nullptr)) {
-        GPT_TRY(kbuild_terms(c, st, terms, 1, c->dX, c->dn, N, c->dX, c->dn, head, 1, 0, 0, c->d_erry, noise_var, diag_add,
+        GPT_TRY(kbuild_terms(c, st, c->terms, 1, c->dX, c->dn, N, c->dX, c->dn, head, 1, 0, 0, c->d_erry, noise_var, diag_add,
                              c->dA, NP));
         if (head_flag) {
             // "the head columns are built" as a flag word raised from this stream (a one-thread kernel behind the build);
@@ -1625,11 +1758,11 @@ static int fit_terms_once(gpt_ctx *c, const std::vector<KParams> &terms, double 
         } else {
             GPT_HIP_CHECK(hipEventRecord(e_head, st));
         }
-        GPT_TRY(kbuild_terms(c, st, terms, 1, c->dX + head * c->D, c->dn + head * c->D, N - head, c->dX + head * c->D,
+        GPT_TRY(kbuild_terms(c, st, c->terms, 1, c->dX + head * c->D, c->dn + head * c->D, N - head, c->dX + head * c->D,
                              c->dn + head * c->D, N - head, 1, head, head, c->d_erry, noise_var, diag_add,
                              c->dA + head * NP + head, NP));
     } else {
-        GPT_TRY(kbuild_terms(c, st, terms, 1, c->dX, c->dn, N, c->dX, c->dn, N, 1, 0, 0, c->d_erry, noise_var, diag_add,
+        GPT_TRY(kbuild_terms(c, st, c->terms, 1, c->dX, c->dn, N, c->dX, c->dn, N, 1, 0, 0, c->d_erry, noise_var, diag_add,
                              c->dA, NP));
     }
     c->have_kernel = true;
@@ -2004,7 +2137,8 @@ extern "C" int gpt_ll_grad(gpt_ctx *c, int nh, const int *term_idx, const int *l
     for (int h = 0; h < nh; h++) {
         if (term_idx[h] < 0 || term_idx[h] >= (int)c->terms.size()) return GPT_E_ARG;
         const KParams &t = c->terms[(size_t)term_idx[h]];
-        if (t.kernel_id != GPT_KERNEL_SE) {
+        const bool is_prod = (size_t)term_idx[h] < c->terms2.size() && c->terms2[(size_t)term_idx[h]].kernel_id >= 0;
+        if (t.kernel_id != GPT_KERNEL_SE || is_prod) {
             gpt_set_error("hyper-parameter derivatives exist for the squared-exponential kernel only "
                           "(ref: matern.py:543-544)");
             return GPT_E_NOTIMPL;
@@ -2366,13 +2500,20 @@ extern "C" int gpt_predict(gpt_ctx *c, const double *Xstar, const int32_t *nstar
     const int D = c->D;
     const int64_t N = c->N, n128 = round_up(N, 128), MP = round_up(M, 64);
     const int64_t Nx = c->Nx;
-    for (const auto &t : c->terms)
+    std::vector<KParams> all_factors(c->terms);
+    bool any_product = false;
+    for (const auto &t2 : c->terms2)
+        if (t2.kernel_id >= 0) {
+            all_factors.push_back(t2);
+            any_product = true;
+        }
+    for (const auto &t : all_factors)
         if (t.kernel_id == GPT_KERNEL_M52) {
             GPT_TRY(check_m52_orders(nstar, M, D));
             break;
         }
-    for (const auto &t : c->terms)
-        if (t.kernel_id == GPT_KERNEL_RQ || t.kernel_id == GPT_KERNEL_MATERN) {
+    for (const auto &t : all_factors)
+        if (t.kernel_id == GPT_KERNEL_RQ || t.kernel_id == GPT_KERNEL_MATERN || any_product) {
             long ms = 0;
             for (int64_t i = 0; i < M; i++) {
                 long sn = 0;
@@ -2423,7 +2564,8 @@ extern "C" int gpt_predict(gpt_ctx *c, const double *Xstar, const int32_t *nstar
                 KParams ks = c->terms[t];
                 ks.symmetric = 1;
                 ks.hyper_deriv = -1;
-                GPT_TRY(launch_kpairs(st, ks, dXs, dXs, dns, dns, M, dkd, t > 0 ? 1 : 0));
+                GPT_TRY(launch_kpairs(st, ks, dXs, dXs, dns, dns, M, dkd, t > 0 ? 1 : 0,
+                                      (t < c->terms2.size() && c->terms2[t].kernel_id >= 0) ? &c->terms2[t] : nullptr));
             }
             GPT_TRY(launch_rowsumsq_sub(st, M, n128, dV, n128, dkd, dvar));
             GPT_HIP_CHECK(hipMemcpyAsync(std_out, dvar, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, st));

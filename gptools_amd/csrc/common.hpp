@@ -126,11 +126,17 @@ __device__ __forceinline__ void edge_poll(const unsigned *word, unsigned value, 
 
 // ---- launchers implemented in the .hip files (all asynchronous on `st`) -------------------
 int launch_kpairs(hipStream_t st, const KParams &kp, const double *dXi, const double *dXj,
-                  const int32_t *dni, const int32_t *dnj, int64_t M, double *dout, int accumulate = 0);
+                  const int32_t *dni, const int32_t *dnj, int64_t M, double *dout, int accumulate = 0,
+                  const KParams *kp2 = nullptr);      // kp2 (kernel_id >= 0): the pair list of the product kp * kp2
 int launch_kbuild(hipStream_t st, const KParams &kp, const double *dXi, const int32_t *dni, int64_t M,
                   const double *dXj, const int32_t *dnj, int64_t P, int lower_only, int64_t i0, int64_t j0,
                   const double *d_err_y, double noise_var, double diag_add, double *dK, int64_t ldk,
-                  int accumulate = 0);
+                  int accumulate = 0, const KParams *kp2 = nullptr);
+int launch_kbuild_prod(hipStream_t st, const KParams &kp1, const KParams &kp2, const double *dXi, const int32_t *dni, int64_t M,
+                       const double *dXj, const int32_t *dnj, int64_t P, int lower_only, int64_t i0, int64_t j0,
+                       const double *d_err_y, double noise_var, double diag_add, double *dK, int64_t ldk, int accumulate);
+int launch_kpairs_prod(hipStream_t st, const KParams &kp1, const KParams &kp2, const double *dXi, const double *dXj,
+                       const int32_t *dni, const int32_t *dnj, int64_t M, double *dout, int accumulate);
 int launch_check_orders(hipStream_t st, const int32_t *dn, int64_t M, int D, int32_t *d_flag);
 int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A, int64_t lda,
                    const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile, int lds_pad,

@@ -10,28 +10,6 @@
 // Fused epilogue: the diagonal loading of ref :1447-1451 ((K + noise_var) + err_y^2) + diag_add.
 #include "kbuild_kernel.hpp"
 
-template <int KID, int D>
-__global__ __launch_bounds__(256) void kpairs_kernel(KParams kp, const double *__restrict__ Xi,
-                                                     const double *__restrict__ Xj,
-                                                     const int32_t *__restrict__ ni,
-                                                     const int32_t *__restrict__ nj, int64_t M,
-                                                     double *__restrict__ out, int accumulate)
-{
-    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (m >= M) return;
-    double xi[D], xj[D];
-    int nir[D], njr[D];
-#pragma unroll
-    for (int d = 0; d < D; d++) {
-        xi[d] = Xi[m * D + d];
-        xj[d] = Xj[m * D + d];
-        nir[d] = ni[m * D + d];
-        njr[d] = nj[m * D + d];
-    }
-    const double v = any_pair<KID, D>(kp, xi, xj, nir, njr);
-    out[m] = accumulate ? out[m] + v : v;
-}
-
 // C[a][b] += noise_k(X[a], X[b], n[a], n[b]) for the symmetric predict(noise=True) term
 // (ref: gptools/gaussian_process.py:985-986, gptools/kernel/noise.py:103-104).
 template <int D>
@@ -73,7 +51,7 @@ static int kbuild_dispatch_d(hipStream_t st, const KParams &kp, const double *dX
     case DD:                                                                                            \
         hipLaunchKernelGGL((kbuild_kernel<KID, DD, false>), grid, block, 0, st, kp, dXi, dni, M, dXj, dnj, P,   \
                            lower_only, i0, j0, d_err_y, noise_var, diag_add, dK, ldk, accumulate,               \
-                           (const KParams *)nullptr, (const double *)nullptr, (int64_t)0);                       \
+                           (const KParams *)nullptr, (const double *)nullptr, (int64_t)0, KParams());            \
         break;
     switch (kp.D) {
         KB_CASE(1) KB_CASE(2) KB_CASE(3) KB_CASE(4) KB_CASE(5) KB_CASE(6) KB_CASE(7) KB_CASE(8)
@@ -89,8 +67,12 @@ static int kbuild_dispatch_d(hipStream_t st, const KParams &kp, const double *dX
 
 int launch_kbuild(hipStream_t st, const KParams &kp, const double *dXi, const int32_t *dni, int64_t M,
                   const double *dXj, const int32_t *dnj, int64_t P, int lower_only, int64_t i0, int64_t j0,
-                  const double *d_err_y, double noise_var, double diag_add, double *dK, int64_t ldk, int accumulate)
+                  const double *d_err_y, double noise_var, double diag_add, double *dK, int64_t ldk, int accumulate,
+                  const KParams *kp2)
 {
+    if (kp2 && kp2->kernel_id >= 0)
+        return launch_kbuild_prod(st, kp, *kp2, dXi, dni, M, dXj, dnj, P, lower_only, i0, j0, d_err_y, noise_var, diag_add, dK, ldk,
+                                  accumulate);
     gpt_jitter(st);
     if (M <= 0 || P <= 0) return GPT_OK;
     switch (kp.kernel_id) {
@@ -125,7 +107,7 @@ static int kpairs_dispatch_d(hipStream_t st, const KParams &kp, const double *dX
     dim3 grid((unsigned)((M + 255) / 256)), block(256);
 #define KP_CASE(DD)                                                                                   \
     case DD:                                                                                          \
-        hipLaunchKernelGGL((kpairs_kernel<KID, DD>), grid, block, 0, st, kp, dXi, dXj, dni, dnj, M, dout, accumulate); \
+        hipLaunchKernelGGL((kpairs_kernel<KID, DD>), grid, block, 0, st, kp, dXi, dXj, dni, dnj, M, dout, accumulate, KParams()); \
         break;
     switch (kp.D) {
         KP_CASE(1) KP_CASE(2) KP_CASE(3) KP_CASE(4) KP_CASE(5) KP_CASE(6) KP_CASE(7) KP_CASE(8)
@@ -140,9 +122,10 @@ static int kpairs_dispatch_d(hipStream_t st, const KParams &kp, const double *dX
 }
 
 int launch_kpairs(hipStream_t st, const KParams &kp, const double *dXi, const double *dXj,
-                  const int32_t *dni, const int32_t *dnj, int64_t M, double *dout, int accumulate)
+                  const int32_t *dni, const int32_t *dnj, int64_t M, double *dout, int accumulate, const KParams *kp2)
 {
     if (M <= 0) return GPT_OK;
+    if (kp2 && kp2->kernel_id >= 0) return launch_kpairs_prod(st, kp, *kp2, dXi, dXj, dni, dnj, M, dout, accumulate);
     switch (kp.kernel_id) {
     case GPT_KERNEL_SE: return kpairs_dispatch_d<GPT_KERNEL_SE>(st, kp, dXi, dXj, dni, dnj, M, dout, accumulate);
     case GPT_KERNEL_M52: return kpairs_dispatch_d<GPT_KERNEL_M52>(st, kp, dXi, dXj, dni, dnj, M, dout, accumulate);

@@ -20,7 +20,7 @@ static int kbuild_batch_d(hipStream_t st, int D, const KParams *d_kps, const dou
 #define KBB_CASE(DD)                                                                                              \
     case DD:                                                                                                      \
         hipLaunchKernelGGL((kbuild_kernel<KID, DD, true>), grid, block, 0, st, dummy, dX, dn, N, dX, dn, N, 2,     \
-                           (int64_t)0, (int64_t)0, d_err_y, 0.0, diag_add, dK, ldk, 0, d_kps, d_nv, bstride);      \
+                           (int64_t)0, (int64_t)0, d_err_y, 0.0, diag_add, dK, ldk, 0, d_kps, d_nv, bstride, dummy); \
         break;
     switch (D) {
         KBB_CASE(1) KBB_CASE(2) KBB_CASE(3) KBB_CASE(4) KBB_CASE(5) KBB_CASE(6) KBB_CASE(7) KBB_CASE(8)

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(KB_THREADS) void kbuild_kernel(
     const double *__restrict__ Xj, const int32_t *__restrict__ nj, int64_t P,
     int lower_only, int64_t i0, int64_t j0, const double *__restrict__ err_y, double noise_one,
     double diag_add, double *__restrict__ K, int64_t ldk, int accumulate, const KParams *__restrict__ kps,
-    const double *__restrict__ nvs, int64_t bstride)
+    const double *__restrict__ nvs, int64_t bstride, KParams kp_two)
 {
     const KParams &kp = BATCH ? kps[blockIdx.z] : kp_one;
     const double noise_var = BATCH ? nvs[blockIdx.z] : noise_one;
@@ -72,7 +72,8 @@ __global__ __launch_bounds__(KB_THREADS) void kbuild_kernel(
         double v[KB_CPT];
 #pragma unroll
         for (int c = 0; c < KB_CPT; c++) {
-            v[c] = any_pair<KID, D>(kp, xi, xj[c], nir, njr[c]);
+            if constexpr (KID == GPT_KERNEL_PRODUCT) v[c] = prod_pair<D>(kp, kp_two, xi, xj[c], nir, njr[c]);
+            else v[c] = any_pair<KID, D>(kp, xi, xj[c], nir, njr[c]);
             // SumKernel (ref: gptools/kernel/core.py:549-584): later terms add to what the earlier passes stored
             if (accumulate && jfirst + c < P) v[c] += K[i * ldk + jfirst + c];
             if (err_y != nullptr && (i + i0 == jfirst + c + j0)) {
@@ -91,3 +92,26 @@ __global__ __launch_bounds__(KB_THREADS) void kbuild_kernel(
     }
 }
 
+template <int KID, int D>
+__global__ __launch_bounds__(256) void kpairs_kernel(KParams kp, const double *__restrict__ Xi,
+                                                     const double *__restrict__ Xj,
+                                                     const int32_t *__restrict__ ni,
+                                                     const int32_t *__restrict__ nj, int64_t M,
+                                                     double *__restrict__ out, int accumulate, KParams kp_two)
+{
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    double xi[D], xj[D];
+    int nir[D], njr[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        xi[d] = Xi[m * D + d];
+        xj[d] = Xj[m * D + d];
+        nir[d] = ni[m * D + d];
+        njr[d] = nj[m * D + d];
+    }
+    double v;
+    if constexpr (KID == GPT_KERNEL_PRODUCT) v = prod_pair<D>(kp, kp_two, xi, xj, nir, njr);
+    else v = any_pair<KID, D>(kp, xi, xj, nir, njr);
+    out[m] = accumulate ? out[m] + v : v;
+}

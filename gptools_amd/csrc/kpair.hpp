@@ -549,3 +549,61 @@ __device__ __forceinline__ double any_pair(const KParams &kp, const double *xi, 
     if (KID == GPT_KERNEL_MATERN) return matern_pair<D>(kp, xi, xj, ni, nj);
     return 0.0;
 }
+
+// ---- product of two native kernels (ref: gptools/kernel/core.py:587-671) --------------------------------------------------
+// The reference walks the power set of the derivative multiset of a pair and multiplies k1 with the subset's orders by k2
+// with the complement's; equal subsets recur, so grouped by how many of the r_s derivatives of slot s (the D orders of ni, then
+// the D of nj) go to k1 that is the general Leibniz rule  sum_a prod_s C(r_s, a_s) k1^(a) k2^(r - a).  Factors by run-time id.
+template <int D>
+__device__ __forceinline__ double factor_pair(const KParams &kp, const double *xi, const double *xj, const int *ni, const int *nj)
+{
+    switch (kp.kernel_id) {
+    case GPT_KERNEL_SE: return se_pair<D>(kp, xi, xj, ni, nj);
+    case GPT_KERNEL_M52: return m52_pair<D>(kp, xi, xj, ni, nj);
+    case GPT_KERNEL_RQ: return rq_pair<D>(kp, xi, xj, ni, nj);
+    case GPT_KERNEL_MATERN: return matern_pair<D>(kp, xi, xj, ni, nj);
+    default: return 0.0;
+    }
+}
+
+template <int D>
+__device__ double prod_pair(const KParams &k1, const KParams &k2, const double *xi, const double *xj, const int *ni, const int *nj)
+{
+    int r[2 * D], a[2 * D];
+#pragma unroll
+    for (int s = 0; s < 2 * D; s++) {
+        r[s] = (s < D) ? ni[s] : nj[s - D];
+        a[s] = 0;
+    }
+    double sum = 0.0;
+    for (;;) {
+        int n1i[D], n1j[D], n2i[D], n2j[D];
+        double w = 1.0;
+#pragma unroll
+        for (int s = 0; s < 2 * D; s++) {
+            // C(r, a), r <= GPT_RQ_MAXORD
+            double c = 1.0;
+            for (int q = 0; q < a[s]; q++) c = c * (double)(r[s] - q) / (double)(q + 1);
+            w *= c;
+            if (s < D) {
+                n1i[s] = a[s];
+                n2i[s] = r[s] - a[s];
+            } else {
+                n1j[s - D] = a[s];
+                n2j[s - D] = r[s] - a[s];
+            }
+        }
+        sum += w * (factor_pair<D>(k1, xi, xj, n1i, n1j) * factor_pair<D>(k2, xi, xj, n2i, n2j));
+        int s = 0;
+        while (s < 2 * D) {
+            if (a[s] < r[s]) {
+                a[s]++;
+                break;
+            }
+            a[s] = 0;
+            s++;
+        }
+        if (s == 2 * D) break;
+    }
+    return sum;
+}

@@ -28,7 +28,7 @@ import scipy.optimize
 from . import _lib
 from . import replicas
 from .error_handling import GPArgumentError, GPImpossibleParamsError
-from .kernel import Kernel, ZeroKernel, DiagonalNoiseKernel, SumKernel
+from .kernel import Kernel, ZeroKernel, DiagonalNoiseKernel, SumKernel, ProductKernel
 from .utils import CombinedBounds
 
 __all__ = ["GaussianProcess"]
@@ -297,6 +297,11 @@ class GaussianProcess(object):
             nj_ = None if Xj is None else np.atleast_2d(np.asarray(nj, dtype=int))
             return self._ctx.kbuild(kid, k.params, Xi, ni, Xj_, nj_, hyper_deriv=hyper_deriv,
                                     noise_n=getattr(k, "n", None))
+        if type(k) is ProductKernel and hyper_deriv is None and k._native_factors() is not None:
+            nat = k._native_factors()
+            Xj_ = None if Xj is None else np.atleast_2d(np.asarray(Xj, dtype=float))
+            nj_ = None if Xj is None else np.atleast_2d(np.asarray(nj, dtype=int))
+            return self._ctx.kbuild2(nat[0], nat[1], nat[2], nat[3], Xi, ni, Xj_, nj_)
         symmetric = Xj is None
         if symmetric:
             Xj, nj = Xi, ni
@@ -369,6 +374,10 @@ class GaussianProcess(object):
             return None if a is None or b is None or len(a) + len(b) > 8 else a + b
         if (getattr(k, "_gpt_kernel_id", None) in _NATIVE_FIT and type(k).__call__ in (Kernel.__call__, _M52_CALL)):
             return [(k._gpt_kernel_id, np.array(k.params, dtype=float))]
+        if type(k) is ProductKernel:
+            # k1 * k2 of two native kernels: one PRODUCT term of the fused builder (ref: gptools/kernel/core.py:587-671)
+            nat = k._native_factors()
+            return None if nat is None else [nat]
         return None
 
     def _fast_fit_possible(self):
@@ -376,6 +385,8 @@ class GaussianProcess(object):
                 isinstance(self.noise_k, (ZeroKernel, DiagonalNoiseKernel)))
 
     def _device_fit(self, ctx, terms, noise_var, y_alph, diag_add):
+        if any(len(t) == 4 for t in terms):
+            return ctx.fit_terms(terms, noise_var, y_alph, self.err_y, diag_add)
         if len(terms) == 1:
             return ctx.fit(terms[0][0], terms[0][1], noise_var, y_alph, self.err_y, diag_add)
         return ctx.fit_sum([t[0] for t in terms], [t[1] for t in terms], noise_var, y_alph, self.err_y, diag_add)
@@ -463,10 +474,10 @@ class GaussianProcess(object):
             # which kernel term each free parameter belongs to; the device path needs every FREE parameter in a
             # squared-exponential term (terms of other kernels may take part in the sum with all their parameters fixed:
             # they have no hyperparameter derivatives in the reference either, kernel/core.py:723-726)
-            bounds = np.cumsum([0] + [len(t[1]) for t in terms])
+            bounds = np.cumsum([0] + [len(t[1]) + (len(t[3]) if len(t) == 4 else 0) for t in terms])
             tix = [int(np.searchsorted(bounds, pi, side="right") - 1) for pi in free_idx]
             lix = [int(pi - bounds[t]) for pi, t in zip(free_idx, tix)]
-        if terms is not None and all(terms[t][0] == _lib.KERNEL_SE for t in tix):
+        if terms is not None and all(len(terms[t]) == 2 and terms[t][0] == _lib.KERNEL_SE for t in tix):
             # device path (gpt_ll_grad): K_tot^-1 once (2 N^3 / 3 flop on the MFMA GEMM, whatever the number of
             # parameters), then one fused pass over the pairs per group of parameters; dK never exists.  With a linear
             # transform T the pass runs over the latent points against T^T K_tot^-1 T (two more GEMMs on the device).
@@ -624,7 +635,7 @@ class GaussianProcess(object):
             self._data_on_device = True
         version = getattr(self, "_data_version", 0)
         if (self.T is None and len(self.y) <= self.batch_grid_max_n and int(self.batch_grid) > 1 and jobs
-                and all(len(j[1]) == 1 for j in jobs)):
+                and all(len(j[1]) == 1 and len(j[1][0]) == 2 for j in jobs)):
             # small N: the whole batch in ONE launch sequence (gpt_fit_batch: every kernel of the factorisation carries the
             # batch in a grid dimension), batch_grid evaluations at a time; bit-identical to one gpt_fit per vector
             kid = jobs[0][1][0][0]

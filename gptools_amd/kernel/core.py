@@ -249,13 +249,35 @@ class ProductKernel(BinaryKernel):
     The reference walks the power set of the derivative multiset of every pair (positions distinct, so equal subsets
     recur); grouped by how many of the ``n`` derivatives of each of the 2 D slots (``ni`` then ``nj``) go to ``k1`` that
     is the general Leibniz rule, ``sum_a prod_slots C(n, a) * k1^(a) * k2^(n - a)`` -- the same sum with each distinct
-    term evaluated once.  Both factors are evaluated through their own ``__call__`` (the GPU pair list for native
-    kernels); a product is not a native term of the fused builder, so ``GaussianProcess`` assembles its K from these
-    calls and keeps factorisation and solves on the device."""
+    term evaluated once.  With two native factors (SE, Matern52, RationalQuadratic, Matern) that sum runs per pair on
+    the device (``GPT_KERNEL_PRODUCT``: ``gpt_kpairs2`` here, the fused builder in ``GaussianProcess``); otherwise both
+    factors are evaluated through their own ``__call__`` and combined on the host."""
+
+    def _native_factors(self):
+        """``(kernel_id1, params1, kernel_id2, params2)`` when both factors are kernels the HIP library evaluates itself
+        (then the product rule runs per pair on the device, GPT_KERNEL_PRODUCT), else ``None``."""
+        from .. import _lib
+        from .matern import Matern52Kernel
+        ok = (_lib.KERNEL_SE, _lib.KERNEL_M52, _lib.KERNEL_RQ, _lib.KERNEL_MATERN)
+        f = []
+        for k in (self.k1, self.k2):
+            kid = getattr(k, "_gpt_kernel_id", None)
+            # (a subclass that overrides __call__ is a Python-defined kernel, whatever id it inherited)
+            if kid not in ok or type(k).__call__ not in (Kernel.__call__, Matern52Kernel.__call__):
+                return None
+            f += [kid, np.array(k.params, dtype=float)]
+        return tuple(f)
 
     def __call__(self, Xi, Xj, ni, nj, hyper_deriv=None, symmetric=False):
         if hyper_deriv is not None:
             raise NotImplementedError("hyper_deriv keyword not yet supported!")
+        nat = self._native_factors()
+        if nat is not None:
+            from .. import _lib
+            return _lib.default_context().kpairs2(nat[0], nat[1], nat[2], nat[3], np.atleast_2d(np.asarray(Xi, dtype=float)),
+                                                  np.atleast_2d(np.asarray(Xj, dtype=float)),
+                                                  np.atleast_2d(np.asarray(ni, dtype=int)),
+                                                  np.atleast_2d(np.asarray(nj, dtype=int)))
         import itertools
         from math import comb
         Xi, Xj = np.atleast_2d(np.asarray(Xi, dtype=float)), np.atleast_2d(np.asarray(Xj, dtype=float))

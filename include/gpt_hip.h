@@ -56,6 +56,12 @@ extern "C" {
                                   * 2^(1-nu)/Gamma(nu) y^((nu-m)/2) K_(nu-m)(sqrt y), overflows in its factors before the
                                   * product is formed; the reference accepts any nu) */
 
+#define GPT_KERNEL_PRODUCT 6     /* k1 * k2 of two of the kernels above (SE, Matern52, RQ, Matern), ref: kernel/core.py:587-671: the product
+                                  * rule over the derivative orders of a pair, sum over sub-multi-indices a of prod_slots C(n, a)
+                                  * k1^(a) k2^(n - a), evaluated per pair on the device (gpt_kpairs2 / gpt_kbuild2 / gpt_fit_terms);
+                                  * combined derivative order of a pair <= GPT_RQ_MAXORD; no hyper-parameter derivatives
+                                  * (NotImplementedError in the reference too) */
+
 #define GPT_MAX_DIM 16      /* largest supported num_dim */
 #define GPT_WS_BLOCK 9216    /* doubles of factorisation workspace per 128 columns (d_invd arguments) */
 
@@ -127,6 +133,11 @@ int gpt_kpairs(gpt_ctx *ctx, int kernel_id, const double *params, int nparams,
                int64_t M, int D, int hyper_deriv, int symmetric, const int32_t *noise_n,
                double *out);
 
+/* The same pair list for the PRODUCT of two native kernels (ProductKernel.__call__, ref: kernel/core.py:587-671). */
+int gpt_kpairs2(gpt_ctx *ctx, int kernel_id1, const double *params1, int nparams1, int kernel_id2, const double *params2,
+                int nparams2, const double *Xi, const double *Xj, const int32_t *ni, const int32_t *nj, int64_t M, int D,
+                double *out);
+
 /* ---- GaussianProcess.compute_Kij ---------------------------------------------------------- */
 /* Replaces  GaussianProcess.compute_Kij(Xi, Xj, ni, nj, noise, hyper_deriv, k) -> (M, P)
  *   ref: gaussian_process.py:1535-1605.  Xj == NULL means Xj = Xi, nj = ni, symmetric = True
@@ -137,6 +148,11 @@ int gpt_kbuild(gpt_ctx *ctx, int kernel_id, const double *params, int nparams,
                const double *Xi, const int32_t *ni, int64_t M,
                const double *Xj, const int32_t *nj, int64_t P, int D,
                int hyper_deriv, const int32_t *noise_n, double *K_out);
+
+/* compute_Kij for the product of two native kernels (Xj == NULL: symmetric). */
+int gpt_kbuild2(gpt_ctx *ctx, int kernel_id1, const double *params1, int nparams1, int kernel_id2, const double *params2,
+                int nparams2, const double *Xi, const int32_t *ni, int64_t M, const double *Xj, const int32_t *nj, int64_t P,
+                int D, double *K_out);
 
 /* ---- GaussianProcess.add_data (device residency) ------------------------------------------ */
 /* Uploads the training inputs the later calls use (ref: gaussian_process.py:376-503 defines the
@@ -169,6 +185,14 @@ int gpt_fit(gpt_ctx *ctx, int kernel_id, const double *params, int nparams, doub
 int gpt_fit_sum(gpt_ctx *ctx, int nterms, const int *kernel_ids, const double *params, const int *nparams,
                 double noise_var, const double *y, const double *err_y, double diag_add, double *ll_data_out,
                 double *logdet_half_out);
+
+/* gpt_fit_sum with PRODUCT terms: term t is kernel_ids[t] alone (kernel_ids2[t] < 0) or the product kernel_ids[t] *
+ * kernel_ids2[t]; its parameters are nparams[t] consecutive entries of `params`, the first nparams1[t] of them the first
+ * factor's (nparams1[t] == nparams[t] for a plain term).  A model like k1 * k2 + k3 therefore runs the fused builder, not a
+ * host-assembled K_tot through gpt_fit_matrix.  gpt_predict afterwards uses the same terms. */
+int gpt_fit_terms(gpt_ctx *ctx, int nterms, const int *kernel_ids, const int *kernel_ids2, const double *params,
+                  const int *nparams, const int *nparams1, double noise_var, const double *y, const double *err_y,
+                  double diag_add, double *ll_data_out, double *logdet_half_out);
 
 /* nbatch INDEPENDENT evaluations of the resident data set in one launch sequence: element b uses params[b * nparams ..],
  * noise_var[b] and the target y[b * N ..] (the mean function may depend on the hyperparameters); err_y (N) is shared.

@@ -1458,3 +1458,67 @@ def test_fit_batch_is_bit_identical_to_single_fits(kern, N, d, deriv):
     ll2, ld2, info2 = c.fit_batch(KID[kern], P[:3], nv[:3], Y[:3], err, 1e2 * EPS)
     assert np.array_equal(ll2, ll[:3]) and np.array_equal(ld2, ld[:3]) and not info2.any()
     c.close()
+
+
+def test_product_kernel_is_a_native_term_of_the_fused_builder(g, golden, oracle):
+    """k1 * k2 of two native kernels (ref kernel/core.py:587-671) as GPT_KERNEL_PRODUCT: the Leibniz sum runs per pair on the
+    device -- pair list (gpt_kpairs2) and Gram matrix (gpt_kbuild2) against the golden g9 vectors from the reference and against
+    the host product rule over the oracle's factors; the model (k1 * k2 + k3) fits through the fused builder (gpt_fit_terms:
+    fit mode "kernel", no host-assembled K_tot), predicts, and ll_batch agrees with sequential evaluation."""
+    from gptools_amd import _lib
+    G = golden("g9_product")
+    mk = lambda cls, p, **kw: cls(num_dim=2, initial_params=list(p), param_bounds=[(0.0, 1e3)] * len(p), **kw)
+    k = mk(g.SquaredExponentialKernel, G["sese_p1"]) * mk(g.SquaredExponentialKernel, G["sese_p2"])
+    assert k._native_factors() is not None
+    assert_close(k(G["sese_Xi"], G["sese_Xj"], G["sese_ni"], G["sese_nj"]), G["sese_k"], rtol=1e-11, msg="SE * SE pairs")
+    ks = mk(g.SquaredExponentialKernel, G["sese_p1"]) * mk(g.Matern52Kernel, G["sese_p2"])
+    assert_close(ks(G["sese_Xi"], G["sese_Xj"], G["sem_ni"], G["sem_nj"]), G["sem_k"], rtol=1e-11, msg="SE * M52 pairs")
+    with pytest.raises(NotImplementedError):
+        ks(G["sese_Xi"], G["sese_Xj"], G["sem_ni"], G["sem_nj"], hyper_deriv=0)
+    with pytest.raises(ValueError):                       # Matern52 factor: order 2 in a point (ref matern.py:545-546)
+        ks(G["sese_Xi"][:2], G["sese_Xj"][:2], np.array([[2, 0], [0, 0]]), np.zeros((2, 2), int))
+    # Gram matrix: device product against products of the oracle's factor matrices (no derivatives) and, with derivative
+    # rows, against the device pair list
+    rs = np.random.RandomState(3)
+    N, d = 500, 2
+    X = rs.rand(N, d)
+    n = np.zeros((N, d), dtype=int)
+    n[-60:, 1] = 1
+    y = np.sin(3 * X.sum(1)) + 0.05 * rs.randn(N)
+    p1, p2, p3 = [1.2, 0.5, 0.7], [0.8, 0.3, 0.9], [0.4, 1.5, 2.0]
+    gp0 = g.GaussianProcess(mk(g.SquaredExponentialKernel, p1) * mk(g.Matern52Kernel, p2))
+    Kd = gp0.compute_Kij(X, None, n, None)
+    n0 = np.zeros_like(n)
+    K00 = gp0.compute_Kij(X, None, n0, None)
+    assert_close(K00, oracle.kbuild("se", p1, X, n0) * oracle.kbuild("m52", p2, X, n0), rtol=1e-12, msg="Gram, no derivatives")
+    ii, jj = np.meshgrid(np.arange(N - 80, N), np.arange(0, N, 7), indexing="ij")
+    pl = gp0.k(X[ii.ravel()], X[jj.ravel()], n[ii.ravel()], n[jj.ravel()])
+    assert_close(Kd[ii.ravel(), jj.ravel()], pl, rtol=1e-13, msg="Gram vs pair list")
+    # the host product rule over GPU factor calls (what round 2 did for every product) gives the same numbers
+    class Host(g.ProductKernel):
+        def _native_factors(self):
+            return None
+    kh = Host(mk(g.SquaredExponentialKernel, p1), mk(g.Matern52Kernel, p2))
+    assert_close(pl, kh(X[ii.ravel()], X[jj.ravel()], n[ii.ravel()], n[jj.ravel()]), rtol=1e-12, msg="device vs host Leibniz")
+    # fit / predict / batch with k1 * k2 + k3
+    kern = mk(g.SquaredExponentialKernel, p1) * mk(g.Matern52Kernel, p2) + mk(g.SquaredExponentialKernel, p3)
+    gp = g.GaussianProcess(kern, X=X, y=y, err_y=0.05, n=n)
+    gp.compute_K_L_alpha_ll()
+    assert gp._fit_mode == "kernel"
+    Kh = kh(np.repeat(X, N, 0), np.tile(X, (N, 1)), np.repeat(n, N, 0), np.tile(n, (N, 1))).reshape(N, N) + oracle.kbuild("se", p3, X, n)
+    import scipy.linalg
+    Kt = Kh + (0.05 ** 2 + 1e2 * EPS) * np.eye(N)
+    L = scipy.linalg.cholesky(Kt, lower=True)
+    alpha = scipy.linalg.cho_solve((L, True), y)
+    ll = -0.5 * y.dot(alpha) - np.log(np.diag(L)).sum() - 0.5 * N * np.log(2 * np.pi)
+    assert abs(gp.ll - gp.hyperprior(gp.params) - ll) <= 1e-9 * abs(ll)
+    Xs = rs.rand(30, d)
+    ns = np.zeros((30, d), dtype=int)
+    ns[::5, 0] = 1
+    mean, std = gp.predict(Xs, n=ns)
+    Ks = (kh(np.repeat(X, 30, 0), np.tile(Xs, (N, 1)), np.repeat(n, 30, 0), np.tile(ns, (N, 1))).reshape(N, 30) +
+          oracle.kbuild("se", p3, X, n, Xs, ns))
+    np.testing.assert_allclose(mean, Ks.T.dot(alpha), rtol=0, atol=1e-7)
+    theta = np.array(gp.free_params[:], dtype=float)
+    pts = [theta, theta * 1.05, theta * 0.97]
+    np.testing.assert_allclose(gp.ll_batch(pts), [-gp.update_hyperparameters(p) for p in pts], rtol=1e-12)
