@@ -76,7 +76,7 @@ nw, wb = big_launch_bytes(src + '/pmc_write/t_counter_collection.csv', 'WRITE_SI
 tj = {"round": int(sys.argv[4]) if len(sys.argv) > 4 else 2, "kernel": "gemm_nt_kernel<64,64>",
       "launch_filter": "main-stream queue, Grid_Size >= %d threads (the >= 1 GFLOP rank-%d trailing updates)" % (MIN_GRID, K_OUTER),
       "launches": nf, "launches_per_evaluation": round(nf / 3.0, 1),
-      "note": "counter collection runs one kernel at a time, so the library falls back to event edges there (api.hip, edge_flags_usable): these are the launches of the EVENT schedule (urgent and rest separate); the timed bench line runs the flag schedule with urgent + rest merged: bytes per launch scale with the flops per launch, the ratio to the algorithmic bytes is what carries over", "fetch_bytes_per_launch_x2_corrected": 2 * fb / nf, "write_bytes_per_launch": wb / nw,
+      "note": "counter collection runs one kernel at a time, so the library falls back to event edges there (api.hip, EvalScope): these are the launches of the EVENT schedule (urgent and rest separate); the timed bench line runs the flag schedule with urgent + rest merged: bytes per launch scale with the flops per launch, the ratio to the algorithmic bytes is what carries over", "fetch_bytes_per_launch_x2_corrected": 2 * fb / nf, "write_bytes_per_launch": wb / nw,
       "hbm_bytes_per_launch": 2 * fb / nf + wb / nw,
       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, scratch/prof_all.sh); FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md"}
 if len(sys.argv) > 3:
