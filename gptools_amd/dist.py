@@ -323,6 +323,13 @@ class DistributedLML(object):
         self.info = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.y = torch.empty((self.NP,), dtype=torch.float64, device=dev)
         self.err = torch.zeros((self.NP,), dtype=torch.float64, device=dev)
+        self.red = torch.zeros((3,), dtype=torch.float64, device=dev)        # sum(log L_ii) part, z.z part, info
+        # pinned staging for the per-fit host traffic (y | err_y up, three scalars down): page-locked by the library's own
+        # allocator (gpt_host_alloc) and only WRAPPED as tensors -- tensors from torch's pinned-memory allocator that live
+        # until interpreter exit crashed the process at teardown ("pure virtual method called", after every result was out)
+        on_gpu = dev.type == "cuda"
+        self._h_in = torch.from_numpy(_lib.pinned_empty((2, self.NP), min_bytes=0)) if on_gpu else None
+        self._h_out = torch.from_numpy(_lib.pinned_empty((3,), min_bytes=0)) if on_gpu else None
         self.timings = {}
         self.trace = False          # record the device-timeline position of every step (timings["steps_ms"])
 
@@ -447,10 +454,18 @@ class DistributedLML(object):
         y = np.ascontiguousarray(y, dtype=np.float64)
         err_y = np.array(np.broadcast_to(err_y, (N,)), dtype=np.float64)
         with ops.queue("main"):
-            self.y[:N] = torch.from_numpy(y).to(self.device)
-            self.err[:N] = torch.from_numpy(err_y).to(self.device)
+            # y | err_y go up from a pinned staging tensor, asynchronously on the main queue (a pageable source makes the copy
+            # synchronous and costs a staging copy inside the runtime); the scalar accumulators are persistent tensors
+            if self._h_in is not None:
+                self._h_in[0, :N].copy_(torch.from_numpy(y))
+                self._h_in[1, :N].copy_(torch.from_numpy(err_y))
+                self.y[:N].copy_(self._h_in[0, :N], non_blocking=True)
+                self.err[:N].copy_(self._h_in[1, :N], non_blocking=True)
+            else:
+                self.y[:N] = torch.from_numpy(y)
+                self.err[:N] = torch.from_numpy(err_y)
             self.info.zero_()
-            self.red = torch.zeros((3,), dtype=torch.float64, device=self.device)
+            self.red.zero_()
             self._t0 = ops.new_timing_event() if self.trace else None
             if self._t0 is not None:
                 self._t0.record()
@@ -481,8 +496,10 @@ class DistributedLML(object):
                 self._allreduce(red[:2], "sum")
                 self._allreduce(info_t, "max")
                 red[2] = info_t[0]
-            logdet_half, zz, info = (float(v) for v in red.cpu())
+            if self._h_out is not None:
+                self._h_out.copy_(red, non_blocking=True)         # pinned: the wait below is the only synchronisation
         ops.synchronize()
+        logdet_half, zz, info = (float(v) for v in (self._h_out if self._h_out is not None else red))
         if self._t0 is not None:
             self.timings["steps_ms"] = [(k, tag, self._t0.elapsed_ms(e)) for k, tag, e in self._marks]
         if info != 0 and info <= N:
