@@ -1522,3 +1522,46 @@ def test_product_kernel_is_a_native_term_of_the_fused_builder(g, golden, oracle)
     theta = np.array(gp.free_params[:], dtype=float)
     pts = [theta, theta * 1.05, theta * 0.97]
     np.testing.assert_allclose(gp.ll_batch(pts), [-gp.update_hyperparameters(p) for p in pts], rtol=1e-12)
+
+
+def test_ll_batch_grid_path_and_thread_path_agree(g):
+    """GaussianProcess.ll_batch at small N goes through gpt_fit_batch (one launch sequence for the whole list); above
+    ``batch_grid_max_n`` -- forced here -- through one context and host thread per evaluation in flight.  Same numbers bit for
+    bit on both routes and from one update_hyperparameters call per vector, for a Matern-5/2 GP with derivative rows and a
+    free noise parameter, a rational-quadratic GP, out-of-bounds vectors (-inf) and a non-positive-definite one (-inf)."""
+    rs = np.random.RandomState(17)
+    N, d = 600, 2
+    X = rs.rand(N, d)
+    n = np.zeros((N, d), dtype=int)
+    n[-50:, 0] = 1
+    y = np.sin(3 * X.sum(1)) + 0.05 * rs.randn(N)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for kind in ("m52", "rq"):
+            if kind == "m52":
+                k = make_kernel(g, "m52", d, [1.0, 0.4, 0.6], param_bounds=[(0.2, 5.0), (0.05, 2.0), (0.05, 2.0)])
+                nk = g.DiagonalNoiseKernel(num_dim=d, initial_noise=0.05, noise_bound=(0.0, 1.0))
+                pts = [[1.0, 0.4, 0.6, 0.05], [1.3, 0.3, 0.5, 0.02], [0.1, 0.4, 0.6, 0.05], [0.9, 0.5, 0.7, 0.0]]
+            else:
+                k = g.RationalQuadraticKernel(num_dim=d, initial_params=[1.0, 1.7, 0.4, 0.6],
+                                              param_bounds=[(0.2, 5.0), (0.1, 10.0), (0.05, 2.0), (0.05, 2.0)])
+                nk = None
+                pts = [[1.0, 1.7, 0.4, 0.6], [1.2, 2.5, 0.3, 0.5], [1.0, 0.05, 0.4, 0.6]]
+            gp = g.GaussianProcess(k, noise_k=nk, X=X, y=y, err_y=0.03, n=n)
+            grid = gp.ll_batch(pts)
+            gp.batch_grid_max_n = 10                    # forces the two-contexts / two-threads route
+            thr = gp.ll_batch(pts)
+            gp.batch_grid_max_n = 2048
+            seq = np.array([-gp.update_hyperparameters(p) for p in pts])
+            assert np.array_equal(grid, thr) and np.array_equal(grid, seq), (kind, grid, thr, seq)
+            assert np.isneginf(grid[2]) and np.isfinite(grid[:2]).all()
+    # an element that is not positive definite inside a batch: -inf for it alone (duplicate points, no noise, no jitter)
+    X2 = np.vstack([X[:200], X[:1]])
+    y2 = np.concatenate([y[:200], y[:1] + 1.0])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        k = make_kernel(g, "se", d, [1.0, 0.4, 0.6], param_bounds=[(0.2, 5.0), (0.05, 2.0), (0.05, 2.0)])
+        nk = g.DiagonalNoiseKernel(num_dim=d, initial_noise=0.05, noise_bound=(0.0, 1.0))
+        gp = g.GaussianProcess(k, noise_k=nk, X=X2, y=y2, err_y=0.0, diag_factor=0.0)
+        out = gp.ll_batch([[1.0, 0.4, 0.6, 0.05], [1.0, 0.4, 0.6, 0.0], [1.1, 0.5, 0.6, 0.02]])
+        assert np.isfinite(out[0]) and np.isneginf(out[1]) and np.isfinite(out[2])
