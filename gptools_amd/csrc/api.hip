@@ -770,6 +770,9 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
     // hipStreamWaitValue32 -- 1.5 us per edge against 8-9 for an event, and no stop event on the chain's kernels (4.5 us
     // each).  In the chain-bound end both edges are on the critical path of every panel.
     // (tile: the edge flags live in the 64x64 / 32x32 GEMM kernels only)
+    // (not with the helper stream: flags + helper -- the helper waiting behind a wait kernel, the merged launch cut at the
+    // split column, code below -- measured the same as events + helper at N = 16384 (27.65 against 27.49 ms), and the helper
+    // in the head of an N = 8192 factorisation still loses, 4.64 against 4.45 ms: round 3)
     const bool use_flags = c->flags_now && !H && c->inner == 0 && !c->leaf256 && !use_early && !use_late
                            && c->defer_rows == 0 && (c->tile == 0 || c->tile == 64);
     if (use_flags && c->edge_seq > 0xf0000000u && !head_wait.word) {           // (the words are only ever raised: start over long before a wrap)
@@ -855,7 +858,8 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
             if (use_flags) GPT_TRY(stream_wait_flag(S, panel_edge));
             else GPT_HIP_CHECK(hipStreamWaitEvent(S, e_panel, 0));
             if (split < n) {
-                GPT_HIP_CHECK(hipStreamWaitEvent(H, e_panel, 0));
+                if (use_flags) GPT_TRY(stream_wait_flag(H, panel_edge));
+                else GPT_HIP_CHECK(hipStreamWaitEvent(H, e_panel, 0));
                 GPT_TRY(gemm_nt(c, H, n - split, n - split, w, -1.0, A + split * lda + c0, lda, A + split * lda + c0,
                                 lda, 1.0, A + split * lda + split, lda, 1, e_help));
             }
@@ -927,11 +931,19 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
                 // tiles of the urgent columns come first on every XCD, write through and raise the flag when THEY are done;
                 // the rest follows in the same launch -- one drain and one ramp-up less per panel on the main stream, and
                 // the small urgent launch (30 TFLOP/s on its own) runs at the large launch's rate.
-                const int64_t nt64m = ((n - u0 + 63) / 64) * ((n - u0 + 63) / 64 + 1) / 2;
-                if (c->merge_urgent && u1 < n && split == n && nt64m >= c->merge_min_tiles && (c->tile == 0 || c->tile == 64) && (u1 - u0) % 64 == 0) {
-                    GPT_TRY(gemm_nt(c, S, n - u0, n - u0, w, -1.0, A + u0 * lda + c0, lda, A + u0 * lda + c0, lda, 1.0,
+                // (with a helper slice the merged launch is the lower trapezoid of the columns [u0, split))
+                const int64_t mtn = (split - u0 + 63) / 64, mtm = (n - u0 + 63) / 64;
+                const int64_t nt64m = mtn * (mtn + 1) / 2 + (mtm - mtn) * mtn;
+                if (c->merge_urgent && u1 < split && nt64m >= c->merge_min_tiles && (c->tile == 0 || c->tile == 64) && (u1 - u0) % 64 == 0) {
+                    if (e_help_prev && !waited) GPT_HIP_CHECK(hipStreamWaitEvent(S, e_help_prev, 0));
+                    e_help_prev = nullptr;
+                    GPT_TRY(gemm_nt(c, S, n - u0, split - u0, w, -1.0, A + u0 * lda + c0, lda, A + u0 * lda + c0, lda, 1.0,
                                     A + u0 * lda + u0, lda, 1, nullptr, cu_edge, EdgeSig(), u1 - u0));
                     cu_edge_prev = cu_edge;
+                    if (split < n) {
+                        s_prev = split;
+                        e_help_prev = e_help;
+                    }
                     c0 += w;
                     continue;
                 }
@@ -1818,7 +1830,7 @@ static int fit_matrix_once(gpt_ctx *c, const double *K_tot, int64_t N, const dou
 // pure latency and the host's launch rate bounds it (0.37 ms at N = 1024).  Here every kernel of that chain carries the
 // whole batch in a grid dimension: element b works on its own matrix A + b NP^2 with its own hyperparameters, the
 // diagonal-block kernel runs nbatch workgroups on nbatch CUs at once, and the launch sequence (3 launches per leaf) is paid
-// once per batch.  No look-ahead, one stream: the parallelism is across the batch.  Same kernels, same tile choice and the
+// once per batch.  No look-ahead, one stream, left-looking leaves: the parallelism is across the batch.  Same kernels, same tile choice and the
 // same summation orders as gpt_fit, so an element's ll / log-determinant carry the very bits gpt_fit returns for it alone
 // (tests/test_gpu_parity.py::test_fit_batch_*).  N <= GPT_BATCH_MAX_N; one native kernel, no transform.
 #define GPT_BATCH_MAX_N 2048
@@ -1890,14 +1902,27 @@ extern "C" int gpt_fit_batch(gpt_ctx *c, int nbatch, int kernel_id, const double
     GPT_TRY(launch_batch_pad(st, h, nbatch, dA, NP, bs, N, NP, 1e300, dinfo));
     GPT_TRY(launch_kbuild_batch(st, kernel_id, c->D, reinterpret_cast<const KParams *>(dmisc + d_off_kp), dmisc + d_off_nv, nbatch,
                                 c->dX, c->dn, N, dmisc, diag_add, dA, NP, bs));
+    // LEFT-looking over the 128-column leaves: leaf j first receives the update of ALL leaves before it in one launch
+    // (k = 128 j; element by element the same sums in the same order as the right-looking rank-128 updates of gpt_fit, whose
+    // accumulators also start from C and walk k upwards: bit-identical), then its diagonal block and TRSM.  A right-looking
+    // batch re-reads and re-writes every element of every trailing matrix once per leaf (16 bytes per 256 flops at k = 128):
+    // 0.77 of the 1.31 ms of a 64 x N = 1024 batch were those updates; here every element of the factor is written once.
+    // (GPT_BATCH_RIGHT=1: the right-looking form, for comparison)
+    // Measured, 64 elements: N = 1024 1.376 against 1.412 ms, N = 2048 5.79 against 6.22 ms, N = 256 0.247 against 0.237 ms.
+    static const bool force_right = getenv("GPT_BATCH_RIGHT") != nullptr;
+    const bool right_looking = force_right || NP <= 512;
     for (int64_t lc = 0; lc < NP; lc += 128) {
+        if (!right_looking && lc > 0)
+            GPT_TRY(launch_gemm_nt(st, NP - lc, 128, lc, -1.0, dA + lc * NP, NP, dA + lc * NP, NP, 1.0, dA + lc * NP + lc, NP, 1, 0, 0,
+                                   nullptr, nullptr, 0, EdgeSig(), EdgeSig(), 0, nbatch, bs));
         GPT_TRY(launch_potf2_diag(st, dA + lc * NP + lc, NP, dws + (lc / 128) * GPT_WS_BLOCK, dinfo, lc, EdgeSig(), nbatch, bs, bws));
         const int64_t r1 = lc + 128, m = NP - r1;
         if (m <= 0) break;
         GPT_TRY(launch_trsm_panel(st, m, dA + lc * NP + lc, NP, dws + (lc / 128) * GPT_WS_BLOCK, dA + r1 * NP + lc, NP, nullptr,
                                   EdgeSig(), nbatch, bs, bws));
-        GPT_TRY(launch_gemm_nt(st, m, m, 128, -1.0, dA + r1 * NP + lc, NP, dA + r1 * NP + lc, NP, 1.0, dA + r1 * NP + r1, NP, 1, 0, 0,
-                               nullptr, nullptr, 0, EdgeSig(), EdgeSig(), 0, nbatch, bs));
+        if (right_looking)
+            GPT_TRY(launch_gemm_nt(st, m, m, 128, -1.0, dA + r1 * NP + lc, NP, dA + r1 * NP + lc, NP, 1.0, dA + r1 * NP + r1, NP, 1, 0, 0,
+                                   nullptr, nullptr, 0, EdgeSig(), EdgeSig(), 0, nbatch, bs));
     }
     GPT_TRY(launch_batch_logdet_dot(st, dA, NP, bs, N, nbatch, dinfo, h + off_res));
     GPT_HIP_CHECK(hipStreamSynchronize(st));
