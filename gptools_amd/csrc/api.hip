@@ -41,7 +41,7 @@ struct DevBuf {
 
 enum { SLOT_XI = 0, SLOT_XJ, SLOT_NI, SLOT_NJ, SLOT_OUT, SLOT_KST, SLOT_KSS, SLOT_XS, SLOT_NS, SLOT_VEC, SLOT_VEC2,
        SLOT_RHS, SLOT_LOW, SLOT_KFULL, SLOT_TK, SLOT_ZERO, SLOT_UINV, SLOT_WINV, SLOT_GPART, SLOT_BINV, SLOT_BTMP,
-       SLOT_BINV2, SLOT_BATCH_A, SLOT_BATCH_WS, SLOT_BATCH_MISC, SLOT_COUNT };
+       SLOT_BINV2, SLOT_BINV3, SLOT_BINV3U, SLOT_BATCH_A, SLOT_BATCH_WS, SLOT_BATCH_MISC, SLOT_COUNT };
 
 struct gpt_ctx {
     int device = 0;
@@ -119,6 +119,7 @@ struct gpt_ctx {
     bool factored = false, alpha_valid = false, have_kernel = false;
     bool binv_valid = false;           // SLOT_BINV holds the inverses of the 512x512 diagonal blocks of the resident factor
     bool binv2_valid = false;          // SLOT_BINV2 those of its 1024x1024 diagonal blocks (solves with very few rows)
+    bool binv3_valid = false;          // SLOT_BINV3 those of its 2048x2048 diagonal blocks (the same, large factors)
     double *h_stage = nullptr;         // pinned staging ring for results that go to pageable host memory (2 x GPT_STAGE_BYTES)
     hipStream_t copy_stream = nullptr; // device-to-host copies that overlap the next block's compute (created on first use)
     hipEvent_t cev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1137,7 +1138,7 @@ static void free_factor(gpt_ctx *c)
     if (c->d_alpha) hipFree(c->d_alpha);
     c->dA = c->d_invd = c->d_y = c->d_erry = c->d_alpha = nullptr;
     c->NP = 0;
-    c->factored = c->alpha_valid = c->binv_valid = c->binv2_valid = false;
+    c->factored = c->alpha_valid = c->binv_valid = c->binv2_valid = c->binv3_valid = false;
 }
 
 extern "C" int gpt_ctx_destroy(gpt_ctx *c)
@@ -1436,7 +1437,7 @@ extern "C" int gpt_set_data(gpt_ctx *c, const double *X, const int32_t *n, int64
         if (sn > c->n_maxsum) c->n_maxsum = sn;
     }
     c->factored = false;
-    c->alpha_valid = c->binv_valid = c->binv2_valid = false;
+    c->alpha_valid = c->binv_valid = c->binv2_valid = c->binv3_valid = false;
     c->have_kernel = false;
     if (c->dT) hipFree(c->dT);          // a transform belongs to one data set
     c->dT = nullptr;
@@ -1459,7 +1460,7 @@ extern "C" int gpt_set_T(gpt_ctx *c, const double *T, int64_t Ny)
     c->dT = nullptr;
     c->Ny = 0;
     c->factored = false;
-    c->alpha_valid = c->binv_valid = c->binv2_valid = false;
+    c->alpha_valid = c->binv_valid = c->binv2_valid = c->binv3_valid = false;
     c->have_kernel = false;
     if (!T || Ny <= 0) return GPT_OK;
     const int64_t NyP = round_up(Ny, 64), NxP = round_up(c->Nx, 16);
@@ -1537,7 +1538,7 @@ static int factor_and_ll(gpt_ctx *c, int64_t N, double *ll_data_out, double *log
         hipEventElapsedTime(&ms, c->tev[0], c->tev[4]);
         c->timings[4] = ms;
     }
-    c->alpha_valid = c->binv_valid = c->binv2_valid = false;
+    c->alpha_valid = c->binv_valid = c->binv2_valid = c->binv3_valid = false;
     if (c->flags_now && c->h_scal[3] != 0.0) {
         // a flag wait of this evaluation timed out (common.hpp): its numbers mean nothing; the caller repeats it on events
         c->factored = false;
@@ -2374,6 +2375,35 @@ static int ensure_block_inverses(gpt_ctx *c, int64_t nb, int64_t nfull, double *
     return GPT_OK;
 }
 
+// The 2048 x 2048 diagonal blocks' inverses, for solves with at most GPT_FEW_ROWS rows against a large factor (the chain of
+// dependent GEMMs -- two per block -- is what such a solve costs: 4 blocks at N = 8192 instead of 8 or 16).  Built from the
+// 512-wide inverses by the GEMM-only triangular inverse of the gradient path (trtri_u_gemm: U = L^-T of the block, N^3/3 flop
+// with the block's zeros skipped -- the identity pushed through the panel TRSM would cost 6 x that), then transposed.
+#define GPT_BINV_NB3 2048
+static int ensure_block_inverses_big(gpt_ctx *c, int64_t nfull, double **out)
+{
+    const int64_t nb = GPT_BINV_NB3;
+    double *W, *U, *T, *Wb;
+    GPT_TRY(ensure(c, SLOT_BINV3, (size_t)nfull * nb * sizeof(double), (void **)&W));
+    *out = W;
+    if (c->binv3_valid) return GPT_OK;
+    GPT_TRY(ensure_block_inverses(c, GPT_BINV_NB, nfull, &Wb));
+    // U strip (nfull x nb, block j at rows [j, j + nb)) followed by one nb x nb scratch block for the products
+    GPT_TRY(ensure(c, SLOT_BINV3U, ((size_t)nfull * nb + (size_t)nb * nb) * sizeof(double), (void **)&U));
+    T = U + nfull * nb;
+    hipStream_t st = c->stream;
+    GPT_HIP_CHECK(hipMemsetAsync(U, 0, (size_t)nfull * nb * sizeof(double), st));
+    for (int64_t j = 0; j < nfull; j += nb) {
+        // (trtri_u_gemm indexes U and T by ABSOLUTE factor rows / columns: bases shifted so that (j, j) is the block's origin)
+        GPT_TRY(trtri_u_gemm(c, st, j, j + nb, Wb, U + j * nb - j * nb - j, nb, T - j * nb - j, nb));
+        hipLaunchKernelGGL(transpose_rect_kernel, dim3((unsigned)(nb / 32), (unsigned)(nb / 32)), dim3(256), 0, st, U + j * nb, nb,
+                           W + j * nb, nb, nb, nb);
+        GPT_LAUNCH_CHECK();
+    }
+    c->binv3_valid = true;
+    return GPT_OK;
+}
+
 // Columns [lo, hi) of V <- the same columns of B L^-T (multiples of nb) by halving; a leaf is ONE out-of-place GEMM against
 // the block inverse, V_j = B_j W_j^T, the update in between B[:, mid:hi] -= V[:, lo:mid] L[mid:hi, lo:mid]^T.  B is consumed.
 static int trsm_rlt_binv(gpt_ctx *c, hipStream_t st, int64_t m, int64_t nb, int64_t lo, int64_t hi, const double *W, double *B,
@@ -2391,26 +2421,41 @@ static int trsm_rlt_binv(gpt_ctx *c, hipStream_t st, int64_t m, int64_t nb, int6
 // V (m x n128, ldv) <- B L^-T for the resident factor (n128 = N rounded up to 128); B (m x n128, ldb) is consumed.
 static int solve_rows_resident(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n128, double *B, int64_t ldb, double *V, int64_t ldv)
 {
-    const int64_t nb = (m <= GPT_FEW_ROWS && n128 >= 4 * GPT_BINV_NB2) ? GPT_BINV_NB2 : GPT_BINV_NB;
-    const int64_t nfull = (n128 / nb) * nb, rem = n128 - nfull;
-    if (nfull < 2 * nb) {
+    const int64_t nfull = (n128 / GPT_BINV_NB) * GPT_BINV_NB;
+    if (nfull < 2 * GPT_BINV_NB) {
         GPT_TRY(launch_copy2d(st, m, n128, B, ldb, V, ldv));
         return trsm_rlt(c, st, m, n128, c->dA, c->NP, c->d_invd, V, ldv);
     }
     double *W;
-    GPT_TRY(ensure_block_inverses(c, nb, nfull, &W));
+    GPT_TRY(ensure_block_inverses(c, GPT_BINV_NB, nfull, &W));
+    const int64_t rem = n128 - nfull;
     if (m <= 256) {
         // few rows: the halving recursion ends in updates with 64..256 rows and k of thousands -- a handful of workgroups
-        // walking long k loops (1.6 ms at N = 8192).  Right-looking instead: after each leaf one rank-nb update of everything
-        // to its right (n/64 workgroups, nb/16 k-steps each).
-        for (int64_t j = 0; j < nfull; j += nb) {
-            GPT_TRY(gemm_nt(c, st, m, nb, nb, 1.0, B + j, ldb, W + j * nb, nb, 0.0, V + j, ldv, 0));
+        // walking long k loops (1.6 ms at N = 8192).  Right-looking instead: after each leaf (one out-of-place GEMM against the
+        // block inverse) one update of everything to its right.  What such a solve costs is the LENGTH of that chain of
+        // dependent GEMMs, so up to GPT_FEW_ROWS rows the widest inverses that fit are used: 2048-wide blocks, then 1024-wide,
+        // then 512-wide ones for what is left (predict with std at 64 points, N = 8192: 16 / 8 / 4 blocks -> 0.91 / 0.43 / ~0.35 ms).
+        double *W3 = nullptr, *W2 = nullptr;
+        int64_t n3 = 0, n2 = 0;
+        if (m <= GPT_FEW_ROWS && n128 >= 4 * GPT_BINV_NB3) {
+            n3 = (n128 / GPT_BINV_NB3) * GPT_BINV_NB3;
+            GPT_TRY(ensure_block_inverses_big(c, n3, &W3));
+        } else if (m <= GPT_FEW_ROWS && n128 >= 4 * GPT_BINV_NB2) {
+            n2 = (n128 / GPT_BINV_NB2) * GPT_BINV_NB2;
+            GPT_TRY(ensure_block_inverses(c, GPT_BINV_NB2, n2, &W2));
+        }
+        int64_t j = 0;
+        while (j < nfull) {
+            const int64_t nb = (j + GPT_BINV_NB3 <= n3) ? GPT_BINV_NB3 : (j + GPT_BINV_NB2 <= n2) ? GPT_BINV_NB2 : GPT_BINV_NB;
+            const double *Wj = (nb == GPT_BINV_NB3) ? W3 + j * nb : (nb == GPT_BINV_NB2) ? W2 + j * nb : W + j * nb;
+            GPT_TRY(gemm_nt(c, st, m, nb, nb, 1.0, B + j, ldb, Wj, nb, 0.0, V + j, ldv, 0));
             const int64_t r0 = j + nb;
             if (r0 < n128)
                 GPT_TRY(gemm_nt(c, st, m, n128 - r0, nb, -1.0, V + j, ldv, c->dA + r0 * c->NP + j, c->NP, 1.0, B + r0, ldb, 0));
+            j = r0;
         }
     } else {
-        GPT_TRY(trsm_rlt_binv(c, st, m, nb, 0, nfull, W, B, ldb, V, ldv));
+        GPT_TRY(trsm_rlt_binv(c, st, m, GPT_BINV_NB, 0, nfull, W, B, ldb, V, ldv));
         if (rem > 0) GPT_TRY(gemm_nt(c, st, m, rem, nfull, -1.0, V, ldv, c->dA + nfull * c->NP, c->NP, 1.0, B + nfull, ldb, 0));
     }
     if (rem > 0) {
