@@ -51,6 +51,7 @@ SIGNATURES = {
     "gpt_predict": (C.c_int, [_vp, _dp, _ip, _i64, C.c_int, _dp, _ip, _dp, _dp, _dp]),
     "gpt_host_alloc": (C.c_int, [_i64, C.POINTER(_vp)]),
     "gpt_host_free": (C.c_int, [_vp]),
+    "gpt_cov_sample": (C.c_int, [_vp, _i64, C.c_double, _dp, _i64, _dp]),
     "gpt_solve_L": (C.c_int, [_vp, _dp, _i64]),
     "gpt_cho_solve": (C.c_int, [_vp, _dp, _i64]),
     "gpt_last_timings": (C.c_int, [_vp, _dp, C.c_int]),
@@ -399,17 +400,26 @@ class Context(object):
         check(self._lib.gpt_get_alpha(self.handle, dptr(a)))
         return a
 
-    def predict(self, Xstar, nstar, want, noise_params=None, noise_n=None):
+    def predict(self, Xstar, nstar, want, noise_params=None, noise_n=None, device_cov=False):
+        """``device_cov`` (with ``want == 2``): the covariance stays on the device (for :meth:`cov_sample`); ``cov`` is None."""
         Xstar, nstar = f64(Xstar), i32(nstar)
         M = Xstar.shape[0]
         mean = np.empty(M)
         std = np.empty(M) if want >= 1 else None
-        cov = pinned_empty((M, M)) if want == 2 else None
+        cov = pinned_empty((M, M)) if (want == 2 and not device_cov) else None
         npar = None if noise_params is None else f64(noise_params)
         nn = None if noise_n is None else i32(noise_n)
         check(self._lib.gpt_predict(self.handle, dptr(Xstar), iptr(nstar), M, int(want), dptr(npar), iptr(nn),
                                     dptr(mean), dptr(std), dptr(cov)))
         return mean, std, cov
+
+    def cov_sample(self, diag_add, rand_vars):
+        """``cholesky(cov + diag_add I) @ rand_vars`` for the covariance the last ``predict(..., want=2, device_cov=True)`` left
+        on the device; ``rand_vars`` (M, S)."""
+        R = f64(np.atleast_2d(rand_vars))
+        out = np.empty(R.shape)
+        check(self._lib.gpt_cov_sample(self.handle, R.shape[0], float(diag_add), dptr(R), R.shape[1], dptr(out)))
+        return out
 
     def solve_L(self, B):
         B2 = np.array(B, dtype=np.float64, order="C")

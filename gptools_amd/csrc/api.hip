@@ -2657,10 +2657,12 @@ extern "C" int gpt_predict(gpt_ctx *c, const double *Xstar, const int32_t *nstar
         // M^2 doubles of the result cross PCIe under the SYRK (M = 4096, N = 8192: 18.3 -> ~10 ms).
         // cov_out == NULL: the covariance stays on the device (lower triangle, SLOT_KSS) for gpt_cov_sample; nothing moves.
         double *dcov;
-        GPT_TRY(ensure(c, SLOT_KSS, (size_t)MP * MP * sizeof(double), (void **)&dcov));
-        GPT_TRY(launch_zero2d(st, MP, MP, dcov, MP));
-        GPT_TRY(kbuild_terms(c, st, c->terms, 1, dXs, dns, M, dXs, dns, M, 0, 0, 0, nullptr, 0.0, 0.0, dcov, MP));
-        if (noise_params) GPT_TRY(launch_add_noise_sym(st, kn, dXs, dns, M, dcov, MP));
+        // (row stride LDC = M rounded up to 128: gpt_cov_sample factors this matrix in place, padded to whole 128-blocks)
+        const int64_t LDC = round_up(M, 128);
+        GPT_TRY(ensure(c, SLOT_KSS, (size_t)LDC * LDC * sizeof(double), (void **)&dcov));
+        GPT_TRY(launch_zero2d(st, LDC, LDC, dcov, LDC));
+        GPT_TRY(kbuild_terms(c, st, c->terms, 1, dXs, dns, M, dXs, dns, M, 0, 0, 0, nullptr, 0.0, 0.0, dcov, LDC));
+        if (noise_params) GPT_TRY(launch_add_noise_sym(st, kn, dXs, dns, M, dcov, LDC));
         c->cov_M = 0;
         const int64_t CB = 512;
         const int64_t nblk = (MP + CB - 1) / CB;
@@ -2670,15 +2672,15 @@ extern "C" int gpt_predict(gpt_ctx *c, const double *Xstar, const int32_t *nstar
         }
         for (int64_t q = 0; q < nblk; q++) {
             const int64_t c0 = q * CB, w = (MP - c0 < CB) ? MP - c0 : CB;
-            GPT_TRY(gemm_nt(c, st, MP - c0, w, n128, -1.0, dV + c0 * n128, n128, dV + c0 * n128, n128, 1.0, dcov + c0 * MP + c0, MP, 1));
+            GPT_TRY(gemm_nt(c, st, MP - c0, w, n128, -1.0, dV + c0 * n128, n128, dV + c0 * n128, n128, 1.0, dcov + c0 * LDC + c0, LDC, 1));
             if (!cov_out) continue;
-            GPT_TRY(launch_mirror_rows(st, dcov, MP, c0, w, MP));
+            GPT_TRY(launch_mirror_rows(st, dcov, LDC, c0, w, MP));
             hipEvent_t e = get_event(c, 100 + (size_t)q);
             if (!e) return GPT_E_HIP;
             GPT_HIP_CHECK(hipEventRecord(e, st));
         }
         if (!cov_out) {
-            GPT_TRY(launch_diag_gather(st, dcov, MP, M, dvar));
+            GPT_TRY(launch_diag_gather(st, dcov, LDC, M, dvar));
             if (std_out) GPT_HIP_CHECK(hipMemcpyAsync(std_out, dvar, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, st));
             GPT_HIP_CHECK(hipStreamSynchronize(st));
             if (std_out)
@@ -2691,7 +2693,7 @@ extern "C" int gpt_predict(gpt_ctx *c, const double *Xstar, const int32_t *nstar
             if (c0 >= M) break;
             const int64_t rows = (M - c0 < CB) ? M - c0 : CB;
             GPT_HIP_CHECK(hipStreamWaitEvent(c->copy_stream, get_event(c, 100 + (size_t)q), 0));
-            GPT_TRY(d2h_rows(c, cov_out + c0 * M, M, dcov + c0 * MP, MP, rows, M));
+            GPT_TRY(d2h_rows(c, cov_out + c0 * M, M, dcov + c0 * LDC, LDC, rows, M));
         }
         GPT_TRY(d2h_finish(c));
         GPT_HIP_CHECK(hipStreamSynchronize(st));
@@ -2700,6 +2702,59 @@ extern "C" int gpt_predict(gpt_ctx *c, const double *Xstar, const int32_t *nstar
         return GPT_OK;
     }
     GPT_HIP_CHECK(hipStreamSynchronize(st));
+    return GPT_OK;
+}
+
+// Posterior samples from the device-resident predictive covariance (ref: gaussian_process.py:1295-1300, :1330, draw_sample
+// with rand_vars and method='cholesky'): after gpt_predict(want = 2, cov_out = NULL),
+//   L = cholesky(cov + diag_add I) in place on the device,  out (M x S) = L rand (M x S)
+// -- the M x M covariance never crosses PCIe (the caller adds the mean).  The resident factor of the fit is untouched (the
+// factorisation here has its own workspace).  Status > 0: that leading minor of the loaded covariance is not positive definite.
+extern "C" int gpt_cov_sample(gpt_ctx *c, int64_t M_rows, double diag_add, const double *rand, int64_t S, double *out)
+{
+    CTX_ENTER(c);
+    if (c->cov_M <= 0) {
+        gpt_set_error("gpt_cov_sample: call gpt_predict(want = 2, cov_out = NULL) first");
+        return GPT_E_STATE;
+    }
+    if (!rand || !out || S <= 0) return GPT_E_ARG;
+    if (M_rows != c->cov_M) {
+        gpt_set_error("gpt_cov_sample: rand has %lld rows, the resident covariance %lld", (long long)M_rows, (long long)c->cov_M);
+        return GPT_E_ARG;
+    }
+    const int64_t M = c->cov_M, LDC = round_up(M, 128), SP = round_up(S, 64);
+    hipStream_t st = c->stream;
+    double *dcov = (double *)c->slots[SLOT_KSS].p, *dzero, *ws, *dlow, *dRt, *dOut;
+    GPT_TRY(ensure(c, SLOT_ZERO, (size_t)M * sizeof(double), (void **)&dzero));
+    GPT_TRY(ensure(c, SLOT_BATCH_WS, ((size_t)(LDC / 128) * GPT_WS_BLOCK + 8) * sizeof(double), (void **)&ws));
+    int32_t *dinfo = reinterpret_cast<int32_t *>(ws + (LDC / 128) * GPT_WS_BLOCK);
+    GPT_TRY(ensure(c, SLOT_LOW, (size_t)LDC * LDC * sizeof(double), (void **)&dlow));
+    GPT_TRY(ensure(c, SLOT_RHS, (size_t)SP * LDC * sizeof(double), (void **)&dRt));
+    GPT_TRY(ensure(c, SLOT_OUT, (size_t)LDC * SP * sizeof(double), (void **)&dOut));
+    c->cov_M = 0;                                                    // (the covariance is consumed)
+    EvalScope scope(c);                                              // counted like an evaluation in flight ...
+    c->flags_now = false;                                            // ... on event edges (no flag-timeout repeat here)
+    GPT_HIP_CHECK(hipMemsetAsync(dzero, 0, (size_t)M * sizeof(double), st));
+    GPT_HIP_CHECK(hipMemsetAsync(dinfo, 0, sizeof(int32_t), st));
+    GPT_TRY(launch_add_diag(st, dcov, LDC, M, dzero, diag_add));
+    GPT_TRY(launch_fill_pad(st, dcov, LDC, M, LDC, nullptr, 0.0));      // unit diagonal on the padding rows
+    // rand^T, zero padded: the GEMM wants the contraction index (rows of rand) contiguous
+    std::vector<double> Rt((size_t)SP * LDC, 0.0);
+    for (int64_t k = 0; k < M; k++)
+        for (int64_t s_ = 0; s_ < S; s_++) Rt[(size_t)s_ * LDC + k] = rand[(size_t)k * S + s_];
+    GPT_HIP_CHECK(hipMemcpyAsync(dRt, Rt.data(), Rt.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    GPT_TRY(potrf_run(c, LDC, dcov, LDC, ws, dinfo));
+    GPT_TRY(launch_extract_lower(st, dcov, LDC, LDC, dlow, LDC));
+    GPT_TRY(gemm_nt(c, st, LDC, SP, LDC, 1.0, dlow, LDC, dRt, LDC, 0.0, dOut, SP, 0));
+    int32_t info = 0;
+    GPT_HIP_CHECK(hipMemcpyAsync(&info, dinfo, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GPT_HIP_CHECK(hipMemcpy2DAsync(out, (size_t)S * sizeof(double), dOut, (size_t)SP * sizeof(double), (size_t)S * sizeof(double),
+                                   (size_t)M, hipMemcpyDeviceToHost, st));
+    GPT_HIP_CHECK(hipStreamSynchronize(st));
+    if (info != 0) {
+        gpt_set_error("%d-th leading minor of the array is not positive definite", (int)info);
+        return (int)(info > M ? M : info);
+    }
     return GPT_OK;
 }
 

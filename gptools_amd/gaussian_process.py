@@ -842,17 +842,8 @@ class GaussianProcess(object):
         return (res_min, len(res))
 
     # ---- prediction (ref: gptools/gaussian_process.py:785-1034) ------------------------------
-    def predict(self, Xstar, n=0, noise=False, return_std=True, return_cov=False, full_output=False,
-                return_samples=False, num_samples=1, samp_kwargs={}, return_mean_func=False, use_MCMC=False,
-                full_MC=False, rejection_func=None, ddof=1, output_transform=None, **kwargs):
-        """Predictive mean (and std / covariance) at ``Xstar`` (M, D) for derivative orders ``n``.
-
-        Returns ``mean``, ``(mean, std)``, ``(mean, cov)`` or the ``full_output`` dict exactly like the
-        reference's non-MCMC branch (``return_samples`` / ``full_MC`` draw through :meth:`draw_sample`); marginalising
-        the hyperparameters by MCMC is outside the accelerated path."""
-        if use_MCMC:
-            raise NotImplementedError("MCMC marginalisation of the hyperparameters is outside the accelerated hot "
-                                      "path (SURVEY.md section 8).")
+    def _check_predict_args(self, Xstar, n, output_transform=None):
+        """Shapes and types of ``predict``'s inputs as the reference checks them (ref: gaussian_process.py:913-963)."""
         Xstar = np.atleast_2d(np.asarray(Xstar, dtype=float))
         if self.num_dim == 1 and Xstar.shape[0] == 1:
             Xstar = Xstar.T
@@ -882,6 +873,20 @@ class GaussianProcess(object):
         if (n < 0).any():
             raise ValueError("All elements of n must be non-negative integers!")
 
+        return Xstar, n, output_transform
+
+    def predict(self, Xstar, n=0, noise=False, return_std=True, return_cov=False, full_output=False,
+                return_samples=False, num_samples=1, samp_kwargs={}, return_mean_func=False, use_MCMC=False,
+                full_MC=False, rejection_func=None, ddof=1, output_transform=None, **kwargs):
+        """Predictive mean (and std / covariance) at ``Xstar`` (M, D) for derivative orders ``n``.
+
+        Returns ``mean``, ``(mean, std)``, ``(mean, cov)`` or the ``full_output`` dict exactly like the
+        reference's non-MCMC branch (``return_samples`` / ``full_MC`` draw through :meth:`draw_sample`); marginalising
+        the hyperparameters by MCMC is outside the accelerated path."""
+        if use_MCMC:
+            raise NotImplementedError("MCMC marginalisation of the hyperparameters is outside the accelerated hot "
+                                      "path (SURVEY.md section 8).")
+        Xstar, n, output_transform = self._check_predict_args(Xstar, n, output_transform)
         self.compute_K_L_alpha_ll()
         need_cov = (return_cov or full_output or return_samples or full_MC or
                     (output_transform is not None and (return_std or return_cov)))
@@ -944,6 +949,28 @@ class GaussianProcess(object):
         the normal quantile function) the square root ``L`` of ``cov + diag_factor * eps * I`` is the lower Cholesky
         factor -- computed on the GPU -- or ``Q sqrt(Lambda)`` from ``scipy.linalg.eigh``.  The predictive mean and
         covariance come from :meth:`predict` (device path) unless given."""
+        if (mean is None and cov is None and rand_vars is not None and method == "cholesky"
+                and set(kwargs) <= {"noise"} and rand_type in ("standard normal", "uniform")):
+            # Device route (gpt_cov_sample): the predictive covariance stays in HBM, its Cholesky factor is formed there and only
+            # L u (M x num_samp) comes back -- nothing of size M^2 crosses PCIe.  Same arithmetic as below (ref :1295-1300, :1330).
+            self.compute_K_L_alpha_ll()
+            if self._fit_mode == "kernel":
+                Xs, ns, _ = self._check_predict_args(Xstar, n)
+                noise = bool(kwargs.get("noise", False))
+                noise_params = noise_n = None
+                if noise and isinstance(self.noise_k, DiagonalNoiseKernel) and not isinstance(self.noise_k, ZeroKernel):
+                    noise_params, noise_n = self.noise_k.params, self.noise_k.n
+                M = Xs.shape[0]
+                ne = M if (num_eig is None or num_eig > M) else max(int(num_eig), 1)
+                rv = np.atleast_2d(np.asarray(rand_vars, dtype=float))[:ne, :]
+                if rv.shape[0] == M:              # (anything else is the reference's shape error: raised by the host route)
+                    mean_d, _, _ = self._ctx.predict(Xs, ns, 2, noise_params, noise_n, device_cov=True)
+                    if self.mu is not None:
+                        mean_d = mean_d + self.mu(Xs, ns)
+                    if rand_type == "uniform":
+                        from scipy.stats import norm as _norm
+                        rv = _norm.ppf(rv)
+                    return np.atleast_2d(mean_d).T + self._ctx.cov_sample(diag_factor * sys.float_info.epsilon, rv)
         if mean is None or cov is None:
             out = self.predict(Xstar, n=n, full_output=True, **kwargs)
             mean, cov = out["mean"], out["cov"]

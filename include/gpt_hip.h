@@ -243,6 +243,14 @@ int gpt_predict(gpt_ctx *ctx, const double *Xstar, const int32_t *nstar, int64_t
                 const double *noise_params, const int32_t *noise_n,
                 double *mean_out, double *std_out, double *cov_out);
 
+/* Posterior samples from the predictive covariance left on the device by gpt_predict(want = 2, cov_out = NULL)
+ * (ref: gaussian_process.py:1295-1300, :1330 -- draw_sample with rand_vars, method = 'cholesky'):
+ *   out (M x S, row-major) = cholesky(cov + diag_add I, lower) * rand (M x S, row-major);  the caller adds the mean.
+ * M must be the M of that gpt_predict call (GPT_E_ARG otherwise).
+ * The M x M covariance never leaves the device; the fit's resident factor is untouched; the covariance is consumed.
+ * Status > 0: that leading minor is not positive definite (numpy.linalg.LinAlgError, as scipy.linalg.cholesky). */
+int gpt_cov_sample(gpt_ctx *ctx, int64_t M, double diag_add, const double *rand, int64_t S, double *out);
+
 /* Generic right-hand sides against the resident factor (host in/out, row-major):
  *   gpt_solve_L   : B (N, nrhs) <- L^-1 B          (ref: gaussian_process.py:983 solve_triangular)
  *   gpt_cho_solve : B (N, nrhs) <- K_tot^-1 B      (ref: gaussian_process.py:1462,1487,1503 cho_solve) */

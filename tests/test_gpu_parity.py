@@ -1258,6 +1258,47 @@ def test_draw_sample_cholesky_and_eig(g):
         gp.draw_sample(Xs, rand_vars=u, rand_type="triangular")
 
 
+def test_draw_sample_device_route_matches_host_route(g):
+    """gpt_cov_sample: draw_sample(rand_vars=...) keeps the predictive covariance on the device (gpt_predict with
+    cov_out NULL), factors it there and returns mean + L u; the host route (mean= and cov= handed in, factor through
+    gpt_potrf_host) is the same arithmetic on the same matrix.  M not a multiple of 128, derivative rows, noise=True,
+    and the fit's factor survives."""
+    rs = np.random.RandomState(14)
+    X = rs.rand(700, 2)
+    y = np.sin(4 * X[:, 0]) * np.cos(3 * X[:, 1]) + 0.05 * rs.randn(700)
+    k = make_kernel(g, "se", 2, [1.3, 0.35, 0.5])
+    nk = g.DiagonalNoiseKernel(2, initial_noise=0.08, fixed_noise=True)
+    gp = g.GaussianProcess(k, noise_k=nk, X=X, y=y, err_y=0.03)
+    ll0 = gp.update_hyperparameters(gp.free_params[:]) if hasattr(gp, "update_hyperparameters") else None
+    M = 333
+    Xs = rs.rand(M, 2)
+    ns = np.zeros((M, 2), dtype=int)
+    ns[::7, 0] = 1
+    u = rs.randn(M, 5)
+    for noise in (False, True):
+        out = gp.predict(Xs, n=ns, noise=noise, full_output=True)
+        host = gp.draw_sample(Xs, n=ns, rand_vars=u, mean=out["mean"], cov=out["cov"])
+        dev = gp.draw_sample(Xs, n=ns, rand_vars=u, noise=noise)
+        assert dev.shape == (M, 5)
+        # (the loaded covariance is close to singular without the noise term: compare at the size of the jitter's root)
+        np.testing.assert_allclose(dev, host, rtol=0, atol=1e-6 if not noise else 1e-10)
+        Ld = gp.draw_sample(Xs, n=ns, rand_vars=np.eye(M), noise=noise) - out["mean"][:, None]
+        assert np.abs(np.triu(Ld, 1)).max() == 0.0
+        np.testing.assert_allclose(Ld.dot(Ld.T), out["cov"] + 1e3 * EPS * np.eye(M), rtol=0, atol=1e-11)
+        with pytest.raises(ValueError):                      # (M x M) . (40 x 5): the reference's own shape error
+            gp.draw_sample(Xs, n=ns, rand_vars=u, num_eig=40, noise=noise)
+    if ll0 is not None:
+        assert gp.update_hyperparameters(gp.free_params[:]) == ll0
+    again = gp.predict(Xs, n=ns, full_output=True)
+    np.testing.assert_array_equal(again["mean"], gp.predict(Xs, n=ns, return_std=False))
+    # the C-ABI refuses a second draw from a covariance that was consumed
+    with pytest.raises(Exception):
+        gp._ctx.cov_sample(0.0, u)
+    gp._ctx.predict(Xs, ns, 2, device_cov=True)
+    with pytest.raises(Exception):                           # wrong number of rows for the resident covariance
+        gp._ctx.cov_sample(0.0, u[:100])
+
+
 def test_device_ll_gradient_against_host_path_and_finite_differences(g):
     """gpt_ll_grad (K_tot^-1 on the device + fused pair pass) against the reference-shaped host path
     (dK per parameter, two triangular solves each, ref gaussian_process.py:1471-1520) and against central finite
