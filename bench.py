@@ -509,7 +509,7 @@ def main():
             pl = {}
             lib_ = _lib.load()
             for M_, want_, tag in ((64, 1, "M64_std"), (4096, 1, "M4096_std"), (4096, 2, "M4096_cov"),
-                                   (4096, 3, "M4096_cov_device_resident")):
+                                   (4096, 3, "M4096_cov_device_resident"), (4096, 4, "M4096_draw_16_samples")):
                 Xs_ = rsp.rand(M_, d)
                 ns_ = np.zeros((M_, d), dtype=np.int32)
                 if want_ == 3:
@@ -519,6 +519,14 @@ def main():
                     def call_():
                         _lib.check(lib_.gpt_predict(ctx.handle, _lib.dptr(Xs_), _lib.iptr(ns_), M_, 2, None, None,
                                                     _lib.dptr(m_), _lib.dptr(s_), None))
+                elif want_ == 4:
+                    # draw_sample's device route: the covariance stays in HBM, is factored there (+ 1e3 eps I) and 16 samples
+                    # mean + L u come back (gpt_predict with cov_out NULL + gpt_cov_sample)
+                    u_ = rsp.randn(M_, 16)
+
+                    def call_():
+                        m2_, _, _ = ctx.predict(Xs_, ns_, 2, device_cov=True)
+                        return m2_[:, None] + ctx.cov_sample(1e3 * np.finfo(float).eps, u_)
                 else:
                     def call_():
                         return ctx.predict(Xs_, ns_, want_)
@@ -532,12 +540,15 @@ def main():
                 barrier()
                 tp_ = (time.perf_counter() - tp0) / reps_
                 fl_ = float(N) * N * M_ + (float(N) * M_ * M_ if want_ >= 2 else 2.0 * N * M_)
+                if want_ == 4:
+                    fl_ += float(M_) ** 3 / 3.0 + 2.0 * float(M_) * M_ * 16
                 pl[tag] = {"M": M_, "ms": tp_ * 1e3, "flops": fl_, "TFLOPs": fl_ / tp_ * 1e-12,
                            "frac_fp64_mfma_peak": fl_ / tp_ * 1e-12 / FP64_MFMA_PEAK_TFLOPS}
             del r_
             pl["note"] = ("wall time of gpt_predict incl. host->device Xstar and device->host results (cov: M^2 doubles = "
                           "134 MB over PCIe at M=4096, written by DMA into a pooled pinned buffer while the SYRK runs; "
-                          "device_resident: cov_out = NULL, nothing of size M^2 moves); flops = N^2 M (triangular solve) + "
+                          "device_resident: cov_out = NULL, nothing of size M^2 moves; draw: + M^3/3 Cholesky of that covariance on the device and "
+                          "2 M^2 S for 16 samples, only M x 16 doubles come back); flops = N^2 M (triangular solve) + "
                           "N M^2 (cov) or 2 N M (std)")
             extra["predict"] = pl
         extra["kbuild_ms"] = tk / args.steps
