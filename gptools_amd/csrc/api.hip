@@ -63,6 +63,8 @@ struct gpt_ctx {
     unsigned edge_seq = 0;                 // value of the last edge raised (monotonic over the context's life)
     int64_t merge_min_tiles = 512;         // ... while the merged launch has at least this many 64x64 tiles (>= 512: it needs an order table)
     int64_t purg_rows_flags = 0;           // purg_rows while flag edges + merged launches are in use
+    int64_t tail_wait = 0;                 // 1: the main stream's last launch of a panel awaits the NEXT panel's flag at its end (gemm.hip "tail wait";
+                                           //    measured the same: 4.459 / 4.471 ms at N = 8192 -- the launches' own drain hides the wait kernel)
     int64_t merge_urgent = 1;              // 1: with flag edges, urgent + rest of a panel are ONE launch (urgent tiles first, partial flag)
     int64_t edge_flags = 1;                // 1: those two edges of the look-ahead may be flag words instead of events (see EvalScope)
     bool flags_now = false;                // ... and ARE, in the evaluation in progress (set by EvalScope)
@@ -331,7 +333,8 @@ static int check_rq_orders(const int32_t *ni, int64_t M, const int32_t *nj, int6
 // ------------------------------------------------------------------------------------------------
 static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A,
                    int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri,
-                   hipEvent_t done = nullptr, EdgeSig edge = EdgeSig(), EdgeSig wait = EdgeSig(), int64_t edge_cols = 0)
+                   hipEvent_t done = nullptr, EdgeSig edge = EdgeSig(), EdgeSig wait = EdgeSig(), int64_t edge_cols = 0,
+                   EdgeSig tail = EdgeSig())
 {
     // algorithmic flop count: 2k per computed element of C (lower trapezoid when tri)
     const double elems = tri ? 0.5 * (double)n * (double)(n + 1) + (double)(m - n) * (double)n : (double)m * (double)n;
@@ -372,7 +375,7 @@ static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, 
     // (option gemm_prio >= 0: every GEMM of this context -- the panel-side context of the block-cyclic engine, whose
     // launches all sit on the chain)
     const int prio = (c->gemm_prio >= 0) ? (int)c->gemm_prio : (!on_main && c->lookahead) ? (int)c->panel_prio : 0;
-    int rc = launch_gemm_nt(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, c->tile, lds_pad, e0, e1, prio, edge, wait, edge_cols);
+    int rc = launch_gemm_nt(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, c->tile, lds_pad, e0, e1, prio, edge, wait, edge_cols, 1, 0, tail);
     if (!ext) {
         if (prof) GPT_HIP_CHECK(hipEventRecord(gp->e1, st));
         if (done) GPT_HIP_CHECK(hipEventRecord(done, st));
@@ -784,6 +787,7 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
         c->edge_seq = 0;
     }
     EdgeSig cu_edge_prev, rest_edge_prev;
+    EdgeSig next_panel_edge;      // the NEXT panel's edge, allocated early: the main stream's last launch of this panel awaits it at its end
     struct PendingRest { bool on; int64_t c0, w, u1, split; hipStream_t S; } pend = {false, 0, 0, 0, 0, nullptr};
     auto launch_rest = [&](const PendingRest &r) -> int {
         return gemm_nt(c, r.S, n - r.u1, r.split - r.u1, r.w, -1.0, A + r.u1 * lda + r.c0, lda, A + r.u1 * lda + r.c0, lda,
@@ -824,11 +828,18 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
         hipEvent_t e_first = pend.on ? get_event(c, 8 + 4 * widths.size() + k) : nullptr;
         if (pend.on && !e_first) return GPT_E_HIP;
         EdgeSig panel_edge;
+        bool panel_awaited = false;      // (by the tail wait of the previous panel's last main-stream launch)
         if (use_flags && c0 + w + ext_k < n) {
-            panel_edge.word = c->d_edge;
-            panel_edge.value = ++c->edge_seq;
-            panel_edge = with_err(c, panel_edge);
+            if (next_panel_edge.word) {
+                panel_edge = next_panel_edge;
+                panel_awaited = true;
+            } else {
+                panel_edge.word = c->d_edge;
+                panel_edge.value = ++c->edge_seq;
+                panel_edge = with_err(c, panel_edge);
+            }
         }
+        next_panel_edge = EdgeSig();
         GPT_TRY(panel_ext(c, P, A, lda, n, c0, w, invd, info, e_cu_prev, use_flags ? nullptr : e_panel, ext_k, e_first, cu_edge_prev,
                           panel_edge));
         cu_edge_prev = EdgeSig();
@@ -856,8 +867,19 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
                 GPT_HIP_CHECK(hipEventRecord(e_sdone, S));
                 GPT_HIP_CHECK(hipStreamWaitEvent(H, e_sdone, 0));
             }
-            if (use_flags) GPT_TRY(stream_wait_flag(S, panel_edge));
-            else GPT_HIP_CHECK(hipStreamWaitEvent(S, e_panel, 0));
+            if (use_flags) {
+                if (!panel_awaited) GPT_TRY(stream_wait_flag(S, panel_edge));
+            } else {
+                GPT_HIP_CHECK(hipStreamWaitEvent(S, e_panel, 0));
+            }
+            // Tail wait: the last launch of this panel on the main stream ends only when the NEXT panel's flag is up, so the
+            // next panel's launch follows it without a wait kernel in between (the flag's value is fixed here, one panel early).
+            EdgeSig tail;
+            if (use_flags && c->tail_wait && split == n && k + 1 < widths.size() && c0 + w + wn + ext_k1 < n) {
+                tail.word = c->d_edge;
+                tail.value = ++c->edge_seq;
+                tail = with_err(c, tail);
+            }
             if (split < n) {
                 if (use_flags) GPT_TRY(stream_wait_flag(H, panel_edge));
                 else GPT_HIP_CHECK(hipStreamWaitEvent(H, e_panel, 0));
@@ -939,7 +961,8 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
                     if (e_help_prev && !waited) GPT_HIP_CHECK(hipStreamWaitEvent(S, e_help_prev, 0));
                     e_help_prev = nullptr;
                     GPT_TRY(gemm_nt(c, S, n - u0, split - u0, w, -1.0, A + u0 * lda + c0, lda, A + u0 * lda + c0, lda, 1.0,
-                                    A + u0 * lda + u0, lda, 1, nullptr, cu_edge, EdgeSig(), u1 - u0));
+                                    A + u0 * lda + u0, lda, 1, nullptr, cu_edge, EdgeSig(), u1 - u0, tail));
+                    next_panel_edge = tail;
                     cu_edge_prev = cu_edge;
                     if (split < n) {
                         s_prev = split;
@@ -962,8 +985,11 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
                 if (!H && c->defer_rows > 0 && n - c0 <= c->defer_rows && k + 1 < widths.size() && !c->use_graph) {
                     pend = PendingRest{true, c0, w, u1, split, S};
                 } else {
+                    // (tail wait on the 64x64 / 32x32 kernels only; an event may not ride on the same launch)
+                    const bool tl = tail.word && (c->tile == 0 || c->tile == 64);
                     GPT_TRY(gemm_nt(c, S, n - u1, split - u1, w, -1.0, A + u1 * lda + c0, lda, A + u1 * lda + c0, lda, 1.0,
-                                    A + u1 * lda + u1, lda, 1));
+                                    A + u1 * lda + u1, lda, 1, nullptr, EdgeSig(), EdgeSig(), 0, tl ? tail : EdgeSig()));
+                    if (tl) next_panel_edge = tail;
                 }
                 if (split < n) {
                     s_prev = split;
@@ -1201,6 +1227,7 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "edge_flags")) c->edge_flags = value;
     else if (!strcmp(key, "head_wait_wgs")) c->head_wait_wgs = value;
     else if (!strcmp(key, "merge_urgent")) c->merge_urgent = value;
+    else if (!strcmp(key, "tail_wait")) c->tail_wait = value;
     else if (!strcmp(key, "purg_rows_flags")) c->purg_rows_flags = value;
     else if (!strcmp(key, "merge_min_tiles")) c->merge_min_tiles = value < 512 ? 512 : value;
     else if (!strcmp(key, "gemm_prio")) c->gemm_prio = value;

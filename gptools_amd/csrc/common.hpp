@@ -141,7 +141,8 @@ int launch_check_orders(hipStream_t st, const int32_t *dn, int64_t M, int D, int
 int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A, int64_t lda,
                    const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile, int lds_pad,
                    hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int prio = 0, EdgeSig edge = EdgeSig(),
-                   EdgeSig wait = EdgeSig(), int64_t edge_cols = 0, int64_t nbatch = 1, int64_t bstride = 0);
+                   EdgeSig wait = EdgeSig(), int64_t edge_cols = 0, int64_t nbatch = 1, int64_t bstride = 0,
+                   EdgeSig tail = EdgeSig());
 int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base,
                       EdgeSig wait = EdgeSig(), int64_t nbatch = 1, int64_t bstride_a = 0, int64_t bstride_ws = 0);
 int launch_gemm_nt_stair(hipStream_t st, int64_t m, int64_t nseg, int64_t seg_cols, int64_t k, double alpha,

@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     int64_t m, int64_t n, int64_t k, double alpha, const double *__restrict__ A, int64_t lda,
     const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
     int tri, int64_t ntm, int64_t ntn, int64_t nwg, const int2 *__restrict__ order, int64_t seg_cols, int64_t bskip, int prio, unsigned *edge, unsigned edge_val,
-    unsigned edge_total, const unsigned *wait_word, unsigned wait_val, unsigned *wait_err, int edge_cols, int64_t bstride)
+    unsigned edge_total, const unsigned *wait_word, unsigned wait_val, unsigned *wait_err, int edge_cols, int64_t bstride,
+    const unsigned *tail_word, unsigned tail_val, unsigned *tail_err)
 {
     // batched launches (gpt_fit_batch: independent small matrices, blockIdx.y = batch element): A, B and C all lie inside
     // the element's own matrix, bstride elements apart
@@ -192,7 +193,10 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     int64_t ti, tj;
     if (order != nullptr) {
         const int2 t = order[blockIdx.x];
-        if (t.x < 0) return;
+        if (t.x < 0) {
+            if (tail_word != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) edge_poll<16, false>(tail_word, tail_val, tail_err);
+            return;
+        }
         ti = t.x;
         tj = t.y;
     } else {
@@ -308,6 +312,12 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
         }
     GM_STAMP(3);
     if (edge) edge_signal(edge, edge_val, edge_total);
+    // Tail wait (EdgeSig `tail`, main stream's trailing updates): the launch does not END before *tail_word is up -- the
+    // workgroup dispatched last polls it when its own tile is stored.  What the NEXT launch on this stream waits for (the next
+    // panel, factored by the panel stream meanwhile) is thereby awaited without a wait kernel between the two launches (~5 us
+    // per panel while the updates set the pace; the word is then up long before this point and the poll is one load), and the
+    // next launch still starts behind a kernel boundary, i.e. with the caches invalidated AFTER the word was seen.
+    if (tail_word != nullptr && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && tid == 0) edge_poll<16, false>(tail_word, tail_val, tail_err);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -559,7 +569,8 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
                          int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri,
                          int lds_pad, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int64_t seg_cols = 0,
                          int64_t bskip = 0, int64_t row_step = 0, int prio = 0, EdgeSig edge = EdgeSig(),
-                         EdgeSig wait = EdgeSig(), int64_t edge_cols_elems = 0, int64_t nbatch = 1, int64_t bstride = 0)
+                         EdgeSig wait = EdgeSig(), int64_t edge_cols_elems = 0, int64_t nbatch = 1, int64_t bstride = 0,
+                         EdgeSig tail = EdgeSig())
 {
     const int64_t ntm = (m + BM - 1) / BM, ntn = (n + BN - 1) / BN;
     int64_t nwg = (tri == 1) ? ntn * (ntn + 1) / 2 + (ntm - ntn) * ntn : ntm * ntn;
@@ -589,11 +600,13 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
     if (ev0 || ev1)
         hipExtLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg, (unsigned)nbatch), dim3(256), dyn, st, ev0, ev1, 0,
                               m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip, prio, edge.word, edge.value,
-                              (unsigned)(edge_cols_elems > 0 ? nedge : nreal), wait.word, wait.value, wait.err, (int)(edge_cols_elems / BN), bstride);
+                              (unsigned)(edge_cols_elems > 0 ? nedge : nreal), wait.word, wait.value, wait.err, (int)(edge_cols_elems / BN), bstride,
+                              tail.word, tail.value, tail.err);
     else
         hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg, (unsigned)nbatch), dim3(256), dyn, st, m, n, k, alpha,
                            A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip, prio, edge.word, edge.value,
-                              (unsigned)(edge_cols_elems > 0 ? nedge : nreal), wait.word, wait.value, wait.err, (int)(edge_cols_elems / BN), bstride);
+                              (unsigned)(edge_cols_elems > 0 ? nedge : nreal), wait.word, wait.value, wait.err, (int)(edge_cols_elems / BN), bstride,
+                              tail.word, tail.value, tail.err);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
@@ -632,7 +645,7 @@ int gemm_small_threshold()
 int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A, int64_t lda,
                    const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile, int lds_pad,
                    hipEvent_t ev0, hipEvent_t ev1, int prio, EdgeSig edge, EdgeSig wait, int64_t edge_cols, int64_t nbatch,
-                   int64_t bstride)
+                   int64_t bstride, EdgeSig tail)
 {
     gpt_jitter(st);
     if (m <= 0 || n <= 0) {
@@ -688,10 +701,10 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
             if (const char *e = getenv("GPT_GEMM_SMALL_STAGES")) stages = atoi(e);
         }
         if ((stages == 4 && k >= 64) || (stages == 0 && k >= 256))
-            return gemm_launch_t<32, 32, 2, 4>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0, ev0, ev1, 0, 0, 0, prio, edge, wait, 0, nbatch, bstride);
-        return gemm_launch_t<32, 32, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0, ev0, ev1, 0, 0, 0, prio, edge, wait, 0, nbatch, bstride);
+            return gemm_launch_t<32, 32, 2, 4>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0, ev0, ev1, 0, 0, 0, prio, edge, wait, 0, nbatch, bstride, tail);
+        return gemm_launch_t<32, 32, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0, ev0, ev1, 0, 0, 0, prio, edge, wait, 0, nbatch, bstride, tail);
     }
-    if ((edge.word || wait.word || edge_cols) && tile != 64) {
+    if ((edge.word || wait.word || edge_cols || tail.word) && tile != 64) {
         gpt_set_error("gemm_nt: edge flags exist for the 64x64 / 32x32 kernels only");
         return GPT_E_ARG;
     }
@@ -702,7 +715,7 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
     // DMA wait, so everything uses the 2-stage kernel.
     if (force_tile == 65) return gemm_launch_t<64, 64, 1, 4>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0);
     return gemm_launch_t<64, 64, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, lds_pad, ev0, ev1, 0, 0, 0, prio, edge, wait, edge_cols,
-                                       nbatch, bstride);
+                                       nbatch, bstride, tail);
 }
 
 // Staircase update: C (m x nseg*seg_cols) += alpha * A B_q^T per column segment q, where segment q (seg_cols

@@ -81,6 +81,12 @@ __global__ __launch_bounds__(KB_THREADS) void kbuild_kernel(
                 v[c] = ((v[c] + noise_var) + e * e) + diag_add;
             }
         }
+#ifdef KB_DEBUG_NOCOMPUTE           // (measurement builds, scratch/kb_variants.sh: the store pattern alone / the arithmetic alone.
+        v[0] = (double)i;           //  Round 3, N = 8192 lower triangle: stores alone 5.6 TB/s; arithmetic alone = the product's time, for
+#endif                             //  SE as for Matern-5/2: the builder is bound by its ~57 VALU + ~45 SALU instructions per row and wave)
+#ifdef KB_DEBUG_NOSTORE
+        if (v[0] != 12345.678) continue;
+#endif
         if (KB_CPT == 2 && vec) {
             f64x2 w = {v[0], v[KB_CPT - 1]};
             *reinterpret_cast<f64x2 *>(K + i * ldk + jfirst) = w;
