@@ -1861,7 +1861,7 @@ static int fit_matrix_once(gpt_ctx *c, const double *K_tot, int64_t N, const dou
 // once per batch.  No look-ahead, one stream, left-looking leaves: the parallelism is across the batch.  Same kernels, same tile choice and the
 // same summation orders as gpt_fit, so an element's ll / log-determinant carry the very bits gpt_fit returns for it alone
 // (tests/test_gpu_parity.py::test_fit_batch_*).  N <= GPT_BATCH_MAX_N; one native kernel, no transform.
-#define GPT_BATCH_MAX_N 2048
+#define GPT_BATCH_MAX_N 8192
 extern "C" int gpt_fit_batch(gpt_ctx *c, int nbatch, int kernel_id, const double *params, int nparams,
                              const double *noise_var, const double *y, const double *err_y, double diag_add,
                              double *ll_data_out, double *logdet_half_out, int32_t *info_out)
@@ -1937,6 +1937,9 @@ extern "C" int gpt_fit_batch(gpt_ctx *c, int nbatch, int kernel_id, const double
     // 0.77 of the 1.31 ms of a 64 x N = 1024 batch were those updates; here every element of the factor is written once.
     // (GPT_BATCH_RIGHT=1: the right-looking form, for comparison)
     // Measured, 64 elements: N = 1024 1.376 against 1.412 ms, N = 2048 5.79 against 6.22 ms, N = 256 0.247 against 0.237 ms.
+    // Larger N (round 3, bit-identical throughout): N = 3000 x 32 elements 7.8 ms (4100 evaluations/s against 1109 one by one and
+    // 1848 with two contexts in two threads), N = 4096 x 32 18.2 ms (1755 / 774 / 1168), N = 8192 x 8 34.3 ms (233 / 224 / 248: a
+    // single evaluation fills the chip there -- GaussianProcess.ll_batch takes this path up to N = 4096).
     static const bool force_right = getenv("GPT_BATCH_RIGHT") != nullptr;
     const bool right_looking = force_right || NP <= 512;
     for (int64_t lc = 0; lc < NP; lc += 128) {

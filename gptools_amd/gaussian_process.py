@@ -560,7 +560,9 @@ class GaussianProcess(object):
     #: at most this many points: ll_batch (hence compute_ll_matrix, the finite-difference gradients of
     #: optimize_hyperparameters) evaluates ``batch_grid`` hyperparameter vectors per launch sequence (gpt_fit_batch) instead
     #: of one per context and host thread; measured on MI355X at N = 1024: see DESIGN.md section 7.2
-    batch_grid_max_n = 2048
+    batch_grid_max_n = 4096
+    #: device memory the batch's matrices may take (bytes): the chunk size is batch_grid or what fits, whichever is smaller
+    batch_grid_bytes = 16 << 30
     batch_grid = 64
 
     def _batch_contexts(self, count):
@@ -641,7 +643,8 @@ class GaussianProcess(object):
             kid = jobs[0][1][0][0]
             err_y = np.asarray(self.err_y, dtype=float)
             self._cache = {}
-            G = int(self.batch_grid)
+            NP = -(-(len(self.y) + 1) // 128) * 128
+            G = max(1, min(int(self.batch_grid), int(self.batch_grid_bytes) // (8 * NP * NP)))
             for s0 in range(0, len(jobs), G):
                 chunk = jobs[s0:s0 + G]
                 try:

@@ -197,8 +197,8 @@ int gpt_fit_terms(gpt_ctx *ctx, int nterms, const int *kernel_ids, const int *ke
 /* nbatch INDEPENDENT evaluations of the resident data set in one launch sequence: element b uses params[b * nparams ..],
  * noise_var[b] and the target y[b * N ..] (the mean function may depend on the hyperparameters); err_y (N) is shared.
  * Replaces the loops over hyperparameter vectors of the reference's likelihood grid and random starts
- * (ref: gaussian_process.py:1607-1692, :723-735, gp_utils.py:98-115) at the sizes those run at: N <= 2048 resident
- * points, one native kernel, no transform (GPT_E_ARG otherwise: the caller falls back to one gpt_fit per vector).
+ * (ref: gaussian_process.py:1607-1692, :723-735, gp_utils.py:98-115) at the sizes those run at: N <= 8192 resident
+ * points (it pays up to N ~ 4096: 2.3x one gpt_fit per vector there, 9.5x at 1024; nbatch N^2 doubles of device memory), one native kernel, no transform (GPT_E_ARG otherwise: the caller falls back to one gpt_fit per vector).
  * Every kernel of the factorisation carries the batch in a grid dimension; an element's results are bit-identical to
  * gpt_fit's for the same inputs.  info_out[b] = 0, or the LAPACK index of the leading minor that is not positive
  * definite (ll_data_out[b] is then meaningless); the call itself returns GPT_OK in both cases. */

@@ -1467,7 +1467,8 @@ def test_device_ll_gradient_with_transform_mixed_sum_and_block_inverses(g, case)
             np.testing.assert_allclose(-grad[:3], fd[:3], rtol=5e-5, atol=1e-4 * np.abs(fd[:3]).max())
 
 
-@pytest.mark.parametrize("kern,N,d,deriv", [("m52", 700, 3, True), ("se", 1100, 2, False), ("se", 130, 1, False)])
+@pytest.mark.parametrize("kern,N,d,deriv", [("m52", 700, 3, True), ("se", 1100, 2, False), ("se", 130, 1, False),
+                                            ("m52", 2700, 2, True)])
 def test_fit_batch_is_bit_identical_to_single_fits(kern, N, d, deriv):
     """gpt_fit_batch (every kernel of the small-N factorisation carries the batch in a grid dimension; SURVEY 8f-2, ref
     gaussian_process.py:1607-1692 / :723-735) against one gpt_fit per hyperparameter vector: ll and log-determinant
@@ -1479,7 +1480,7 @@ def test_fit_batch_is_bit_identical_to_single_fits(kern, N, d, deriv):
         n[:] = 0
     err = np.full(N, 0.05)
     rs = np.random.RandomState(N)
-    B = 23
+    B = 23 if N < 2048 else 7
     P = np.column_stack([0.5 + rs.rand(B)] + [0.1 + 0.6 * rs.rand(B) for _ in range(d)])
     nv = 0.01 * rs.rand(B)
     Y = y[None, :] + 0.01 * rs.randn(B, N)
@@ -1592,7 +1593,9 @@ def test_ll_batch_grid_path_and_thread_path_agree(g):
             grid = gp.ll_batch(pts)
             gp.batch_grid_max_n = 10                    # forces the two-contexts / two-threads route
             thr = gp.ll_batch(pts)
-            gp.batch_grid_max_n = 2048
+            gp.batch_grid_max_n = 4096
+            gp.batch_grid_bytes = 3 * 8 * 640 * 640     # (chunks of 3: the memory cap of the grid route)
+            assert np.array_equal(gp.ll_batch(pts), grid)
             seq = np.array([-gp.update_hyperparameters(p) for p in pts])
             assert np.array_equal(grid, thr) and np.array_equal(grid, seq), (kind, grid, thr, seq)
             assert np.isneginf(grid[2]) and np.isfinite(grid[:2]).all()
