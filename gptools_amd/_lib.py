@@ -44,6 +44,7 @@ SIGNATURES = {
     "gpt_fit": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, C.c_double, _dp, _dp]),
     "gpt_fit_sum": (C.c_int, [_vp, C.c_int, _ip, _dp, _ip, C.c_double, _dp, _dp, C.c_double, _dp, _dp]),
     "gpt_fit_batch": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, _dp, C.c_double, _dp, _dp, _ip]),
+    "gpt_fit_batch_sum": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _dp, _ip, _dp, _dp, _dp, C.c_double, _dp, _dp, _ip]),
     "gpt_fit_matrix": (C.c_int, [_vp, _dp, _i64, _dp, _dp, _dp]),
     "gpt_get_L": (C.c_int, [_vp, _dp]),
     "gpt_get_alpha": (C.c_int, [_vp, _dp]),
@@ -374,6 +375,20 @@ class Context(object):
         ll, ld, info = np.empty(B), np.empty(B), np.zeros(B, dtype=np.int32)
         check(self._lib.gpt_fit_batch(self.handle, B, kernel_id, dptr(params), params.shape[1], dptr(noise_var), dptr(y),
                                       dptr(err_y), float(diag_add), dptr(ll), dptr(ld), iptr(info)))
+        return ll, ld, info
+
+    def fit_batch_sum(self, kernel_ids, params, nparams, noise_var, y, err_y, diag_add):
+        """gpt_fit_batch_sum: as :meth:`fit_batch` for a sum of native kernels; ``params`` (B, sum(nparams)) holds each
+        element's term parameters concatenated."""
+        ids, npar = i32(kernel_ids), i32(nparams)
+        params, noise_var, y, err_y = f64(np.atleast_2d(params)), f64(noise_var), f64(np.atleast_2d(y)), f64(err_y)
+        B = params.shape[0]
+        if (noise_var.shape != (B,) or y.shape[0] != B or y.shape[1] != err_y.shape[0] or len(ids) != len(npar)
+                or params.shape[1] != int(npar.sum())):
+            raise ValueError("fit_batch_sum: params (B, sum(nparams)), noise_var (B,), y (B, N), err_y (N,) expected")
+        ll, ld, info = np.empty(B), np.empty(B), np.zeros(B, dtype=np.int32)
+        check(self._lib.gpt_fit_batch_sum(self.handle, B, len(ids), iptr(ids), dptr(params), iptr(npar), dptr(noise_var),
+                                          dptr(y), dptr(err_y), float(diag_add), dptr(ll), dptr(ld), iptr(info)))
         return ll, ld, info
 
     def ll_grad(self, term_idx, local_idx):

@@ -1862,36 +1862,59 @@ static int fit_matrix_once(gpt_ctx *c, const double *K_tot, int64_t N, const dou
 // same summation orders as gpt_fit, so an element's ll / log-determinant carry the very bits gpt_fit returns for it alone
 // (tests/test_gpu_parity.py::test_fit_batch_*).  N <= GPT_BATCH_MAX_N; one native kernel, no transform.
 #define GPT_BATCH_MAX_N 8192
+extern "C" int gpt_fit_batch_sum(gpt_ctx *c, int nbatch, int nterms, const int *kernel_ids, const double *params,
+                                 const int *nparams_t, const double *noise_var, const double *y, const double *err_y,
+                                 double diag_add, double *ll_data_out, double *logdet_half_out, int32_t *info_out);
+
 extern "C" int gpt_fit_batch(gpt_ctx *c, int nbatch, int kernel_id, const double *params, int nparams,
                              const double *noise_var, const double *y, const double *err_y, double diag_add,
                              double *ll_data_out, double *logdet_half_out, int32_t *info_out)
+{
+    return gpt_fit_batch_sum(c, nbatch, 1, &kernel_id, params, &nparams, noise_var, y, err_y, diag_add, ll_data_out, logdet_half_out,
+                             info_out);
+}
+
+// The same for a SumKernel of native kernels (ref: kernel/core.py:549-584): element b's parameters are the terms' parameters
+// concatenated (ptot = sum of nparams_t doubles per element); one accumulating builder pass per term for the whole batch, as
+// gpt_fit_sum does for one matrix -- same kernels, same order: bit-identical to gpt_fit_sum per element.
+extern "C" int gpt_fit_batch_sum(gpt_ctx *c, int nbatch, int nterms, const int *kernel_ids, const double *params,
+                                 const int *nparams_t, const double *noise_var, const double *y, const double *err_y,
+                                 double diag_add, double *ll_data_out, double *logdet_half_out, int32_t *info_out)
 {
     CTX_ENTER(c);
     if (!c->dX) {
         gpt_set_error("gpt_fit_batch: call gpt_set_data first");
         return GPT_E_STATE;
     }
-    if (nbatch < 1 || nbatch > 65535 || !params || !noise_var || !y || !err_y || !ll_data_out || !info_out) return GPT_E_ARG;
+    if (nbatch < 1 || nbatch > 65535 || nterms < 1 || nterms > 8 || !kernel_ids || !nparams_t || !params || !noise_var || !y ||
+        !err_y || !ll_data_out || !info_out)
+        return GPT_E_ARG;
     if (c->dT || c->Nx > GPT_BATCH_MAX_N) {
         gpt_set_error("gpt_fit_batch: needs N <= %d and no linear transform (N = %lld)", GPT_BATCH_MAX_N, (long long)c->Nx);
         return GPT_E_ARG;
     }
-    if (kernel_id != GPT_KERNEL_SE && kernel_id != GPT_KERNEL_M52 && kernel_id != GPT_KERNEL_RQ && kernel_id != GPT_KERNEL_MATERN) {
-        gpt_set_error("gpt_fit_batch: kernel_id must be SE, Matern52, RationalQuadratic or Matern");
-        return GPT_E_ARG;
-    }
-    if ((kernel_id == GPT_KERNEL_RQ || kernel_id == GPT_KERNEL_MATERN) && 2 * c->n_maxsum > GPT_RQ_MAXORD) {
-        gpt_set_error("RationalQuadratic / Matern kernel: derivative orders of a pair sum to %ld, the device builder supports %d",
-                      2 * c->n_maxsum, GPT_RQ_MAXORD);
-        return GPT_E_VALUE;
+    int ptot = 0;
+    for (int t = 0; t < nterms; t++) {
+        const int kernel_id = kernel_ids[t];
+        if (kernel_id != GPT_KERNEL_SE && kernel_id != GPT_KERNEL_M52 && kernel_id != GPT_KERNEL_RQ && kernel_id != GPT_KERNEL_MATERN) {
+            gpt_set_error("gpt_fit_batch: kernel_id must be SE, Matern52, RationalQuadratic or Matern");
+            return GPT_E_ARG;
+        }
+        if ((kernel_id == GPT_KERNEL_RQ || kernel_id == GPT_KERNEL_MATERN) && 2 * c->n_maxsum > GPT_RQ_MAXORD) {
+            gpt_set_error("RationalQuadratic / Matern kernel: derivative orders of a pair sum to %ld, the device builder supports %d",
+                          2 * c->n_maxsum, GPT_RQ_MAXORD);
+            return GPT_E_VALUE;
+        }
+        if (nparams_t[t] < 1) return GPT_E_ARG;
+        ptot += nparams_t[t];
     }
     const int64_t N = c->Nx, NP = round_up(N + 1, 128), nleaf = NP / 128, bs = NP * NP, bws = nleaf * GPT_WS_BLOCK;
-    // pinned staging: [y: nbatch N | err: N | noise: nbatch | KParams: nbatch | results: 4 nbatch]; err .. KParams go to the
-    // device in one copy
+    // pinned staging: [y: nbatch N | err: N | noise: nbatch | KParams: nterms x nbatch | results: 4 nbatch]; err .. KParams go
+    // to the device in one copy
     static_assert(sizeof(KParams) % 8 == 0, "KParams is copied as an array of doubles");
     const size_t kp_doubles = sizeof(KParams) / 8;
     const size_t off_err = (size_t)nbatch * N, off_nv = off_err + (size_t)N, off_kp = off_nv + (size_t)nbatch,
-                 off_res = off_kp + (size_t)nbatch * kp_doubles;
+                 off_res = off_kp + (size_t)nterms * nbatch * kp_doubles;
     const size_t need = (off_res + 4 * (size_t)nbatch) * sizeof(double);
     if (c->h_batch_cap < need) {
         if (c->h_batch) GPT_HIP_CHECK(hipHostFree(c->h_batch));
@@ -1905,15 +1928,20 @@ extern "C" int gpt_fit_batch(gpt_ctx *c, int nbatch, int kernel_id, const double
     memcpy(h + off_err, err_y, (size_t)N * sizeof(double));
     memcpy(h + off_nv, noise_var, (size_t)nbatch * sizeof(double));
     for (int b = 0; b < nbatch; b++) {
-        KParams kp;
-        GPT_TRY(make_kparams(kernel_id, params + (size_t)b * nparams, nparams, c->D, -1, 1, nullptr, &kp));
-        memcpy(reinterpret_cast<char *>(h + off_kp) + (size_t)b * kp_doubles * 8, &kp, sizeof(KParams));
+        const double *pb = params + (size_t)b * ptot;
+        for (int t = 0; t < nterms; t++) {                                  // term-major on the device: [t][b]
+            KParams kp;
+            GPT_TRY(make_kparams(kernel_ids[t], pb, nparams_t[t], c->D, -1, 1, nullptr, &kp));
+            memcpy(reinterpret_cast<char *>(h + off_kp) + ((size_t)t * nbatch + (size_t)b) * kp_doubles * 8, &kp, sizeof(KParams));
+            pb += nparams_t[t];
+        }
     }
     double *dA, *dws, *dmisc;
     GPT_TRY(ensure(c, SLOT_BATCH_A, (size_t)nbatch * bs * sizeof(double), (void **)&dA));
     GPT_TRY(ensure(c, SLOT_BATCH_WS, (size_t)nbatch * bws * sizeof(double), (void **)&dws));
     // device side of the small inputs: [err: N | noise: nbatch | KParams: nbatch | info: nbatch]
-    const size_t d_off_nv = (size_t)N, d_off_kp = d_off_nv + (size_t)nbatch, d_off_info = d_off_kp + (size_t)nbatch * kp_doubles;
+    const size_t d_off_nv = (size_t)N, d_off_kp = d_off_nv + (size_t)nbatch,
+                 d_off_info = d_off_kp + (size_t)nterms * nbatch * kp_doubles;
     GPT_TRY(ensure(c, SLOT_BATCH_MISC, (d_off_info + (size_t)nbatch) * sizeof(double), (void **)&dmisc));
     int32_t *dinfo = reinterpret_cast<int32_t *>(dmisc + d_off_info);
     EvalScope scope(c);                      // (an evaluation in flight like any other for the flag-edge accounting; uses none)
@@ -1925,11 +1953,14 @@ extern "C" int gpt_fit_batch(gpt_ctx *c, int nbatch, int kernel_id, const double
         GPT_HIP_CHECK(hipEventRecord(e, c->stream));
         GPT_HIP_CHECK(hipStreamWaitEvent(st, e, 0));
     }
-    GPT_HIP_CHECK(hipMemcpyAsync(dmisc, h + off_err, ((size_t)N + (size_t)nbatch + (size_t)nbatch * kp_doubles) * sizeof(double),
+    GPT_HIP_CHECK(hipMemcpyAsync(dmisc, h + off_err,
+                                 ((size_t)N + (size_t)nbatch + (size_t)nterms * nbatch * kp_doubles) * sizeof(double),
                                  hipMemcpyHostToDevice, st));
     GPT_TRY(launch_batch_pad(st, h, nbatch, dA, NP, bs, N, NP, 1e300, dinfo));
-    GPT_TRY(launch_kbuild_batch(st, kernel_id, c->D, reinterpret_cast<const KParams *>(dmisc + d_off_kp), dmisc + d_off_nv, nbatch,
-                                c->dX, c->dn, N, dmisc, diag_add, dA, NP, bs));
+    for (int t = 0; t < nterms; t++)                                        // (as kbuild_terms: later terms accumulate, the last
+        GPT_TRY(launch_kbuild_batch(st, kernel_ids[t], c->D,                //  one carries the diagonal epilogue)
+                                    reinterpret_cast<const KParams *>(dmisc + d_off_kp) + (size_t)t * nbatch, dmisc + d_off_nv, nbatch,
+                                    c->dX, c->dn, N, t + 1 == nterms ? dmisc : nullptr, diag_add, dA, NP, bs, t > 0 ? 1 : 0));
     // LEFT-looking over the 128-column leaves: leaf j first receives the update of ALL leaves before it in one launch
     // (k = 128 j; element by element the same sums in the same order as the right-looking rank-128 updates of gpt_fit, whose
     // accumulators also start from C and walk k upwards: bit-identical), then its diagonal block and TRSM.  A right-looking

@@ -160,7 +160,7 @@ int launch_trsm_panel(hipStream_t st, int64_t m, const double *L, int64_t ldl, c
 // batched small fits (gpt_fit_batch)
 int launch_kbuild_batch(hipStream_t st, int kernel_id, int D, const KParams *d_kps, const double *d_noise_var, int64_t nbatch,
                         const double *dX, const int32_t *dn, int64_t N, const double *d_err_y, double diag_add, double *dK,
-                        int64_t ldk, int64_t bstride);
+                        int64_t ldk, int64_t bstride, int accumulate = 0);
 int launch_batch_pad(hipStream_t st, const double *h_y, int64_t nbatch, double *A, int64_t lda, int64_t bstride, int64_t n_valid,
                      int64_t n_pad, double big, int32_t *info);
 int launch_batch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_t bstride, int64_t n, int64_t nbatch,

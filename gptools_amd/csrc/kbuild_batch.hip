@@ -10,7 +10,7 @@
 template <int KID>
 static int kbuild_batch_d(hipStream_t st, int D, const KParams *d_kps, const double *d_nv, int64_t nbatch, const double *dX,
                           const int32_t *dn, int64_t N, const double *d_err_y, double diag_add, double *dK, int64_t ldk,
-                          int64_t bstride)
+                          int64_t bstride, int accumulate)
 {
     const int64_t nrt = (N + KB_ROWS - 1) / KB_ROWS;
     int64_t ntile = 0;
@@ -20,7 +20,7 @@ static int kbuild_batch_d(hipStream_t st, int D, const KParams *d_kps, const dou
 #define KBB_CASE(DD)                                                                                              \
     case DD:                                                                                                      \
         hipLaunchKernelGGL((kbuild_kernel<KID, DD, true>), grid, block, 0, st, dummy, dX, dn, N, dX, dn, N, 2,     \
-                           (int64_t)0, (int64_t)0, d_err_y, 0.0, diag_add, dK, ldk, 0, d_kps, d_nv, bstride, dummy); \
+                           (int64_t)0, (int64_t)0, d_err_y, 0.0, diag_add, dK, ldk, accumulate, d_kps, d_nv, bstride, dummy); \
         break;
     switch (D) {
         KBB_CASE(1) KBB_CASE(2) KBB_CASE(3) KBB_CASE(4) KBB_CASE(5) KBB_CASE(6) KBB_CASE(7) KBB_CASE(8)
@@ -36,14 +36,14 @@ static int kbuild_batch_d(hipStream_t st, int D, const KParams *d_kps, const dou
 
 int launch_kbuild_batch(hipStream_t st, int kernel_id, int D, const KParams *d_kps, const double *d_noise_var, int64_t nbatch,
                         const double *dX, const int32_t *dn, int64_t N, const double *d_err_y, double diag_add, double *dK,
-                        int64_t ldk, int64_t bstride)
+                        int64_t ldk, int64_t bstride, int accumulate)
 {
     if (N <= 0 || nbatch <= 0) return GPT_OK;
     switch (kernel_id) {
-    case GPT_KERNEL_SE: return kbuild_batch_d<GPT_KERNEL_SE>(st, D, d_kps, d_noise_var, nbatch, dX, dn, N, d_err_y, diag_add, dK, ldk, bstride);
-    case GPT_KERNEL_M52: return kbuild_batch_d<GPT_KERNEL_M52>(st, D, d_kps, d_noise_var, nbatch, dX, dn, N, d_err_y, diag_add, dK, ldk, bstride);
-    case GPT_KERNEL_RQ: return kbuild_batch_d<GPT_KERNEL_RQ>(st, D, d_kps, d_noise_var, nbatch, dX, dn, N, d_err_y, diag_add, dK, ldk, bstride);
-    case GPT_KERNEL_MATERN: return kbuild_batch_d<GPT_KERNEL_MATERN>(st, D, d_kps, d_noise_var, nbatch, dX, dn, N, d_err_y, diag_add, dK, ldk, bstride);
+    case GPT_KERNEL_SE: return kbuild_batch_d<GPT_KERNEL_SE>(st, D, d_kps, d_noise_var, nbatch, dX, dn, N, d_err_y, diag_add, dK, ldk, bstride, accumulate);
+    case GPT_KERNEL_M52: return kbuild_batch_d<GPT_KERNEL_M52>(st, D, d_kps, d_noise_var, nbatch, dX, dn, N, d_err_y, diag_add, dK, ldk, bstride, accumulate);
+    case GPT_KERNEL_RQ: return kbuild_batch_d<GPT_KERNEL_RQ>(st, D, d_kps, d_noise_var, nbatch, dX, dn, N, d_err_y, diag_add, dK, ldk, bstride, accumulate);
+    case GPT_KERNEL_MATERN: return kbuild_batch_d<GPT_KERNEL_MATERN>(st, D, d_kps, d_noise_var, nbatch, dX, dn, N, d_err_y, diag_add, dK, ldk, bstride, accumulate);
     default:
         gpt_set_error("kbuild_batch: kernel_id %d is not a fit kernel", kernel_id);
         return GPT_E_ARG;

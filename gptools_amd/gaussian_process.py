@@ -637,10 +637,12 @@ class GaussianProcess(object):
             self._data_on_device = True
         version = getattr(self, "_data_version", 0)
         if (self.T is None and len(self.y) <= self.batch_grid_max_n and int(self.batch_grid) > 1 and jobs
-                and all(len(j[1]) == 1 and len(j[1][0]) == 2 for j in jobs)):
+                and all(len(t) == 2 for j in jobs for t in j[1])
+                and all([t[0] for t in j[1]] == [t[0] for t in jobs[0][1]] for j in jobs)):
             # small N: the whole batch in ONE launch sequence (gpt_fit_batch: every kernel of the factorisation carries the
             # batch in a grid dimension), batch_grid evaluations at a time; bit-identical to one gpt_fit per vector
-            kid = jobs[0][1][0][0]
+            kids = [t[0] for t in jobs[0][1]]                    # (one native kernel, or a SumKernel of them)
+            npar = [len(t[1]) for t in jobs[0][1]]
             err_y = np.asarray(self.err_y, dtype=float)
             self._cache = {}
             NP = -(-(len(self.y) + 1) // 128) * 128
@@ -648,9 +650,10 @@ class GaussianProcess(object):
             for s0 in range(0, len(jobs), G):
                 chunk = jobs[s0:s0 + G]
                 try:
-                    ll, _, info = self._ctx.fit_batch(kid, np.array([j[1][0][1] for j in chunk]),
-                                                      np.array([j[3] for j in chunk]), np.array([j[4] for j in chunk]),
-                                                      err_y, diag_add)
+                    ll, _, info = self._ctx.fit_batch_sum(kids, np.array([np.concatenate([np.asarray(t[1], dtype=float)
+                                                                                          for t in j[1]]) for j in chunk]),
+                                                          npar, np.array([j[3] for j in chunk]),
+                                                          np.array([j[4] for j in chunk]), err_y, diag_add)
                 except (ValueError, ArithmeticError):
                     # an argument the library rejects for one element (e.g. a kernel parameter out of its domain) fails the
                     # whole call: that chunk one vector at a time, with the +inf policy of update_hyperparameters

@@ -206,6 +206,13 @@ int gpt_fit_batch(gpt_ctx *ctx, int nbatch, int kernel_id, const double *params,
                   const double *noise_var, const double *y, const double *err_y, double diag_add,
                   double *ll_data_out, double *logdet_half_out, int32_t *info_out);
 
+/* The same for a SumKernel of native kernels (ref: kernel/core.py:549-584; gpt_fit_sum for one matrix): element b's
+ * parameters are the terms' parameters concatenated, params[b * ptot ..] with ptot = sum of nparams[t].  Bit-identical to
+ * gpt_fit_sum per element. */
+int gpt_fit_batch_sum(gpt_ctx *ctx, int nbatch, int nterms, const int *kernel_ids, const double *params,
+                      const int *nparams, const double *noise_var, const double *y, const double *err_y,
+                      double diag_add, double *ll_data_out, double *logdet_half_out, int32_t *info_out);
+
 /* Same as gpt_fit but for an explicit, caller-assembled symmetric K_tot (host, (N, N) row-major;
  * only the lower triangle is read): used for the `T` (linear transform) branch,
  * ref: gaussian_process.py:1443-1446, where K_tot = T (K + noise_K) T^T + ... is (N_y, N_y). */

@@ -1212,10 +1212,25 @@ def test_sum_of_native_kernels_on_device(g, oracle):
     np.testing.assert_allclose(std ** 2, np.diag(Kss - v.T.dot(v)), rtol=0, atol=1e-7)
     mean2, cov = gp.predict(Xs, n=ns, return_cov=True)
     np.testing.assert_allclose(cov, Kss - v.T.dot(v), rtol=0, atol=1e-7)
-    thetas = [list(p1) + list(p2), list(1.1 * p1) + list(0.9 * p2)]
-    b = gp.ll_batch(thetas)
+    thetas = [list(p1) + list(p2), list(1.1 * p1) + list(0.9 * p2), list(0.8 * p1) + list(1.3 * p2)]
+    b = gp.ll_batch(thetas)                          # gpt_fit_batch_sum: the sum in the batched evaluator, one launch sequence
     s = np.array([-gp.update_hyperparameters(t) for t in thetas])
-    np.testing.assert_allclose(b, s, rtol=1e-12, atol=0)
+    assert np.array_equal(b, s), (b, s)
+    gp.batch_grid_max_n = 10                         # (the thread route gives the same bits)
+    assert np.array_equal(gp.ll_batch(thetas), s)
+    # the C ABI directly: per-element noise variances and targets, a non-positive-definite element reported alone
+    from gptools_amd import _lib
+    c = _lib.Context(0)
+    c.set_data(X, n)
+    P = np.array(thetas)
+    nv = np.array([0.0, 0.02, -50.0])
+    Y = np.vstack([y, y + 0.01, y])
+    llb, ldb, info = c.fit_batch_sum([KID["se"], KID["m52"]], P, [3, 3], nv, Y, np.full(N, 0.05), 1e2 * EPS)
+    assert info[2] > 0 and info[0] == 0 and info[1] == 0
+    for e in (0, 1):
+        l1, d1 = c.fit_sum([KID["se"], KID["m52"]], [P[e, :3], P[e, 3:]], nv[e], Y[e], np.full(N, 0.05), 1e2 * EPS)
+        assert (l1, d1) == (llb[e], ldb[e])
+    c.close()
 
 
 def test_draw_sample_cholesky_and_eig(g):
