@@ -425,8 +425,11 @@ static int leaf256_factor(gpt_ctx *c, hipStream_t st, double *Ad, int64_t lda, i
 //   * an evaluation (EvalScope, below) takes the flag edges only if it is the only one in flight in the process when it
 //     starts, nobody has announced concurrent evaluations (gpt_concurrency_hint: ll_batch and bench.py bracket their
 //     threaded sections with it), the context owns its streams, and the process has not tripped a flag timeout;
-//   * an evaluation that starts while a flag-mode evaluation is in flight first waits for that one to end (one evaluation's
-//     time, once: from then on each of the two finds the other in flight and both stay on events);
+//   * an evaluation that starts while a flag-mode evaluation is in flight first waits for that one to end, and the process
+//     then stays on event edges while un-announced evaluations keep overlapping (every overlapping start re-arms a 100 ms
+//     window; without it two un-hinted threads would take turns, each alone at its start and on flags, the other waiting:
+//     one at a time).  Measured, two contexts in two threads at N = 4096: 990-1176 evaluations/s un-hinted, 1147-1168 hinted,
+//     765 from one thread (scratch/two_thread_modes.py); a lone evaluation 100 ms later is back on flags;
 //   * every wait is bounded (common.hpp); a timeout -- queues oversubscribed by ANOTHER process on the same GPU, a tool that
 //     serialises kernels and is not recognised below -- ends the evaluation with an internal status, the process goes to
 //     event edges for good (g_flags_tripped) and the evaluation is repeated (fit_terms / gpt_fit_matrix).
@@ -435,6 +438,7 @@ static int leaf256_factor(gpt_ctx *c, hipStream_t st, double *Ad, int64_t lda, i
 // for jobs that share a GPU between processes), under graph capture, on a caller-supplied stream (its other work is
 // invisible to the accounting above).
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 static std::mutex g_eval_mu;
@@ -443,6 +447,7 @@ static int g_evals = 0;                 // evaluations in flight in this process
 static int g_flag_evals = 0;            // ... of which on flag edges (0 or 1)
 static int g_announced = 0;             // gpt_concurrency_hint depth
 static std::atomic<bool> g_flags_tripped{false};
+static std::chrono::steady_clock::time_point g_contention_until;   // (under g_eval_mu) overlapping evaluations seen recently: no flags before
 #define GPT_I_EDGE_TIMEOUT (-100)       // internal status of an evaluation whose flag wait timed out (never leaves the library)
 
 static bool edge_flags_env_ok()
@@ -462,9 +467,21 @@ struct EvalScope {
     explicit EvalScope(gpt_ctx *c_) : c(c_), flags(false)
     {
         std::unique_lock<std::mutex> lk(g_eval_mu);
-        g_eval_cv.wait(lk, [] { return g_flag_evals == 0; });
+        const auto now = std::chrono::steady_clock::now();
+        if (g_flag_evals != 0) {
+            // Somebody else's flag-mode evaluation is in flight: this process runs evaluations from several threads without
+            // having said so (gpt_concurrency_hint).  Wait for that one -- a flag-mode evaluation must be alone -- and keep the
+            // process on event edges for a while: otherwise two un-hinted threads take turns, each alone at its start, each on
+            // flags, the other one waiting -- serialised (measured: 2 x 600 evaluations at N = 4096 in 1.6 s against 0.8 s for
+            // 600).  On events they overlap (1.5 x one at a time).
+            g_contention_until = now + std::chrono::milliseconds(100);
+            g_eval_cv.wait(lk, [] { return g_flag_evals == 0; });
+        }
         flags = edge_flags_env_ok() && !g_flags_tripped.load() && g_evals == 0 && g_announced == 0 && c->edge_flags &&
-                c->own_stream && c->d_edge && !c->use_graph;
+                c->own_stream && c->d_edge && !c->use_graph && now >= g_contention_until;
+        // (un-announced overlap seen: stay on events for the next 100 ms; announced sections -- ll_batch, bench.py -- end with
+        // their bracket and the next lone evaluation is back on flags at once)
+        if (g_evals != 0 && g_announced == 0) g_contention_until = now + std::chrono::milliseconds(100);
         g_evals++;
         if (flags) g_flag_evals++;
         c->flags_now = flags;

@@ -115,7 +115,8 @@ int64_t gpt_ctx_edge_count(gpt_ctx *ctx);
  * process concurrently (GaussianProcess.ll_batch: one host thread per context; ref gaussian_process.py:723-735, 1607-1692
  * are the reference's pool.map sites this replaces).  While the count is positive every evaluation keeps its look-ahead on
  * event edges (a kernel spinning on a flag must not share the hardware queues with a second chain).  Optional: without it
- * the library notices the overlap itself at the cost of serialising the first two evaluations.  Returns the new count. */
+ * the library notices the overlap itself (the first two evaluations are serialised, then the process stays on event edges
+ * while evaluations keep overlapping and for 100 ms after the last overlap).  Returns the new count. */
 int gpt_concurrency_hint(int delta);
 
 /* ---- Kernel.__call__ ---------------------------------------------------------------------- */

@@ -419,7 +419,20 @@ def test_two_threads_without_the_concurrency_hint_do_not_crawl():
         "for x in th: x.join()\n"
         "t = time.time() - t\n"
         "ok = all(r == ref for rr in res for r in rr)\n"
-        "print('RESULT', json.dumps({'ok': ok, 't': t}))\n")
+        "e_thr = [c.edge_count for c in cs]\n"
+        "time.sleep(0.25)\n"
+        "cs[0].fit(0, p, 0.0, y, err, 2.2e-14)\n"
+        "e_after = cs[0].edge_count - e_thr[0]\n"
+        "t1 = time.time()\n"
+        "for _ in range(60): cs[0].fit(0, p, 0.0, y, err, 2.2e-14)\n"
+        "t1 = time.time() - t1\n"
+        "print('RESULT', json.dumps({'ok': ok, 't': t, 'edges_threads': e_thr, 'edges_after': e_after, 't_one': t1}))\n")
     out, _ = _run_fresh(code)
     assert out["ok"]
     assert out["t"] < 3.0, "120 evaluations at N=4096 took %.2f s" % out["t"]
+    # the overlap is noticed: after the first hand-over the two threads run side by side on event edges (a flag-mode evaluation
+    # raises ~31 edges at this size: 60 of them would be ~1900 per context) instead of taking turns on flags ...
+    assert max(out["edges_threads"]) < 600, out
+    assert out["t"] < 1.6 * out["t_one"], out          # ... i.e. 2 x 60 evaluations in well under twice the time of 60
+    # ... and a lone evaluation a moment later is back on the flag schedule
+    assert out["edges_after"] > 0, out
