@@ -11,7 +11,7 @@ for a in sys.argv[4:]:
     name, _, opts = a.partition(":")
     cfgs.append((name, [(o.split("=")[0], int(o.split("=")[1])) for o in opts.split(",") if o]))
 DEFAULTS = {"inner": 0, "inner_rows": 4608, "nb_outer": 0, "fuse_trsm": 8192, "gemm_pad": 1024, "helper_tf": 35, "ramp": 0,
-            "early_rows": 0, "leaf256": 0, "defer_rows": 0, "late_rows": 0, "nb_early": 0, "nb_switch_rows": 4608, "purg_rows": 6144, "late_pad": 0, "late_pad_rows": 4608, "panel_prio": 2, "helper_min_n": 12288, "helper_tf": 45, "edge_flags": 1, "merge_urgent": 1, "merge_min_tiles": 512, "purg_rows_flags": 0, "tail_wait": 0}
+            "early_rows": 0, "leaf256": 0, "defer_rows": 0, "late_rows": 0, "nb_early": 0, "nb_switch_rows": 4608, "purg_rows": 6144, "late_pad": 0, "late_pad_rows": 4608, "panel_prio": 2, "helper_min_n": 12288, "helper_tf": 45, "edge_flags": 1, "merge_urgent": 1, "merge_min_tiles": 512, "purg_rows_flags": 0, "tail_wait": 0, "tile": 0}
 ctx = _lib.Context(0)
 ctx.set_option("timing", 1)
 kernel, N, d, deriv = bench.WORKLOADS[wl]
