@@ -563,7 +563,8 @@ class GaussianProcess(object):
     batch_grid_max_n = 4096
     #: device memory the batch's matrices may take (bytes): the chunk size is batch_grid or what fits, whichever is smaller
     batch_grid_bytes = 16 << 30
-    batch_grid = 64
+    batch_grid = 256                                          # (measured: N = 256 262 k / 569 k / 699 k evaluations/s at 64 / 256 / 1024
+                                                              #  per launch sequence, N = 1024 45 k / 62 k / 64 k at 64 / 256 / 512)
 
     def _batch_contexts(self, count):
         self._ctx                                            # creates the pool together with the main context
