@@ -433,6 +433,6 @@ def test_two_threads_without_the_concurrency_hint_do_not_crawl():
     # the overlap is noticed: after the first hand-over the two threads run side by side on event edges (a flag-mode evaluation
     # raises ~31 edges at this size: 60 of them would be ~1900 per context) instead of taking turns on flags ...
     assert max(out["edges_threads"]) < 600, out
-    assert out["t"] < 1.6 * out["t_one"], out          # ... i.e. 2 x 60 evaluations in well under twice the time of 60
+    assert out["t"] < 1.8 * out["t_one"], out          # ... i.e. 2 x 60 evaluations in under twice the time of 60 (measured 1.3 x)
     # ... and a lone evaluation a moment later is back on the flag schedule
     assert out["edges_after"] > 0, out
