@@ -45,6 +45,8 @@ SIGNATURES = {
     "gpt_fit_sum": (C.c_int, [_vp, C.c_int, _ip, _dp, _ip, C.c_double, _dp, _dp, C.c_double, _dp, _dp]),
     "gpt_fit_batch": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_int, _dp, _dp, _dp, C.c_double, _dp, _dp, _ip]),
     "gpt_fit_batch_sum": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _dp, _ip, _dp, _dp, _dp, C.c_double, _dp, _dp, _ip]),
+    "gpt_mem_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "gpt_release_batch_scratch": (C.c_int, [_vp]),
     "gpt_fit_matrix": (C.c_int, [_vp, _dp, _i64, _dp, _dp, _dp]),
     "gpt_get_L": (C.c_int, [_vp, _dp]),
     "gpt_get_alpha": (C.c_int, [_vp, _dp]),
@@ -390,6 +392,15 @@ class Context(object):
         check(self._lib.gpt_fit_batch_sum(self.handle, B, len(ids), iptr(ids), dptr(params), iptr(npar), dptr(noise_var),
                                           dptr(y), dptr(err_y), float(diag_add), dptr(ll), dptr(ld), iptr(info)))
         return ll, ld, info
+
+    def mem_info(self):
+        """(free, total) bytes of this context's GPU."""
+        f, t = _i64(), _i64()
+        check(self._lib.gpt_mem_info(self.handle, C.byref(f), C.byref(t)))
+        return int(f.value), int(t.value)
+
+    def release_batch_scratch(self):
+        check(self._lib.gpt_release_batch_scratch(self.handle))
 
     def ll_grad(self, term_idx, local_idx):
         """Data-term gradient for the listed (term, parameter) pairs plus the noise trace term (last entry)."""

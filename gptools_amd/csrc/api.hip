@@ -41,7 +41,7 @@ struct DevBuf {
 
 enum { SLOT_XI = 0, SLOT_XJ, SLOT_NI, SLOT_NJ, SLOT_OUT, SLOT_KST, SLOT_KSS, SLOT_XS, SLOT_NS, SLOT_VEC, SLOT_VEC2,
        SLOT_RHS, SLOT_LOW, SLOT_KFULL, SLOT_TK, SLOT_ZERO, SLOT_UINV, SLOT_WINV, SLOT_GPART, SLOT_BINV, SLOT_BTMP,
-       SLOT_BINV2, SLOT_BINV3, SLOT_BINV3U, SLOT_BATCH_A, SLOT_BATCH_WS, SLOT_BATCH_MISC, SLOT_COUNT };
+       SLOT_BINV2, SLOT_BINV3, SLOT_BINV3U, SLOT_BINVU, SLOT_BATCH_A, SLOT_BATCH_WS, SLOT_BATCH_MISC, SLOT_COUNT };
 
 struct gpt_ctx {
     int device = 0;
@@ -122,6 +122,10 @@ struct gpt_ctx {
     bool binv_valid = false;           // SLOT_BINV holds the inverses of the 512x512 diagonal blocks of the resident factor
     bool binv2_valid = false;          // SLOT_BINV2 those of its 1024x1024 diagonal blocks (solves with very few rows)
     bool binv3_valid = false;          // SLOT_BINV3 those of its 2048x2048 diagonal blocks (the same, large factors)
+    // (all three are always built for the whole padded order, floor(NP / width) blocks, whatever extent the caller needs:
+    // gpt_ll_grad and the solves ask for different extents at N = 512 k - 128, and a valid flag says nothing about how far)
+    int64_t debug_poison = 0;          // option "debug_poison": gpt_ll_grad fills its scratch matrices with NaN first (test aid)
+    int64_t edge_test_stall = 0;       // option "edge_test_stall": the next head flag is withheld once (test aid, see fit_terms_once)
     double *h_stage = nullptr;         // pinned staging ring for results that go to pageable host memory (2 x GPT_STAGE_BYTES)
     hipStream_t copy_stream = nullptr; // device-to-host copies that overlap the next block's compute (created on first use)
     hipEvent_t cev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -461,13 +465,22 @@ static bool edge_flags_env_ok()
 }
 
 // One synchronous evaluation (K build + factorisation + reduction, ends with the streams drained): decides c->flags_now.
+// never_flags: work that is in flight like an evaluation but has no flag edges of its own (gpt_fit_batch, gpt_cov_sample): it
+// is COUNTED (a flag-mode evaluation started meanwhile sees it and stays on events) but never takes the flag-mode slot itself
+// -- holding it would make every other thread's evaluation wait out the whole batch in the constructor below.
 struct EvalScope {
     gpt_ctx *c;
     bool flags;
-    explicit EvalScope(gpt_ctx *c_) : c(c_), flags(false)
+    explicit EvalScope(gpt_ctx *c_, bool never_flags = false) : c(c_), flags(false)
     {
         std::unique_lock<std::mutex> lk(g_eval_mu);
         const auto now = std::chrono::steady_clock::now();
+        if (never_flags) {
+            if (g_evals != 0 && g_announced == 0) g_contention_until = now + std::chrono::milliseconds(100);
+            g_evals++;
+            c->flags_now = false;
+            return;
+        }
         if (g_flag_evals != 0) {
             // Somebody else's flag-mode evaluation is in flight: this process runs evaluations from several threads without
             // having said so (gpt_concurrency_hint).  Wait for that one -- a flag-mode evaluation must be alone -- and keep the
@@ -1258,6 +1271,9 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "helper_min_n")) c->helper_min_n = value;
     else if (!strcmp(key, "fuse_trsm")) c->fuse_trsm = value;
     else if (!strcmp(key, "leaf256")) c->leaf256 = value ? 1 : 0;
+    else if (!strcmp(key, "debug_poison")) c->debug_poison = value;
+    else if (!strcmp(key, "alpha_invalidate")) c->alpha_valid = false;          // (measurement aid: the next gpt_get_alpha recomputes)
+    else if (!strcmp(key, "edge_test_stall")) c->edge_test_stall = value;
     else if (!strcmp(key, "tile")) {
         if (value != 0 && value != 64 && value != 65 && value != 128 && value != 129) {
             gpt_set_error("tile must be 0, 64 or 128");
@@ -1529,7 +1545,7 @@ static int ensure_factor_storage(gpt_ctx *c, int64_t N)
     GPT_HIP_CHECK(hipMalloc(&c->d_y, (size_t)2 * NP * sizeof(double)));          // y | err_y, one upload per evaluation
     c->d_erry = c->d_y + NP;
     GPT_HIP_CHECK(hipHostMalloc((void **)&c->h_yerr, (size_t)2 * NP * sizeof(double), hipHostMallocDefault));
-    GPT_HIP_CHECK(hipMalloc(&c->d_alpha, (size_t)NP * sizeof(double)));
+    GPT_HIP_CHECK(hipMalloc(&c->d_alpha, (size_t)2 * NP * sizeof(double)));      // alpha | work vector of its substitution
     c->NP = NP;
     return GPT_OK;
 }
@@ -1807,10 +1823,10 @@ static int fit_terms_once(gpt_ctx *c, const std::vector<KParams> &terms, double 
             c->head_wait.word = c->d_edge + 48;
             c->head_wait.value = ++c->edge_seq;
             c->head_wait = with_err(c, c->head_wait);
-            // (GPT_EDGE_TEST_STALL=1, test aid: the flag is NOT raised, once -- the waiter must time out, the evaluation be
-            // repeated on events and give the right numbers: tests/test_gpu_a_dist_processes.py)
-            static bool stall_once = getenv("GPT_EDGE_TEST_STALL") != nullptr;
-            if (stall_once) stall_once = false;
+            // (option "edge_test_stall", test aid: the flag is NOT raised, once -- the waiter must time out, the evaluation be
+            // repeated on events and give the right numbers: tests/test_gpu_a_dist_processes.py.  An explicit option of the
+            // context, not an environment variable: a stray variable must not be able to push a process off its flag edges)
+            if (c->edge_test_stall) c->edge_test_stall = 0;
             else GPT_TRY(launch_set_flag(st, c->head_wait.word, c->head_wait.value));
         } else {
             GPT_HIP_CHECK(hipEventRecord(e_head, st));
@@ -1961,7 +1977,7 @@ extern "C" int gpt_fit_batch_sum(gpt_ctx *c, int nbatch, int nterms, const int *
                  d_off_info = d_off_kp + (size_t)nterms * nbatch * kp_doubles;
     GPT_TRY(ensure(c, SLOT_BATCH_MISC, (d_off_info + (size_t)nbatch) * sizeof(double), (void **)&dmisc));
     int32_t *dinfo = reinterpret_cast<int32_t *>(dmisc + d_off_info);
-    EvalScope scope(c);                      // (an evaluation in flight like any other for the flag-edge accounting; uses none)
+    EvalScope scope(c, true);                // (in flight like an evaluation for the flag-edge accounting; has no flag edges)
     // everything on the panel stream: unmasked (all 256 CUs), the main stream is idle here
     hipStream_t st = c->panel_stream;
     {
@@ -2080,15 +2096,35 @@ extern "C" int gpt_get_L(gpt_ctx *c, double *L_out)
     return GPT_OK;
 }
 
-// alpha = L^-T z with z = the augmented row (z = L^-1 y)
+// alpha = L^-T z with z = the augmented row (z = L^-1 y)   (ref: gaussian_process.py:1462, the second half of cho_solve)
+// In 512-wide steps against the inverse transposes of the factor's 512 x 512 diagonal blocks (solve.hip launch_trsv_lt_wide;
+// the blocks' inverses are the ones predict and the gradient use, built once per factorisation by a dozen batched launches):
+// 2 N / 512 dependent launches instead of 2 N / 128 -- N = 8192: ~1.0 -> ~0.3 ms including the inverses, ~0.2 ms with them
+// cached.  What is left of the order beyond the last whole 512-block falls in 128-wide steps first (last rows first).
+// GPT_ALPHA_NARROW=1 (measurement aid): the 128-wide form throughout.
+static int ensure_block_inverses(gpt_ctx *c, int64_t nb, int64_t nfull, double **out, double **out_u = nullptr);
 static int ensure_alpha(gpt_ctx *c)
 {
     if (c->alpha_valid) return GPT_OK;
-    const int64_t N = c->N, n128 = round_up(N, 128);
+    const int64_t N = c->N, NP = c->NP, n128 = round_up(N, 128);
     hipStream_t st = c->stream;
-    GPT_HIP_CHECK(hipMemsetAsync(c->d_alpha, 0, (size_t)c->NP * sizeof(double), st));
-    GPT_HIP_CHECK(hipMemcpyAsync(c->d_alpha, c->dA + N * c->NP, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, st));
-    GPT_TRY(launch_trsv_lt(st, n128, c->dA, c->NP, c->d_invd, c->d_alpha));
+    static const bool narrow = getenv("GPT_ALPHA_NARROW") != nullptr;
+    const int64_t nwide = (n128 / 512) * 512;
+    GPT_HIP_CHECK(hipMemsetAsync(c->d_alpha, 0, (size_t)2 * NP * sizeof(double), st));
+    if (narrow || nwide < 1024) {
+        GPT_HIP_CHECK(hipMemcpyAsync(c->d_alpha, c->dA + N * NP, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, st));
+        GPT_TRY(launch_trsv_lt(st, n128, c->dA, NP, c->d_invd, c->d_alpha));
+        c->alpha_valid = true;
+        return GPT_OK;
+    }
+    double *W = nullptr, *U = nullptr, *w = c->d_alpha + NP;
+    GPT_TRY(ensure_block_inverses(c, 512, nwide, &W, &U));
+    GPT_HIP_CHECK(hipMemcpyAsync(w, c->dA + N * NP, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (n128 > nwide) {
+        GPT_TRY(launch_trsv_lt(st, n128, c->dA, NP, c->d_invd, w, nwide / 128));
+        GPT_HIP_CHECK(hipMemcpyAsync(c->d_alpha + nwide, w + nwide, (size_t)(n128 - nwide) * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    GPT_TRY(launch_trsv_lt_wide(st, nwide, c->dA, NP, U, w, c->d_alpha));
     c->alpha_valid = true;
     return GPT_OK;
 }
@@ -2180,7 +2216,6 @@ extern "C" int gpt_dev_trinv(gpt_ctx *c, int64_t n, const double *dL, int64_t ld
 
 #define GPT_BINV_NB 512
 #define GPT_BINV_NB2 1024
-static int ensure_block_inverses(gpt_ctx *c, int64_t nb, int64_t nfull, double **out);
 static int trsm_rlt_binv(gpt_ctx *c, hipStream_t st, int64_t m, int64_t nb, int64_t lo, int64_t hi, const double *W, double *B,
                          int64_t ldb, double *V, int64_t ldv);
 
@@ -2281,6 +2316,8 @@ extern "C" int gpt_ll_grad(gpt_ctx *c, int nh, const int *term_idx, const int *l
         GPT_HIP_CHECK(hipStreamWaitEvent(st, e, 0));
     }
     GPT_TRY(ensure_alpha(c));                                  // (main stream; joined below before the pair pass)
+    if (c->debug_poison)                                       // test aid: every byte 0xff = NaN in whatever is not written below
+        GPT_HIP_CHECK(hipMemsetAsync(W, 0xff, (size_t)NP * NP * sizeof(double), st));
     GPT_HIP_CHECK(hipMemsetAsync(U, 0, (size_t)NP * NP * sizeof(double), st));
     if (Wb) {
         GPT_TRY(trtri_u_gemm(c, st, 0, nfull, Wb, U, NP, W, NP));           // (W doubles as the scratch matrix T)
@@ -2341,7 +2378,11 @@ extern "C" int gpt_ll_grad(gpt_ctx *c, int nh, const int *term_idx, const int *l
         hipLaunchKernelGGL(transpose_rect_kernel, dim3((unsigned)((N + 31) / 32), (unsigned)((Nx + 31) / 32)), dim3(256), 0, st,
                            c->dT, NxP, TT, NyP, Nx, N);
         GPT_LAUNCH_CHECK();
-        GPT_TRY(launch_mirror_rows(st, W, NP, 0, N, N));
+        // (the GEMM below runs its k loop to NyP = round_up(N, 64) and reads W[j][k] for every j, k < NyP: the whole NyP x NyP
+        // block must hold finite numbers -- its lower triangle does (rows >= N: the inverse of the padded matrix' augmented /
+        // padding part, multiplied by the zero padding of T^T), the strictly upper entries only once mirrored.  Mirroring just
+        // the N x N part left the columns [N, NyP) to whatever the scratch slot held: ADVICE r3.)
+        GPT_TRY(launch_mirror_rows(st, W, NP, 0, NyP, NyP));
         GPT_TRY(gemm_nt(c, st, NxQ, NyP, NyP, 1.0, TT, NyP, W, NP, 0.0, Yt, NyP, 0));
         GPT_TRY(ensure(c, SLOT_KFULL, ((size_t)NxQ * NxQ + (size_t)NxQ) * sizeof(double), (void **)&Wt));
         at = Wt + NxQ * NxQ;
@@ -2430,18 +2471,83 @@ extern "C" int gpt_ll_grad(gpt_ctx *c, int nh, const int *term_idx, const int *l
 // additionally nb = 1024 for solves with at most GPT_FEW_ROWS rows, whose time is the LENGTH of the chain of dependent
 // GEMMs (two per block), not their flops.
 #define GPT_FEW_ROWS 128
-static int ensure_block_inverses(gpt_ctx *c, int64_t nb, int64_t nfull, double **out)
+__global__ void eye_strip_kernel(double *__restrict__ U, int64_t n, int64_t w)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) U[i * w + i % w] = 1.0;
+}
+
+// W_b (w x w) = U_b^T for every block b of a strip (blockIdx.z), through a 32x33 LDS tile
+__global__ __launch_bounds__(256) void transpose_strip_kernel(const double *__restrict__ U, double *__restrict__ W, int64_t w)
+{
+    __shared__ double t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32, o = (int64_t)blockIdx.z * w * w;
+    for (int i = ty; i < 32; i += 8) t[i][tx] = U[o + (r0 + i) * w + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) W[o + (c0 + i) * w + r0 + tx] = t[tx][i];
+}
+
+// The inverses of ALL 512 x 512 diagonal blocks of the resident factor at once: U (strip, block j at rows [512 j, 512 j + 512),
+// row stride 512) = L_jj^-T, W = L_jj^-1 = its transpose.  The recursion of trtri_u -- leaves by the panel TRSM on the identity,
+// U12 = -(U11 L21^T) L22^-T per level -- with every launch BATCHED over the blocks (blockIdx.y; the three operands of the
+// GEMMs lie in three arrays with a stride each): 2 + 4 + 4 + 4 + 1 = 15 launches whatever the order, where the per-block
+// loop of round 3 needed 10 per block (N = 8192: 160 launches, ~1.3 ms before the first predict / gradient / alpha).
+static int build_block_inverses_512(gpt_ctx *c, hipStream_t st, int64_t nblk, double *U, double *W)
+{
+    const int64_t nb = 512, bs = nb * nb, NP = c->NP, bsl = nb * (NP + 1), WS = GPT_WS_BLOCK;
+    GPT_HIP_CHECK(hipMemsetAsync(U, 0, (size_t)nblk * bs * sizeof(double), st));
+    hipLaunchKernelGGL(eye_strip_kernel, dim3((unsigned)((nblk * nb + 255) / 256)), dim3(256), 0, st, U, nblk * nb, nb);
+    GPT_LAUNCH_CHECK();
+    for (int p = 0; p < 4; p++)                                        // leaves: the identity through the panel TRSM
+        GPT_TRY(launch_trsm_panel(st, 128, nullptr, 0, c->d_invd + p * WS, U + (int64_t)p * 128 * nb + p * 128, nb, nullptr, EdgeSig(),
+                                  nblk, bs, 4 * WS));
+    for (int q = 0; q < 4; q += 2) {                                   // 128 -> 256: the pairs (0, 1) and (2, 3) of every block
+        const int64_t lo = q * 128, mid = lo + 128;
+        GPT_TRY(launch_gemm_nt(st, 128, 128, 128, -1.0, U + lo * nb + lo, nb, c->dA + mid * NP + lo, NP, 0.0, U + lo * nb + mid, nb, 0,
+                               0, 0, nullptr, nullptr, 0, EdgeSig(), EdgeSig(), 0, nblk, bs, EdgeSig(), bsl, bs));
+        GPT_TRY(launch_trsm_panel(st, 128, nullptr, 0, c->d_invd + (q + 1) * WS, U + lo * nb + mid, nb, nullptr, EdgeSig(), nblk, bs,
+                                  4 * WS));
+    }
+    // 256 -> 512: U12 = -(U11 L21^T), then the right-TRSM against L22 in two 128-column leaves
+    GPT_TRY(launch_gemm_nt(st, 256, 256, 256, -1.0, U, nb, c->dA + 256 * NP, NP, 0.0, U + 256, nb, 0, 0, 0, nullptr, nullptr, 0, EdgeSig(),
+                           EdgeSig(), 0, nblk, bs, EdgeSig(), bsl, bs));
+    GPT_TRY(launch_trsm_panel(st, 256, nullptr, 0, c->d_invd + 2 * WS, U + 256, nb, nullptr, EdgeSig(), nblk, bs, 4 * WS));
+    GPT_TRY(launch_gemm_nt(st, 256, 128, 128, -1.0, U + 256, nb, c->dA + 384 * NP + 256, NP, 1.0, U + 384, nb, 0, 0, 0, nullptr, nullptr, 0,
+                           EdgeSig(), EdgeSig(), 0, nblk, bs, EdgeSig(), bsl, bs));
+    GPT_TRY(launch_trsm_panel(st, 256, nullptr, 0, c->d_invd + 3 * WS, U + 384, nb, nullptr, EdgeSig(), nblk, bs, 4 * WS));
+    hipLaunchKernelGGL(transpose_strip_kernel, dim3((unsigned)(nb / 32), (unsigned)(nb / 32), (unsigned)nblk), dim3(256), 0, st, U, W, nb);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
+// (the inverses are always built for the WHOLE padded order -- floor(NP / nb) blocks -- whatever extent `nfull` the
+// caller is going to use: gpt_ll_grad asks for floor(NP / 512) blocks, the solves for floor(round_up(N, 128) / 512), one block
+// less at N = 512 k - 128; a strip sized for the smaller request used to be reallocated, and not rebuilt, by the larger one)
+static int ensure_block_inverses(gpt_ctx *c, int64_t nb, int64_t nfull, double **out, double **out_u)
 {
     const bool big = (nb == GPT_BINV_NB2);
-    double *W;
-    GPT_TRY(ensure(c, big ? SLOT_BINV2 : SLOT_BINV, (size_t)nfull * nb * sizeof(double), (void **)&W));
+    const int64_t nall = (c->NP / nb) * nb;
+    if (nfull > nall || nall <= 0) {
+        gpt_set_error("block inverses: extent %lld exceeds the padded order %lld", (long long)nfull, (long long)c->NP);
+        return GPT_E_ARG;
+    }
+    double *W, *Us = nullptr;
+    GPT_TRY(ensure(c, big ? SLOT_BINV2 : SLOT_BINV, (size_t)nall * nb * sizeof(double), (void **)&W));
+    if (!big) GPT_TRY(ensure(c, SLOT_BINVU, (size_t)nall * nb * sizeof(double), (void **)&Us));
     *out = W;
+    if (out_u) *out_u = Us;
     bool &valid = big ? c->binv2_valid : c->binv_valid;
     if (valid) return GPT_OK;
     hipStream_t st = c->stream;
+    if (!big) {
+        GPT_TRY(build_block_inverses_512(c, st, nall / nb, Us, W));
+        valid = true;
+        return GPT_OK;
+    }
     double *U;
     GPT_TRY(ensure(c, SLOT_UINV, (size_t)nb * nb * sizeof(double), (void **)&U));
-    for (int64_t j = 0; j < nfull; j += nb) {
+    for (int64_t j = 0; j < nall; j += nb) {
         GPT_HIP_CHECK(hipMemsetAsync(U, 0, (size_t)nb * nb * sizeof(double), st));
         hipLaunchKernelGGL(eye_blocks_kernel, dim3((unsigned)(nb / 256)), dim3(256), 0, st, U, nb, nb);
         GPT_LAUNCH_CHECK();
@@ -2462,6 +2568,8 @@ static int ensure_block_inverses_big(gpt_ctx *c, int64_t nfull, double **out)
 {
     const int64_t nb = GPT_BINV_NB3;
     double *W, *U, *T, *Wb;
+    if (nfull > (c->NP / nb) * nb) return GPT_E_ARG;
+    nfull = (c->NP / nb) * nb;                                  // (always the whole padded order, see ensure_block_inverses)
     GPT_TRY(ensure(c, SLOT_BINV3, (size_t)nfull * nb * sizeof(double), (void **)&W));
     *out = W;
     if (c->binv3_valid) return GPT_OK;
@@ -2618,6 +2726,34 @@ extern "C" int gpt_host_alloc(int64_t bytes, void **out)
     if (!out || bytes <= 0) return GPT_E_ARG;
     *out = nullptr;
     GPT_HIP_CHECK(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+    return GPT_OK;
+}
+
+// Free / total device memory of the context's GPU (hipMemGetInfo): callers that size scratch by what is there (the batched
+// evaluator of GaussianProcess.ll_batch) ask first instead of failing in hipMalloc.
+extern "C" int gpt_mem_info(gpt_ctx *c, int64_t *free_bytes, int64_t *total_bytes)
+{
+    CTX_ENTER(c);
+    size_t f = 0, t = 0;
+    GPT_HIP_CHECK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return GPT_OK;
+}
+
+// Returns the scratch of the batched evaluator (gpt_fit_batch*: nbatch matrices) to the device: the slots are otherwise kept
+// until the context is destroyed, which suits a grid walked in many chunks and nobody else.
+extern "C" int gpt_release_batch_scratch(gpt_ctx *c)
+{
+    CTX_ENTER(c);
+    GPT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    GPT_HIP_CHECK(hipStreamSynchronize(c->panel_stream));
+    for (int slot : {SLOT_BATCH_A, SLOT_BATCH_WS, SLOT_BATCH_MISC}) {
+        DevBuf &b = c->slots[slot];
+        if (b.p) GPT_HIP_CHECK(hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
     return GPT_OK;
 }
 
@@ -2810,8 +2946,7 @@ extern "C" int gpt_cov_sample(gpt_ctx *c, int64_t M_rows, double diag_add, const
     GPT_TRY(ensure(c, SLOT_RHS, (size_t)SP * LDC * sizeof(double), (void **)&dRt));
     GPT_TRY(ensure(c, SLOT_OUT, (size_t)LDC * SP * sizeof(double), (void **)&dOut));
     c->cov_M = 0;                                                    // (the covariance is consumed)
-    EvalScope scope(c);                                              // counted like an evaluation in flight ...
-    c->flags_now = false;                                            // ... on event edges (no flag-timeout repeat here)
+    EvalScope scope(c, true);                                        // counted like an evaluation in flight, on event edges
     GPT_HIP_CHECK(hipMemsetAsync(dzero, 0, (size_t)M * sizeof(double), st));
     GPT_HIP_CHECK(hipMemsetAsync(dinfo, 0, sizeof(int32_t), st));
     GPT_TRY(launch_add_diag(st, dcov, LDC, M, dzero, diag_add));

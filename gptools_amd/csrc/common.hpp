@@ -142,13 +142,16 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
                    const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile, int lds_pad,
                    hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int prio = 0, EdgeSig edge = EdgeSig(),
                    EdgeSig wait = EdgeSig(), int64_t edge_cols = 0, int64_t nbatch = 1, int64_t bstride = 0,
-                   EdgeSig tail = EdgeSig());
+                   EdgeSig tail = EdgeSig(), int64_t bstride_b = -1, int64_t bstride_c = -1);      // batch strides of B / C (< 0: bstride)
 int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base,
                       EdgeSig wait = EdgeSig(), int64_t nbatch = 1, int64_t bstride_a = 0, int64_t bstride_ws = 0);
 int launch_gemm_nt_stair(hipStream_t st, int64_t m, int64_t nseg, int64_t seg_cols, int64_t k, double alpha,
                          const double *A, int64_t lda, const double *B, int64_t ldb, int64_t b_stride, int64_t row_step,
                          double beta, double *C, int64_t ldc, int lds_pad, hipEvent_t ev0 = nullptr,
                          hipEvent_t ev1 = nullptr);
+int launch_gemm_nt_gridstair(hipStream_t st, int64_t m, int64_t nseg, int64_t seg_cols, int64_t k, double alpha, const double *A,
+                             int64_t lda, const double *B, int64_t ldb, int64_t off, int64_t num, int64_t den, int64_t base,
+                             double beta, double *C, int64_t ldc, int lds_pad, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int launch_potf2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
                       unsigned *flag, unsigned flag_base, hipEvent_t done = nullptr, EdgeSig edge = EdgeSig(),
                       EdgeSig wait = EdgeSig());
@@ -185,7 +188,8 @@ int launch_fill_pad(hipStream_t st, double *A, int64_t lda, int64_t n_valid, int
 int launch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_t n, const int32_t *d_info, double *d_part,
                       double *out4, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, unsigned *edge_err = nullptr);
 int launch_extract_lower(hipStream_t st, const double *A, int64_t lda, int64_t n, double *out, int64_t ldo);
-int launch_trsv_lt(hipStream_t st, int64_t n, const double *L, int64_t ldl, const double *invd, double *x);
+int launch_trsv_lt(hipStream_t st, int64_t n, const double *L, int64_t ldl, const double *invd, double *x, int64_t b_lo = 0);
+int launch_trsv_lt_wide(hipStream_t st, int64_t nwide, const double *L, int64_t ldl, const double *U, double *w, double *x);
 int launch_gemv_n(hipStream_t st, int64_t m, int64_t n, const double *A, int64_t lda, const double *x, double *y);
 int launch_rowsumsq_sub(hipStream_t st, int64_t m, int64_t n, const double *V, int64_t ldv, const double *kdiag,
                         double *var_out);

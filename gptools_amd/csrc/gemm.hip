@@ -164,13 +164,14 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
     int tri, int64_t ntm, int64_t ntn, int64_t nwg, const int2 *__restrict__ order, int64_t seg_cols, int64_t bskip, int prio, unsigned *edge, unsigned edge_val,
     unsigned edge_total, const unsigned *wait_word, unsigned wait_val, unsigned *wait_err, int edge_cols, int64_t bstride,
-    const unsigned *tail_word, unsigned tail_val, unsigned *tail_err)
+    const unsigned *tail_word, unsigned tail_val, unsigned *tail_err, int64_t bstride_b, int64_t bstride_c)
 {
-    // batched launches (gpt_fit_batch: independent small matrices, blockIdx.y = batch element): A, B and C all lie inside
-    // the element's own matrix, bstride elements apart
+    // batched launches (blockIdx.y = batch element).  gpt_fit_batch: independent small matrices, A, B and C all inside the
+    // element's own matrix, one stride; the batched block inverses (api.hip build_block_inverses): three operands in three
+    // different arrays, a stride each
     A += (int64_t)blockIdx.y * bstride;
-    B += (int64_t)blockIdx.y * bstride;
-    C += (int64_t)blockIdx.y * bstride;
+    B += (int64_t)blockIdx.y * bstride_b;
+    C += (int64_t)blockIdx.y * bstride_c;
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int RM = WM / 16, RN = WN / 16;
     // NSTAGE LDS buffers per operand: 2 for the large launches (four workgroups per CU hide the DMA latency for each
@@ -458,6 +459,7 @@ struct TileOrder {
     int64_t ntm, ntn;
     int tri, dev;
     int64_t seg_t, rss_t;          // staircase tables: tiles per column segment, row-start step per segment (tiles)
+    int64_t g_off, g_num, g_den, g_base;      // grid staircase (tri == 3), see tile_needed
     int2 *d_tab;
     int64_t grid;
     int64_t ntiles;                // entries of the table that hold a tile (the rest are (-1, -1) padding)
@@ -468,18 +470,32 @@ static std::mutex g_orders_mu;
 
 // tri == 2: staircase.  Column segment q = j / seg_t starts (its diagonal block) at tile row q * rss_t; tile (i, j) is
 // needed iff i >= q * rss_t + (j - q * seg_t).
-static inline bool tile_needed(int tri, int64_t i, int64_t j, int64_t seg_t, int64_t rss_t)
+// tri == 3: grid staircase (2-D block-cyclic layout, gptools_amd/dist.py GridLML).  Column segment q is local block column q of
+// the update, global block column J = J0 + q * num; the local block rows hold the global block rows I = pr + li * den.  Its
+// first needed block row is the first I >= J:  rs(q) = ceil((off + q * num) / den) - base  with off = J0 - pr and base = the
+// local index of the update's first block row.  Below that row the segment is a full rectangle; the first block itself is a
+// DIAGONAL block of the matrix iff (off + q * num) is a multiple of den, and then only its lower tiles are needed.
+struct GridStair { int64_t off = 0, num = 0, den = 1, base = 0; };
+static inline bool tile_needed(int tri, int64_t i, int64_t j, int64_t seg_t, int64_t rss_t, const GridStair &g = GridStair())
 {
     if (tri == 1) return j <= i;
     if (tri == 2) {
         const int64_t q = j / seg_t;
         return i >= q * rss_t + (j - q * seg_t);
     }
+    if (tri == 3) {
+        const int64_t q = j / seg_t, v = g.off + q * g.num;
+        const int64_t i0 = ((v + g.den - 1) / g.den - g.base) * seg_t;
+        if (i < i0) return false;
+        if (v % g.den == 0 && i < i0 + seg_t) return (i - i0) >= (j - q * seg_t);
+        return true;
+    }
     return true;
 }
 
 static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64_t *grid, int64_t seg_t = 0,
-                      int64_t rss_t = 0, int64_t *ntiles = nullptr, int64_t edge_cols = 0, int64_t *nedge = nullptr)
+                      int64_t rss_t = 0, int64_t *ntiles = nullptr, int64_t edge_cols = 0, int64_t *nedge = nullptr,
+                      const GridStair &gs = GridStair())
 {
     static int sgm = 0, sgn = 0, mode = 0;
     if (sgm == 0) {
@@ -493,7 +509,8 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
     GPT_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_orders_mu);
     for (const auto &o : g_orders)
-        if (o.ntm == ntm && o.ntn == ntn && o.tri == tri && o.dev == dev && o.seg_t == seg_t && o.rss_t == rss_t && o.edge_cols == edge_cols) {
+        if (o.ntm == ntm && o.ntn == ntn && o.tri == tri && o.dev == dev && o.seg_t == seg_t && o.rss_t == rss_t && o.edge_cols == edge_cols &&
+            o.g_off == gs.off && o.g_num == gs.num && o.g_den == gs.den && o.g_base == gs.base) {
             *tab = o.d_tab;
             *grid = o.grid;
             if (ntiles) *ntiles = o.ntiles;
@@ -510,7 +527,7 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
             bool any = false;
             for (int64_t i = si * sgm; i < (si + 1) * sgm && i < ntm; i++)
                 for (int64_t j = sj * sgn; j < (sj + 1) * sgn && j < ntn; j++) {
-                    if (!tile_needed(tri, i, j, seg_t, rss_t)) continue;
+                    if (!tile_needed(tri, i, j, seg_t, rss_t, gs)) continue;
                     (j < edge_cols ? sequ : dst).push_back(make_int2((int)i, (int)j));
                     any = true;
                 }
@@ -539,6 +556,10 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
     o.dev = dev;
     o.seg_t = seg_t;
     o.rss_t = rss_t;
+    o.g_off = gs.off;
+    o.g_num = gs.num;
+    o.g_den = gs.den;
+    o.g_base = gs.base;
     o.edge_cols = edge_cols;
     o.nedge = (int64_t)sequ.size();
     o.grid = (int64_t)flat.size();
@@ -570,8 +591,10 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
                          int lds_pad, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int64_t seg_cols = 0,
                          int64_t bskip = 0, int64_t row_step = 0, int prio = 0, EdgeSig edge = EdgeSig(),
                          EdgeSig wait = EdgeSig(), int64_t edge_cols_elems = 0, int64_t nbatch = 1, int64_t bstride = 0,
-                         EdgeSig tail = EdgeSig())
+                         EdgeSig tail = EdgeSig(), int64_t bstride_b = -1, int64_t bstride_c = -1, const GridStair &gs = GridStair())
 {
+    if (bstride_b < 0) bstride_b = bstride;
+    if (bstride_c < 0) bstride_c = bstride;
     const int64_t ntm = (m + BM - 1) / BM, ntn = (n + BN - 1) / BN;
     int64_t nwg = (tri == 1) ? ntn * (ntn + 1) / 2 + (ntm - ntn) * ntn : ntm * ntn;
     int64_t nreal = nwg;                   // workgroups that compute a tile (and count towards an edge flag)
@@ -580,6 +603,10 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
     if (tri == 2) {                        // staircase: the tile list always comes from a table
         int64_t grid = 0;
         GPT_TRY_RC(tile_order(ntm, ntn, 2, &order, &grid, seg_cols / BN, row_step / BM, &nreal));
+        nwg = grid;
+    } else if (tri == 3) {                 // grid staircase: likewise
+        int64_t grid = 0;
+        GPT_TRY_RC(tile_order(ntm, ntn, 3, &order, &grid, seg_cols / BN, 0, &nreal, 0, nullptr, gs));
         nwg = grid;
     } else if (nwg >= 512) {               // large launches only: small ones live in L2 anyway
         int64_t grid = 0;
@@ -601,12 +628,12 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
         hipExtLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg, (unsigned)nbatch), dim3(256), dyn, st, ev0, ev1, 0,
                               m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip, prio, edge.word, edge.value,
                               (unsigned)(edge_cols_elems > 0 ? nedge : nreal), wait.word, wait.value, wait.err, (int)(edge_cols_elems / BN), bstride,
-                              tail.word, tail.value, tail.err);
+                              tail.word, tail.value, tail.err, bstride_b, bstride_c);
     else
         hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WPS, NSTAGE>), dim3((unsigned)nwg, (unsigned)nbatch), dim3(256), dyn, st, m, n, k, alpha,
                            A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip, prio, edge.word, edge.value,
                               (unsigned)(edge_cols_elems > 0 ? nedge : nreal), wait.word, wait.value, wait.err, (int)(edge_cols_elems / BN), bstride,
-                              tail.word, tail.value, tail.err);
+                              tail.word, tail.value, tail.err, bstride_b, bstride_c);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
@@ -645,7 +672,7 @@ int gemm_small_threshold()
 int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A, int64_t lda,
                    const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri, int force_tile, int lds_pad,
                    hipEvent_t ev0, hipEvent_t ev1, int prio, EdgeSig edge, EdgeSig wait, int64_t edge_cols, int64_t nbatch,
-                   int64_t bstride, EdgeSig tail)
+                   int64_t bstride, EdgeSig tail, int64_t bstride_b, int64_t bstride_c)
 {
     gpt_jitter(st);
     if (m <= 0 || n <= 0) {
@@ -701,8 +728,8 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
             if (const char *e = getenv("GPT_GEMM_SMALL_STAGES")) stages = atoi(e);
         }
         if ((stages == 4 && k >= 64) || (stages == 0 && k >= 256))
-            return gemm_launch_t<32, 32, 2, 4>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0, ev0, ev1, 0, 0, 0, prio, edge, wait, 0, nbatch, bstride, tail);
-        return gemm_launch_t<32, 32, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0, ev0, ev1, 0, 0, 0, prio, edge, wait, 0, nbatch, bstride, tail);
+            return gemm_launch_t<32, 32, 2, 4>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0, ev0, ev1, 0, 0, 0, prio, edge, wait, 0, nbatch, bstride, tail, bstride_b, bstride_c);
+        return gemm_launch_t<32, 32, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0, ev0, ev1, 0, 0, 0, prio, edge, wait, 0, nbatch, bstride, tail, bstride_b, bstride_c);
     }
     if ((edge.word || wait.word || edge_cols || tail.word) && tile != 64) {
         gpt_set_error("gemm_nt: edge flags exist for the 64x64 / 32x32 kernels only");
@@ -715,7 +742,7 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
     // DMA wait, so everything uses the 2-stage kernel.
     if (force_tile == 65) return gemm_launch_t<64, 64, 1, 4>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0);
     return gemm_launch_t<64, 64, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, lds_pad, ev0, ev1, 0, 0, 0, prio, edge, wait, edge_cols,
-                                       nbatch, bstride, tail);
+                                       nbatch, bstride, tail, bstride_b, bstride_c);
 }
 
 // Staircase update: C (m x nseg*seg_cols) += alpha * A B_q^T per column segment q, where segment q (seg_cols
@@ -737,4 +764,28 @@ int launch_gemm_nt_stair(hipStream_t st, int64_t m, int64_t nseg, int64_t seg_co
     }
     return gemm_launch_t<64, 64, 2, 2>(st, m, nseg * seg_cols, k, alpha, A, lda, B, ldb, beta, C, ldc, 2, lds_pad, ev0,
                                        ev1, seg_cols, b_stride - seg_cols, row_step);
+}
+
+// Grid staircase (2-D block-cyclic trailing update, see tile_needed): C (m x nseg*seg_cols) += alpha * A * B^T where column
+// segment q takes its B rows from B + q * seg_cols rows and only the block rows from  ceil((off + q * num) / den) - base  on
+// are touched.  One launch per step and rank, one XCD-aware tile order.
+int launch_gemm_nt_gridstair(hipStream_t st, int64_t m, int64_t nseg, int64_t seg_cols, int64_t k, double alpha, const double *A,
+                             int64_t lda, const double *B, int64_t ldb, int64_t off, int64_t num, int64_t den, int64_t base,
+                             double beta, double *C, int64_t ldc, int lds_pad, hipEvent_t ev0, hipEvent_t ev1)
+{
+    gpt_jitter(st);
+    if (m <= 0 || nseg <= 0) return GPT_OK;
+    if (alpha == 0.0 || k <= 0 || (k % GM_BK) != 0 || (lda & 1) || (ldb & 1) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) ||
+        seg_cols <= 0 || (seg_cols % 64) || num <= 0 || den <= 0 || off <= -den) {
+        gpt_set_error("gemm_nt_gridstair: bad arguments (k multiple of %d, seg_cols a multiple of 64, num, den > 0, 16-byte "
+                      "aligned operands)", GM_BK);
+        return GPT_E_ARG;
+    }
+    GridStair gs;
+    gs.off = off;
+    gs.num = num;
+    gs.den = den;
+    gs.base = base;
+    return gemm_launch_t<64, 64, 2, 2>(st, m, nseg * seg_cols, k, alpha, A, lda, B, ldb, beta, C, ldc, 3, lds_pad, ev0, ev1, seg_cols, 0,
+                                       0, 0, EdgeSig(), EdgeSig(), 0, 1, 0, EdgeSig(), -1, -1, gs);
 }

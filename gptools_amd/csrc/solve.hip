@@ -5,6 +5,7 @@
 // ref: gptools/gaussian_process.py:1462-1467 (alpha, ll), :971 (mean = Kstar^T alpha),
 //      :987,1006 (cov diagonal / std).
 #include "common.hpp"
+#define GPT_TRY_RC_SOLVE(expr) do { int rc_ = (expr); if (rc_ != GPT_OK) return rc_; } while (0)
 
 // Rows [n_valid, n_pad) of the padded matrix: zero, unit diagonal.  If dy != NULL row n_valid
 // carries y^T (the "augmented row": after the factorisation it holds z^T = (L^-1 y)^T) and its
@@ -444,13 +445,15 @@ __global__ __launch_bounds__(256) void trsv_lt_update_kernel(int64_t ncols, cons
     w[col] -= acc;
 }
 
-int launch_trsv_lt(hipStream_t st, int64_t n, const double *L, int64_t ldl, const double *invd, double *x)
+// (b_lo > 0: only the blocks b >= b_lo are solved -- their updates still reach every column to their left; the caller
+// continues from there with wider steps, launch_trsv_lt_wide)
+int launch_trsv_lt(hipStream_t st, int64_t n, const double *L, int64_t ldl, const double *invd, double *x, int64_t b_lo)
 {
     if (n % 128) {
         gpt_set_error("trsv_lt: n must be a multiple of 128");
         return GPT_E_ARG;
     }
-    for (int64_t b = n / 128 - 1; b >= 0; b--) {
+    for (int64_t b = n / 128 - 1; b >= b_lo; b--) {
         const double *Lbb = L + (b * 128) * ldl + b * 128;
         hipLaunchKernelGGL(trsv_lt_diag_kernel, dim3(1), dim3(256), 0, st, Lbb, ldl, invd + b * GPT_WS_BLOCK, x + b * 128);
         if (b > 0) {
@@ -458,6 +461,63 @@ int launch_trsv_lt(hipStream_t st, int64_t n, const double *L, int64_t ldl, cons
             hipLaunchKernelGGL(trsv_lt_update_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, st, ncols,
                                L + (b * 128) * ldl, ldl, x + b * 128, x);
         }
+    }
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
+// ---- the same substitution in 512-wide steps against explicit inverses of the diagonal blocks -------------------------------
+// 127 dependent launches of ~8 us are what the 128-wide form costs at n = 8192 (1 ms, a fifth of an evaluation).  With
+// U_j = L_jj^-T of the 512 x 512 diagonal blocks at hand (api.hip build_block_inverses: a dozen batched launches for all of
+// them) a step is  x_j = U_j w_j  (launch_gemv_n: one workgroup per row)  and  w[0 : j0) -= L[j0 : j0 + 512, 0 : j0)^T x_j
+// (this kernel): 2 n / 512 launches.  A workgroup takes 64 columns; its four waves split the 512 rows and walk them with
+// eight loads in flight per lane (a row segment is 512 contiguous bytes); the four partial sums meet in LDS in a fixed order.
+#define TW_NB 512
+__global__ __launch_bounds__(256) void gemv_t_sub_kernel(int64_t ncols, const double *__restrict__ M, int64_t ldm,
+                                                         const double *__restrict__ x, double *__restrict__ w)
+{
+    __shared__ double xs[TW_NB];
+    __shared__ double part[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+    for (int i = tid; i < TW_NB; i += 256) xs[i] = x[i];
+    __syncthreads();
+    const int64_t col = (int64_t)blockIdx.x * 64 + lane;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (col < ncols) {
+        const double *p = M + (int64_t)(g * (TW_NB / 4)) * ldm + col;
+        const double *xv = xs + g * (TW_NB / 4);
+#pragma unroll 2
+        for (int r = 0; r < TW_NB / 4; r += 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = p[(int64_t)(r + q) * ldm];
+            a0 = fma(v[0], xv[r + 0], a0);
+            a1 = fma(v[1], xv[r + 1], a1);
+            a2 = fma(v[2], xv[r + 2], a2);
+            a3 = fma(v[3], xv[r + 3], a3);
+            a0 = fma(v[4], xv[r + 4], a0);
+            a1 = fma(v[5], xv[r + 5], a1);
+            a2 = fma(v[6], xv[r + 6], a2);
+            a3 = fma(v[7], xv[r + 7], a3);
+        }
+    }
+    part[g][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (g == 0 && col < ncols) w[col] -= (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+// Blocks [0, nwide / 512) of  L^T x = w : U = the strip of the blocks' inverse transposes (block j at rows [512 j, 512 j + 512),
+// row stride 512), w (in: right-hand side, already updated by every block right of nwide; consumed) and x (out) distinct.
+int launch_trsv_lt_wide(hipStream_t st, int64_t nwide, const double *L, int64_t ldl, const double *U, double *w, double *x)
+{
+    if (nwide % TW_NB) {
+        gpt_set_error("trsv_lt_wide: the extent must be a multiple of %d", TW_NB);
+        return GPT_E_ARG;
+    }
+    for (int64_t j0 = nwide - TW_NB; j0 >= 0; j0 -= TW_NB) {
+        GPT_TRY_RC_SOLVE(launch_gemv_n(st, TW_NB, TW_NB, U + j0 * TW_NB, TW_NB, w + j0, x + j0));
+        if (j0 > 0)
+            hipLaunchKernelGGL(gemv_t_sub_kernel, dim3((unsigned)((j0 + 63) / 64)), dim3(256), 0, st, j0, L + j0 * ldl, ldl, x + j0, w);
     }
     GPT_LAUNCH_CHECK();
     return GPT_OK;

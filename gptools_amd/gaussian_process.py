@@ -57,7 +57,7 @@ class GaussianProcess(object):
     """
 
     def __init__(self, k, noise_k=None, X=None, y=None, err_y=0, n=0, T=None, diag_factor=1e2, mu=None,
-                 use_hyper_deriv=False, verbose=False, device=0):
+                 use_hyper_deriv=False, verbose=False, device=0, eager_alpha=False):
         if not isinstance(k, Kernel):
             raise TypeError("Argument k must be an instance of Kernel when constructing GaussianProcess!")
         if noise_k is None:
@@ -71,6 +71,8 @@ class GaussianProcess(object):
         self.use_hyper_deriv = use_hyper_deriv
         self.verbose = verbose
         self.device = device
+        if eager_alpha:
+            self.eager_alpha = True
         self.y = np.array([], dtype=float)
         self.X = None
         self.err_y = np.array([], dtype=float)
@@ -100,6 +102,11 @@ class GaussianProcess(object):
 
     partitioned = False
     partition_block = 512
+    #: ``eager_alpha = True``: every fit also computes ``alpha`` and brings it to the host, like the reference's
+    #: ``compute_K_L_alpha_ll`` (gaussian_process.py:1462) -- for drop-in users who read ``gp.alpha`` after every
+    #: ``update_hyperparameters``.  Default False: ``alpha`` is computed on first use (``gp.alpha``, ``predict``, the analytic
+    #: gradient); the MAP loop never reads it.  Cost at N = 8192: ~0.3 ms per evaluation (bench.py ``with_alpha``).
+    eager_alpha = False
 
     def _partitioned_possible(self):
         if not self.partitioned or self.use_hyper_deriv or self.T is not None or not self._fast_fit_possible():
@@ -445,6 +452,8 @@ class GaussianProcess(object):
             self._data_on_device = False
             self._fit_mode = "matrix"
         self.ll = ll_data + self.hyperprior(self.params)          # log-posterior (ref :1469)
+        if self.eager_alpha:
+            self._cache["alpha"] = ctx.get_alpha(len(self.y)).reshape(-1, 1)      # (ref :1462)
         if self.use_hyper_deriv:
             self._compute_ll_deriv()
         self.K_up_to_date = True
@@ -647,14 +656,23 @@ class GaussianProcess(object):
             err_y = np.asarray(self.err_y, dtype=float)
             self._cache = {}
             NP = -(-(len(self.y) + 1) // 128) * 128
-            G = max(1, min(int(self.batch_grid), int(self.batch_grid_bytes) // (8 * NP * NP)))
-            for s0 in range(0, len(jobs), G):
+            # chunk size: batch_grid, or what fits batch_grid_bytes, or what fits HALF of the device memory that is free right now
+            # (other ranks / processes may share the GPU) -- and should the allocation still fail, half as many, down to the
+            # one-context-per-thread path below (a MemoryError used to abort ll_batch / compute_ll_matrix)
+            budget = min(int(self.batch_grid_bytes), self._ctx.mem_info()[0] // 2)
+            G = max(1, min(int(self.batch_grid), budget // (8 * NP * NP + 8 * 9216 * (NP // 128))))
+            s0 = 0
+            while s0 < len(jobs) and G >= 1:
                 chunk = jobs[s0:s0 + G]
                 try:
                     ll, _, info = self._ctx.fit_batch_sum(kids, np.array([np.concatenate([np.asarray(t[1], dtype=float)
                                                                                           for t in j[1]]) for j in chunk]),
                                                           npar, np.array([j[3] for j in chunk]),
                                                           np.array([j[4] for j in chunk]), err_y, diag_add)
+                except MemoryError:
+                    self._ctx.release_batch_scratch()
+                    G //= 2
+                    continue
                 except (ValueError, ArithmeticError):
                     # an argument the library rejects for one element (e.g. a kernel parameter out of its domain) fails the
                     # whole call: that chunk one vector at a time, with the +inf policy of update_hyperparameters
@@ -667,7 +685,12 @@ class GaussianProcess(object):
                 for j, l, bad in zip(chunk, ll, info):
                     if bad == 0:
                         out[j[0]] = l + j[5]
-            return out
+                s0 += len(chunk)
+            if 8 * NP * NP * min(G, len(jobs)) > (2 << 30):
+                self._ctx.release_batch_scratch()            # a large scratch goes back to the device once the list is done
+            if s0 >= len(jobs):
+                return out
+            jobs = jobs[s0:]                                  # (no chunk size fits: the rest one context per thread)
         ctxs = [[self._ctx, version]] + self._batch_contexts(B)
         for c in ctxs[1:]:
             if c[1] != version:                                      # data added since this context last saw it

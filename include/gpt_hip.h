@@ -99,12 +99,16 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
  *   "timing"       0/1: record per-phase HIP events (gpt_last_timings)
  *   "profile_gemm" 0/1: HIP-event timing of each large GEMM launch (gpt_gemm_profile_read)
  *   "tile"         0 auto, 64, 65 (4-stage), 128 (persistent), 129: force the GEMM macro-tile
+ *   "debug_poison" 0/1 (test aid): gpt_ll_grad fills its scratch matrices with NaN before use
+ *   "edge_test_stall" 1 (test aid): the next evaluation's first flag is withheld once, so that the bounded wait, the repeat on
+ *                  event edges and the switch of the process to event edges can be tested
  *   measured and off by default: "ramp", "inner", "inner_rows", "leaf256", "defer_rows", "late_rows",
  *   "early_rows", "nb_early", "nb_switch_rows", "late_pad", "late_pad_rows"
  * Environment: GPT_RESERVE_CUS (CUs the main stream leaves to the panel stream, default 32), GPT_TILE_ORDER
  * ("rows,cols,mode": supertile shape and deal of the GEMM's XCD-aware tile order, default 64,8,1), GPT_GRAD_TIMING,
  * GPT_EDGE_FLAGS=0 (event edges only: set it for jobs that share one GPU between several processes), GPT_GEMM_SMALL (64x64-tile count under which a GEMM launch uses 32x32 tiles, 512),
- * GPT_JITTER (test aid: random delay kernels in front of every dense launch). */
+ * GPT_JITTER (test aid: random delay kernels in front of every dense launch), GPT_ALPHA_NARROW (measurement aid: gpt_get_alpha
+ * by 128-wide substitution steps instead of the 512-wide block inverses). */
 int gpt_ctx_set_option(gpt_ctx *ctx, const char *key, int64_t value);
 int gpt_ctx_synchronize(gpt_ctx *ctx);
 void *gpt_ctx_stream(gpt_ctx *ctx);
@@ -213,6 +217,11 @@ int gpt_fit_batch(gpt_ctx *ctx, int nbatch, int kernel_id, const double *params,
 int gpt_fit_batch_sum(gpt_ctx *ctx, int nbatch, int nterms, const int *kernel_ids, const double *params,
                       const int *nparams, const double *noise_var, const double *y, const double *err_y,
                       double diag_add, double *ll_data_out, double *logdet_half_out, int32_t *info_out);
+
+/* Free / total bytes of the context's GPU, and the release of the batched evaluator's scratch (nbatch matrices; otherwise kept
+ * until gpt_ctx_destroy): GaussianProcess.ll_batch sizes its chunks by the first and returns the memory with the second. */
+int gpt_mem_info(gpt_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes);
+int gpt_release_batch_scratch(gpt_ctx *ctx);
 
 /* Same as gpt_fit but for an explicit, caller-assembled symmetric K_tot (host, (N, N) row-major;
  * only the lower triangle is read): used for the `T` (linear transform) branch,

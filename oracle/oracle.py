@@ -43,8 +43,11 @@ def build(force=False):
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(os.path.join(HERE, "libgpt_oracle.so"))
+        # GPT_ORACLE_LIB: an alternative build of the same source (scripts/asan_cpu.sh points it at the ASan / UBSan one)
+        alt = os.environ.get("GPT_ORACLE_LIB")
+        if not alt:
+            build()
+        _lib = C.CDLL(alt or os.path.join(HERE, "libgpt_oracle.so"))
         _lib.orc_eval_hermite.restype = C.c_double
         _lib.orc_eval_hermite.argtypes = [C.c_long, C.c_double]
         _lib.orc_eval_hermitenorm.restype = C.c_double

@@ -4,6 +4,8 @@
 import os
 import pickle
 import re
+import subprocess
+import sys
 import warnings
 
 import numpy as np
@@ -272,3 +274,27 @@ def test_bench_self_launch_starts_the_ranks_and_relays_their_status():
     seen = eval(lines[1])
     assert [s[:4] for s in seen] == [(str(r), str(r), "3", "127.0.0.1") for r in range(3)]
     assert all(s[4].endswith("bench.py") for s in seen)
+
+
+def test_oracle_restatement_is_clean_under_asan_and_ubsan():
+    """SURVEY.md section 5 (sanitizers on the CPU build): scripts/asan_cpu.sh builds oracle/gpt_oracle.c with
+    -fsanitize=address,undefined and runs the golden-vector suite against it with the runtime preloaded; any report aborts.
+    Skipped where gcc ships no libasan."""
+    import shutil
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not shutil.which("gcc") or not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("gcc has no AddressSanitizer runtime here")
+    p = subprocess.run([os.path.join(ROOT, "scripts", "asan_cpu.sh")], capture_output=True, text=True, timeout=900)
+    if p.returncode == 77:
+        pytest.skip("asan runtime not found")
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    assert "passed" in p.stdout and "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr
+    # the sanitised build really was the library under test
+    q = subprocess.run([sys.executable, "-c",
+                        "import os, sys; sys.path.insert(0, %r)\n"
+                        "from oracle import oracle as O\n"
+                        "O.lib(); print([l.split()[-1] for l in open('/proc/self/maps') if 'libgpt_oracle' in l][0])" % ROOT],
+                       capture_output=True, text=True,
+                       env=dict(os.environ, GPT_ORACLE_LIB=os.path.join(ROOT, "oracle", "libgpt_oracle_asan.so"),
+                                LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0"))
+    assert q.stdout.strip().endswith("libgpt_oracle_asan.so"), (q.stdout, q.stderr[-500:])

@@ -347,7 +347,7 @@ def test_gaussian_process_reaches_the_flag_schedule_by_default():
 
 
 def test_flag_wait_times_out_and_the_evaluation_is_repeated_on_events():
-    """Every flag wait is bounded (common.hpp edge_poll): with the head flag withheld once (test aid GPT_EDGE_TEST_STALL) the
+    """Every flag wait is bounded (common.hpp edge_poll): with the head flag withheld once (context option `edge_test_stall`) the
     first leaf times out after 250 ms instead of hanging, the evaluation is repeated on event edges and returns the right
     numbers, and the process stays on events from then on."""
     code = (
@@ -356,14 +356,14 @@ def test_flag_wait_times_out_and_the_evaluation_is_repeated_on_events():
         "from test_gpu_parity import c3_inputs\n"
         "X, n, y = c3_inputs(3000, 3)\n"
         "err, p = np.full(3000, 0.05), np.array([1.0, 0.3, 0.3, 0.3])\n"
-        "ctx = _lib.Context(0); ctx.set_data(X, n)\n"
+        "ctx = _lib.Context(0); ctx.set_data(X, n); ctx.set_option('edge_test_stall', 1)\n"
         "t0 = time.time(); r0 = ctx.fit(1, p, 0.0, y, err, 2.2e-14); t0 = time.time() - t0\n"
         "e0 = ctx.edge_count\n"
         "t1 = time.time(); r1 = ctx.fit(1, p, 0.0, y, err, 2.2e-14); t1 = time.time() - t1\n"
         "e1 = ctx.edge_count\n"
         "ctx.set_option('edge_flags', 0); r2 = ctx.fit(1, p, 0.0, y, err, 2.2e-14)\n"
         "print('RESULT', json.dumps({'r': [r0, r1, r2], 't': [t0, t1], 'e': [e0, e1]}))\n")
-    out, err = _run_fresh(code, {"GPT_EDGE_TEST_STALL": "1"})
+    out, err = _run_fresh(code)
     assert out["r"][0] == out["r"][1] == out["r"][2], out
     assert 0.2 < out["t"][0] < 20.0 and out["t"][1] < 0.2, out["t"]
     assert out["e"][1] == out["e"][0], "after a timeout the process must stay on event edges"

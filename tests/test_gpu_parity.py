@@ -1624,3 +1624,80 @@ def test_ll_batch_grid_path_and_thread_path_agree(g):
         gp = g.GaussianProcess(k, noise_k=nk, X=X2, y=y2, err_y=0.0, diag_factor=0.0)
         out = gp.ll_batch([[1.0, 0.4, 0.6, 0.05], [1.0, 0.4, 0.6, 0.0], [1.1, 0.5, 0.6, 0.02]])
         assert np.isfinite(out[0]) and np.isneginf(out[1]) and np.isfinite(out[2])
+
+
+@pytest.mark.parametrize("kern,N,d", [("m52", 1408, 3), ("se", 2047, 2), ("se", 3000, 2), ("m52", 1024, 3), ("se", 1100, 2)])
+def test_alpha_by_wide_steps_matches_the_oracle_and_the_narrow_form(oracle, kern, N, d):
+    """alpha = L^-T z (ref gaussian_process.py:1462) in 512-wide steps against the batched block inverses (api.hip ensure_alpha,
+    solve.hip launch_trsv_lt_wide), with a ragged tail of 128-wide steps (N = 1408, 3000), exactly whole blocks (1024) and just
+    below a block (2047): against the oracle's alpha, against K_tot alpha = y, and the block inverses themselves through
+    cho_solve / solve_L of a few right-hand sides."""
+    from gptools_amd import _lib
+    X, n, y = c3_inputs(N, d)
+    p = np.concatenate(([1.0], 0.3 * np.ones(d)))
+    err = 0.05 * np.ones(N)
+    ref = oracle.fit(kern, p, X, n, y, err, chol="scipy")
+    c = _lib.Context(0)
+    try:
+        c.set_data(X, n)
+        c.fit(KID[kern], p, 0.0, y, err, 1e2 * EPS)
+        a = c.get_alpha(N)
+        scale = np.abs(ref["alpha"]).max()
+        np.testing.assert_allclose(a, ref["alpha"], rtol=0, atol=2e-7 * scale)
+        K = oracle.kbuild(kern, p, X, n)
+        K[np.diag_indices(N)] += err ** 2 + 1e2 * EPS
+        np.testing.assert_allclose(K.dot(a), y, rtol=0, atol=1e-7 * max(1.0, np.abs(y).max()))
+        B = np.random.RandomState(3).randn(N, 3)
+        Z = c.cho_solve(B.copy())
+        np.testing.assert_allclose(K.dot(Z), B, rtol=0, atol=1e-6 * np.abs(B).max())
+    finally:
+        c.close()
+
+
+def test_block_inverse_extents_fit_predict_then_gradient(g):
+    """at N = 512 k - 128 the solves (predict with std) and gpt_ll_grad ask for block inverses over different
+    extents; fit -> predict(std) -> ll_grad must give the gradient ll_grad gives straight after the fit."""
+    N, d = 1408, 2
+    rs = np.random.RandomState(11)
+    X = rs.rand(N, d)
+    y = np.sin(3 * X.sum(1)) + 0.05 * rs.randn(N)
+    from gptools_amd import _lib
+    p = np.array([1.1, 0.4, 0.6])
+    err = 0.05 * np.ones(N)
+    n = np.zeros((N, d), dtype=int)
+    res = []
+    for with_predict in (False, True):
+        c = _lib.Context(0)
+        try:
+            c.set_data(X, n)
+            c.fit(0, p, 0.0, y, err, 1e2 * EPS)
+            if with_predict:
+                c.predict(rs.rand(300, d), np.zeros((300, d), int), 1)
+                c.solve_L(rs.randn(N, 2))
+            res.append(c.ll_grad([0, 0, 0], [0, 1, 2]))
+        finally:
+            c.close()
+    np.testing.assert_array_equal(res[0], res[1])
+    assert np.all(np.isfinite(res[0]))
+
+
+def test_transform_gradient_does_not_read_unwritten_scratch(g):
+    """with a transform and N % 64 != 0 the T^T W T product reads W up to round_up(N, 64); the scratch matrix is
+    pre-filled with NaN (context option debug_poison) and the gradient must still be the clean one."""
+    rs = np.random.RandomState(5)
+    d, Nx, Ny = 2, 700, 330
+    X = rs.rand(Nx, d)
+    n = np.zeros((Nx, d), dtype=int)
+    T = rs.rand(Ny, Nx) / Nx
+    y = T.dot(np.sin(3 * X.sum(1))) + 1e-3 * rs.randn(Ny)
+    grads = []
+    for poison in (0, 1):
+        k = make_kernel(g, "se", d, [1.1, 0.4, 0.6])
+        nk = g.DiagonalNoiseKernel(num_dim=d, initial_noise=0.05, noise_bound=(0.0, 5.0))
+        gp = g.GaussianProcess(k, noise_k=nk, use_hyper_deriv=True)
+        gp.add_data(X, y, err_y=1e-3, n=n, T=T)
+        gp._ctx.set_option("debug_poison", poison)
+        val, grad = gp.update_hyperparameters(np.array(gp.free_params[:], dtype=float))
+        grads.append(np.array(grad))
+    assert np.all(np.isfinite(grads[1]))
+    np.testing.assert_array_equal(grads[0], grads[1])
