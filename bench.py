@@ -325,7 +325,7 @@ def main():
     ap.add_argument("--no-predict", action="store_true", help="N=1: skip the predict leg")
     ap.add_argument("--no-gp-api", action="store_true", help="N=1: skip the GaussianProcess.update_hyperparameters leg")
     ap.add_argument("--no-ref", action="store_true", help="N>1: skip the single-GPU run of the same workload on rank 0")
-    ap.add_argument("--schedule", default=None, help="N>1: fix the schedule+exchange (e.g. pipelined+bcast) instead of tuning")
+    ap.add_argument("--schedule", default=None, help="N>1: fix the layout (1d+bcast, 1d+scatter_gather, grid2x4, ...) instead of tuning")
     ap.add_argument("--no-probe", action="store_true", help="N>1: skip the step trace and the link probes after the timed region")
     args = ap.parse_args()
 
@@ -651,16 +651,27 @@ def main():
             extra["kbuild_standalone"] = {"error": repr(e_)}
         parallelism = "1 GPU, look-ahead on a second HIP stream"
     else:
-        from gptools_amd.dist import DistributedLML, HipPanelOps
+        from gptools_amd.dist import DistributedLML, GridLML, HipPanelOps
         ops = HipPanelOps(local_rank)
         plans = {}
         plan = None
 
-        def get_plan(nb_):
-            if nb_ not in plans:
-                shared = next(iter(plans.values())).group_tail if plans else None
-                plans[nb_] = DistributedLML(X, n, nb=nb_, ops=ops, group_tail=shared)
-            return plans[nb_]
+        # A leg of the partitioned bench is named "<layout>@<nb>": layout = "1d+bcast" / "1d+scatter_gather" (1-D block-cyclic
+        # block columns, whole panels, moved by one broadcast or by scatter + all-gather) or "grid<Pr>x<Pc>" (2-D block-cyclic
+        # over a process grid, gptools_amd.dist.GridLML: the per-panel column update and solve split over a process column).
+        def get_plan(name):
+            layout, nb_ = name.split("@")
+            nb_ = int(nb_)
+            if layout.startswith("grid"):
+                if name not in plans:
+                    g_ = tuple(int(v) for v in layout[4:].split("x"))
+                    plans[name] = GridLML(X, n, g_, nb=nb_, ops=ops)
+                return plans[name]
+            key = "1d@%d" % nb_
+            if key not in plans:
+                plans[key] = DistributedLML(X, n, nb=nb_, ops=ops)
+            plans[key].exchange = layout.split("+")[1]
+            return plans[key]
 
         def step():
             return plan.fit(KID[kernel], params, y, err)
@@ -695,27 +706,31 @@ def main():
             return t_ / nsteps, r_
         roof_box = [None]
 
-        # (1) The whole-panel schedule at nb = 512 -- the one this code base has run longest: W warm-up steps, K timed
-        # steps, a complete line.  (2) Only then the other block width / schedule / exchange combinations of
-        # gptools_amd.dist, each run once (communicator set-up) and timed over two evaluations; if the fastest of them
-        # beats (1) by more than 3 % it gets its own W warm-up + K timed steps and becomes the line.  Everything after
-        # (1) runs under the watchdog above.  All timings are reported (`schedules_ms`).
+        # (1) The 1-D whole-panel schedule at nb = 512, panels moved by one broadcast -- the one this code base has run longest:
+        # W warm-up steps, K timed steps, a complete line.  (2) Only then the other legs -- scatter + all-gather, the process
+        # grids of this world size, other block widths -- each run once (communicator set-up) and timed over two evaluations;
+        # if the fastest of them beats (1) by more than 3 % it gets its own W warm-up + K timed steps and becomes the line.
+        # Everything after (1) runs under the watchdog above (none of it has run on more than one real GPU).  All timings are
+        # reported (`schedules_ms`).
         nb0 = args.nb or 512
-        base_name = "bcast+bcast@%d" % nb0
+        base_name = "1d+bcast@%d" % nb0
         if args.schedule:
             base_name = "%s@%d" % (args.schedule, nb0)
-        plan = get_plan(nb0)
-        plan.schedule, plan.exchange = base_name.split("@")[0].split("+")
+        plan = get_plan(base_name)
 
-        def describe():
-            return "1-D block-cyclic block columns (nb=%d) over %d ranks, %s panels over RCCL (%s)" % (
-                plan.nb, world, "row-chunked" if plan.schedule == "pipelined" else "whole", plan.exchange)
+        def describe(name):
+            layout, nb_ = name.split("@")
+            if layout.startswith("grid"):
+                return "2-D block-cyclic (nb=%s) over a %s process grid: diagonal block -> inverse down the process column -> row " \
+                       "slices by GEMM -> row broadcast + column exchange over RCCL" % (nb_, layout[4:])
+            return "1-D block-cyclic block columns (nb=%s) over %d ranks, whole panels over RCCL (%s)" % (
+                nb_, world, layout.split("+")[1])
         for _ in range(args.warmup):
             ll, ld = step()
         per, (ll, ld) = timed(args.steps, profile=True)
         roof = roof_box[0]
         elapsed = per * args.steps
-        parallelism = describe()
+        parallelism = describe(base_name)
         tune, failed = {base_name: per * 1e3}, {}
         extra["schedules_ms"] = tune
         extra["schedule"] = base_name
@@ -735,27 +750,18 @@ def main():
         wd.arm(float(os.environ.get("GPT_BENCH_WATCHDOG_S", 0)) or 120.0 + 30.0 * per * (args.steps + args.warmup + 20))
         if os.environ.get("GPT_BENCH_FAKE_HANG"):        # (test hook for the watchdog: scratch/README.md)
             time.sleep(3600)
-        # name -> (nb, schedule, exchange, chunk_blocks)
-        default_chunks = (2, 3, 8, 32)
-        combos = {"pipelined+bcast@%d" % nb0: (nb0, "pipelined", "bcast", default_chunks),
-                  "pipelined+scatter_gather@%d" % nb0: (nb0, "pipelined", "scatter_gather", default_chunks),
-                  "bcast+scatter_gather@%d" % nb0: (nb0, "bcast", "scatter_gather", default_chunks),
-                  "pipelined+bcast@%d chunks 2,3,16" % nb0: (nb0, "pipelined", "bcast", (2, 3, 16))}
+        grids_ = {1: [(1, 1)], 2: [(2, 1), (1, 2)], 4: [(2, 2), (4, 1)], 8: [(2, 4), (4, 2)]}.get(world, [])
+        combos = ["1d+scatter_gather@%d" % nb0] + ["grid%dx%d@%d" % (g_[0], g_[1], nb0) for g_ in grids_]
         if not args.nb:
-            combos.update({"bcast+bcast@384": (384, "bcast", "bcast", default_chunks),
-                           "bcast+bcast@256": (256, "bcast", "bcast", default_chunks),
-                           "pipelined+bcast@256": (256, "pipelined", "bcast", default_chunks)})
+            combos += ["1d+bcast@384", "1d+bcast@256"] + ["grid%dx%d@256" % g_ for g_ in grids_[:1]]
         if args.schedule:
-            combos = {}
+            combos = []
         if world == 1:
-            combos = {k_: v_ for k_, v_ in combos.items() if v_[2] == "bcast"}
-        combos[base_name] = (nb0,) + tuple(base_name.split("@")[0].split("+")) + (default_chunks,)
+            combos = [c_ for c_ in combos if "scatter_gather" not in c_]
+        combos.append(base_name)
 
         def select(name):
-            nb_, sched_, exch_, chunks_ = combos[name]
-            pl = get_plan(nb_)
-            pl.schedule, pl.exchange, pl.chunk_blocks = sched_, exch_, chunks_
-            return pl
+            return get_plan(name)
         for name in [k_ for k_ in combos if k_ != base_name]:
             wd.phase = "tuning pass, " + name
             try:
@@ -783,7 +789,7 @@ def main():
             if per2 < per:
                 per, ll, ld = per2, ll2, ld2
                 elapsed = per * args.steps
-                parallelism = describe()
+                parallelism = describe(best)
                 extra["schedule"] = best
                 wd.line = build_out()
             else:
@@ -800,8 +806,8 @@ def main():
                 k5, N5, d5, der5 = WORKLOADS["c5"]
                 X5, n5, y5, err5, params5 = synth(k5, N5, d5, der5)
                 main_plan = plan
-                plan5 = DistributedLML(X5, n5, nb=main_plan.nb, ops=ops, group_tail=main_plan.group_tail,
-                                       schedule=main_plan.schedule, exchange=main_plan.exchange)
+                plan5 = (GridLML(X5, n5, (main_plan.Pr, main_plan.Pc), nb=main_plan.nb, ops=ops) if isinstance(main_plan, GridLML)
+                         else DistributedLML(X5, n5, nb=main_plan.nb, ops=ops, exchange=main_plan.exchange))
                 plan = plan5
                 step5 = lambda: plan5.fit(KID[k5], params5, y5, err5)
                 step5()

@@ -65,6 +65,9 @@ SIGNATURES = {
                                  _ip, C.c_int, _i64, _i64, _vp, C.c_double, C.c_double, _vp, _i64]),
     "gpt_dev_gemm_nt": (C.c_int, [_vp, _i64, _i64, _i64, C.c_double, _vp, _i64, _vp, _i64, C.c_double, _vp, _i64, C.c_int]),
     "gpt_dev_gemm_nt_stair": (C.c_int, [_vp, _i64, _i64, _i64, _i64, C.c_double, _vp, _i64, _vp, _i64, _i64, _i64, C.c_double, _vp, _i64]),
+    "gpt_dev_gemm_nt_gridstair": (C.c_int, [_vp, _i64, _i64, _i64, _i64, C.c_double, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64,
+                                           C.c_double, _vp, _i64]),
+    "gpt_dev_row_sumsq": (C.c_int, [_vp, _vp, _i64, _vp]),
     "gpt_dev_potrf_panel": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64]),
     "gpt_dev_potrf": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
     "gpt_dev_trsm_rlt": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64]),

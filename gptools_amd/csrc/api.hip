@@ -3108,6 +3108,50 @@ extern "C" int gpt_dev_gemm_nt_stair(gpt_ctx *c, int64_t m, int64_t nseg, int64_
                                 ldc, 0, e0, e1);
 }
 
+// Trailing update of one rank of the 2-D block-cyclic engine in one launch (gemm.hip launch_gemm_nt_gridstair; profiled like the
+// staircase above).
+extern "C" int gpt_dev_gemm_nt_gridstair(gpt_ctx *c, int64_t m, int64_t nseg, int64_t seg_cols, int64_t k, double alpha,
+                                         const double *dA, int64_t lda, const double *dB, int64_t ldb, int64_t off, int64_t num,
+                                         int64_t den, int64_t base, double beta, double *dC, int64_t ldc)
+{
+    CTX_ENTER(c);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->prof_gemm && !c->use_graph && den > 0 && seg_cols > 0) {
+        double elems = 0.0;
+        for (int64_t q = 0; q < nseg; q++) {
+            const int64_t v = off + q * num, rs = (v + den - 1) / den - base;
+            const double mq = (double)(m - rs * seg_cols), w = (double)seg_cols;
+            if (mq <= 0) continue;
+            elems += (v % den == 0) ? 0.5 * w * (w + 1.0) + (mq - w > 0 ? (mq - w) * w : 0.0) : mq * w;
+        }
+        const double flops = 2.0 * (double)k * elems;
+        if (flops >= 1.0e9) {
+            if (c->gprof_used == c->gprof.size()) {
+                gpt_ctx::GemmProf g;
+                GPT_HIP_CHECK(hipEventCreate(&g.e0));
+                GPT_HIP_CHECK(hipEventCreate(&g.e1));
+                g.flops = 0;
+                g.stop = g.e1;
+                c->gprof.push_back(g);
+            }
+            gpt_ctx::GemmProf *gp = &c->gprof[c->gprof_used++];
+            gp->flops = flops;
+            gp->stop = gp->e1;
+            e0 = gp->e0;
+            e1 = gp->e1;
+        }
+    }
+    const int lds_pad = c->lookahead ? c->gemm_pad : 0;
+    return launch_gemm_nt_gridstair(c->stream, m, nseg, seg_cols, k, alpha, dA, lda, dB, ldb, off, num, den, base, beta, dC, ldc,
+                                    lds_pad, e0, e1);
+}
+
+extern "C" int gpt_dev_row_sumsq(gpt_ctx *c, const double *d_row, int64_t w, double *d_acc)
+{
+    CTX_ENTER(c);
+    return launch_row_sumsq(c->stream, d_row, w, d_acc);
+}
+
 extern "C" int gpt_dev_potrf_panel(gpt_ctx *c, int64_t m, int64_t nb, double *dA, int64_t lda, double *d_invd,
                                    int32_t *d_info, int64_t info_base)
 {

@@ -202,4 +202,5 @@ int launch_copy2d(hipStream_t st, int64_t rows, int64_t cols, const double *src,
 int launch_zero2d(hipStream_t st, int64_t rows, int64_t cols, double *dst, int64_t ldd);
 int launch_pad_block(hipStream_t st, double *A, int64_t lda, int64_t c0, int64_t nb, int64_t n_valid, int64_t n_pad,
                      const double *dy, double big);
+int launch_row_sumsq(hipStream_t st, const double *row, int64_t w, double *acc);
 int launch_panel_scalars(hipStream_t st, const double *P, int64_t ldp, int64_t w, int64_t zrow, double *acc);

@@ -706,3 +706,24 @@ int launch_panel_scalars(hipStream_t st, const double *P, int64_t ldp, int64_t w
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
+
+// acc[0] += sum_{c < w} row[c]^2 (one workgroup, fixed order): the z.z part of ll (ref gaussian_process.py:1463) from the piece
+// of the augmented row a rank of the 2-D block-cyclic engine holds (gptools_amd/dist.py GridLML)
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const double *__restrict__ row, int64_t w, double *__restrict__ acc)
+{
+    __shared__ double s1[4];
+    double b = 0.0;
+    for (int64_t i = threadIdx.x; i < w; i += 256) b = fma(row[i], row[i], b);
+    for (int off = 32; off > 0; off >>= 1) b += __shfl_down(b, off);
+    if ((threadIdx.x & 63) == 0) s1[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) acc[0] += ((s1[0] + s1[1]) + s1[2]) + s1[3];
+}
+
+int launch_row_sumsq(hipStream_t st, const double *row, int64_t w, double *acc)
+{
+    if (w <= 0) return GPT_OK;
+    hipLaunchKernelGGL(row_sumsq_kernel, dim3(1), dim3(256), 0, st, row, w, acc);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}

@@ -17,13 +17,11 @@ pool over independent hyperparameter samples); what must match is the *result* o
     finishes applying panel k, so the transfer and the latency-bound panel hide behind the updates.
   * ``z = L^-1 y`` rides along as the augmented row N of the matrix, so the only
     other collective is one all-reduce of three scalars (log-det part, z.z part, info).
-  * Two schedules (``schedule=``): ``"bcast"`` factors a panel whole and then broadcasts it; ``"pipelined"``
-    cuts every panel into a few row chunks of growing size (2, 1, 5, 24, ... blocks): the owner factors the
-    diagonal block with the first chunk and sends it at once, the TRSM of the later chunks, their transfer and
-    the next owner's column update proceed chunk by chunk behind it, so the serial chain through the panels
-    carries only the small head chunks (its own communicator) instead of whole panels.  Two ways to move a
-    chunk (``exchange=``): one broadcast, or scatter + all-gather (every xGMI link of the root carries 1/world
-    of the chunk, then all links carry the all-gather) for chunks above ``sag_min_bytes``.
+  * Two ways to move a panel (``exchange=``): one broadcast, or scatter + all-gather (every xGMI link of the root carries
+    1/world of the panel, then all links carry the all-gather) for panels above ``sag_min_bytes``.
+  * :class:`GridLML` (below) is the same evaluation on a ``P_r x P_c`` process grid (2-D block-cyclic): the per-panel
+    serial work is split over a process column.  (A row-chunked "pipelined" 1-D schedule existed in rounds 1-3; modelled at
+    22 % of the 8-GPU peak it was removed: scratch/attic/dist_pipelined_schedule.py.txt.)
 
 All dense work goes through a small ``ops`` object.  The product implementation is
 :class:`HipPanelOps` (C ABI of libgpt_hip.so on CUDA tensors; raises without a GPU).  The
@@ -83,10 +81,11 @@ class PanelOps(object):
         """dst <- src, two 2-D views of equal shape (staging a block column into a panel buffer)."""
         dst.copy_(src)
 
-    def pad_block(self, A, lj, c0, nb, N, NP, y, big):
+    def pad_block(self, A, lj, c0, nb, N, NP, y, big, row_shift=0):
         """Rows [N, NP) of the local block column ``lj`` (global first column ``c0``): augmented row y^T, unit diagonal on
-        the padding, ``big`` under the augmented row, zeros elsewhere."""
-        blk = A[N:, lj * nb:(lj + 1) * nb]
+        the padding, ``big`` under the augmented row, zeros elsewhere.  ``row_shift``: global row r of
+        the matrix is local row ``r + row_shift`` of ``A`` (the 2-D layout holds only some block rows)."""
+        blk = A[N + row_shift:NP + row_shift, lj * nb:(lj + 1) * nb]
         blk.zero_()
         c1 = min(c0 + nb, N)
         if c0 < N:
@@ -94,15 +93,31 @@ class PanelOps(object):
         p0 = max(c0, N)
         if p0 < c0 + nb:
             idx = torch.arange(p0, c0 + nb, device=A.device)
-            A[idx, lj * nb + (idx - c0)] = 1.0
+            A[idx + row_shift, lj * nb + (idx - c0)] = 1.0
             if c0 <= N < c0 + nb:
-                A[N, lj * nb + (N - c0)] = big
+                A[N + row_shift, lj * nb + (N - c0)] = big
 
     def panel_scalars(self, buf, w, zrow, red, q="panel"):
-        """red[0] += sum(log diag(buf[:w, :w])); red[1] += |buf[zrow, :w]|^2."""
+        """red[0] += sum(log diag(buf[:w, :w])); if zrow >= 0 also red[1] += |buf[zrow, :w]|^2."""
         red[0] += torch.log(torch.diagonal(buf[:w, :w])).sum()
-        z = buf[zrow, :w]
-        red[1] += (z * z).sum()
+        if zrow >= 0:
+            z = buf[zrow, :w]
+            red[1] += (z * z).sum()
+
+    def row_sumsq(self, row, red, q="panel"):
+        """red[1] += |row|^2 (``row`` a contiguous 1-D view: a piece of the augmented row)."""
+        red[1] += (row * row).sum()
+
+    def gemm_nt_gridstair(self, m, nseg, seg_cols, k, alpha, A, lda, B, ldb, off, num, den, base, beta, C, ldc, q="main"):
+        """Default of the 2-D block-cyclic trailing update (gpt_dev_gemm_nt_gridstair): one ``gemm_nt`` per column segment, a
+        lower trapezoid where the segment starts on a diagonal block of the matrix, a rectangle otherwise."""
+        for s in range(nseg):
+            v = off + s * num
+            r = (-((-v) // den) - base) * seg_cols
+            if r >= m:
+                continue
+            self.gemm_nt(m - r, seg_cols, k, alpha, A + r * lda * 8, lda, B + s * seg_cols * ldb * 8, ldb, beta,
+                         C + (r * ldc + s * seg_cols) * 8, ldc, 1 if v % den == 0 else 0, q=q)
 
     def gemm_nt_stair(self, m, nseg, seg_cols, k, alpha, A, lda, B, ldb, b_stride, row_step, beta, C, ldc, q="main"):
         """Default: one lower-trapezoid ``gemm_nt`` per column segment (8-byte elements)."""
@@ -200,9 +215,28 @@ class HipPanelOps(PanelOps):
         _lib.check(self.lib.gpt_dev_copy2d(self._ctx[q].handle, src.shape[0], src.shape[1], src.data_ptr(), src.stride(0),
                                            dst.data_ptr(), dst.stride(0)))
 
-    def pad_block(self, A, lj, c0, nb, N, NP, y, big):
-        _lib.check(self.lib.gpt_dev_pad_block(self.ctx_main.handle, _ptr(A, 0, lj * nb), A.stride(0), c0, nb, N, NP,
-                                              y.data_ptr(), float(big)))
+    def pad_block(self, A, lj, c0, nb, N, NP, y, big, row_shift=0):
+        # (row_shift: the library addresses row r of the block column as base + r * lda; a shifted base makes that the local row)
+        _lib.check(self.lib.gpt_dev_pad_block(self.ctx_main.handle, _ptr(A, 0, lj * nb) + row_shift * A.stride(0) * 8, A.stride(0),
+                                              c0, nb, N, NP, y.data_ptr(), float(big)))
+
+    def kbuild_rect(self, kernel_id, params, Xi, ni, r0, r1, Xj, nj, c0, c1, out, ld):
+        """out[(i - r0) * ld + (j - c0)] = k(Xi[i], Xj[j]) for i in [r0, r1), j in [c0, c1): a plain rectangle, no diagonal
+        terms (the 2-D layout's blocks below the diagonal; rows of ``Xi`` are the rank's own block rows, gathered)."""
+        params = _lib.f64(params)
+        D = Xi.shape[1]
+        _lib.check(self.lib.gpt_dev_kbuild(
+            self.ctx_main.handle, int(kernel_id), _lib.dptr(params), len(params),
+            Xi.data_ptr() + r0 * D * 8, ni.data_ptr() + r0 * D * 4, r1 - r0,
+            Xj.data_ptr() + c0 * D * 8, nj.data_ptr() + c0 * D * 4, c1 - c0, D,
+            -1, 1, None, 0, 0, 0, None, 0.0, 0.0, out, ld))
+
+    def row_sumsq(self, row, red, q="panel"):
+        _lib.check(self.lib.gpt_dev_row_sumsq(self._ctx[q].handle, row.data_ptr(), row.numel(), red.data_ptr() + 8))
+
+    def gemm_nt_gridstair(self, m, nseg, seg_cols, k, alpha, A, lda, B, ldb, off, num, den, base, beta, C, ldc, q="main"):
+        _lib.check(self.lib.gpt_dev_gemm_nt_gridstair(self._ctx[q].handle, m, nseg, seg_cols, k, float(alpha), A, lda, B, ldb,
+                                                      off, num, den, base, float(beta), C, ldc))
 
     def panel_scalars(self, buf, w, zrow, red, q="panel"):
         _lib.check(self.lib.gpt_dev_panel_scalars(self._ctx[q].handle, buf.data_ptr(), buf.stride(0), w, zrow,
@@ -243,17 +277,15 @@ class DistributedLML(object):
     ``fit(kernel_id, params, y, err_y, ...)`` returns ``(ll_data, logdet_half)`` on every rank and
     raises ``numpy.linalg.LinAlgError`` if K_tot is not positive definite.
 
-    ``schedule``: ``"bcast"`` (whole panels, the default) or ``"pipelined"`` (row-chunked panels; needs look-ahead);
-    ``exchange``: ``"bcast"`` or ``"scatter_gather"`` (chunks of at least ``sag_min_bytes`` whose row count divides by
-    the world size; smaller ones are broadcast); ``chunk_blocks``: panel-local block rows at which a panel is cut.
-    All three may be changed between ``fit`` calls (bench.py times the combinations during warm-up).  Several plans
-    (e.g. of different ``nb``) may share one ``ops`` object and one ``group_tail`` communicator.
+    ``exchange``: ``"bcast"`` or ``"scatter_gather"`` (panels of at least ``sag_min_bytes`` whose row count divides by
+    the world size; smaller ones are broadcast); may be changed between ``fit`` calls (bench.py times both).  Several plans
+    (e.g. of different ``nb``) may share one ``ops`` object.
     """
     NBUF = 4
 
     def __init__(self, X, n, nb=512, group=None, ops=None, device=None, lookahead=True, layout=None,
-                 schedule="bcast", exchange="bcast", chunk_blocks=(2, 3, 8, 32), sag_min_bytes=8 << 20,
-                 owner_first=None, inv_trsm=True, inv_min_rows=8192, group_tail=None):
+                 schedule="bcast", exchange="bcast", sag_min_bytes=8 << 20, owner_first=None, inv_trsm=True,
+                 inv_min_rows=8192):
         if nb <= 0 or nb % 128:
             raise ValueError("nb must be a positive multiple of 128")
         self.group = group
@@ -272,13 +304,10 @@ class DistributedLML(object):
         # RCCL call pattern can be exercised on a 1-GPU box (tests/test_gpu_a_dist_processes.py).
         self.force_collectives = bool(int(os.environ.get("GPT_DIST_FORCE_COLLECTIVES", "0"))) and dist.is_initialized()
         self.lookahead = bool(lookahead)
-        if schedule not in ("pipelined", "bcast") or exchange not in ("bcast", "scatter_gather"):
-            raise ValueError("schedule must be 'pipelined' or 'bcast', exchange 'bcast' or 'scatter_gather'")
+        if schedule != "bcast" or exchange not in ("bcast", "scatter_gather"):
+            raise ValueError("schedule must be 'bcast' (whole panels), exchange 'bcast' or 'scatter_gather'")
         self.schedule = schedule
         self.exchange = exchange
-        self.chunk_blocks = tuple(int(b) for b in chunk_blocks)
-        if not self.chunk_blocks or self.chunk_blocks[0] < 2 or list(self.chunk_blocks) != sorted(set(self.chunk_blocks)):
-            raise ValueError("chunk_blocks must be increasing and start at 2 or more (the head chunk holds L_kk and L_k+1,k)")
         self.sag_min_bytes = int(sag_min_bytes)
         # owner_first: the owner of panel k+1 starts its own trailing update of step k only after it has produced panel
         # k+1.  Everybody else is waiting for that panel, nobody for the owner's update; and a panel kernel that has to
@@ -286,21 +315,15 @@ class DistributedLML(object):
         # (N=32768, 8 ranks replayed on one GPU: 3.0 ms from first to last chunk of an early panel, against
         # ~0.8 ms when it has the chip).  Pointless with one or two ranks (the owner is always the same / every
         # other step), on by default from three.
-        self.owner_first = (self.world > 2) if owner_first is None else (owner_first if owner_first == "head" else bool(owner_first))
-        # inv_trsm: the rows of a panel below its head chunk (pipelined) / diagonal block (bcast) are solved as ONE GEMM against the
+        self.owner_first = (self.world > 2) if owner_first is None else bool(owner_first)
+        # inv_trsm: the rows of a panel below its diagonal block are solved as ONE GEMM against the
         # explicit inverse of the factored diagonal block (computed once per panel, off the chain) instead of by
         # substitution in four 128-column leaves: twice the flops at several times the rate for tall chunks.
         self.inv_trsm = bool(inv_trsm)
         self.inv_min_rows = int(inv_min_rows)       # whole-panel schedule: panels of at least this many rows take that route
         self._inv_panel = False
-        # the later chunks of the pipelined schedule travel on a communicator of their own, so that a head chunk never
-        # queues behind the bulk of an earlier panel (collectives of one communicator run in issue order)
-        self.group_tail = group if group_tail is None else group_tail
         # RCCL runs the collectives of a communicator in issue order on its stream; other backends need explicit waits
         self._stream_ordered = dist.is_initialized() and dist.get_backend(group) == "nccl"
-        if group_tail is None and dist.is_initialized() and layout is None and (self.world > 1 or self.force_collectives):
-            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
-            self.group_tail = dist.new_group(ranks=ranks)
         X = np.ascontiguousarray(X, dtype=np.float64)
         n = np.ascontiguousarray(n, dtype=np.int32)
         self.N, self.D = X.shape
@@ -519,8 +542,6 @@ class DistributedLML(object):
         if kernel_id in (_lib.KERNEL_RQ, _lib.KERNEL_MATERN) and 2 * self._n_maxsum > 8:
             raise ValueError("RationalQuadratic / Matern kernel: derivative orders of a pair sum to %d, the device builder "
                              "supports 8" % (2 * self._n_maxsum))
-        if self.schedule == "pipelined" and self.lookahead:
-            return self._fit_pipelined(kernel_id, params, y, err_y, noise_var, diag_factor)
         return self._fit_bcast(kernel_id, params, y, err_y, noise_var, diag_factor)
 
     # ------------------------------------------------------------------------------------------
@@ -611,138 +632,425 @@ class DistributedLML(object):
         return self._finish(t_host0)
 
 
-    # ------------------------------------------------------------------------------------------
-    def _chunk_bounds(self, k):
-        """Panel-local block rows at which panel k is cut: [0, 2, 8, 32, ..., blocks of panel k] (``chunk_blocks``);
-        a cut that would leave a last chunk smaller than half of what precedes it is dropped."""
-        mb = self.nblk - k
-        b = [0] + [e for e in self.chunk_blocks if e < mb and 2 * (mb - e) >= e]
-        return b + [mb]
+# ======================================================================================================
+# 2-D block-cyclic layout over a P_r x P_c process grid
+# ======================================================================================================
+def _ceil_div(a, b):
+    return -((-a) // b)
 
-    def _fit_pipelined(self, kernel_id, params, y, err_y, noise_var, diag_factor):
-        """Row-chunked schedule.  Panel k lives in P[k % NBUF], cut at ``_chunk_bounds(k)``.  Its owner, on the panel
-        queue, takes the chunks top down: rows [lo, hi) of the staged column get panel k-1 applied as soon as rows
-        [lo + nb, hi + nb) of panel k-1 are there (block row 1 of panel k-1 is the other operand), then the first chunk
-        is factored (diagonal block + the TRSM of its remaining rows), later ones are solved against the factored
-        diagonal block, and each chunk starts travelling at once -- head chunks on ``group``, the rest on
-        ``group_tail``.  The chain from panel to panel therefore is: head of k-1 arrives -> 2-block update ->
-        diagonal block -> head of k leaves, while the bulk TRSM, the bulk transfer and the next owner's column update
-        overlap chunk by chunk.  (Precisely: the head of panel k reads local blocks 1 AND 2 of panel k-1; block 2 is cut
-        off as a one-block chunk of its own -- ``chunk_blocks`` = (2, 3, 8, 32) -- and travels on the chain communicator
-        right behind the head, so the chain is head -> block 2 -> next head and never waits for a bulk chunk on the tail
-        communicator.  With cuts that leave block 2 inside a larger chunk the results are the same and the chain is
-        longer.)  Other ranks post their side of every exchange on the idle "recv" queue.
-          main queue, step k: every chunk of panel k has arrived -> apply it to the owned block columns right of k+1
-                              (k+1 is its owner's business on the panel queue), column k+2 first ("urgent").
-        Buffer reuse: P[k % NBUF] is written again (staged or received into) only after this rank's main queue is done
-        with step k - NBUF and its panel queue has finished reading panel k - NBUF."""
-        ops = self.ops
+
+class GridLML(object):
+    """The same LML evaluation with K_tot spread over a ``P_r x P_c`` PROCESS GRID.
+
+    Why: in the 1-D layout of :class:`DistributedLML` the serial work per panel -- apply panel k to block column k+1, factor
+    its diagonal block, solve the rows under it -- sits on ONE GPU by construction: 0.6 ms x 64 panels at N = 32768 on 8 ranks,
+    as long as the whole budget.  Here block (I, J) of the ``nb``-blocked matrix lives on grid position
+    ``(I % P_r, J % P_c)`` (rank ``pr * P_c + pc``), so the column update and the solve of a panel are split over the ``P_r``
+    ranks of a process column, and only the ``nb x nb`` diagonal block is serial.  K is still built locally (X replicated).
+
+    Step k (panel k = block column k of L; process column ``pc_k = k % P_c``, diagonal owner ``(k % P_r, pc_k)``):
+      1. diagonal owner: factor A[k][k] in place (``gpt_dev_potrf_panel``), ``W = L_kk^-1`` (``gpt_dev_trinv``), broadcast W
+         down its process column;
+      2. the HEAD block ``L[k+1][k] = A[k+1][k] W^T`` is formed first by its holder ``((k+1) % P_r, pc_k)`` and broadcast to
+         everybody: it is all the next diagonal block needs (``A[k+1][k+1] -= H H^T`` on its owner, which then goes to 1 for
+         k+1 -- the chain from diagonal block to diagonal block is two 512^3 products and two small broadcasts long, whatever
+         the height of the panel), and it is the column operand of the look-ahead update of block column k+1;
+      3. every rank ``(pr, pc_k)`` solves its rows I >= k+2 of the panel as ONE GEMM against W and broadcasts them along its
+         process row: every rank then holds the rows ``R`` of panel k that match its block rows;
+      4. the columns ``C`` of panel k that match a rank's block columns J >= k+2 are blocks of ``R`` on the ranks of process
+         row ``J % P_r``: exchanged inside each process column (one broadcast per contributing process row: one for
+         ``P_r | P_c``, ``P_r / gcd`` in general), on a queue and a communicator of their own;
+      5. look-ahead (panel queue): the ranks of process column ``pc_(k+1)`` apply panel k to block column k+1 themselves
+         (``A[I][k+1] -= R[I] H^T``, needs 2 and 3 only) and go on with 3 for panel k+1;
+      6. main queue: ``A[I][J] -= R[I] C[J]^T`` for the rank's blocks with I >= J >= k+2, one launch
+         (``gpt_dev_gemm_nt_gridstair``), the column the next look-ahead touches first ("urgent").
+    ``z = L^-1 y`` rides along as the augmented row N and is summed where its pieces come to rest; one
+    all-reduce of (sum log L_ii, z.z, info) ends the evaluation.  ``fit`` returns the same ``(ll_data, logdet_half)`` on every
+    rank.  ``grid = (1, W)`` is the 1-D block-column layout, ``(W, 1)`` a block-row layout.  UNMEASURED ON MORE THAN ONE GPU:
+    gloo worlds 2-8 on CPU (tests/test_dist_gloo.py), ranks sharing one GPU through the product ops, and the modelled 8-rank
+    time of scratch/sim_model.py are what exists.
+    """
+    NBUF = 4
+
+    def __init__(self, X, n, grid, nb=512, group=None, ops=None, device=None, lookahead=True, layout=None):
+        if nb <= 0 or nb % 128:
+            raise ValueError("nb must be a positive multiple of 128")
+        self.Pr, self.Pc = int(grid[0]), int(grid[1])
+        if self.Pr < 1 or self.Pc < 1:
+            raise ValueError("grid must be (P_r, P_c) with both >= 1")
+        self.group = group
+        inited = dist.is_initialized()
+        self.rank = dist.get_rank(group) if inited else 0
+        self.world = dist.get_world_size(group) if inited else 1
+        self._model = layout is not None
+        if layout is not None:
+            # position in the grid given explicitly: a subclass supplies ``_xbcast`` / ``_allreduce`` (scratch/sim_model.py
+            # replays one rank of an 8-rank job on one GPU)
+            self.rank, self.world = int(layout), self.Pr * self.Pc
+        if self.world != self.Pr * self.Pc:
+            raise ValueError("grid %d x %d needs %d ranks, the group has %d" % (self.Pr, self.Pc, self.Pr * self.Pc, self.world))
+        self.pr, self.pc = divmod(self.rank, self.Pc)
+        if ops is None:
+            ops = HipPanelOps(0 if device is None else device)
+        self.ops = ops
+        self.device = getattr(ops, "device", torch.device("cpu"))
+        self.force_collectives = bool(int(os.environ.get("GPT_DIST_FORCE_COLLECTIVES", "0"))) and inited
+        self.lookahead = bool(lookahead)
+        self._stream_ordered = inited and dist.get_backend(group) == "nccl"
+        # communicators: one per process row (panel rows), two per process column (the inverse of the diagonal block / the
+        # column exchange: the latter must never queue behind a diagonal block that is still being factored), the whole grid
+        # for the head blocks and the final reduction.  Every rank creates every group, in the same order.
+        self.g_row = self.g_colw = self.g_colx = None
+        self._ranks = list(range(self.world))
+        if inited and layout is None:
+            self._ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+            if self.world > 1 or self.force_collectives:
+                for r in range(self.Pr):
+                    g = dist.new_group(ranks=[self._ranks[r * self.Pc + c] for c in range(self.Pc)])
+                    if r == self.pr:
+                        self.g_row = g
+                for c in range(self.Pc):
+                    members = [self._ranks[r * self.Pc + c] for r in range(self.Pr)]
+                    gw, gx = dist.new_group(ranks=members), dist.new_group(ranks=members)
+                    if c == self.pc:
+                        self.g_colw, self.g_colx = gw, gx
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        n = np.ascontiguousarray(n, dtype=np.int32)
+        self.N, self.D = X.shape
+        self._n_maxsum = int(n.sum(axis=1).max()) if n.size else 0
+        self.nb = nb
+        self.NP = (self.N + 1 + nb - 1) // nb * nb
+        self.nblk = nblk = self.NP // nb
+        self.my_rows = [I for I in range(nblk) if I % self.Pr == self.pr]
+        self.my_cols = [J for J in range(nblk) if J % self.Pc == self.pc]
+        self.my_blocks = [(I, J) for J in self.my_cols for I in self.my_rows if I >= J]
+        self.nlr, self.nlc = len(self.my_rows), len(self.my_cols)
+        self.lcm = self.Pr * self.Pc // math.gcd(self.Pr, self.Pc)
+        dev = self.device
+        self.X = torch.from_numpy(X).to(dev)
+        self.n = torch.from_numpy(n).to(dev)
+        # the rank's own block rows of X / n, gathered (zero rows stand for the padding beyond N)
+        Xr = np.zeros((max(self.nlr, 1) * nb, self.D))
+        nr = np.zeros((max(self.nlr, 1) * nb, self.D), dtype=np.int32)
+        for li, I in enumerate(self.my_rows):
+            r0, r1 = I * nb, min((I + 1) * nb, self.N)
+            if r0 < r1:
+                Xr[li * nb:li * nb + r1 - r0] = X[r0:r1]
+                nr[li * nb:li * nb + r1 - r0] = n[r0:r1]
+        self.Xr = torch.from_numpy(Xr).to(dev)
+        self.nr = torch.from_numpy(nr).to(dev)
+        rows, cols = max(self.nlr, 1) * nb, max(self.nlc, 1) * nb
+        self.A = torch.empty((rows, cols), dtype=torch.float64, device=dev)
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.R = [torch.empty((rows, nb), **f64) for _ in range(self.NBUF)]       # rows of panel k, by local block row
+        self.C = [torch.empty((cols, nb), **f64) for _ in range(self.NBUF)]       # columns of panel k, by local block column
+        self.H = [torch.empty((nb, nb), **f64) for _ in range(self.NBUF)]         # head block L[k+1][k]
+        self.W = [torch.empty((nb, nb), **f64) for _ in range(self.NBUF)]         # L_kk^-1
+        self.piece = torch.empty((cols, nb), **f64)                               # one contributing process row's share of C
+        self.invd = torch.empty(((nb // 128) * 9216,), **f64)
+        self.info = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.y = torch.empty((self.NP,), **f64)
+        self.err = torch.zeros((self.NP,), **f64)
+        self.red = torch.zeros((3,), **f64)
+        on_gpu = dev.type == "cuda"
+        self._h_in = torch.from_numpy(_lib.pinned_empty((2, self.NP), min_bytes=0)) if on_gpu else None
+        self._h_out = torch.from_numpy(_lib.pinned_empty((3,), min_bytes=0)) if on_gpu else None
+        self.timings = {}
+        self.trace = False
+
+    # ---- index helpers ---------------------------------------------------------------------------
+    def li_ge(self, I0):
+        """Local index of the rank's first block row I >= I0 (may equal ``nlr``: none)."""
+        return min(max(_ceil_div(I0 - self.pr, self.Pr), 0), self.nlr)
+
+    def lj_ge(self, J0):
+        return min(max(_ceil_div(J0 - self.pc, self.Pc), 0), self.nlc)
+
+    def _blk(self, I, J):
+        """View of the rank's block (I, J)."""
+        nb, li, lj = self.nb, I // self.Pr, J // self.Pc
+        return self.A[li * nb:(li + 1) * nb, lj * nb:(lj + 1) * nb]
+
+    # ---- communication (overridden by the single-GPU model) --------------------------------------
+    def _on(self, size):
+        return (size > 1 and self.world > 1) or self.force_collectives
+
+    def _xbcast(self, kind, k, buf, src, group, size):
+        """Start the broadcast of the contiguous ``buf`` from grid position ``src`` = (pr, pc) inside ``group`` (``size``
+        members); returns the work handles to wait for.  ``kind`` in "W", "H", "R", "C" and the panel index ``k`` name what moves
+        (the model needs to know; the product path does not)."""
+        if not self._on(size) or buf.numel() == 0:
+            return []
+        gsrc = self._ranks[src[0] * self.Pc + src[1]]
+        return [dist.broadcast(buf, src=gsrc, group=group, async_op=True)]
+
+    def _allreduce(self, t, op):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX, group=self.group)
+
+    # ---- K build ----------------------------------------------------------------------------------
+    def _assemble(self, kernel_id, params, noise_var, diag_add):
+        """The rank's blocks (I, J), I >= J: one rectangle of the fused builder per local block column for the blocks below the
+        diagonal, the diagonal blocks (with the diagonal loading of ref gaussian_process.py:1447-1451) one by one, then the
+        padding / augmented rows where the rank holds the last block row."""
+        N, nb, A, ops = self.N, self.nb, self.A, self.ops
+        ld = A.stride(0)
+        last = self.nblk - 1
+        for lj, J in enumerate(self.my_cols):
+            c0, c1 = J * nb, min((J + 1) * nb, N)
+            if c0 < N:
+                li_s = self.li_ge(J + 1)
+                if li_s < self.nlr:
+                    ops.kbuild_rect(kernel_id, params, self.Xr, self.nr, li_s * nb, self.nlr * nb, self.X, self.n, c0, c1,
+                                    _ptr(A, li_s * nb, lj * nb), ld)
+                if J % self.Pr == self.pr:
+                    ops.kbuild_block(kernel_id, params, self.X, self.n, c0, c1, c0, c1, self.err, noise_var, diag_add,
+                                     _ptr(A, (J // self.Pr) * nb, lj * nb), ld)
+            if last % self.Pr == self.pr:
+                ops.pad_block(A, lj, c0, nb, N, self.NP, self.y, BIG_PIVOT, row_shift=(last // self.Pr - last) * nb)
+
+    # ---- one evaluation -------------------------------------------------------------------------
+    def fit(self, kernel_id, params, y, err_y, noise_var=0.0, diag_factor=1e2):
+        """One LML evaluation; returns ``(ll_data, logdet_half)`` on every rank (``numpy.linalg.LinAlgError`` on every rank
+        if K_tot is not positive definite)."""
+        if kernel_id == _lib.KERNEL_M52 and self._n_maxsum > 1:
+            raise ValueError("Matern52Kernel only supports 0th and 1st order derivatives")      # ref matern.py:545-546
+        if kernel_id in (_lib.KERNEL_RQ, _lib.KERNEL_MATERN) and 2 * self._n_maxsum > 8:
+            raise ValueError("RationalQuadratic / Matern kernel: derivative orders of a pair sum to %d, the device builder "
+                             "supports 8" % (2 * self._n_maxsum))
+        ops, N, nb, NP, nblk, NBUF = self.ops, self.N, self.nb, self.NP, self.nblk, self.NBUF
+        Pr, Pc, pr, pc = self.Pr, self.Pc, self.pr, self.pc
+        A, ld = self.A, self.A.stride(0)
         t_host0 = time.perf_counter()
-        nb, NP, world, rank, NBUF = self.nb, self.NP, self.world, self.rank, self.NBUF
-        nblk = self.nblk
-        owner = lambda J: J % world == rank
-        ev_asm = self._begin(kernel_id, params, y, err_y, noise_var, diag_factor)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        err_y = np.array(np.broadcast_to(err_y, (N,)), dtype=np.float64)
+        with ops.queue("main"):
+            if self._h_in is not None:
+                self._h_in[0, :N].copy_(torch.from_numpy(y))
+                self._h_in[1, :N].copy_(torch.from_numpy(err_y))
+                self.y[:N].copy_(self._h_in[0, :N], non_blocking=True)
+                self.err[:N].copy_(self._h_in[1, :N], non_blocking=True)
+            else:
+                self.y[:N] = torch.from_numpy(y)
+                self.err[:N] = torch.from_numpy(err_y)
+            self.info.zero_()
+            self.red.zero_()
+            self._t0 = ops.new_timing_event() if self.trace else None
+            if self._t0 is not None:
+                self._t0.record()
+            self._assemble(kernel_id, params, noise_var, diag_factor * sys.float_info.epsilon)
+            ev_asm = ops.new_event()
+            ev_asm.record()
+        self._marks = []
         for q in ("panel", "recv"):
-            # nothing on the other queues may run ahead of this rank's own K build / zeroed scalars (a rank that does
-            # not own panel 0 would otherwise stage its first block column while the builder is still writing it)
             with ops.queue(q):
                 ev_asm.wait()
-        ev_urg, ev_done, ev_pq = {}, {}, {}
-        arrivals = {}
+        last = nblk - 1
+        zrow_local = (last // Pr) * nb + (N - last * nb)       # local row of the augmented row on the ranks of its process row
+        ev_urg, ev_done, ev_la = {}, {}, {}
+        arr_R, arr_C, wW, wH = {}, {}, {}, {}
 
-        def produce(k):
-            buf = self.P[k % NBUF]
-            own = owner(k)
-            bl = self._chunk_bounds(k)
-            prev = arrivals.get(k - 1)
-            pbuf = self.P[(k - 1) % NBUF]
-            pb = self._chunk_bounds(k - 1) if k > 0 else None
-            arr = arrivals[k] = []
-            with ops.queue("panel" if own else "recv"):
-                if k - NBUF in ev_done:
-                    ev_done.pop(k - NBUF).wait()
-                if k - NBUF in ev_pq:
-                    ev_pq.pop(k - NBUF).wait()
-                inv = own and self.inv_trsm and len(bl) > 2
-                if own:
-                    if k - 2 in ev_urg:
-                        ev_urg.pop(k - 2).wait()           # column k is up to date with panel k-2
-                    if inv:
-                        # head rows into the panel buffer, the rest into the scratch column S: those rows reach the
-                        # panel buffer as S[rows] * L_kk^-T
-                        h = bl[1] * nb
-                        lk = k // world
-                        col = self.A[k * nb:, lk * nb:(lk + 1) * nb]
-                        ops.copy2d(buf[:h], col[:h])
-                        ops.copy2d(self.S[h:NP - k * nb], col[h:])
-                    else:
-                        self._stage_panel(k, buf, allow_inv=False)      # before any wait for panel k-1
-                src = self.S if inv else buf
-                waited = 0
-                for c in range(len(bl) - 1):
-                    lo, hi = bl[c] * nb, bl[c + 1] * nb
-                    ev = None
-                    if own:
-                        if k > 0:
-                            # last block row of panel k-1 this chunk reads: local block bl[c+1]
-                            need = max(j for j in range(len(pb) - 1) if pb[j] <= bl[c + 1])
-                            while waited <= need:
-                                prev[waited].wait()
-                                waited += 1
-                            ops.gemm_nt(hi - lo, nb, nb, -1.0, _ptr(pbuf, lo + nb, 0), nb, _ptr(pbuf, nb, 0), nb, 1.0,
-                                        _ptr(buf if c == 0 else src, lo, 0), nb, 1 if c == 0 else 0, q="panel")
-                        if c == 0:
-                            ops.potrf_panel(hi, nb, buf.data_ptr(), nb, self.invd, self.info, k * nb)
-                        elif inv:
-                            ops.gemm_nt(hi - lo, nb, nb, 1.0, _ptr(src, lo, 0), nb, self.Winv.data_ptr(), nb, 0.0,
-                                        _ptr(buf, lo, 0), nb, 0, q="panel")
-                        else:
-                            ops.trsm_rlt(hi - lo, nb, buf.data_ptr(), nb, self.invd, _ptr(buf, lo, 0), nb)
-                        ev = ops.new_event()
-                        ev.record()
-                    # The chain communicator carries the head AND local block 2: the head of panel k+1 (local blocks
-                    # 0-1 = global k+1, k+2) is updated with local blocks 1 and 2 of panel k, so block 2 must not queue
-                    # behind this panel's bulk (with the default cuts it is a chunk of its own, sent right after the head).
-                    works = self._exchange(buf[lo:hi], k % world, group=self.group if bl[c + 1] <= 3 else self.group_tail,
-                                           tag=(k, lo))
-                    arr.append(_Arrival(works, ev))
-                    if inv and c == 0:
-                        # after the head is on its way: the inverse the later chunks are multiplied by
-                        ops.trinv(nb, buf.data_ptr(), nb, self.invd, self.Winv.data_ptr(), nb)
-                if own:
-                    self._factored.append((k, buf))
-                    self._accumulate_scalars()
-                    if k > 0:
-                        ev_pq[k - 1] = ops.new_event()     # this queue no longer reads panel k-1 ...
-                        ev_pq[k - 1].record()
-                    ev_pq[k] = ops.new_event()             # ... nor (scalars) its own panel
-                    ev_pq[k].record()
+        def reuse(k):
+            """Slot k % NBUF is about to be written for panel k: whoever still read panel k - NBUF from it must be through."""
+            for d in (ev_done, ev_la):
+                if k - NBUF in d:
+                    d.pop(k - NBUF).wait()
 
-        produce(0)
-        for k in range(nblk):
-            buf = self.P[k % NBUF]
+        def diag(k):
+            """Step 1 on the panel queue of every rank of process column pc_k (the owner computes, all take part in the
+            broadcast of W)."""
+            s = k % NBUF
+            if pc != k % Pc:
+                return
+            if pr == k % Pr:
+                blk = self._blk(k, k)
+                ops.potrf_panel(nb, nb, blk.data_ptr(), ld, self.invd, self.info, k * nb)
+                ops.trinv(nb, blk.data_ptr(), ld, self.invd, self.W[s].data_ptr(), nb)
+                w = min(nb, N - k * nb)
+                if w > 0:
+                    ops.panel_scalars(blk, w, N - k * nb if k == last else -1, self.red)
+            wW[k] = self._xbcast("W", k, self.W[s], (k % Pr, k % Pc), self.g_colw, Pr)
+
+        def panel(k):
+            """Steps 2 and 3 on the panel queue (W of panel k is on its way): head block, then the rank's rows of the panel,
+            each broadcast as soon as it exists.  Every rank takes part in the head broadcast."""
+            s = k % NBUF
+            mine = pc == k % Pc
+            lk = k // Pc
+            if mine:
+                for w_ in wW.pop(k, []):
+                    w_.wait()
             if k + 1 < nblk:
-                produce(k + 1)
+                if mine and pr == (k + 1) % Pr:
+                    ops.gemm_nt(nb, nb, nb, 1.0, self._blk(k + 1, k).data_ptr(), ld, self.W[s].data_ptr(), nb, 0.0,
+                                self.H[s].data_ptr(), nb, 0, q="panel")
+                    if k + 1 == last:
+                        ops.row_sumsq(self.H[s][N - last * nb], self.red)
+                wH[k] = self._xbcast("H", k, self.H[s], ((k + 1) % Pr, k % Pc), self.group, self.world)
+            li0 = self.li_ge(k + 2)
+            m = (self.nlr - li0) * nb
+            ev = None
+            if mine and m > 0:
+                ops.gemm_nt(m, nb, nb, 1.0, _ptr(A, li0 * nb, lk * nb), ld, self.W[s].data_ptr(), nb, 0.0,
+                            _ptr(self.R[s], li0 * nb, 0), nb, 0, q="panel")
+                if pr == last % Pr and last >= k + 2:
+                    ops.row_sumsq(self.R[s][zrow_local], self.red)
+                ev = ops.new_event()
+                ev.record()
+            works = self._xbcast("R", k, self.R[s][li0 * nb:self.nlr * nb], (pr, k % Pc), self.g_row, Pc) if m > 0 else []
+            arr_R[k] = _Arrival(works, ev)
+
+        def exchange(k):
+            """Step 4 on the "recv" queue: the rank's columns J >= k + 2 of panel k, gathered from the process rows that hold
+            them.  Source process row q holds the blocks J = J_q0 + t * lcm(P_r, P_c); in its R they are ``lcm / P_r`` block rows
+            apart, in C ``lcm / P_c`` block columns."""
+            s = k % NBUF
+            lj0 = self.lj_ge(k + 2)
+            if lj0 >= self.nlc:
+                arr_C[k] = _Arrival([], None)
+                return
+            sc, sr = self.lcm // Pc, self.lcm // Pr
+            bb = nb * nb
+            with ops.queue("recv"):
+                reuse_c(k)
+                arr_R[k].wait()
+                Cv = self.C[s]
+                for q in range(Pr):
+                    J0 = next((J for J in self.my_cols[lj0:lj0 + sc] if J % Pr == q), None)
+                    if J0 is None:
+                        continue
+                    nt = (nblk - 1 - J0) // self.lcm + 1
+                    ljq = J0 // Pc
+                    direct = sc == 1                       # one contributing process row: its share IS the rank's C
+                    dst = Cv[ljq * nb:(ljq + nt) * nb] if direct else self.piece[:nt * nb]
+                    if q == pr:
+                        liq = J0 // Pr
+                        src = torch.as_strided(self.R[s], (nt, bb), (sr * bb, 1), liq * bb)
+                        ops.copy2d(dst.view(nt, bb), src, q="recv")
+                    for w_ in self._xbcast("C", k, dst, (q, pc), self.g_colx, Pr):
+                        w_.wait()
+                    if not direct:
+                        ops.copy2d(torch.as_strided(Cv, (nt, bb), (sc * bb, 1), ljq * bb), dst.view(nt, bb), q="recv")
+                ev = ops.new_event()
+                ev.record()
+            arr_C[k] = _Arrival([], ev)
+
+        ev_cq = {}
+
+        def reuse_c(k):
+            if k - NBUF in ev_cq:
+                ev_cq.pop(k - NBUF).wait()
+
+        def step_panel(k):
+            """Panel / "recv" queues, after panel k is on its way: everything of panel k + 1 (steps 1-5)."""
+            s, nxt = k % NBUF, k + 1
+            with ops.queue("panel"):
+                reuse(nxt)
+                if not self.lookahead:
+                    ev_done[k].wait()                                  # nothing of step k+1 before update k is through
+                in_col = pc == nxt % Pc
+                urg = ev_urg.pop(k - 1, None)
+                if in_col and urg is not None:
+                    urg.wait()                                         # block column k+1 is up to date with panel k-1
+                hw = wH.pop(k, [])
+                if in_col:
+                    for w_ in hw:
+                        w_.wait()
+                    if pr == nxt % Pr:
+                        # the next diagonal block needs the head block only (step 2): update, factor, invert, send
+                        ops.gemm_nt(nb, nb, nb, -1.0, self.H[s].data_ptr(), nb, self.H[s].data_ptr(), nb, 1.0,
+                                    self._blk(nxt, nxt).data_ptr(), ld, 1, q="panel")
+                else:
+                    self._late_h += hw                                 # (receive side of a broadcast nobody here reads)
+                diag(nxt)
+                if in_col:
+                    # step 5: the rest of block column k+1 against this rank's rows of panel k
+                    li0 = self.li_ge(k + 2)
+                    m = (self.nlr - li0) * nb
+                    if m > 0:
+                        arr_R[k].wait()
+                        ops.gemm_nt(m, nb, nb, -1.0, _ptr(self.R[s], li0 * nb, 0), nb, self.H[s].data_ptr(), nb, 1.0,
+                                    _ptr(A, li0 * nb, (nxt // Pc) * nb), ld, 0, q="panel")
+                    ev_la[k] = ops.new_event()
+                    ev_la[k].record()
+                panel(nxt)
+            exchange(nxt)
+
+        def step_main(k):
+            """Step 6: panel k applied to the rank's blocks with I >= J >= k + 2."""
+            s = k % NBUF
             with ops.queue("main"):
-                if self.owner_first and k + 1 < nblk and owner(k + 1):
-                    # own panel first (see __init__): all of it, or ("head") only the chunks on the chain -- the head and
-                    # block 2, which the next owner's head needs; the bulk below them is then produced beside this rank's
-                    # own trailing update (it is needed by the main queues, which lag the chain while updates dominate)
-                    own = arrivals[k + 1]
-                    own[min(1, len(own) - 1) if self.owner_first == "head" else -1].ev.wait()
-                for a in arrivals.pop(k):
-                    a.wait()
+                arr_R[k].wait()
+                arr_C[k].wait()
                 self._mark(k, "arrived")
-                mine = [J for J in self.my_blocks if J > k + 1]
-                urgent = k + 2
-                if urgent in mine:
-                    self._update_block(k, urgent, buf)
-                    mine.remove(urgent)
-                    ev_urg[k] = ops.new_event()
-                    ev_urg[k].record()
-                if mine:
-                    self._update_blocks(k, mine, buf)
+                li0 = self.li_ge(k + 2)
+                lj0 = self.lj_ge(k + 2)
+                m = (self.nlr - li0) * nb
+                nseg = self.nlc - lj0
+                if m > 0 and nseg > 0:
+                    J0 = self.my_cols[lj0]
+                    urgent = 1 if (self.lookahead and J0 == k + 2) else 0
+                    for (q0, ns) in ((0, urgent), (urgent, nseg - urgent)):
+                        if ns > 0:
+                            ops.gemm_nt_gridstair(m, ns, nb, nb, -1.0, _ptr(self.R[s], li0 * nb, 0), nb,
+                                                  _ptr(self.C[s], (lj0 + q0) * nb, 0), nb, J0 + q0 * Pc - pr, Pc, Pr, li0, 1.0,
+                                                  _ptr(A, li0 * nb, (lj0 + q0) * nb), ld, q="main")
+                        if q0 == 0 and urgent:
+                            ev_urg[k] = ops.new_event()
+                            ev_urg[k].record()
                 ev_done[k] = ops.new_event()
                 ev_done[k].record()
+                ev_cq[k] = ev_done[k]
                 self._mark(k, "applied")
+
+        # ---- the schedule.  Look-ahead: the chain (panel k + 1) is enqueued before update k and overlaps it; without it the
+        # same operations run one after the other.
+        self._late_h = []
+        with ops.queue("panel"):
+            diag(0)
+            panel(0)
+        exchange(0)
+        for k in range(nblk):
+            if self.lookahead:
+                if k + 1 < nblk:
+                    step_panel(k)
+                step_main(k)
+            else:
+                step_main(k)
+                if k + 1 < nblk:
+                    step_panel(k)
+            arr_R.pop(k, None)
+            arr_C.pop(k, None)
         return self._finish(t_host0)
+
+    def _mark(self, k, tag):
+        if self._t0 is not None:
+            e = self.ops.new_timing_event()
+            e.record()
+            self._marks.append((k, tag, e))
+
+    def _finish(self, t_host0):
+        ops, N = self.ops, self.N
+        self.timings["host_enqueue_s"] = time.perf_counter() - t_host0
+        with ops.queue("panel"):
+            for w_ in getattr(self, "_late_h", []):
+                w_.wait()
+            self._late_h = []
+            red = self.red
+            red[2] = self.info.to(torch.float64)[0]
+            if self.world > 1 or self.force_collectives or self._model:
+                info_t = red[2:3].clone()
+                self._allreduce(red[:2], "sum")
+                self._allreduce(info_t, "max")
+                red[2] = info_t[0]
+            if self._h_out is not None:
+                self._h_out.copy_(red, non_blocking=True)
+        ops.synchronize()
+        logdet_half, zz, info = (float(v) for v in (self._h_out if self._h_out is not None else red))
+        if self._t0 is not None:
+            self.timings["steps_ms"] = [(k, tag, self._t0.elapsed_ms(e)) for k, tag, e in self._marks]
+        if info != 0 and info <= N:
+            raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % int(info))
+        ll_data = -0.5 * zz - logdet_half - 0.5 * N * math.log(2.0 * math.pi)
+        if info != 0 or not math.isfinite(ll_data):
+            raise np.linalg.LinAlgError("factorisation failed in the augmented row (non-finite y or K_tot?)")
+        return ll_data, logdet_half

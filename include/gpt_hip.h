@@ -326,6 +326,21 @@ int gpt_dev_gemm_nt_stair(gpt_ctx *ctx, int64_t m, int64_t nseg, int64_t seg_col
                           const double *dA, int64_t lda, const double *dB, int64_t ldb, int64_t b_stride,
                           int64_t row_step, double beta, double *dC, int64_t ldc);
 
+/* Trailing update of one rank of the 2-D block-cyclic engine (gptools_amd/dist.py GridLML) in
+ * one launch.  The rank holds the global block rows I = pr + li * den and block columns J = pc + lj * num of the matrix (block
+ * size seg_cols both ways).  C = its local matrix from the update's first block row / column on, A (m x k) = the rank's rows of
+ * the panel, B = its columns of the panel (column segment q: rows [q * seg_cols, (q + 1) * seg_cols)).  Segment q (global block
+ * column J0 + q * num) is updated from its first block row with I >= J on: local block row ceil((off + q * num) / den) - base,
+ * with off = J0 - pr and base = the local index of the update's first block row; where that first block is a diagonal block
+ * of the matrix ((off + q * num) % den == 0) only its lower 64 x 64 tiles are computed.  The reference has nothing to mirror here
+ * (gaussian_process.py:1452 is one LAPACK call). */
+int gpt_dev_gemm_nt_gridstair(gpt_ctx *ctx, int64_t m, int64_t nseg, int64_t seg_cols, int64_t k, double alpha,
+                              const double *dA, int64_t lda, const double *dB, int64_t ldb, int64_t off, int64_t num,
+                              int64_t den, int64_t base, double beta, double *dC, int64_t ldc);
+/* d_acc[0] += sum_{c < w} d_row[c]^2: the z.z part of ll (ref gaussian_process.py:1463) from the piece of the augmented row a
+ * rank of that engine holds (one workgroup, fixed order). */
+int gpt_dev_row_sumsq(gpt_ctx *ctx, const double *d_row, int64_t w, double *d_acc);
+
 /* Factor one block column ("panel"): A is (m x nb), its top nb x nb block is the diagonal block.
  * On exit the top block holds L_kk (lower) and the rows below hold A21 * L_kk^-T.  d_invd:
  * workspace/output of GPT_WS_BLOCK (= 9216) doubles per 128 columns: the inverses of L's 16x16 diagonal

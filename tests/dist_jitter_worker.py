@@ -30,7 +30,7 @@ if world == 1:
 else:
     dist.init_process_group('gloo', rank=rank, world_size=world)
 os.environ["GPT_JITTER"] = "60"          # ... and inside the library: in front of every launch of the panel routines
-from gptools_amd.dist import DistributedLML, HipPanelOps
+from gptools_amd.dist import DistributedLML, GridLML, HipPanelOps
 from test_gpu_parity import c3_inputs
 rng = random.Random(100 + rank)
 
@@ -78,24 +78,45 @@ class JitterOps(HipPanelOps):
             nap()
         return HipPanelOps.gemm_nt_stair(self, *a, **k)
 
+    def gemm_nt_gridstair(self, *a, **k):
+        with torch.cuda.stream(self._stream[k.get("q", "main")]):
+            nap()
+        return HipPanelOps.gemm_nt_gridstair(self, *a, **k)
+
+    def kbuild_rect(self, *a, **k):
+        nap(4000000)
+        return HipPanelOps.kbuild_rect(self, *a, **k)
+
+    def copy2d(self, *a, **k):
+        with torch.cuda.stream(self._stream[k.get("q", "panel")]):
+            nap(300000)
+        return HipPanelOps.copy2d(self, *a, **k)
+
 
 X, n, y = c3_inputs(2500, 3)
 p = np.array([1.0, 0.3, 0.3, 0.3])
 ref = DistributedLML(X, n, nb=128, device=0, schedule="bcast").fit(1, p, y, 0.05 * np.ones(2500))
-plan = DistributedLML(X, n, nb=128, ops=JitterOps(0), owner_first=(rank % 2 == 0) if world == 2 else None, sag_min_bytes=0)
+jops = JitterOps(0)
+plan = DistributedLML(X, n, nb=128, ops=jops, owner_first=(rank % 2 == 0) if world == 2 else None, sag_min_bytes=0)
+# the process grids this many ranks allow (world 1: the collectives of a 1 x 1 grid are forced on)
+grids = {1: [(1, 1)], 2: [(1, 2), (2, 1)], 3: [(3, 1), (1, 3)], 4: [(2, 2)]}[world]
+cases = [("1-D bcast", plan, "bcast"), ("1-D scatter+all-gather" if world == 1 else "1-D bcast again", plan,
+                                        "scatter_gather" if world == 1 else "bcast")]
+cases += [("grid %d x %d" % g, GridLML(X, n, g, nb=128, ops=jops), None) for g in grids]
 bad = 0
-for sched, cb in (('bcast', (2, 8, 32)), ('pipelined', (2, 8, 32)), ('pipelined', (2, 4, 6, 10))):
-    plan.schedule, plan.chunk_blocks = sched, cb
-    plan.exchange = "scatter_gather" if (world == 1 and cb == (2, 8, 32)) else "bcast"
-    for rep in range(int(os.environ.get("JITTER_REPS", "6"))):
+reps = int(os.environ.get("JITTER_REPS", "6"))
+for name, pl, exch in cases:
+    if exch is not None:
+        pl.exchange = exch
+    for rep in range(reps):
         try:
-            r = plan.fit(1, p, y, 0.05 * np.ones(2500))
+            r = pl.fit(1, p, y, 0.05 * np.ones(2500))
             ok = abs(r[0] - ref[0]) <= 1e-10 * abs(ref[0]) and abs(r[1] - ref[1]) <= 1e-11 * abs(ref[1])
         except np.linalg.LinAlgError as e:
             r, ok = ("LinAlgError", str(e)[:40]), False
         bad += (not ok)
         if not ok:
-            print("rank %d %s %s rep %d: %s  (reference %s)" % (rank, sched, cb, rep, r, ref), flush=True)
-print("rank %d: %d bad of %d" % (rank, bad, 3 * int(os.environ.get("JITTER_REPS", "6"))), flush=True)
+            print("rank %d %s rep %d: %s  (reference %s)" % (rank, name, rep, r, ref), flush=True)
+print("rank %d: %d bad of %d" % (rank, bad, len(cases) * reps), flush=True)
 dist.destroy_process_group()
 sys.exit(1 if bad else 0)

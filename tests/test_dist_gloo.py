@@ -50,6 +50,10 @@ class _NumpyDense(object):
                 K[j - r0, j - c0] = ((K[j - r0, j - c0] + noise_var) + e[j] ** 2) + diag_add
         _view(out, r1 - r0, c1 - c0, ld)[:, :] = K
 
+    def kbuild_rect(self, kernel_id, params, Xi, ni, r0, r1, Xj, nj, c0, c1, out, ld):
+        K = self.O.kbuild(kernel_id, params, Xi.numpy()[r0:r1], ni.numpy()[r0:r1], Xj.numpy()[c0:c1], nj.numpy()[c0:c1])
+        _view(out, r1 - r0, c1 - c0, ld)[:, :] = K
+
     def potrf_panel(self, m, nb, A, lda, invd, info, info_base):
         import scipy.linalg
         P = _view(A, m, nb, lda)
@@ -74,6 +78,14 @@ class _NumpyDense(object):
 
     def gemm_nt(self, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, q="main"):
         Av, Bv, Cv = _view(A, m, k, lda).copy(), _view(B, n, k, ldb).copy(), _view(C, m, n, ldc)
+        if tri:
+            # like the library: only the lower trapezoid is written (what lies above the diagonal block's diagonal is never
+            # read by anybody; poisoning it here proves that)
+            res = alpha * Av.dot(Bv.T) + (beta * Cv if beta != 0.0 else 0.0)
+            iu = np.triu_indices(n, 1)
+            res[iu] = np.nan
+            Cv[:, :] = res
+            return
         Cv[:, :] = alpha * Av.dot(Bv.T) + (beta * Cv if beta != 0.0 else 0.0)
 
 
@@ -92,12 +104,16 @@ def _worker(rank, world, port, N, d, nb, kernel_id, lookahead, bad, q, plan_kw=N
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from gptools_amd.dist import DistributedLML
+        from gptools_amd.dist import DistributedLML, GridLML
         X, n, y = _inputs(N, d)
         if bad:
             X[1] = X[0]
             n[:] = 0
-        plan = DistributedLML(X, n, nb=nb, ops=_numpy_ops(), lookahead=lookahead, **(plan_kw or {}))
+        plan_kw = dict(plan_kw or {})
+        if "grid" in plan_kw:
+            plan = GridLML(X, n, plan_kw.pop("grid"), nb=nb, ops=_numpy_ops(), lookahead=lookahead, **plan_kw)
+        else:
+            plan = DistributedLML(X, n, nb=nb, ops=_numpy_ops(), lookahead=lookahead, **plan_kw)
         p = np.concatenate(([1.0], 0.3 * np.ones(d)))
         try:
             res = plan.fit(kernel_id, p, y, 0.0 if bad else 0.05, diag_factor=0.0 if bad else 1e2)
@@ -136,10 +152,6 @@ def _run(world, N, d, nb, kernel_id, lookahead, bad=False, plan_kw=None):
 _WHOLE = {"schedule": "bcast"}
 _WHOLE_INV = {"schedule": "bcast", "inv_min_rows": 0}        # rows below the diagonal block by inverse + GEMM
 _WHOLE_SAG = {"schedule": "bcast", "exchange": "scatter_gather", "sag_min_bytes": 0}
-_PIPE = {"schedule": "pipelined"}                                                  # chunks cut at 2, 8, 32 blocks
-_PIPE_SUBST = {"schedule": "pipelined", "inv_trsm": False}                         # tail chunks by substitution
-_PIPE_FINE = {"schedule": "pipelined", "chunk_blocks": (2, 3, 5), "exchange": "scatter_gather", "sag_min_bytes": 0}
-_PIPE_HEAD = {"schedule": "pipelined", "chunk_blocks": (2, 3), "owner_first": "head"}    # owner waits for its head only
 
 
 @pytest.mark.parametrize("world,N,d,nb,kid,lookahead,plan_kw", [
@@ -150,14 +162,7 @@ _PIPE_HEAD = {"schedule": "pipelined", "chunk_blocks": (2, 3), "owner_first": "h
     (2, 700, 3, 128, 1, True, _WHOLE_SAG),  # panels moved by scatter + all-gather
     (3, 700, 3, 128, 1, True, _WHOLE_INV),
     (2, 700, 3, 128, 1, False, _WHOLE_INV),
-    (2, 1500, 3, 128, 1, True, _PIPE),      # 12 block columns: panels of 12, 11, ... blocks cut into 2-3 row chunks
-    (3, 1500, 2, 128, 0, True, _PIPE_FINE), # up to 4 chunks per panel; scatter + all-gather where rows divide by 3
-    (2, 1500, 3, 128, 1, True, _PIPE_SUBST),
-    (2, 100, 2, 256, 0, True, _PIPE),       # one block column, idle rank
-    (4, 900, 2, 128, 0, True, _PIPE_FINE),  # more ranks than panel buffers minus one
-    (8, 1900, 2, 128, 0, True, _PIPE),      # the world size of the 8-GPU node: 15 block columns, owner_first on
     (8, 1900, 2, 128, 0, True, _WHOLE_INV),
-    (3, 1500, 2, 128, 0, True, _PIPE_HEAD),
 ])
 def test_distributed_fit_matches_single_process_oracle(world, N, d, nb, kid, lookahead, plan_kw):
     from oracle import oracle as O
@@ -176,8 +181,52 @@ def test_distributed_fit_matches_single_process_oracle(world, N, d, nb, kid, loo
     assert len({r[1] for r in out}) == 1                            # every rank reports the same numbers
 
 
+@pytest.mark.parametrize("world,grid,N,d,nb,kid,lookahead", [
+    (4, (2, 2), 1100, 3, 128, 1, True),      # 9 block rows / columns over 2 x 2, Matern52 with derivative rows
+    (4, (2, 2), 1100, 3, 128, 1, False),
+    (8, (2, 4), 1900, 2, 128, 0, True),      # the grids of the 8-GPU node: P_r | P_c (one contributing process row per column)
+    (8, (2, 4), 1900, 2, 128, 0, False),
+    (8, (4, 2), 1900, 2, 128, 0, True),      # P_c | P_r: two process rows contribute to every rank's columns
+    (8, (4, 2), 1900, 2, 128, 0, False),
+    (6, (2, 3), 1500, 2, 128, 1, True),      # coprime: every process row contributes, uneven ownership
+    (6, (3, 2), 1500, 3, 128, 0, True),
+    (4, (2, 2), 100, 2, 256, 0, True),       # one block: three idle ranks must still take part
+    (4, (2, 2), 500, 2, 256, 0, True),       # 2 x 2 blocks: every rank owns at most one block
+    (2, (1, 2), 700, 3, 128, 1, True),       # the 1-D block-column layout as a grid
+    (2, (2, 1), 700, 3, 128, 1, True),       # a block-row layout: the column exchange is an all-gather over all ranks
+    (8, (2, 4), 1023, 2, 128, 0, True),      # N + 1 a multiple of nb: no padding rows beyond the augmented row
+    (4, (2, 2), 1024, 2, 128, 0, True),      # N a multiple of nb: the augmented row opens a block row of its own
+])
+def test_grid_fit_matches_single_process_oracle(world, grid, N, d, nb, kid, lookahead):
+    """2-D block-cyclic layout (gptools_amd.dist.GridLML): every rank returns the oracle's ll / log-determinant
+    (1e-9 / 1e-10), all ranks the same bits, the blocks of the lower triangle are covered exactly once, and a second
+    evaluation with other hyperparameters reuses the buffers."""
+    from oracle import oracle as O
+    out = _run(world, N, d, nb, kid, lookahead, plan_kw={"grid": grid})
+    X, n, y = _inputs(N, d)
+    p = np.concatenate(([1.0], 0.3 * np.ones(d)))
+    ref = O.fit(kid, p, X, n, y, 0.05 * np.ones(N))
+    ref2 = O.fit(kid, 1.1 * p, X, n, y, 0.05 * np.ones(N))
+    owned = []
+    for rank, res, res2, blocks in out:
+        assert abs(res[0] - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"]), (rank, res, ref["ll_data"])
+        assert abs(res[1] - ref["logdet_half"]) <= 1e-10 * abs(ref["logdet_half"])
+        assert abs(res2[0] - ref2["ll_data"]) <= 1e-9 * abs(ref2["ll_data"])
+        owned += blocks
+    nblk = (N + 1 + nb - 1) // nb
+    assert sorted(owned) == sorted((I, J) for J in range(nblk) for I in range(J, nblk))
+    assert len({r[1] for r in out}) == 1 and len({r[2] for r in out}) == 1
+
+
+def test_grid_not_positive_definite_raises_on_every_rank():
+    for grid, world in (((2, 2), 4), ((2, 4), 8)):
+        out = _run(world, 300, 2, 128, 0, True, bad=True, plan_kw={"grid": grid})
+        for rank, res, _, _ in out:
+            assert res[0] == "LinAlgError" and "not positive definite" in res[1]
+
+
 def test_distributed_not_positive_definite_raises_on_every_rank():
-    for plan_kw in (_WHOLE, _PIPE):
+    for plan_kw in (_WHOLE, _WHOLE_INV):
         out = _run(2, 300, 2, 128, 0, True, bad=True, plan_kw=plan_kw)
         for rank, res, _, _ in out:
             assert res[0] == "LinAlgError" and "not positive definite" in res[1]

@@ -42,15 +42,18 @@ def test_distributed_plan_rccl_single_rank(oracle):
         "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29517', GPT_DIST_FORCE_COLLECTIVES='1')\n"
         "torch.cuda.set_device(0)\n"
         "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
-        "from gptools_amd.dist import DistributedLML\n"
+        "from gptools_amd.dist import DistributedLML, GridLML\n"
         "from test_gpu_parity import c3_inputs\n"
         "X, n, y = c3_inputs(1500, 3)\n"
         "plan = DistributedLML(X, n, nb=128, device=0, sag_min_bytes=0)\n"
         "assert plan.force_collectives and plan.lookahead and plan.schedule == 'bcast'\n"
-        "for sched, exch in (('bcast', 'bcast'), ('bcast', 'scatter_gather'), ('pipelined', 'bcast'), ('pipelined', 'scatter_gather')):\n"
-        "    plan.schedule, plan.exchange = sched, exch\n"
-        "    print('RESULT', *plan.fit(1, np.array([1.0, 0.3, 0.3, 0.3]), y, 0.05 * np.ones(1500)))\n"
-        "    print('RESULT2', *plan.fit(1, np.array([1.0, 0.3, 0.3, 0.3]), y, 0.05 * np.ones(1500)))\n"
+        "grid = GridLML(X, n, (1, 1), nb=128, ops=plan.ops)       # row / column / grid communicators of one rank each\n"
+        "assert grid.force_collectives and grid.g_row is not None and grid.g_colx is not None\n"
+        "for pl, exch in ((plan, 'bcast'), (plan, 'scatter_gather'), (grid, None), (grid, 'no_lookahead')):\n"
+        "    if pl is plan: plan.exchange = exch\n"
+        "    else: grid.lookahead = exch is None\n"
+        "    print('RESULT', *pl.fit(1, np.array([1.0, 0.3, 0.3, 0.3]), y, 0.05 * np.ones(1500)))\n"
+        "    print('RESULT2', *pl.fit(1, np.array([1.0, 0.3, 0.3, 0.3]), y, 0.05 * np.ones(1500)))\n"
         "dist.destroy_process_group()\n" % ((os.path.dirname(os.path.dirname(os.path.abspath(__file__))),) * 2))
     out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -66,8 +69,9 @@ def test_distributed_plan_rccl_single_rank(oracle):
 @pytest.mark.parametrize("case", ["m52_d3_nb128", "c4_shape_se_d4_nb512"])
 def test_distributed_plan_two_ranks_sharing_the_gpu(oracle, case):
     """The product ops under a real two-rank data flow: two gloo ranks, both on cuda:0 (gloo moves CUDA tensors through
-    the host), whole-panel and row-chunked schedules.  Exercises what a single rank cannot: receiving into panel
-    buffers on the idle queue, waiting for foreign chunks from the panel and the main queue, buffer reuse.
+    the host): the 1-D whole-panel schedule and the process grids 1 x 2 and 2 x 1 of GridLML.  Exercises what
+    a single rank cannot: receiving into panel buffers, waiting for foreign rows / columns from the panel, "recv" and main
+    queues, the column exchange, buffer reuse.
     Second case: BASELINE configs[3]'s shape (SquaredExponential, d=4, no derivative rows) at the product block width
     nb=512, N=4100 -- the C4 workload scaled to what two ranks on one GPU finish in seconds."""
     kern, kid, N, d, nb, deriv = {"m52_d3_nb128": ("m52", 1, 2500, 3, 128, True),
@@ -84,17 +88,16 @@ def test_distributed_plan_two_ranks_sharing_the_gpu(oracle, case):
         "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29523')\n"
         "torch.cuda.set_device(0)\n"
         "dist.init_process_group('gloo', rank=rank, world_size=2)\n"
-        "from gptools_amd.dist import DistributedLML\n"
+        "from gptools_amd.dist import DistributedLML, GridLML\n"
         "from test_gpu_parity import c3_inputs\n"
         "kid, N, d, nb, deriv = %d, %d, %d, %d, %d\n"
         "X, n, y = c3_inputs(N, d)\n"
         "if not deriv: n[:] = 0\n"
         "p = np.concatenate(([1.0], 0.3 * np.ones(d)))\n"
         "plan = DistributedLML(X, n, nb=nb, device=0)\n"
-        "for sched, cb in (('bcast', (2, 8, 32)), ('pipelined', (2, 3, 8, 32)), ('pipelined', (2, 4, 6, 10))):\n"
-        "    plan.schedule, plan.chunk_blocks = sched, cb\n"
+        "for pl in (plan, GridLML(X, n, (1, 2), nb=nb, ops=plan.ops), GridLML(X, n, (2, 1), nb=nb, ops=plan.ops)):\n"
         "    for rep in range(3):\n"
-        "        print('RESULT', *plan.fit(kid, p, y, 0.05 * np.ones(N)))\n"
+        "        print('RESULT', *pl.fit(kid, p, y, 0.05 * np.ones(N)))\n"
         "dist.destroy_process_group()\n" % (root, root, kid, N, d, nb, int(deriv)))
     procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for r in range(2)]
@@ -110,6 +113,46 @@ def test_distributed_plan_two_ranks_sharing_the_gpu(oracle, case):
         for v in vals:
             assert abs(float(v[0]) - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"])
             assert abs(float(v[1]) - ref["logdet_half"]) <= 1e-10 * abs(ref["logdet_half"])
+
+
+def test_grid_four_ranks_sharing_the_gpu(oracle):
+    """GridLML on a 2 x 2 process grid through the product ops: four gloo ranks on cuda:0 -- row broadcasts, the inverse of the
+    diagonal block down a process column, the head block to everybody and the column exchange all cross rank boundaries, with
+    and without look-ahead (VERDICT r3 #1: what can run of the 2-D layout on a one-GPU box)."""
+    root = ROOT
+    N, d, nb = 2300, 3, 128
+    code = (
+        "import faulthandler; faulthandler.dump_traceback_later(400, exit=True)\n"
+        "import os, sys, numpy as np, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "rank = int(sys.argv[1])\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29531')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('gloo', rank=rank, world_size=4)\n"
+        "from gptools_amd.dist import GridLML\n"
+        "from test_gpu_parity import c3_inputs\n"
+        "X, n, y = c3_inputs(%d, %d)\n"
+        "p = np.concatenate(([1.0], 0.3 * np.ones(%d)))\n"
+        "plan = GridLML(X, n, (2, 2), nb=%d, device=0)\n"
+        "for la in (True, False, True):\n"
+        "    plan.lookahead = la\n"
+        "    print('RESULT', *plan.fit(1, p, y, 0.05 * np.ones(%d)))\n"
+        "dist.destroy_process_group()\n" % (root, root, N, d, d, nb, N))
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(4)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    X, n, y = c3_inputs(N, d)
+    ref = oracle.fit("m52", np.concatenate(([1.0], 0.3 * np.ones(d))), X, n, y, 0.05 * np.ones(N), chol="scipy")
+    allvals = []
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+        vals = [l.split()[1:] for l in so.splitlines() if l.startswith("RESULT")]
+        assert len(vals) == 3
+        for v in vals:
+            assert abs(float(v[0]) - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"])
+            assert abs(float(v[1]) - ref["logdet_half"]) <= 1e-10 * abs(ref["logdet_half"])
+        allvals.append(vals)
+    assert all(v == allvals[0] for v in allvals)          # every rank: the same bits
 
 
 @pytest.mark.parametrize("world", [1, 2, 3])

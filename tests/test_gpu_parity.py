@@ -970,11 +970,12 @@ def test_full_size_c4_single_gpu_and_block_cyclic(ctx, oracle):
     assert np.array_equal(np.triu(L[:256, :256], 1), np.zeros((256, 256)))
     del L, Ltx
     gc.collect()
-    for sched in ("bcast", "pipelined"):
-        plan = DistributedLML(X, n, nb=512, device=0, schedule=sched)
+    from gptools_amd.dist import GridLML
+    for make in (lambda: DistributedLML(X, n, nb=512, device=0), lambda: GridLML(X, n, (1, 1), nb=512, device=0)):
+        plan = make()
         ll2, ld2 = plan.fit(KID["se"], p, y, err)
-        assert abs(ll2 - ll) <= 1e-10 * abs(ll), sched
-        assert abs(ld2 - ld) <= 1e-11 * abs(ld), sched
+        assert abs(ll2 - ll) <= 1e-10 * abs(ll), type(plan).__name__
+        assert abs(ld2 - ld) <= 1e-11 * abs(ld), type(plan).__name__
         del plan
         gc.collect()
 
@@ -982,16 +983,17 @@ def test_full_size_c4_single_gpu_and_block_cyclic(ctx, oracle):
 def test_distributed_plan_on_one_gpu(ctx, oracle):
     """gptools_amd.dist with the product ops (HipPanelOps, device API of the C ABI) and world_size 1:
     same ll / log|K| as the single-context path and the oracle."""
-    from gptools_amd.dist import DistributedLML
+    from gptools_amd.dist import DistributedLML, GridLML
     X, n, y = c3_inputs(1500, 3)
     p = np.array([1.0, 0.3, 0.3, 0.3])
     err = 0.05 * np.ones(1500)
     ref = oracle.fit("m52", p, X, n, y, err, chol="scipy")
     for nb, kw in ((128, {"schedule": "bcast"}), (256, {"schedule": "bcast"}), (512, {"schedule": "bcast"}),
                    (128, {"schedule": "bcast", "inv_min_rows": 0}), (512, {"schedule": "bcast", "inv_min_rows": 0}),
-                   (128, {"schedule": "pipelined"}), (128, {"schedule": "pipelined", "chunk_blocks": (2, 3, 5)}),
-                   (256, {"schedule": "pipelined"})):
-        plan = DistributedLML(X, n, nb=nb, device=0, **kw)
+                   (128, {"grid": (1, 1)}), (256, {"grid": (1, 1), "lookahead": False}), (512, {"grid": (1, 1)})):
+        kw = dict(kw)
+        plan = (GridLML(X, n, kw.pop("grid"), nb=nb, device=0, **kw) if "grid" in kw else
+                DistributedLML(X, n, nb=nb, device=0, **kw))
         ll, ld = plan.fit(1, p, y, err)
         assert abs(ll - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"]), (nb, kw)
         assert abs(ld - ref["logdet_half"]) <= 1e-10 * abs(ref["logdet_half"]), (nb, kw)
