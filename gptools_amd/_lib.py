@@ -73,6 +73,7 @@ SIGNATURES = {
     "gpt_dev_trsm_rlt": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64]),
     "gpt_dev_trinv": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64]),
     "gpt_dev_copy2d": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _i64]),
+    "gpt_dev_copy2d_on": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64]),
     "gpt_dev_pad_block": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, C.c_double]),
     "gpt_dev_panel_scalars": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
 }

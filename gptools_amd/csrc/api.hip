@@ -3187,6 +3187,13 @@ extern "C" int gpt_dev_copy2d(gpt_ctx *c, int64_t rows, int64_t cols, const doub
     return launch_copy2d(c->stream, rows, cols, d_src, lds, d_dst, ldd);
 }
 
+extern "C" int gpt_dev_copy2d_on(gpt_ctx *c, void *stream, int64_t rows, int64_t cols, const double *d_src, int64_t lds, double *d_dst,
+                                 int64_t ldd)
+{
+    CTX_ENTER(c);
+    return launch_copy2d(stream ? (hipStream_t)stream : c->stream, rows, cols, d_src, lds, d_dst, ldd);
+}
+
 extern "C" int gpt_dev_pad_block(gpt_ctx *c, double *dA, int64_t lda, int64_t c0, int64_t nb, int64_t n_valid,
                                  int64_t n_pad, const double *d_y, double big)
 {

@@ -212,8 +212,12 @@ class HipPanelOps(PanelOps):
 
     def copy2d(self, dst, src, q="panel"):
         assert dst.shape == src.shape and dst.stride(1) == 1 and src.stride(1) == 1
-        _lib.check(self.lib.gpt_dev_copy2d(self._ctx[q].handle, src.shape[0], src.shape[1], src.data_ptr(), src.stride(0),
-                                           dst.data_ptr(), dst.stride(0)))
+        if q in self._ctx:
+            _lib.check(self.lib.gpt_dev_copy2d(self._ctx[q].handle, src.shape[0], src.shape[1], src.data_ptr(), src.stride(0),
+                                               dst.data_ptr(), dst.stride(0)))
+        else:       # a queue without a library context of its own ("recv"): the library's kernel on that queue's stream
+            _lib.check(self.lib.gpt_dev_copy2d_on(self.ctx_panel.handle, self._stream[q].cuda_stream, src.shape[0], src.shape[1],
+                                                  src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0)))
 
     def pad_block(self, A, lj, c0, nb, N, NP, y, big, row_shift=0):
         # (row_shift: the library addresses row r of the block column as base + r * lda; a shifted base makes that the local row)

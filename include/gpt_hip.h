@@ -377,6 +377,10 @@ int gpt_dev_trinv(gpt_ctx *ctx, int64_t n, const double *dL, int64_t ldl, const 
  *                          the two scalars of ll (ref gaussian_process.py:1463-1467) taken from a factored panel buffer
  *                          (P = its diagonal block, row stride ldp); accumulated in a fixed order (one workgroup). */
 int gpt_dev_copy2d(gpt_ctx *ctx, int64_t rows, int64_t cols, const double *d_src, int64_t lds, double *d_dst, int64_t ldd);
+/* The same copy on an explicit stream of the caller (a hipStream_t; NULL = the context's): the column exchange of the 2-D
+ * engine gathers / scatters panel blocks on a queue that carries nothing else and has no context of its own. */
+int gpt_dev_copy2d_on(gpt_ctx *ctx, void *stream, int64_t rows, int64_t cols, const double *d_src, int64_t lds, double *d_dst,
+                      int64_t ldd);
 int gpt_dev_pad_block(gpt_ctx *ctx, double *dA, int64_t lda, int64_t c0, int64_t nb, int64_t n_valid, int64_t n_pad,
                       const double *d_y, double big);
 int gpt_dev_panel_scalars(gpt_ctx *ctx, const double *dP, int64_t ldp, int64_t w, int64_t zrow, double *d_acc);
