@@ -872,6 +872,7 @@ class GridLML(object):
                 w = min(nb, N - k * nb)
                 if w > 0:
                     ops.panel_scalars(blk, w, N - k * nb if k == last else -1, self.red)
+                self._mark(k, "W made")
             wW[k] = self._xbcast("W", k, self.W[s], (k % Pr, k % Pc), self.g_colw, Pr)
 
         def panel(k):
@@ -889,6 +890,7 @@ class GridLML(object):
                                 self.H[s].data_ptr(), nb, 0, q="panel")
                     if k + 1 == last:
                         ops.row_sumsq(self.H[s][N - last * nb], self.red)
+                    self._mark(k, "H made")
                 wH[k] = self._xbcast("H", k, self.H[s], ((k + 1) % Pr, k % Pc), self.group, self.world)
             li0 = self.li_ge(k + 2)
             m = (self.nlr - li0) * nb
@@ -900,6 +902,7 @@ class GridLML(object):
                     ops.row_sumsq(self.R[s][zrow_local], self.red)
                 ev = ops.new_event()
                 ev.record()
+                self._mark(k, "R made")
             works = self._xbcast("R", k, self.R[s][li0 * nb:self.nlr * nb], (pr, k % Pc), self.g_row, Pc) if m > 0 else []
             arr_R[k] = _Arrival(works, ev)
 
@@ -936,6 +939,7 @@ class GridLML(object):
                         ops.copy2d(torch.as_strided(Cv, (nt, bb), (sc * bb, 1), ljq * bb), dst.view(nt, bb), q="recv")
                 ev = ops.new_event()
                 ev.record()
+                self._mark(k, "C there")
             arr_C[k] = _Arrival([], ev)
 
         ev_cq = {}
@@ -976,6 +980,7 @@ class GridLML(object):
                                     _ptr(A, li0 * nb, (nxt // Pc) * nb), ld, 0, q="panel")
                     ev_la[k] = ops.new_event()
                     ev_la[k].record()
+                    self._mark(k, "LA done")
                 panel(nxt)
             exchange(nxt)
 

@@ -76,9 +76,11 @@ class Handle(object):
             return
         plan, kind, k, buf, src, t = self.args
         cur.wait_event(self.issued)
+        # the copy first, the gate behind it: the payload lands WHILE the modelled transfer is under way (the arrival time
+        # already contains bytes / bw), so the receiver pays max(copy, transfer), not their sum
+        plan._payload(kind, k, buf, src)
         if t is not None and t > 0.0:
             gate.gate_wait(ctypes.c_void_p(cur.cuda_stream), ctypes.c_void_p(plan.t0_dev.data_ptr()), int(t * 1e5))   # ms -> 10 ns ticks
-        plan._payload(kind, k, buf, src)
         self.done = torch.cuda.Event()
         self.done.record(cur)
 
@@ -178,6 +180,26 @@ for it in range(iters):
         it, " ".join("%.1f" % e for e in ends), max(ends), delta), flush=True)
     if it >= 2 and delta < 0.15:
         break
+if os.environ.get("SIM_TRACE"):
+    # one more replay of one rank with its main-queue marks and the times its own pieces were produced
+    r = int(os.environ["SIM_TRACE"])
+    p = plans[r]
+    p.trace = True
+    p.arrive, p.produced = arrive, {}
+    p.fit(kid, params, y, err)
+    torch.cuda.synchronize()
+    st = p.timings.get("steps_ms", [])
+    arr_ = {k: t for k, tag, t in st if tag == "arrived"}
+    app_ = {k: t for k, tag, t in st if tag == "applied"}
+    other = {}
+    for k, tag, t in st:
+        if tag not in ("arrived", "applied"):
+            other.setdefault(k, []).append("%s %.2f" % (tag, t))
+    print("rank %d = (%d, %d): step: panel k arrived on main | update done | marks of the panel / recv queues (ms from the start)" % (r, p.pr, p.pc))
+    for k in sorted(arr_):
+        print("  %2d: %7.2f | %7.2f | %s" % (k, arr_[k], app_.get(k, 0.0), "  ".join(other.get(k, []))))
+    sys.stdout.flush()
+    os._exit(0)
 if os.environ.get("SIM_DUMP"):
     # the converged chain: when W / H of every SIM_DUMP-th panel were produced, and rank 0's main-queue marks
     allprod = {}

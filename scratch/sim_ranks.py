@@ -61,9 +61,8 @@ print("world 1 (block-cyclic engine): %.1f ms" % ((t1 - t0) * 1e3))
 panels = rec.saved
 tot = []
 for r in ranks:
-    plan = OneRank(X, n, nb=int(os.environ.get("SIM_NB", "512")), ops=ops, layout=(r, W), schedule=sched,
-                   owner_first=("head" if os.environ.get("SIM_OWNER_FIRST", "1") == "head" else bool(int(os.environ.get("SIM_OWNER_FIRST", "1")))),
-                   chunk_blocks=tuple(int(v) for v in os.environ.get("SIM_CHUNKS", "2,3,8,32").split(",")),
+    plan = OneRank(X, n, nb=int(os.environ.get("SIM_NB", "512")), ops=ops, layout=(r, W), schedule="bcast",      # (the row-chunked schedule left the product in round 4)
+                   owner_first=bool(int(os.environ.get("SIM_OWNER_FIRST", "1"))),
                    inv_trsm=bool(int(os.environ.get("SIM_INV_TRSM", "1"))))
     plan.force_collectives = True          # takes the world > 1 code path (scalar reduction included, as a no-op)
     plan.panels = panels
