@@ -479,3 +479,37 @@ def test_two_threads_without_the_concurrency_hint_do_not_crawl():
     assert out["t"] < 1.8 * out["t_one"], out          # ... i.e. 2 x 60 evaluations in under twice the time of 60 (measured 1.3 x)
     # ... and a lone evaluation a moment later is back on the flag schedule
     assert out["edges_after"] > 0, out
+
+
+def test_flag_edges_across_xcds_with_stale_l2_lines():
+    """The flag-edge protocol of common.hpp ("memory model") under the conditions it is built for: producer
+    and waiter pinned to DIFFERENT XCDs (CU-masked streams), the waiter's L2 pre-warmed with stale lines of the payload before
+    the flag goes up, 10^4 hand-overs per form, every word checked (gptools_amd/csrc/test_aids/edge_stress.hip, which uses the
+    product's edge_signal / edge_poll and the product's store / load forms).  The three forms the library uses must never see a
+    stale word; with the write-through stores or the acquire compiled out the same harness must SHOW stale words -- otherwise
+    it would not be testing anything."""
+    import ctypes
+    so = os.path.join(ROOT, "gptools_amd", "csrc", "build", "libedge_stress.so")
+    assert os.path.exists(so), "run __graft_entry__.build() (make -C gptools_amd/csrc edge_stress)"
+    code = (
+        "import ctypes, json, sys\n"
+        "lib = ctypes.CDLL(%r)\n"
+        "lib.edge_stress_run.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong)]\n"
+        "res = {}\n"
+        "for mode, iters in ((0, 10000), (1, 10000), (4, 10000), (2, 2000), (3, 2000)):\n"
+        "    out = (ctypes.c_longlong * 8)()\n"
+        "    rc = lib.edge_stress_run(mode, iters, 1 << 16, 8, out)\n"
+        "    res[str(mode)] = [rc] + list(out)[:5]\n"
+        "print('RESULT', json.dumps(res))\n" % so)
+    out, _ = _run_fresh(code, timeout=900)
+    if any(v[0] == -5 for v in out.values()):
+        pytest.skip("no CU masks that select single XCDs on this GPU")
+    for mode in ("0", "1", "4", "2", "3"):
+        rc, xp, xc, bad_iters, bad_words, timed_out = out[mode]
+        assert rc == 0 and timed_out == 0, (mode, out[mode])
+        assert xp != xc, "producer and consumer ran on the same XCD: %r" % (out[mode],)
+    for mode in ("0", "1", "4"):            # the library's three consumer forms: never a stale word
+        assert out[mode][3] == 0 and out[mode][4] == 0, (mode, out[mode])
+    # negative controls: the harness does catch a missing acquire (2) and missing write-through stores (3)
+    assert out["2"][3] > 0, "plain loads without an acquire saw no stale line: the harness is not exercising the hazard (%r)" % (out["2"],)
+    assert out["3"][3] > 0, "plain (write-back) stores were visible across XCDs without a release: %r" % (out["3"],)
