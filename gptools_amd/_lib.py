@@ -47,6 +47,7 @@ SIGNATURES = {
     "gpt_fit_batch_sum": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _dp, _ip, _dp, _dp, _dp, C.c_double, _dp, _dp, _ip]),
     "gpt_mem_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "gpt_release_batch_scratch": (C.c_int, [_vp]),
+    "gpt_fit_batch_terms": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _ip, _dp, _ip, _ip, _dp, _dp, _dp, C.c_double, _dp, _dp, _ip]),
     "gpt_fit_matrix": (C.c_int, [_vp, _dp, _i64, _dp, _dp, _dp]),
     "gpt_get_L": (C.c_int, [_vp, _dp]),
     "gpt_get_alpha": (C.c_int, [_vp, _dp]),
@@ -395,6 +396,26 @@ class Context(object):
         ll, ld, info = np.empty(B), np.empty(B), np.zeros(B, dtype=np.int32)
         check(self._lib.gpt_fit_batch_sum(self.handle, B, len(ids), iptr(ids), dptr(params), iptr(npar), dptr(noise_var),
                                           dptr(y), dptr(err_y), float(diag_add), dptr(ll), dptr(ld), iptr(info)))
+        return ll, ld, info
+
+    def fit_batch_terms(self, terms_list, noise_var, y, err_y, diag_add):
+        """gpt_fit_batch_terms: ``terms_list[b]`` is element b's model in the form :meth:`fit_terms` takes (the same kernels in
+        every element, only the parameters differ); ``y`` (B, Ny); with a transform set (:meth:`set_T`) K_tot is T (K + noise) T^T."""
+        first = terms_list[0]
+        ids = i32(np.asarray([t[0] for t in first]))
+        ids2 = i32(np.asarray([t[2] if len(t) == 4 else -1 for t in first]))
+        npar1 = i32(np.asarray([len(t[1]) for t in first]))
+        npar = i32(np.asarray([len(t[1]) + (len(t[3]) if len(t) == 4 else 0) for t in first]))
+        params = f64(np.array([np.concatenate([np.concatenate([np.asarray(t[1], dtype=float)] +
+                                                              ([np.asarray(t[3], dtype=float)] if len(t) == 4 else []))
+                                               for t in terms]) for terms in terms_list]))
+        noise_var, y, err_y = f64(noise_var), f64(np.atleast_2d(y)), f64(err_y)
+        B = params.shape[0]
+        if noise_var.shape != (B,) or y.shape[0] != B or y.shape[1] != err_y.shape[0] or params.shape[1] != int(npar.sum()):
+            raise ValueError("fit_batch_terms: one parameter set per element, noise_var (B,), y (B, N), err_y (N,) expected")
+        ll, ld, info = np.empty(B), np.empty(B), np.zeros(B, dtype=np.int32)
+        check(self._lib.gpt_fit_batch_terms(self.handle, B, len(ids), iptr(ids), iptr(ids2), dptr(params), iptr(npar), iptr(npar1),
+                                            dptr(noise_var), dptr(y), dptr(err_y), float(diag_add), dptr(ll), dptr(ld), iptr(info)))
         return ll, ld, info
 
     def mem_info(self):

@@ -1895,16 +1895,16 @@ static int fit_matrix_once(gpt_ctx *c, const double *K_tot, int64_t N, const dou
 // same summation orders as gpt_fit, so an element's ll / log-determinant carry the very bits gpt_fit returns for it alone
 // (tests/test_gpu_parity.py::test_fit_batch_*).  N <= GPT_BATCH_MAX_N; one native kernel, no transform.
 #define GPT_BATCH_MAX_N 8192
-extern "C" int gpt_fit_batch_sum(gpt_ctx *c, int nbatch, int nterms, const int *kernel_ids, const double *params,
-                                 const int *nparams_t, const double *noise_var, const double *y, const double *err_y,
-                                 double diag_add, double *ll_data_out, double *logdet_half_out, int32_t *info_out);
+static int fit_batch_impl(gpt_ctx *c, int nbatch, int nterms, const int *kernel_ids, const int *kernel_ids2, const double *params,
+                          const int *nparams_t, const int *nparams1_t, const double *noise_var, const double *y, const double *err_y,
+                          double diag_add, double *ll_data_out, double *logdet_half_out, int32_t *info_out);
 
 extern "C" int gpt_fit_batch(gpt_ctx *c, int nbatch, int kernel_id, const double *params, int nparams,
                              const double *noise_var, const double *y, const double *err_y, double diag_add,
                              double *ll_data_out, double *logdet_half_out, int32_t *info_out)
 {
-    return gpt_fit_batch_sum(c, nbatch, 1, &kernel_id, params, &nparams, noise_var, y, err_y, diag_add, ll_data_out, logdet_half_out,
-                             info_out);
+    return fit_batch_impl(c, nbatch, 1, &kernel_id, nullptr, params, &nparams, nullptr, noise_var, y, err_y, diag_add, ll_data_out,
+                          logdet_half_out, info_out);
 }
 
 // The same for a SumKernel of native kernels (ref: kernel/core.py:549-584): element b's parameters are the terms' parameters
@@ -1914,40 +1914,68 @@ extern "C" int gpt_fit_batch_sum(gpt_ctx *c, int nbatch, int nterms, const int *
                                  const int *nparams_t, const double *noise_var, const double *y, const double *err_y,
                                  double diag_add, double *ll_data_out, double *logdet_half_out, int32_t *info_out)
 {
+    return fit_batch_impl(c, nbatch, nterms, kernel_ids, nullptr, params, nparams_t, nullptr, noise_var, y, err_y, diag_add, ll_data_out,
+                          logdet_half_out, info_out);
+}
+
+// ... and for every model gpt_fit_terms takes (the reference's likelihood grid works for any model, ref
+// gaussian_process.py:1607-1692, gp_utils.py:98-115): PRODUCT terms (kernel_ids2[t] >= 0: term t is kernel_ids[t] *
+// kernel_ids2[t], the first nparams1[t] of its nparams[t] parameters the first factor's) and, when gpt_set_T has set one, the
+// linear TRANSFORM -- every element's full K over the latent points, then T K T^T as two batched fp64-MFMA GEMMs with the shared,
+// resident T (batch stride 0), the diagonal loading and the factorisation as above over the Ny observations.  Same kernels and
+// summation orders as gpt_fit_terms: bit-identical per element.
+extern "C" int gpt_fit_batch_terms(gpt_ctx *c, int nbatch, int nterms, const int *kernel_ids, const int *kernel_ids2,
+                                   const double *params, const int *nparams_t, const int *nparams1_t, const double *noise_var,
+                                   const double *y, const double *err_y, double diag_add, double *ll_data_out,
+                                   double *logdet_half_out, int32_t *info_out)
+{
+    return fit_batch_impl(c, nbatch, nterms, kernel_ids, kernel_ids2, params, nparams_t, nparams1_t, noise_var, y, err_y, diag_add,
+                          ll_data_out, logdet_half_out, info_out);
+}
+
+static int fit_batch_impl(gpt_ctx *c, int nbatch, int nterms, const int *kernel_ids, const int *kernel_ids2, const double *params,
+                          const int *nparams_t, const int *nparams1_t, const double *noise_var, const double *y, const double *err_y,
+                          double diag_add, double *ll_data_out, double *logdet_half_out, int32_t *info_out)
+{
     CTX_ENTER(c);
     if (!c->dX) {
         gpt_set_error("gpt_fit_batch: call gpt_set_data first");
         return GPT_E_STATE;
     }
     if (nbatch < 1 || nbatch > 65535 || nterms < 1 || nterms > 8 || !kernel_ids || !nparams_t || !params || !noise_var || !y ||
-        !err_y || !ll_data_out || !info_out)
+        !err_y || !ll_data_out || !info_out || (kernel_ids2 && !nparams1_t))
         return GPT_E_ARG;
-    if (c->dT || c->Nx > GPT_BATCH_MAX_N) {
-        gpt_set_error("gpt_fit_batch: needs N <= %d and no linear transform (N = %lld)", GPT_BATCH_MAX_N, (long long)c->Nx);
+    const int64_t Nx = c->Nx, N = c->dT ? c->Ny : Nx;                   // latent points / order of K_tot
+    if (Nx > GPT_BATCH_MAX_N || N > GPT_BATCH_MAX_N) {
+        gpt_set_error("gpt_fit_batch: needs N <= %d (N = %lld)", GPT_BATCH_MAX_N, (long long)(Nx > N ? Nx : N));
         return GPT_E_ARG;
     }
     int ptot = 0;
+    bool any_prod = false;
     for (int t = 0; t < nterms; t++) {
-        const int kernel_id = kernel_ids[t];
-        if (kernel_id != GPT_KERNEL_SE && kernel_id != GPT_KERNEL_M52 && kernel_id != GPT_KERNEL_RQ && kernel_id != GPT_KERNEL_MATERN) {
-            gpt_set_error("gpt_fit_batch: kernel_id must be SE, Matern52, RationalQuadratic or Matern");
+        const bool prod = kernel_ids2 && kernel_ids2[t] >= 0;
+        any_prod = any_prod || prod;
+        if (!native_fit_kernel(kernel_ids[t]) || (prod && !native_fit_kernel(kernel_ids2[t]))) {
+            gpt_set_error("gpt_fit_batch: kernel ids must be SE, Matern52, RationalQuadratic or Matern");
             return GPT_E_ARG;
         }
-        if ((kernel_id == GPT_KERNEL_RQ || kernel_id == GPT_KERNEL_MATERN) && 2 * c->n_maxsum > GPT_RQ_MAXORD) {
-            gpt_set_error("RationalQuadratic / Matern kernel: derivative orders of a pair sum to %ld, the device builder supports %d",
-                          2 * c->n_maxsum, GPT_RQ_MAXORD);
+        const bool any_chain = kernel_ids[t] == GPT_KERNEL_RQ || kernel_ids[t] == GPT_KERNEL_MATERN ||
+                               (prod && (kernel_ids2[t] == GPT_KERNEL_RQ || kernel_ids2[t] == GPT_KERNEL_MATERN));
+        if ((any_chain || prod) && 2 * c->n_maxsum > GPT_RQ_MAXORD) {
+            gpt_set_error("derivative orders of a pair sum to %ld, the device builder supports %d for products and the "
+                          "RationalQuadratic / Matern kernels", 2 * c->n_maxsum, GPT_RQ_MAXORD);
             return GPT_E_VALUE;
         }
-        if (nparams_t[t] < 1) return GPT_E_ARG;
+        if (nparams_t[t] < 1 || (prod && (nparams1_t[t] < 1 || nparams1_t[t] >= nparams_t[t]))) return GPT_E_ARG;
         ptot += nparams_t[t];
     }
-    const int64_t N = c->Nx, NP = round_up(N + 1, 128), nleaf = NP / 128, bs = NP * NP, bws = nleaf * GPT_WS_BLOCK;
-    // pinned staging: [y: nbatch N | err: N | noise: nbatch | KParams: nterms x nbatch | results: 4 nbatch]; err .. KParams go
-    // to the device in one copy
+    const int64_t NP = round_up(N + 1, 128), nleaf = NP / 128, bs = NP * NP, bws = nleaf * GPT_WS_BLOCK;
+    // pinned staging: [y: nbatch N | err: N | noise: nbatch | KParams: nterms x nbatch (| second factors: the same) | results: 4
+    // nbatch]; err .. KParams go to the device in one copy
     static_assert(sizeof(KParams) % 8 == 0, "KParams is copied as an array of doubles");
     const size_t kp_doubles = sizeof(KParams) / 8;
-    const size_t off_err = (size_t)nbatch * N, off_nv = off_err + (size_t)N, off_kp = off_nv + (size_t)nbatch,
-                 off_res = off_kp + (size_t)nterms * nbatch * kp_doubles;
+    const size_t nkp = (size_t)nterms * nbatch * kp_doubles * (any_prod ? 2 : 1);
+    const size_t off_err = (size_t)nbatch * N, off_nv = off_err + (size_t)N, off_kp = off_nv + (size_t)nbatch, off_res = off_kp + nkp;
     const size_t need = (off_res + 4 * (size_t)nbatch) * sizeof(double);
     if (c->h_batch_cap < need) {
         if (c->h_batch) GPT_HIP_CHECK(hipHostFree(c->h_batch));
@@ -1960,23 +1988,37 @@ extern "C" int gpt_fit_batch_sum(gpt_ctx *c, int nbatch, int nterms, const int *
     memcpy(h, y, (size_t)nbatch * N * sizeof(double));
     memcpy(h + off_err, err_y, (size_t)N * sizeof(double));
     memcpy(h + off_nv, noise_var, (size_t)nbatch * sizeof(double));
+    char *hkp = reinterpret_cast<char *>(h + off_kp), *hkp2 = hkp + (size_t)nterms * nbatch * kp_doubles * 8;
     for (int b = 0; b < nbatch; b++) {
         const double *pb = params + (size_t)b * ptot;
         for (int t = 0; t < nterms; t++) {                                  // term-major on the device: [t][b]
-            KParams kp;
-            GPT_TRY(make_kparams(kernel_ids[t], pb, nparams_t[t], c->D, -1, 1, nullptr, &kp));
-            memcpy(reinterpret_cast<char *>(h + off_kp) + ((size_t)t * nbatch + (size_t)b) * kp_doubles * 8, &kp, sizeof(KParams));
+            const bool prod = kernel_ids2 && kernel_ids2[t] >= 0;
+            const int n1 = prod ? nparams1_t[t] : nparams_t[t];
+            KParams kp, kp2 = KParams();
+            GPT_TRY(make_kparams(kernel_ids[t], pb, n1, c->D, -1, 1, nullptr, &kp));
+            memcpy(hkp + ((size_t)t * nbatch + (size_t)b) * kp_doubles * 8, &kp, sizeof(KParams));
+            if (any_prod) {
+                kp2.kernel_id = -1;
+                if (prod) GPT_TRY(make_kparams(kernel_ids2[t], pb + n1, nparams_t[t] - n1, c->D, -1, 1, nullptr, &kp2));
+                memcpy(hkp2 + ((size_t)t * nbatch + (size_t)b) * kp_doubles * 8, &kp2, sizeof(KParams));
+            }
             pb += nparams_t[t];
         }
     }
+    // device scratch: the nbatch matrices to factor (+ with a transform every element's K over the latent points and T K)
+    const int64_t NxP = c->dT ? c->NxP : 0, NyP = c->dT ? round_up(N, 64) : 0;
+    const size_t kfull = (size_t)NxP * NxP, tk = (size_t)NyP * NxP;
     double *dA, *dws, *dmisc;
-    GPT_TRY(ensure(c, SLOT_BATCH_A, (size_t)nbatch * bs * sizeof(double), (void **)&dA));
+    GPT_TRY(ensure(c, SLOT_BATCH_A, ((size_t)nbatch * bs + (size_t)nbatch * (kfull + tk)) * sizeof(double), (void **)&dA));
+    double *dKf = dA + (size_t)nbatch * bs, *dTK = dKf + (size_t)nbatch * kfull;
     GPT_TRY(ensure(c, SLOT_BATCH_WS, (size_t)nbatch * bws * sizeof(double), (void **)&dws));
-    // device side of the small inputs: [err: N | noise: nbatch | KParams: nbatch | info: nbatch]
-    const size_t d_off_nv = (size_t)N, d_off_kp = d_off_nv + (size_t)nbatch,
-                 d_off_info = d_off_kp + (size_t)nterms * nbatch * kp_doubles;
-    GPT_TRY(ensure(c, SLOT_BATCH_MISC, (d_off_info + (size_t)nbatch) * sizeof(double), (void **)&dmisc));
+    // device side of the small inputs: [err: N | noise: nbatch | KParams (| second factors) | info: nbatch | zeros: Nx]
+    const size_t d_off_nv = (size_t)N, d_off_kp = d_off_nv + (size_t)nbatch, d_off_info = d_off_kp + nkp,
+                 d_off_zero = d_off_info + (size_t)nbatch;
+    GPT_TRY(ensure(c, SLOT_BATCH_MISC, (d_off_zero + (size_t)(c->dT ? Nx : 0)) * sizeof(double), (void **)&dmisc));
     int32_t *dinfo = reinterpret_cast<int32_t *>(dmisc + d_off_info);
+    const KParams *dkp = reinterpret_cast<const KParams *>(dmisc + d_off_kp);
+    const KParams *dkp2 = any_prod ? dkp + (size_t)nterms * nbatch : nullptr;
     EvalScope scope(c, true);                // (in flight like an evaluation for the flag-edge accounting; has no flag edges)
     // everything on the panel stream: unmasked (all 256 CUs), the main stream is idle here
     hipStream_t st = c->panel_stream;
@@ -1986,14 +2028,31 @@ extern "C" int gpt_fit_batch_sum(gpt_ctx *c, int nbatch, int nterms, const int *
         GPT_HIP_CHECK(hipEventRecord(e, c->stream));
         GPT_HIP_CHECK(hipStreamWaitEvent(st, e, 0));
     }
-    GPT_HIP_CHECK(hipMemcpyAsync(dmisc, h + off_err,
-                                 ((size_t)N + (size_t)nbatch + (size_t)nterms * nbatch * kp_doubles) * sizeof(double),
-                                 hipMemcpyHostToDevice, st));
-    GPT_TRY(launch_batch_pad(st, h, nbatch, dA, NP, bs, N, NP, 1e300, dinfo));
-    for (int t = 0; t < nterms; t++)                                        // (as kbuild_terms: later terms accumulate, the last
-        GPT_TRY(launch_kbuild_batch(st, kernel_ids[t], c->D,                //  one carries the diagonal epilogue)
-                                    reinterpret_cast<const KParams *>(dmisc + d_off_kp) + (size_t)t * nbatch, dmisc + d_off_nv, nbatch,
-                                    c->dX, c->dn, N, t + 1 == nterms ? dmisc : nullptr, diag_add, dA, NP, bs, t > 0 ? 1 : 0));
+    GPT_HIP_CHECK(hipMemcpyAsync(dmisc, h + off_err, ((size_t)N + (size_t)nbatch + nkp) * sizeof(double), hipMemcpyHostToDevice, st));
+    auto term_kp2 = [&](int t) -> const KParams * {
+        return (kernel_ids2 && kernel_ids2[t] >= 0) ? dkp2 + (size_t)t * nbatch : nullptr;
+    };
+    if (c->dT) {
+        // K_tot = T (K + noise_var I) T^T + diag(err_y^2) + diag_add I per element (ref :1443-1451), as fit_terms_once does for one
+        double *dzero = dmisc + d_off_zero;
+        GPT_HIP_CHECK(hipMemsetAsync(dzero, 0, (size_t)Nx * sizeof(double), st));
+        if (NxP > Nx) GPT_HIP_CHECK(hipMemsetAsync(dKf, 0, (size_t)nbatch * kfull * sizeof(double), st));
+        for (int t = 0; t < nterms; t++)
+            GPT_TRY(launch_kbuild_batch(st, kernel_ids[t], c->D, dkp + (size_t)t * nbatch, dmisc + d_off_nv, nbatch, c->dX, c->dn, Nx,
+                                        t + 1 == nterms ? dzero : nullptr, 0.0, dKf, NxP, (int64_t)kfull, t > 0 ? 1 : 0, 1, term_kp2(t)));
+        GPT_TRY(launch_gemm_nt(st, NyP, NxP, NxP, 1.0, c->dT, NxP, dKf, NxP, 0.0, dTK, NxP, 0, 0, 0, nullptr, nullptr, 0, EdgeSig(),
+                               EdgeSig(), 0, nbatch, 0, EdgeSig(), (int64_t)kfull, (int64_t)tk));
+        GPT_TRY(launch_gemm_nt(st, NyP, NyP, NxP, 1.0, dTK, NxP, c->dT, NxP, 0.0, dA, NP, 1, 0, 0, nullptr, nullptr, 0, EdgeSig(),
+                               EdgeSig(), 0, nbatch, (int64_t)tk, EdgeSig(), 0, bs));
+        GPT_TRY(launch_add_diag(st, dA, NP, N, dmisc, diag_add, nbatch, bs));
+        GPT_TRY(launch_batch_pad(st, h, nbatch, dA, NP, bs, N, NP, 1e300, dinfo));
+    } else {
+        GPT_TRY(launch_batch_pad(st, h, nbatch, dA, NP, bs, N, NP, 1e300, dinfo));
+        for (int t = 0; t < nterms; t++)                                    // (as kbuild_terms: later terms accumulate, the last
+            GPT_TRY(launch_kbuild_batch(st, kernel_ids[t], c->D, dkp + (size_t)t * nbatch, dmisc + d_off_nv, nbatch,   //  one carries the
+                                        c->dX, c->dn, N, t + 1 == nterms ? dmisc : nullptr, diag_add, dA, NP, bs,     //  diagonal epilogue)
+                                        t > 0 ? 1 : 0, 0, term_kp2(t)));
+    }
     // LEFT-looking over the 128-column leaves: leaf j first receives the update of ALL leaves before it in one launch
     // (k = 128 j; element by element the same sums in the same order as the right-looking rank-128 updates of gpt_fit, whose
     // accumulators also start from C and walk k upwards: bit-identical), then its diagonal block and TRSM.  A right-looking
@@ -2021,7 +2080,6 @@ extern "C" int gpt_fit_batch_sum(gpt_ctx *c, int nbatch, int nterms, const int *
     }
     GPT_TRY(launch_batch_logdet_dot(st, dA, NP, bs, N, nbatch, dinfo, h + off_res));
     GPT_HIP_CHECK(hipStreamSynchronize(st));
-    int bad = 0;
     for (int b = 0; b < nbatch; b++) {
         const double logdet_half = h[off_res + 4 * b], zz = h[off_res + 4 * b + 1];
         int32_t info = (int32_t)h[off_res + 4 * b + 2];
@@ -2031,9 +2089,7 @@ extern "C" int gpt_fit_batch_sum(gpt_ctx *c, int nbatch, int nterms, const int *
         info_out[b] = info;
         ll_data_out[b] = ll;
         if (logdet_half_out) logdet_half_out[b] = logdet_half;
-        bad += info != 0;
     }
-    (void)bad;
     return GPT_OK;
 }
 

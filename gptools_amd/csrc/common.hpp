@@ -163,7 +163,7 @@ int launch_trsm_panel(hipStream_t st, int64_t m, const double *L, int64_t ldl, c
 // batched small fits (gpt_fit_batch)
 int launch_kbuild_batch(hipStream_t st, int kernel_id, int D, const KParams *d_kps, const double *d_noise_var, int64_t nbatch,
                         const double *dX, const int32_t *dn, int64_t N, const double *d_err_y, double diag_add, double *dK,
-                        int64_t ldk, int64_t bstride, int accumulate = 0);
+                        int64_t ldk, int64_t bstride, int accumulate = 0, int full = 0, const KParams *d_kps2 = nullptr);
 int launch_batch_pad(hipStream_t st, const double *h_y, int64_t nbatch, double *A, int64_t lda, int64_t bstride, int64_t n_valid,
                      int64_t n_pad, double big, int32_t *info);
 int launch_batch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_t bstride, int64_t n, int64_t nbatch,
@@ -172,7 +172,8 @@ int launch_batch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_
 int grad_reduce_blocks(int64_t N);
 int launch_grad_reduce(hipStream_t st, const KParams &kp, int nh, const int *hl, const double *dX, const int32_t *dn,
                        int64_t N, const double *dalpha, const double *dW, int64_t ldw, double *dpartial);
-int launch_add_diag(hipStream_t st, double *A, int64_t lda, int64_t n, const double *err, double diag_add);
+int launch_add_diag(hipStream_t st, double *A, int64_t lda, int64_t n, const double *err, double diag_add, int64_t nbatch = 1,
+                    int64_t bstride = 0);
 // Test aid (GPT_JITTER=<max microseconds> in the environment): a delay kernel of random length on `st`, called in front of
 // every dense launch.  The schedules express every dependency as an event, so results must not move with the relative
 // timing of the streams; a missing edge shows up as a wrong number (tests/test_gpu_parity.py).  Off: one branch.

@@ -51,7 +51,7 @@ static int kbuild_dispatch_d(hipStream_t st, const KParams &kp, const double *dX
     case DD:                                                                                            \
         hipLaunchKernelGGL((kbuild_kernel<KID, DD, false>), grid, block, 0, st, kp, dXi, dni, M, dXj, dnj, P,   \
                            lower_only, i0, j0, d_err_y, noise_var, diag_add, dK, ldk, accumulate,               \
-                           (const KParams *)nullptr, (const double *)nullptr, (int64_t)0, KParams());            \
+                           (const KParams *)nullptr, (const double *)nullptr, (int64_t)0, KParams(), (const KParams *)nullptr);  \
         break;
     switch (kp.D) {
         KB_CASE(1) KB_CASE(2) KB_CASE(3) KB_CASE(4) KB_CASE(5) KB_CASE(6) KB_CASE(7) KB_CASE(8)

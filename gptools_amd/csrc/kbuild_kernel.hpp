@@ -19,9 +19,10 @@ __global__ __launch_bounds__(KB_THREADS) void kbuild_kernel(
     const double *__restrict__ Xj, const int32_t *__restrict__ nj, int64_t P,
     int lower_only, int64_t i0, int64_t j0, const double *__restrict__ err_y, double noise_one,
     double diag_add, double *__restrict__ K, int64_t ldk, int accumulate, const KParams *__restrict__ kps,
-    const double *__restrict__ nvs, int64_t bstride, KParams kp_two)
+    const double *__restrict__ nvs, int64_t bstride, KParams kp_two_one, const KParams *__restrict__ kps2)
 {
     const KParams &kp = BATCH ? kps[blockIdx.z] : kp_one;
+    const KParams &kp_two = (BATCH && kps2 != nullptr) ? kps2[blockIdx.z] : kp_two_one;      // second factor of a product term
     const double noise_var = BATCH ? nvs[blockIdx.z] : noise_one;
     if (BATCH) K += (int64_t)blockIdx.z * bstride;
     int64_t rt, ct;

@@ -22,7 +22,7 @@ int launch_kbuild_prod(hipStream_t st, const KParams &kp1, const KParams &kp2, c
     case DD:                                                                                                          \
         hipLaunchKernelGGL((kbuild_kernel<GPT_KERNEL_PRODUCT, DD, false>), grid, block, 0, st, kp1, dXi, dni, M, dXj,  \
                            dnj, P, lower_only, i0, j0, d_err_y, noise_var, diag_add, dK, ldk, accumulate,              \
-                           (const KParams *)nullptr, (const double *)nullptr, (int64_t)0, kp2);                        \
+                           (const KParams *)nullptr, (const double *)nullptr, (int64_t)0, kp2, (const KParams *)nullptr);  \
         break;
     switch (kp1.D) {
         KBP_CASE(1) KBP_CASE(2) KBP_CASE(3) KBP_CASE(4) KBP_CASE(5) KBP_CASE(6) KBP_CASE(7) KBP_CASE(8)

@@ -130,18 +130,21 @@ int launch_fill_pad(hipStream_t st, double *A, int64_t lda, int64_t n_valid, int
 
 // A[i][i] = (A[i][i] + err[i]^2) + diag_add  (ref: gptools/gaussian_process.py:1447-1451 on an assembled matrix)
 __global__ void add_diag_kernel(double *__restrict__ A, int64_t lda, int64_t n, const double *__restrict__ err,
-                                double diag_add)
+                                double diag_add, int64_t bstride)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    A += (int64_t)blockIdx.y * bstride;                 // (batched: one matrix per blockIdx.y, the same err for all)
     const double e = err[i];
     A[i * lda + i] = (A[i * lda + i] + e * e) + diag_add;
 }
 
-int launch_add_diag(hipStream_t st, double *A, int64_t lda, int64_t n, const double *err, double diag_add)
+int launch_add_diag(hipStream_t st, double *A, int64_t lda, int64_t n, const double *err, double diag_add, int64_t nbatch,
+                    int64_t bstride)
 {
-    if (n <= 0) return GPT_OK;
-    hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, lda, n, err, diag_add);
+    if (n <= 0 || nbatch <= 0) return GPT_OK;
+    hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nbatch), dim3(256), 0, st, A, lda, n, err, diag_add,
+                       bstride);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }

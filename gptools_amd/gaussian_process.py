@@ -646,13 +646,13 @@ class GaussianProcess(object):
             self._upload_data(self._ctx)
             self._data_on_device = True
         version = getattr(self, "_data_version", 0)
-        if (self.T is None and len(self.y) <= self.batch_grid_max_n and int(self.batch_grid) > 1 and jobs
-                and all(len(t) == 2 for j in jobs for t in j[1])
-                and all([t[0] for t in j[1]] == [t[0] for t in jobs[0][1]] for j in jobs)):
-            # small N: the whole batch in ONE launch sequence (gpt_fit_batch: every kernel of the factorisation carries the
-            # batch in a grid dimension), batch_grid evaluations at a time; bit-identical to one gpt_fit per vector
-            kids = [t[0] for t in jobs[0][1]]                    # (one native kernel, or a SumKernel of them)
-            npar = [len(t[1]) for t in jobs[0][1]]
+        if (max(len(self.y), self.X.shape[0]) <= self.batch_grid_max_n and int(self.batch_grid) > 1 and jobs
+                and all([(t[0], t[2] if len(t) == 4 else -1) for t in j[1]] == [(t[0], t[2] if len(t) == 4 else -1) for t in jobs[0][1]]
+                        for j in jobs)):
+            # small N: the whole batch in ONE launch sequence (gpt_fit_batch_terms: every kernel of the factorisation carries the
+            # batch in a grid dimension), batch_grid evaluations at a time; bit-identical to one gpt_fit_terms per vector.  Any
+            # model of native kernels -- sums, products, with or without the linear transform T (the reference's
+            # grids take any model: ref gaussian_process.py:1607-1692)
             err_y = np.asarray(self.err_y, dtype=float)
             self._cache = {}
             NP = -(-(len(self.y) + 1) // 128) * 128
@@ -660,15 +660,17 @@ class GaussianProcess(object):
             # (other ranks / processes may share the GPU) -- and should the allocation still fail, half as many, down to the
             # one-context-per-thread path below (a MemoryError used to abort ll_batch / compute_ll_matrix)
             budget = min(int(self.batch_grid_bytes), self._ctx.mem_info()[0] // 2)
-            G = max(1, min(int(self.batch_grid), budget // (8 * NP * NP + 8 * 9216 * (NP // 128))))
+            per = 8 * NP * NP + 8 * 9216 * (NP // 128)
+            if self.T is not None:                               # + every element's K over the latent points and T K
+                NxP = -(-self.X.shape[0] // 16) * 16
+                per += 8 * NxP * NxP + 8 * (-(-len(self.y) // 64) * 64) * NxP
+            G = max(1, min(int(self.batch_grid), budget // per))
             s0 = 0
             while s0 < len(jobs) and G >= 1:
                 chunk = jobs[s0:s0 + G]
                 try:
-                    ll, _, info = self._ctx.fit_batch_sum(kids, np.array([np.concatenate([np.asarray(t[1], dtype=float)
-                                                                                          for t in j[1]]) for j in chunk]),
-                                                          npar, np.array([j[3] for j in chunk]),
-                                                          np.array([j[4] for j in chunk]), err_y, diag_add)
+                    ll, _, info = self._ctx.fit_batch_terms([j[1] for j in chunk], np.array([j[3] for j in chunk]),
+                                                            np.array([j[4] for j in chunk]), err_y, diag_add)
                 except MemoryError:
                     self._ctx.release_batch_scratch()
                     G //= 2

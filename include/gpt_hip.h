@@ -203,7 +203,8 @@ int gpt_fit_terms(gpt_ctx *ctx, int nterms, const int *kernel_ids, const int *ke
  * noise_var[b] and the target y[b * N ..] (the mean function may depend on the hyperparameters); err_y (N) is shared.
  * Replaces the loops over hyperparameter vectors of the reference's likelihood grid and random starts
  * (ref: gaussian_process.py:1607-1692, :723-735, gp_utils.py:98-115) at the sizes those run at: N <= 8192 resident
- * points (it pays up to N ~ 4096: 2.3x one gpt_fit per vector there, 9.5x at 1024; nbatch N^2 doubles of device memory), one native kernel, no transform (GPT_E_ARG otherwise: the caller falls back to one gpt_fit per vector).
+ * points (it pays up to N ~ 4096: 2.3x one gpt_fit per vector there, 9.5x at 1024; nbatch N^2 doubles of device memory), one native kernel
+ * (sums, products and a linear transform: gpt_fit_batch_sum / gpt_fit_batch_terms below).
  * Every kernel of the factorisation carries the batch in a grid dimension; an element's results are bit-identical to
  * gpt_fit's for the same inputs.  info_out[b] = 0, or the LAPACK index of the leading minor that is not positive
  * definite (ll_data_out[b] is then meaningless); the call itself returns GPT_OK in both cases. */
@@ -217,6 +218,14 @@ int gpt_fit_batch(gpt_ctx *ctx, int nbatch, int kernel_id, const double *params,
 int gpt_fit_batch_sum(gpt_ctx *ctx, int nbatch, int nterms, const int *kernel_ids, const double *params,
                       const int *nparams, const double *noise_var, const double *y, const double *err_y,
                       double diag_add, double *ll_data_out, double *logdet_half_out, int32_t *info_out);
+
+/* The batched evaluator for every model gpt_fit_terms takes: product terms (kernel_ids2 / nparams1 as in gpt_fit_terms) and, when
+ * gpt_set_T has set one, the linear transform (y then holds nbatch x Ny targets, err_y Ny entries; K_tot = T (K + noise_var I) T^T +
+ * ... per element by two batched GEMMs with the shared T).  Needs Nx, Ny <= 8192; bit-identical to gpt_fit_terms per element.
+ * ref: gaussian_process.py:1607-1692, gp_utils.py:98-115 (the reference's grids work for any model). */
+int gpt_fit_batch_terms(gpt_ctx *ctx, int nbatch, int nterms, const int *kernel_ids, const int *kernel_ids2, const double *params,
+                        const int *nparams, const int *nparams1, const double *noise_var, const double *y, const double *err_y,
+                        double diag_add, double *ll_data_out, double *logdet_half_out, int32_t *info_out);
 
 /* Free / total bytes of the context's GPU, and the release of the batched evaluator's scratch (nbatch matrices; otherwise kept
  * until gpt_ctx_destroy): GaussianProcess.ll_batch sizes its chunks by the first and returns the memory with the second. */

@@ -1703,3 +1703,62 @@ def test_transform_gradient_does_not_read_unwritten_scratch(g):
         grads.append(np.array(grad))
     assert np.all(np.isfinite(grads[1]))
     np.testing.assert_array_equal(grads[0], grads[1])
+
+
+@pytest.mark.parametrize("case", ["product_plus_term", "transform", "transform_product"])
+def test_fit_batch_terms_products_and_transform_bit_identical(g, case):
+    """gpt_fit_batch_terms: a batch of evaluations of a model with a PRODUCT term (k1 * k2 + k3) and / or a
+    linear TRANSFORM T (K_tot = T (K + noise) T^T + ..., two batched GEMMs with the shared T) carries, per element, the very
+    bits one gpt_fit_terms call returns; and GaussianProcess.ll_batch routes such models through it (same values as one
+    update_hyperparameters per vector).  ref: gaussian_process.py:1607-1692 (the reference's grids take any model)."""
+    from gptools_amd import _lib
+    rs = np.random.RandomState(21)
+    d, Nx = 2, 700
+    X = rs.rand(Nx, d)
+    n = np.zeros((Nx, d), dtype=int)
+    n[-50:, 0] = 1
+    with_T = case.startswith("transform")
+    Ny = 260 if with_T else Nx
+    T = rs.rand(Ny, Nx) / Nx if with_T else None
+    f = np.sin(3 * X.sum(1))
+    y = (T.dot(f) if with_T else f) + 1e-2 * rs.randn(Ny)
+    err = np.full(Ny, 0.02)
+    B = 9
+
+    def terms(b):
+        s = 1.0 + 0.05 * b
+        if case == "transform":
+            return [(0, np.array([1.1 * s, 0.4, 0.6]))]
+        return [(0, np.array([1.1 * s, 0.4, 0.6]), 1, np.array([0.9, 1.5 * s, 2.0])), (4, np.array([0.3, 1.7, 0.8 * s, 0.9]))]
+    c = _lib.Context(0)
+    try:
+        c.set_data(X, n)
+        if with_T:
+            c.set_T(T)
+        nv = 1e-3 * (1.0 + np.arange(B))
+        Y = y[None, :] + 1e-3 * rs.randn(B, Ny)
+        ll, ld, info = c.fit_batch_terms([terms(b) for b in range(B)], nv, Y, err, 1e2 * EPS)
+        assert not info.any()
+        for b in range(B):
+            l1, d1 = c.fit_terms(terms(b), nv[b], Y[b], err, 1e2 * EPS)
+            assert (l1, d1) == (ll[b], ld[b]), (case, b, l1 - ll[b], d1 - ld[b])
+    finally:
+        c.close()
+    # through the plugin API: ll_batch == one update_hyperparameters per vector
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        k = make_kernel(g, "se", d, [1.1, 0.4, 0.6])
+        if case != "transform":
+            k = k * make_kernel(g, "m52", d, [0.9, 1.5, 2.0]) + g.RationalQuadraticKernel(
+                num_dim=d, initial_params=[0.3, 1.7, 0.8, 0.9], param_bounds=[(0.0, 1e3)] * 4)
+        gp = g.GaussianProcess(k, noise_k=g.DiagonalNoiseKernel(num_dim=d, initial_noise=0.03, noise_bound=(0.0, 5.0)))
+        gp.add_data(X, y, err_y=0.02, n=n, T=T)
+        theta = np.array(gp.free_params[:], dtype=float)
+        pts = [theta * (1.0 + 0.02 * i) for i in range(5)]
+        calls = []
+        orig = gp._ctx.fit_batch_terms
+        gp._ctx.fit_batch_terms = lambda *a, **kw: (calls.append(1), orig(*a, **kw))[1]
+        vals = gp.ll_batch(pts)
+        assert calls, "ll_batch did not take the batched evaluator for case %s" % case
+        one = np.array([-gp.update_hyperparameters(p) for p in pts])
+        np.testing.assert_array_equal(vals, one)
