@@ -207,6 +207,7 @@ static int make_kparams(int kernel_id, const double *params, int nparams, int D,
             kp->l[d] = l;
             kp->inv_l[d] = 1.0 / l;
             kp->inv_var[d] = 1.0 / (l * l);
+            if (l == 0.0) kp->zero_l = 1;
         }
     } else if (kernel_id == GPT_KERNEL_RQ) {
         // RationalQuadraticKernel: [sigma_f, alpha, l_1 .. l_D] (ref: rational_quadratic.py:30-45)

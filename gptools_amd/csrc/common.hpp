@@ -55,6 +55,8 @@ struct KParams {
     double m_mu;              // nu - round(nu), |mu| <= 1/2
     int m_nint;               // round(nu)
     int m_isint;              // nu is an integer (the reference then averages nu -+ 0.001 near the origin)
+    int zero_l;               // some length scale is exactly 0 (1 / l = inf): the squared-exponential pair function then applies the
+    int pad_;                 //   reference's 0/0 -> 0 rule per dimension (core.py:416); otherwise it is one multiply
     double m_gampl, m_gammi, m_gam1, m_gam2;      // Temme's 1/Gamma(1 +- mu) and their combinations
     double m_g[2], m_gm[2], m_nus[2];             // Gamma(nu_s), Gamma(-nu_s), nu_s for the small-y series (nu_s = nu, or nu -+ 0.001)
 };

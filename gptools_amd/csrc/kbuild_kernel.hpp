@@ -62,6 +62,44 @@ __global__ __launch_bounds__(KB_THREADS) void kbuild_kernel(
     // both columns in range and the pair 16-byte aligned -> one dwordx4 store per row
     const bool vec = (jfirst + KB_CPT <= P) && ((ldk & 1) == 0) && ((((uintptr_t)K >> 3) + (uint64_t)jfirst) & 1) == 0;
     const int64_t rend = (rbase + KB_ROWS < M) ? rbase + KB_ROWS : M;
+    // PLAIN tiles (round 4).  Most of a real Gram matrix pairs value rows with value columns: if none of the
+    // tile's rows and none of this wave's columns carries a derivative order, the row loop needs no class logic at all -- no
+    // derivative-order loads, no index selection (the ~25 scalar and ~6 vector instructions per row the general loop spends on
+    // choosing among four formulas).  The test is once per tile and wave: the orders of the rows in one or two vector loads
+    // and a ballot.  C3 (last quarter derivative rows): 56 % of the lower triangle's pairs.
+    if constexpr ((KID == GPT_KERNEL_SE || KID == GPT_KERNEL_M52) && KB_CPT == 1) {
+        int cn = 0;
+#pragma unroll
+        for (int d = 0; d < D; d++) cn |= njr[0][d];
+        bool plain = kp.hyper_deriv < 0 && __builtin_amdgcn_ballot_w64(cn != 0) == 0;
+        if (plain) {
+            int rn = 0;
+            const int64_t cnt = (rend - rbase) * D;
+            for (int64_t q = threadIdx.x & 63; q < cnt; q += 64) rn |= ni[rbase * D + q];
+            plain = __builtin_amdgcn_ballot_w64(rn != 0) == 0;
+        }
+        if (plain) {
+            for (int64_t i = rbase; i < rend; i++) {
+                double xi[D];
+#pragma unroll
+                for (int d = 0; d < D; d++) xi[d] = Xi[i * D + d];          // wave-uniform addresses -> scalar loads
+                double v = plain_pair<KID, D>(kp, xi, xj[0]);
+                if (accumulate && jfirst < P) v += K[i * ldk + jfirst];
+                if (err_y != nullptr && (i + i0 == jfirst + j0)) {
+                    const double e = err_y[i + i0];
+                    v = ((v + noise_var) + e * e) + diag_add;
+                }
+#ifdef KB_DEBUG_NOCOMPUTE
+                v = (double)i;
+#endif
+#ifdef KB_DEBUG_NOSTORE
+                if (v != 12345.678) continue;
+#endif
+                if (jfirst < P) K[i * ldk + jfirst] = v;
+            }
+            return;
+        }
+    }
     for (int64_t i = rbase; i < rend; i++) {
         double xi[D];
         int nir[D];

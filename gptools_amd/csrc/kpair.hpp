@@ -25,6 +25,33 @@
 #define GPT_SQRT5 2.2360679774997898
 #define GPT_FIVE_THIRDS 1.6666666666666667
 
+// exp(-x) for x >= 0: k = rint(-x log2 e), r = -x - k ln 2 in two fused steps (|r| <= ln2 / 2), then
+// exp(r) = 1 + r (1 + r q(r)) with q of degree 9 (Chebyshev interpolant of (e^r - 1 - r) / r^2, error 1.7e-17 relative;
+// scratch note in DESIGN.md section 4), scaled by 2^k with one v_ldexp.  x is clamped at 800 (exp(-800) = 0 in double
+// precision) so that k fits v_cvt_i32; the clamp (v_max) drops a NaN, which every caller multiplies back in through the
+// factors that carry r.  18 instructions against the ~35 of the library exp with its overflow / denormal handling,
+// within 1 ulp of it (the Matern-5/2 builder is bound by its arithmetic).
+__device__ __forceinline__ double exp_neg(double x)
+{
+    const double t = fmax(-x, -800.0);
+    const double k = __builtin_rint(t * 1.4426950408889634);
+    double r = fma(k, -6.93147180369123816490e-01, t);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double q = 2.5100274028176466e-08;
+    q = fma(q, r, 2.7620076086460433e-07);
+    q = fma(q, r, 2.7557268773616192e-06);
+    q = fma(q, r, 2.48015213222418e-05);
+    q = fma(q, r, 1.9841269862757975e-04);
+    q = fma(q, r, 1.3888888917196432e-03);
+    q = fma(q, r, 8.3333333333301673e-03);
+    q = fma(q, r, 4.1666666666624164e-02);
+    q = fma(q, r, 1.6666666666666669e-01);
+    q = fma(q, r, 5.0000000000000011e-01);
+    q = fma(q, r, 1.0);
+    q = fma(q, r, 1.0);
+    return __builtin_amdgcn_ldexp(q, (int)k);
+}
+
 template <int D>
 __device__ __forceinline__ double se_pair(const KParams &kp, const double *xi, const double *xj,
                                           const int *ni, const int *nj)
@@ -35,13 +62,18 @@ __device__ __forceinline__ double se_pair(const KParams &kp, const double *xi, c
 #pragma unroll
     for (int d = 0; d < D; d++) {
         tau[d] = xi[d] - xj[d];
-        // core.py:416: a 0/0 term counts as 0 (tau * inf would be NaN)
-        double t = (tau[d] == 0.0) ? 0.0 : tau[d] * kp.inv_l[d];
+        // core.py:416: a 0/0 term counts as 0 (tau * inf would be NaN) -- only where a length scale IS zero (wave-uniform
+        // flag from the host, api.hip make_kparams): the compare and two selects per dimension were ~10 % of the plain pair
+        double t = tau[d] * kp.inv_l[d];
+        if (kp.zero_l) t = (tau[d] == 0.0) ? 0.0 : t;
         r2 = fma(t, t, r2);
         nsum += ni[d] + nj[d];
         nisum += ni[d];
     }
-    double k = kp.sigma * kp.sigma * exp(-0.5 * r2);
+    // exp(-r2 / 2) by the builder's own exp(-x) (18 instructions, within 1 ulp of the library's ~35: exp_neg above).  Its clamp
+    // drops a NaN of r2 (non-finite inputs), which is put back through sigma_f^2; r2 = +inf (a zero length scale between
+    // distinct points) must stay exp(-inf) = 0 as in the reference, so the NaN is selected, not multiplied in
+    double k = ((r2 != r2) ? r2 : kp.sigma * kp.sigma) * exp_neg(0.5 * r2);
     const int hd = kp.hyper_deriv;
     if (nsum != 0 || hd > 0) {
         double prod = 1.0;
@@ -73,33 +105,6 @@ __device__ __forceinline__ double se_pair(const KParams &kp, const double *xi, c
     return k;
 }
 
-// exp(-x) for x >= 0: k = rint(-x log2 e), r = -x - k ln 2 in two fused steps (|r| <= ln2 / 2), then
-// exp(r) = 1 + r (1 + r q(r)) with q of degree 9 (Chebyshev interpolant of (e^r - 1 - r) / r^2, error 1.7e-17 relative;
-// scratch note in DESIGN.md section 4), scaled by 2^k with one v_ldexp.  x is clamped at 800 (exp(-800) = 0 in double
-// precision) so that k fits v_cvt_i32; the clamp (v_max) drops a NaN, which every caller multiplies back in through the
-// factors that carry r.  18 instructions against the ~35 of the library exp with its overflow / denormal handling,
-// within 1 ulp of it (the Matern-5/2 builder is bound by its arithmetic).
-__device__ __forceinline__ double exp_neg(double x)
-{
-    const double t = fmax(-x, -800.0);
-    const double k = __builtin_rint(t * 1.4426950408889634);
-    double r = fma(k, -6.93147180369123816490e-01, t);
-    r = fma(k, -1.90821492927058770002e-10, r);
-    double q = 2.5100274028176466e-08;
-    q = fma(q, r, 2.7620076086460433e-07);
-    q = fma(q, r, 2.7557268773616192e-06);
-    q = fma(q, r, 2.48015213222418e-05);
-    q = fma(q, r, 1.9841269862757975e-04);
-    q = fma(q, r, 1.3888888917196432e-03);
-    q = fma(q, r, 8.3333333333301673e-03);
-    q = fma(q, r, 4.1666666666624164e-02);
-    q = fma(q, r, 1.6666666666666669e-01);
-    q = fma(q, r, 5.0000000000000011e-01);
-    q = fma(q, r, 1.0);
-    q = fma(q, r, 1.0);
-    return __builtin_amdgcn_ldexp(q, (int)k);
-}
-
 // (keeps what depends on v inside the branch it is written in: hipcc otherwise speculates the cheap arithmetic of every
 // class above the class test and all pairs pay for it)
 __device__ __forceinline__ double pin_here(double v)
@@ -123,15 +128,19 @@ __device__ __forceinline__ double m52_pair(const KParams &kp, const double *xi, 
     }
     // r = sqrt(r2) and 1/r2 from ONE v_rsq_f64 + a Newton step (1/sqrt(r2) to 1.5 * 2^-52): the correctly rounded
     // sqrt and the IEEE division of the (e_a, e_b) class were ~50 of this kernel's instructions, and the Matern-5/2
-    // builder is bound by its arithmetic, not by the stores.  Coincident points (r2 == 0:
-    // matern.c:83-84, :100-101, :123-127) run the same arithmetic on r2 = 1 and take their constant at the end.
-    const bool zero = (r2 == 0.0);
-    const double r2s = zero ? 1.0 : r2;
+    // builder is bound by its arithmetic, not by the stores.
+    // Coincident points (r2 == 0: matern.c:83-84, :100-101, :123-127).  Round 2 ran the arithmetic on r2 = 1 and selected
+    // the reference's constants at the end (a compare and four 32-bit selects per pair); round 4 clamps r2 at 2^-600
+    // instead -- ONE v_max -- because every class then reaches its limit by itself: r = sqrt5 2^-300 vanishes against 1 and
+    // exp(-r) == 1, so the value class gives exactly 1; a first-derivative class multiplies by the zero displacement; the
+    // (e_a, e_a) class forms g (2^-600 / var_a) (1 / 2^-600) = (5/3) / var_a (2^600 is exact and finite), the (e_a, e_b)
+    // class 0.  v_max drops a NaN, so a non-finite r2 is multiplied back in through sigma_f^2 (one FMA).
+    const double r2s = fmax(r2, 0x1p-600);
     const double y0 = __builtin_amdgcn_rsq(r2s);
     const double yr = fma(0.5 * y0, fma(-(r2s * y0), y0, 1.0), y0);
     const double s5r = GPT_SQRT5 * (r2s * yr);
     const double e = exp_neg(s5r);
-    double v, v0;
+    double v;
     // The class of a pair -- which side carries a derivative -- is the same for all 64 columns of a wave nearly
     // everywhere (the rows are wave-uniform, the columns of one class are contiguous in any sensible ordering), so each
     // class has its own branch and a wave executes one of them; the select-everything form of round 1 computed all four
@@ -139,7 +148,6 @@ __device__ __forceinline__ double m52_pair(const KParams &kp, const double *xi, 
     if (__builtin_amdgcn_ballot_w64(ij >= 0) == 0) {
         if (ii < 0) {
             v = fma(GPT_FIVE_THIRDS, r2s, 1.0 + s5r) * e;
-            v0 = 1.0;
         } else {
             const double ep = pin_here(e);
             double di = 0.0, ivi = 0.0;
@@ -149,7 +157,6 @@ __device__ __forceinline__ double m52_pair(const KParams &kp, const double *xi, 
                 if (d == ii) { di = dd; ivi = kp.inv_var[d]; }
             }
             v = -(GPT_FIVE_THIRDS * (1.0 + s5r) * ep) * (di * ivi);
-            v0 = 0.0;
         }
     } else {
         const double ep = pin_here(e);
@@ -164,7 +171,6 @@ __device__ __forceinline__ double m52_pair(const KParams &kp, const double *xi, 
         if (ii < 0) {
             v = (ij >= 0) ? g * (dj * ivj)                                // arguments swapped => sign flips (matern.c:182-184)
                           : fma(GPT_FIVE_THIRDS, r2s, 1.0 + s5r) * ep;
-            v0 = (ij >= 0) ? 0.0 : 1.0;
         } else {
             double d2r = (di * ivi) * (dj * ivj);
             const double cross = d2r;
@@ -172,11 +178,9 @@ __device__ __forceinline__ double m52_pair(const KParams &kp, const double *xi, 
             const double d2k = GPT_FIVE_THIRDS * (5.0 * r2s - s5r - 1.0) * ep;
             const double both = (-g * d2r - d2k * cross) * (yr * yr);     // term1 + term2 over r^2, matern.c:143-146
             v = (ij >= 0) ? both : -g * (di * ivi);
-            v0 = (ij >= 0 && ii == ij) ? GPT_FIVE_THIRDS * ivi : 0.0;
         }
     }
-    v = zero ? v0 : v;
-    return kp.sigma * kp.sigma * v;
+    return fma(r2, 0.0, kp.sigma * kp.sigma) * v;            // (sigma_f^2, with a NaN of r2 multiplied back in)
 }
 
 template <int D>
@@ -536,6 +540,37 @@ __device__ __forceinline__ double matern_pair(const KParams &kp, const double *x
     for (int m = 1; m <= deg; m++)
         if (c[m] != 0.0) v = fma(c[m], F[m], v);
     return s2 * ((njtot & 1) ? -v : v);
+}
+
+// The value class alone -- no derivative order on either side, no hyper-parameter derivative: what the builder's row loop
+// runs for a tile whose 32 rows and whose wave's 64 columns are all plain (kbuild_kernel.hpp), with none of the class logic.
+// Same arithmetic, in the same order, as the value branch of se_pair / m52_pair: the same bits.
+template <int KID, int D>
+__device__ __forceinline__ double plain_pair(const KParams &kp, const double *xi, const double *xj)
+{
+    double r2 = 0.0;
+    if constexpr (KID == GPT_KERNEL_SE) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const double tau = xi[d] - xj[d];
+            double t = tau * kp.inv_l[d];
+            if (kp.zero_l) t = (tau == 0.0) ? 0.0 : t;
+            r2 = fma(t, t, r2);
+        }
+        return ((r2 != r2) ? r2 : kp.sigma * kp.sigma) * exp_neg(0.5 * r2);
+    } else {
+#pragma unroll
+        for (int d = D - 1; d >= 0; d--) {
+            const double disp = xi[d] - xj[d];
+            r2 = fma(disp * disp, kp.inv_var[d], r2);
+        }
+        const double r2s = fmax(r2, 0x1p-600);
+        const double y0 = __builtin_amdgcn_rsq(r2s);
+        const double yr = fma(0.5 * y0, fma(-(r2s * y0), y0, 1.0), y0);
+        const double s5r = GPT_SQRT5 * (r2s * yr);
+        const double e = exp_neg(s5r);
+        return fma(r2, 0.0, kp.sigma * kp.sigma) * (fma(GPT_FIVE_THIRDS, r2s, 1.0 + s5r) * e);
+    }
 }
 
 template <int KID, int D>

@@ -750,7 +750,10 @@ class GridLML(object):
         self.C = [torch.empty((cols, nb), **f64) for _ in range(self.NBUF)]       # columns of panel k, by local block column
         self.H = [torch.empty((nb, nb), **f64) for _ in range(self.NBUF)]         # head block L[k+1][k]
         self.W = [torch.empty((nb, nb), **f64) for _ in range(self.NBUF)]         # L_kk^-1
-        self.piece = torch.empty((cols, nb), **f64)                               # one contributing process row's share of C
+        # one contributing process row's share of C, where several rows contribute (lcm / P_c > 1): a buffer per slot and
+        # contributing row (a single one would serialise consecutive exchanges on it)
+        nq = (self.Pr // math.gcd(self.Pr, self.Pc)) if self.lcm // self.Pc > 1 else 0
+        self.piece = [[torch.empty((-(-cols // (self.lcm // self.Pc)), nb), **f64) for _ in range(nq)] for _ in range(self.NBUF)]
         self.invd = torch.empty(((nb // 128) * 9216,), **f64)
         self.info = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.y = torch.empty((self.NP,), **f64)
@@ -921,6 +924,7 @@ class GridLML(object):
                 reuse_c(k)
                 arr_R[k].wait()
                 Cv = self.C[s]
+                qi = 0
                 for q in range(Pr):
                     J0 = next((J for J in self.my_cols[lj0:lj0 + sc] if J % Pr == q), None)
                     if J0 is None:
@@ -928,7 +932,8 @@ class GridLML(object):
                     nt = (nblk - 1 - J0) // self.lcm + 1
                     ljq = J0 // Pc
                     direct = sc == 1                       # one contributing process row: its share IS the rank's C
-                    dst = Cv[ljq * nb:(ljq + nt) * nb] if direct else self.piece[:nt * nb]
+                    dst = Cv[ljq * nb:(ljq + nt) * nb] if direct else self.piece[s][qi][:nt * nb]
+                    qi += 1
                     if q == pr:
                         liq = J0 // Pr
                         src = torch.as_strided(self.R[s], (nt, bb), (sr * bb, 1), liq * bb)

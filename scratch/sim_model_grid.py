@@ -6,11 +6,13 @@ ranks and the links, is MODELLED:
   * a broadcast produced by another rank becomes readable here at  arrive = max(production, link free) + bytes / bw + latency,
     production = the time the OWNER's replay recorded behind the kernels that produce it; one FIFO per directed link
     (source -> destination: xGMI is point to point, a root feeds its peers over different links at the same time);
-  * the receiving side: the first queue that waits for the broadcast is held by a one-wave gate kernel until the device clock
-    reaches the arrival time, then copies the payload (taken from a complete factor computed up front) into the buffer the
-    broadcast would have filled -- the receiver pays a device-to-device copy, about what landing the data in HBM costs -- and
-    an event releases the other queues that wait for the same data.  (No extra streams: more busy streams than hardware
-    queues alias, and a gate that spins on a shared queue would hold the wrong work back.)
+  * the receiving side pays nothing for the data movement (an ideal DMA engine: every buffer a broadcast would fill exists up
+    front -- one slot per panel, NBUF = number of panels -- and holds the payload already, taken from a complete factor
+    computed first); it only may not read it earlier: the first queue that waits for the broadcast is held by a one-wave gate
+    kernel until the device clock reaches the arrival time, and an event releases the other queues that wait for the same
+    data.  (No extra streams: more busy streams than hardware queues alias, and a gate that spins on a shared queue would
+    hold the wrong work back.  A first version copied the payload at arrival time: the strided device-to-device copies --
+    50-100 MB per step on the receiving queues -- cost 15 ms per rank and evaluation, an artefact of the model.)
 Production depends on arrivals and vice versa: the W replays are swept (Gauss-Seidel over the ranks) to the fixed point.
 NOT modelled: RCCL's own launch overhead and CU usage, contention between concurrent transfers on the fabric, host jitter.
 
@@ -65,8 +67,6 @@ class Handle(object):
     """Receive side of one modelled broadcast: delivered by the first queue that waits for it."""
     def __init__(self, plan, kind, k, buf, src, t):
         self.args = (plan, kind, k, buf, src, t)
-        self.issued = torch.cuda.Event()
-        self.issued.record(torch.cuda.current_stream())      # (the buffer may be written only after what the issuing queue waited for)
         self.done = None
 
     def wait(self):
@@ -75,10 +75,6 @@ class Handle(object):
             cur.wait_event(self.done)
             return
         plan, kind, k, buf, src, t = self.args
-        cur.wait_event(self.issued)
-        # the copy first, the gate behind it: the payload lands WHILE the modelled transfer is under way (the arrival time
-        # already contains bytes / bw), so the receiver pays max(copy, transfer), not their sum
-        plan._payload(kind, k, buf, src)
         if t is not None and t > 0.0:
             gate.gate_wait(ctypes.c_void_p(cur.cuda_stream), ctypes.c_void_p(plan.t0_dev.data_ptr()), int(t * 1e5))   # ms -> 10 ns ticks
         self.done = torch.cuda.Event()
@@ -144,10 +140,33 @@ def members(kind, k, src):
 
 
 plans = []
+ModelRank.NBUF = nblk                      # one slot per panel: nothing a broadcast would fill is ever written twice
 for r in range(W):
     p = ModelRank(X, n, (Pr, Pc), nb=NB, ops=ops, layout=r, lookahead=LA)
     p.t0_dev = torch.zeros(1, dtype=torch.int64, device="cuda")
     p.arrive, p.produced = {}, {}
+    # every foreign payload up front, where the broadcast would have put it
+    for k in range(nblk):
+        me = (p.pr, p.pc)
+        if p.pc == k % Pc and me != (k % Pr, k % Pc):
+            p._payload("W", k, p.W[k], None)
+        if k + 1 < nblk and me != ((k + 1) % Pr, k % Pc):
+            p._payload("H", k, p.H[k], None)
+        li0 = p.li_ge(k + 2)
+        if p.pc != k % Pc and li0 < p.nlr:
+            p._payload("R", k, p.R[k][li0 * NB:p.nlr * NB], None)
+        lj0 = p.lj_ge(k + 2)
+        if lj0 < p.nlc:
+            sc, qi = p.lcm // Pc, 0
+            for q in range(Pr):
+                J0 = next((J for J in p.my_cols[lj0:lj0 + sc] if J % Pr == q), None)
+                if J0 is None:
+                    continue
+                nt = (nblk - 1 - J0) // p.lcm + 1
+                dst = p.C[k][(J0 // Pc) * NB:(J0 // Pc + nt) * NB] if sc == 1 else p.piece[k][qi][:nt * NB]
+                qi += 1
+                if q != p.pr:
+                    p._payload("C", k, dst, (q, p.pc))
     plans.append(p)
 torch.cuda.synchronize()
 arrive, link_free_hist, hist = {}, None, []
