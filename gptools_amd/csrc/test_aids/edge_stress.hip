@@ -18,6 +18,7 @@
 //   4  producer: as 0         consumer = one-wave wait kernel (step 3) and a SEPARATE reader kernel behind it on the same stream,
 //      plain loads: the kernel boundary's own acquire                                                                     [product: stream-side wait]
 #include "../common.hpp"
+#include <stdlib.h>
 #include <vector>
 
 __global__ void xcc_probe_kernel(unsigned *out)
@@ -128,6 +129,11 @@ extern "C" int edge_stress_run(int mode, int iters, long long n_doubles, int wgs
             if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(h.data(), d_x, 1024 * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -4;
             bool one = true;
             for (unsigned v : h) one = one && v == h[0];
+            if (getenv("GPT_EDGE_STRESS_DEBUG")) {
+                unsigned seen = 0;
+                for (unsigned v : h) seen |= 1u << v;
+                fprintf(stderr, "edge_stress: CU mask layout %d group %d (%zu CUs) -> XCC ids seen 0x%x\n", layout, g, cus.size(), seen);
+            }
             if (one && !sp) { sp = st; xp = (int)h[0]; }
             else if (one && (int)h[0] != xp) { sc = st; xc = (int)h[0]; }
             else hipStreamDestroy(st);
