@@ -124,6 +124,7 @@ struct gpt_ctx {
     bool binv3_valid = false;          // SLOT_BINV3 those of its 2048x2048 diagonal blocks (the same, large factors)
     // (all three are always built for the whole padded order, floor(NP / width) blocks, whatever extent the caller needs:
     // gpt_ll_grad and the solves ask for different extents at N = 512 k - 128, and a valid flag says nothing about how far)
+    unsigned alpha_counter = 0;        // value of the step counter of the wide back-substitution (d_edge[40], only ever raised)
     int64_t debug_poison = 0;          // option "debug_poison": gpt_ll_grad fills its scratch matrices with NaN first (test aid)
     int64_t edge_test_stall = 0;       // option "edge_test_stall": the next head flag is withheld once (test aid, see fit_terms_once)
     double *h_stage = nullptr;         // pinned staging ring for results that go to pageable host memory (2 x GPT_STAGE_BYTES)
@@ -816,6 +817,7 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
         GPT_HIP_CHECK(hipMemsetAsync(c->d_edge, 0, 256, S));
         GPT_HIP_CHECK(hipStreamSynchronize(S));
         c->edge_seq = 0;
+        c->alpha_counter = 0;                  // (the step counter of the wide back-substitution lives in the same words)
     }
     EdgeSig cu_edge_prev, rest_edge_prev;
     EdgeSig next_panel_edge;      // the NEXT panel's edge, allocated early: the main stream's last launch of this panel awaits it at its end
@@ -2181,7 +2183,7 @@ static int ensure_alpha(gpt_ctx *c)
         GPT_TRY(launch_trsv_lt(st, n128, c->dA, NP, c->d_invd, w, nwide / 128));
         GPT_HIP_CHECK(hipMemcpyAsync(c->d_alpha + nwide, w + nwide, (size_t)(n128 - nwide) * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
-    GPT_TRY(launch_trsv_lt_wide(st, nwide, c->dA, NP, U, w, c->d_alpha));
+    GPT_TRY(launch_trsv_lt_wide(st, nwide, c->dA, NP, U, w, c->d_alpha, c->d_edge + 40, &c->alpha_counter));
     c->alpha_valid = true;
     return GPT_OK;
 }
