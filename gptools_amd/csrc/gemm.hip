@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
 // The same 64x64 tile kernel with a TILE LOOP (round 4, VERDICT r3 #4: "remove the per-launch / per-tile fixed cost"): a
 // workgroup walks every G-th entry of the order table instead of one, and pipelines ACROSS tiles -- the k-tile counter runs
 // on through the tile boundary, so the first operand tile of the next output tile is requested by the LDS-DMA of the last
-// k-tile of this one, and the next C tile is requested three k-tiles before the end.  What a fresh workgroup spends before
+// k-tile of this one; the next C tile follows the stores straight into the accumulators.  What a fresh workgroup spends before
 // its first MFMA (per-workgroup stamps, profiles/r02_gemm_stamps.txt: 10.1 of its 53.5 us -- table entry, addresses, C and
 // the first operand tiles requested and waited for) happens under the previous tile's MFMAs; at any time 73 % of the
 // resident workgroups were in their main loop, now all of them are except in the tile's first / last k-tile.
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
 // (same L2 reuse as the one-tile kernel), and the tiles of the urgent columns (partial edge flag) are still the first ones.
 // Launched for the large main-stream updates only (an order table exists, nobody waits inside the kernel, no batch).
 template <int BM, int BN, int WPS>
-__global__ __launch_bounds__(256, WPS) void gemm_nt_loop_kernel(
+__global__ __launch_bounds__(256, 4) void gemm_nt_loop_kernel(
     int64_t m, int64_t n, int64_t k, double alpha, const double *__restrict__ A, int64_t lda,
     const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
     const int2 *__restrict__ order, int64_t order_len, int64_t seg_cols, int64_t bskip, int prio, unsigned *edge_word, unsigned edge_val,
@@ -365,13 +365,13 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_loop_kernel(
     __builtin_amdgcn_s_setprio(3);
 #endif
     int64_t row0 = (int64_t)t.x * BM, col0 = (int64_t)t.y * BN;
-    const double *srcA[BM / 32], *srcB[BN / 32], *nsrcA[BM / 32], *nsrcB[BN / 32];
+    const double *srcA[BM / 32], *srcB[BN / 32];
     stage_ptrs<BM>(A, lda, row0, m, wave, lane, srcA);
     {
         const int64_t brow0 = seg_cols ? col0 + (col0 / seg_cols) * bskip : col0;
         stage_ptrs<BN>(B, ldb, brow0, seg_cols ? (int64_t)1 << 62 : n, wave, lane, srcB);
     }
-    f64x4 acc[RM][RN], cn[RM][RN];
+    f64x4 acc[RM][RN];
 #define GL_LOADC(DST, R0, C0)                                                                              \
     _Pragma("unroll") for (int i = 0; i < RM; i++)                                                         \
     _Pragma("unroll") for (int j = 0; j < RN; j++) {                                                       \
@@ -396,35 +396,27 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_loop_kernel(
     else if (prio == 2) __builtin_amdgcn_s_setprio(2);
 #endif
     int cur = 0;                                    // LDS buffer of the k-tile being multiplied (the counter runs across tiles)
-    const int64_t ctrig = (nk >= 4) ? nk - 3 : 0;   // the k-tile under which the next C tile is requested
     for (;;) {
-        // the next tile of this workgroup, known before the k loop: its addresses are formed under the first MFMAs
+        // the next tile of this workgroup is known before the k loop (one table load under the first MFMAs)
         const int64_t ne = e + G;
         const int2 nt = (ne < order_len) ? order[ne] : make_int2(-1, -1);
         const bool has_next = nt.x >= 0;
-        int64_t nrow0 = 0, ncol0 = 0;
-        if (has_next) {
-            nrow0 = (int64_t)nt.x * BM;
-            ncol0 = (int64_t)nt.y * BN;
-            stage_ptrs<BM>(A, lda, nrow0, m, wave, lane, nsrcA);
-            const int64_t nbrow0 = seg_cols ? ncol0 + (ncol0 / seg_cols) * bskip : ncol0;
-            stage_ptrs<BN>(B, ldb, nbrow0, seg_cols ? (int64_t)1 << 62 : n, wave, lane, nsrcB);
-        }
+        const int64_t nrow0 = (int64_t)nt.x * BM, ncol0 = (int64_t)nt.y * BN;
         for (int64_t kt = 0; kt < nk; kt++) {
             if (kt + 1 < nk) {
                 stage_issue<BM>(srcA, (kt + 1) * GM_BK, ldsA + (cur ^ 1) * ABYTES, wave);
                 stage_issue<BN>(srcB, (kt + 1) * GM_BK, ldsB + (cur ^ 1) * BBYTES, wave);
             } else if (has_next) {
-                stage_issue<BM>(nsrcA, 0, ldsA + (cur ^ 1) * ABYTES, wave);
-                stage_issue<BN>(nsrcB, 0, ldsB + (cur ^ 1) * BBYTES, wave);
+                // last k-tile: this tile's operand pointers are spent -- they become the next tile's, whose first operand
+                // tile is requested here, under this k-tile's MFMAs
+                stage_ptrs<BM>(A, lda, nrow0, m, wave, lane, srcA);
+                const int64_t nbrow0 = seg_cols ? ncol0 + (ncol0 / seg_cols) * bskip : ncol0;
+                stage_ptrs<BN>(B, ldb, nbrow0, seg_cols ? (int64_t)1 << 62 : n, wave, lane, srcB);
+                stage_issue<BM>(srcA, 0, ldsA + (cur ^ 1) * ABYTES, wave);
+                stage_issue<BN>(srcB, 0, ldsB + (cur ^ 1) * BBYTES, wave);
             }
-            // (the C loads are issued BEHIND this k-tile's DMA: loads return in order, so the counted wait below lets the
-            // sixteen of them stay in flight over the barrier instead of exposing their latency here)
-            const bool cload = has_next && kt == ctrig;
-            if (cload) { GL_LOADC(cn, nrow0, ncol0); }
             mma_ktile<RM, RN>(sA[cur], sB[cur], wm * WM, wn * WN, fr, fk, acc);
-            if (cload) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RM * RN * 4) : "memory");
-            else dma_wait();
+            dma_wait();
             __syncthreads();
             cur ^= 1;
         }
@@ -447,18 +439,17 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_loop_kernel(
             }
         if (edge) edge_signal(edge, edge_val, edge_total);
         if (!has_next) break;
-#pragma unroll
-        for (int i = 0; i < RM; i++)
-#pragma unroll
-            for (int j = 0; j < RN; j++) acc[i][j] = cn[i][j] * cs;
+        // the next C tile straight into the accumulators (its operand tile is already on its way; the wait for C sits in front
+        // of the first MFMA, where the other three workgroups of the CU cover it)
         e = ne;
         t = nt;
         row0 = nrow0;
         col0 = ncol0;
+        GL_LOADC(acc, row0, col0);
 #pragma unroll
-        for (int q = 0; q < BM / 32; q++) srcA[q] = nsrcA[q];
+        for (int i = 0; i < RM; i++)
 #pragma unroll
-        for (int q = 0; q < BN / 32; q++) srcB[q] = nsrcB[q];
+            for (int j = 0; j < RN; j++) acc[i][j] = acc[i][j] * cs;
     }
 #undef GL_LOADC
     if (tail_word != nullptr && is_last_wg && tid == 0) edge_poll<16, false>(tail_word, tail_val, tail_err);

@@ -38,12 +38,8 @@ gate.gate_stamp.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 gate.gate_wait.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong]
 
 
-class TimedOps(HipPanelOps):
-    def new_event(self):
-        return _StreamEvent(timing=True)
-
-
-ops = TimedOps(0)
+ops = HipPanelOps(0)          # (plain events on the queues, as in the product: a timing-capable event is a barrier packet, ~6 us of
+                              #  command-processor time each, and the engine records about ten per step)
 
 
 class Recorder(DistributedLML):
