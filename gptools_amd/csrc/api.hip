@@ -350,6 +350,15 @@ static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, 
     // durations with the main stream's would count the same wall time twice)
     const bool on_main = (st == c->stream) || (c->early_stream && st == c->early_stream);
     const bool prof = c->prof_gemm && flops >= 1.0e9 && on_main;
+    // GPT_GEMM_LOG=<file> (evidence aid, scratch/collect_r04.sh): the shape of every >= 1 GFLOP main-stream launch, in launch order, so
+    // that a profiler's per-dispatch counters can be set against the algorithmic flops / bytes of THE SAME launches
+    {
+        static FILE *glog = getenv("GPT_GEMM_LOG") ? fopen(getenv("GPT_GEMM_LOG"), "a") : nullptr;
+        if (glog && flops >= 1.0e9 && on_main) {
+            fprintf(glog, "%lld %lld %lld %d %.6e\n", (long long)m, (long long)n, (long long)k, tri, flops);
+            fflush(glog);
+        }
+    }
     gpt_ctx::GemmProf *gp = nullptr;
     if (prof) {
         if (c->gprof_used == c->gprof.size()) {

@@ -162,13 +162,16 @@ class HipPanelOps(PanelOps):
         # "recv": where a rank that does not own a panel posts its side of the exchange -- an otherwise empty stream,
         # so that the receive never queues up behind this rank's own panel work
         self.recv_stream = torch.cuda.Stream(self.device, priority=-1)
-        self._ctx = {"main": self.ctx_main, "panel": self.ctx_panel}
+        # (a context of its own for "recv": GridLML runs the bulk half of its panel work there -- GEMMs, copies, reductions)
+        self.ctx_recv = _lib.Context(self.device.index, stream=self.recv_stream.cuda_stream)
+        self._ctx = {"main": self.ctx_main, "panel": self.ctx_panel, "recv": self.ctx_recv}
         self._stream = {"main": self.main_stream, "panel": self.panel_stream, "recv": self.recv_stream}
         for c in self._ctx.values():
             c.set_option("lookahead", 0)
         # everything the panel context launches sits on the chain and shares CUs with the main context's trailing update:
         # its GEMM main loops keep a raised wave priority (gemm.hip; the TRSM / fused kernels carry theirs themselves)
         self.ctx_panel.set_option("gemm_prio", int(os.environ.get("GPT_DIST_PANEL_PRIO", "2")))
+        self.ctx_recv.set_option("gemm_prio", int(os.environ.get("GPT_DIST_PANEL_PRIO", "2")))
 
     def queue(self, q):
         return torch.cuda.stream(self._stream[q])
@@ -652,22 +655,30 @@ class GridLML(object):
     ``(I % P_r, J % P_c)`` (rank ``pr * P_c + pc``), so the column update and the solve of a panel are split over the ``P_r``
     ranks of a process column, and only the ``nb x nb`` diagonal block is serial.  K is still built locally (X replicated).
 
-    Step k (panel k = block column k of L; process column ``pc_k = k % P_c``, diagonal owner ``(k % P_r, pc_k)``):
-      1. diagonal owner: factor A[k][k] in place (``gpt_dev_potrf_panel``), ``W = L_kk^-1`` (``gpt_dev_trinv``), broadcast W
-         down its process column;
-      2. the HEAD block ``L[k+1][k] = A[k+1][k] W^T`` is formed first by its holder ``((k+1) % P_r, pc_k)`` and broadcast to
-         everybody: it is all the next diagonal block needs (``A[k+1][k+1] -= H H^T`` on its owner, which then goes to 1 for
-         k+1 -- the chain from diagonal block to diagonal block is two 512^3 products and two small broadcasts long, whatever
-         the height of the panel), and it is the column operand of the look-ahead update of block column k+1;
-      3. every rank ``(pr, pc_k)`` solves its rows I >= k+2 of the panel as ONE GEMM against W and broadcasts them along its
-         process row: every rank then holds the rows ``R`` of panel k that match its block rows;
-      4. the columns ``C`` of panel k that match a rank's block columns J >= k+2 are blocks of ``R`` on the ranks of process
-         row ``J % P_r``: exchanged inside each process column (one broadcast per contributing process row: one for
-         ``P_r | P_c``, ``P_r / gcd`` in general), on a queue and a communicator of their own;
-      5. look-ahead (panel queue): the ranks of process column ``pc_(k+1)`` apply panel k to block column k+1 themselves
-         (``A[I][k+1] -= R[I] H^T``, needs 2 and 3 only) and go on with 3 for panel k+1;
-      6. main queue: ``A[I][J] -= R[I] C[J]^T`` for the rank's blocks with I >= J >= k+2, one launch
-         (``gpt_dev_gemm_nt_gridstair``), the column the next look-ahead touches first ("urgent").
+    Panel k = block column k of L; process column ``pc_k = k % P_c``, diagonal owner ``(k % P_r, pc_k)``.  Three in-order queues
+    per rank, and what each carries is chosen so that the serial CHAIN never queues behind BULK work:
+      CHAIN queue ("panel", high priority):
+        1. diagonal owner: ``A[k][k] -= H(k-1) H(k-1)^T``, factor it in place (``gpt_dev_potrf_panel``), ``W = L_kk^-1``
+           (``gpt_dev_trinv``), broadcast W down its process column;
+        2. the HEAD block ``H(k) = L[k+1][k]`` on its holder ``((k+1) % P_r, pc_k)``: ``A[k+1][k] -= R0(k-1) H(k-1)^T`` (R0:
+           below), ``H(k) = A[k+1][k] W^T``, broadcast to everybody.  Of panel k-1 the chain reads exactly two blocks,
+           ``H(k-1) = L[k][k-1]`` and ``R0(k-1) = L[k+1][k-1]``, both sent early on communicators of their own; per panel it is
+           one 512 x 512 factorisation + inverse, three 512^3 products and two small broadcasts long, whatever the panel's height.
+      BULK queue ("recv"):
+        3. look-ahead: the ranks of process column ``pc_k`` apply panel k-1 to their rows I >= k+1 of block column k
+           (``A[I][k] -= R(k-1)[I] H(k-1)^T``; the head block is the chain's);
+        4. every rank ``(pr, pc_k)`` solves its rows I >= k+2 of the panel as GEMMs against W -- the EARLY block
+           ``R0(k) = L[k+2][k]`` first where its process row has it -- and broadcasts them along its process row: every rank then
+           holds the rows ``R`` of panel k that match its block rows;
+        5. the columns ``C`` of panel k that match a rank's block columns J >= k+2 are blocks of ``R`` on the ranks of process
+           row ``J % P_r``: exchanged inside each process column (one broadcast per contributing process row: one for
+           ``P_r | P_c``, ``P_r / gcd`` in general).
+      MAIN queue (CU-masked):
+        6. ``A[I][J] -= R[I] C[J]^T`` for the rank's blocks with I >= J >= k+2, one launch (``gpt_dev_gemm_nt_gridstair``), the
+           column the next look-ahead touches first ("urgent").
+    (Round 4's first form had 1-5 on ONE queue: the head block of panel k+1 then waited behind the look-ahead update of step k,
+    which waits for the bulk of panel k to arrive -- modelled at 73-185 ms for C4 on 8 ranks, the chain advancing at the pace of
+    the bulk transfers.)
     ``z = L^-1 y`` rides along as the augmented row N and is summed where its pieces come to rest; one
     all-reduce of (sum log L_ii, z.z, info) ends the evaluation.  ``fit`` returns the same ``(ll_data, logdet_half)`` on every
     rank.  ``grid = (1, W)`` is the 1-D block-column layout, ``(W, 1)`` a block-row layout.  UNMEASURED ON MORE THAN ONE GPU:
@@ -704,15 +715,16 @@ class GridLML(object):
         # communicators: one per process row (panel rows), two per process column (the inverse of the diagonal block / the
         # column exchange: the latter must never queue behind a diagonal block that is still being factored), the whole grid
         # for the head blocks and the final reduction.  Every rank creates every group, in the same order.
-        self.g_row = self.g_colw = self.g_colx = None
+        self.g_row = self.g_row0 = self.g_colw = self.g_colx = None
         self._ranks = list(range(self.world))
         if inited and layout is None:
             self._ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
             if self.world > 1 or self.force_collectives:
                 for r in range(self.Pr):
-                    g = dist.new_group(ranks=[self._ranks[r * self.Pc + c] for c in range(self.Pc)])
+                    members = [self._ranks[r * self.Pc + c] for c in range(self.Pc)]
+                    g, g0 = dist.new_group(ranks=members), dist.new_group(ranks=members)
                     if r == self.pr:
-                        self.g_row = g
+                        self.g_row, self.g_row0 = g, g0
                 for c in range(self.Pc):
                     members = [self._ranks[r * self.Pc + c] for r in range(self.Pr)]
                     gw, gx = dist.new_group(ranks=members), dist.new_group(ranks=members)
@@ -759,6 +771,7 @@ class GridLML(object):
         self.y = torch.empty((self.NP,), **f64)
         self.err = torch.zeros((self.NP,), **f64)
         self.red = torch.zeros((3,), **f64)
+        self.red_b = torch.zeros((3,), **f64)                 # the bulk queue's share of the two ll scalars (its own accumulator)
         on_gpu = dev.type == "cuda"
         self._h_in = torch.from_numpy(_lib.pinned_empty((2, self.NP), min_bytes=0)) if on_gpu else None
         self._h_out = torch.from_numpy(_lib.pinned_empty((3,), min_bytes=0)) if on_gpu else None
@@ -853,148 +866,188 @@ class GridLML(object):
                 ev_asm.wait()
         last = nblk - 1
         zrow_local = (last // Pr) * nb + (N - last * nb)       # local row of the augmented row on the ranks of its process row
-        ev_urg, ev_done, ev_la = {}, {}, {}
-        arr_R, arr_C, wW, wH = {}, {}, {}, {}
+        self.red_b.zero_()
+        CH, BK = "panel", "recv"                               # the CHAIN queue and the BULK queue (see the class docstring)
+        ev_urg, ev_done, ev_ch, ev_bk = {}, {}, {}, {}
+        arr_W, arr_H, arr_R0, arr_R, arr_C = {}, {}, {}, {}, {}
+        self._late = []
 
-        def reuse(k):
-            """Slot k % NBUF is about to be written for panel k: whoever still read panel k - NBUF from it must be through."""
-            for d in (ev_done, ev_la):
-                if k - NBUF in d:
-                    d.pop(k - NBUF).wait()
+        def reuse(p):
+            """Slot p % NBUF is about to be written for panel p by the current queue: whoever still read panel p - NBUF from it
+            -- the main queue's update, the chain queue, the bulk queue -- must be through."""
+            for d in (ev_done, ev_ch, ev_bk):
+                e_ = d.get(p - NBUF)
+                if e_ is not None:
+                    e_.wait()
 
-        def diag(k):
-            """Step 1 on the panel queue of every rank of process column pc_k (the owner computes, all take part in the
-            broadcast of W)."""
-            s = k % NBUF
-            if pc != k % Pc:
-                return
-            if pr == k % Pr:
-                blk = self._blk(k, k)
-                ops.potrf_panel(nb, nb, blk.data_ptr(), ld, self.invd, self.info, k * nb)
-                ops.trinv(nb, blk.data_ptr(), ld, self.invd, self.W[s].data_ptr(), nb)
-                w = min(nb, N - k * nb)
-                if w > 0:
-                    ops.panel_scalars(blk, w, N - k * nb if k == last else -1, self.red)
-                self._mark(k, "W made")
-            wW[k] = self._xbcast("W", k, self.W[s], (k % Pr, k % Pc), self.g_colw, Pr)
+        def wait_all(arrs):
+            for a_ in arrs:
+                if a_ is not None:
+                    a_.wait()
 
-        def panel(k):
-            """Steps 2 and 3 on the panel queue (W of panel k is on its way): head block, then the rank's rows of the panel,
-            each broadcast as soon as it exists.  Every rank takes part in the head broadcast."""
-            s = k % NBUF
-            mine = pc == k % Pc
-            lk = k // Pc
-            if mine:
-                for w_ in wW.pop(k, []):
-                    w_.wait()
-            if k + 1 < nblk:
-                if mine and pr == (k + 1) % Pr:
-                    ops.gemm_nt(nb, nb, nb, 1.0, self._blk(k + 1, k).data_ptr(), ld, self.W[s].data_ptr(), nb, 0.0,
-                                self.H[s].data_ptr(), nb, 0, q="panel")
-                    if k + 1 == last:
-                        ops.row_sumsq(self.H[s][N - last * nb], self.red)
-                    self._mark(k, "H made")
-                wH[k] = self._xbcast("H", k, self.H[s], ((k + 1) % Pr, k % Pc), self.group, self.world)
-            li0 = self.li_ge(k + 2)
-            m = (self.nlr - li0) * nb
-            ev = None
-            if mine and m > 0:
-                ops.gemm_nt(m, nb, nb, 1.0, _ptr(A, li0 * nb, lk * nb), ld, self.W[s].data_ptr(), nb, 0.0,
-                            _ptr(self.R[s], li0 * nb, 0), nb, 0, q="panel")
-                if pr == last % Pr and last >= k + 2:
-                    ops.row_sumsq(self.R[s][zrow_local], self.red)
-                ev = ops.new_event()
-                ev.record()
-                self._mark(k, "R made")
-            works = self._xbcast("R", k, self.R[s][li0 * nb:self.nlr * nb], (pr, k % Pc), self.g_row, Pc) if m > 0 else []
-            arr_R[k] = _Arrival(works, ev)
+        def chain(k):
+            """Chain queue, panel p = k + 1 (k = -1: panel 0): the diagonal block and the head block L[p+1][p] -- what the NEXT
+            diagonal block waits for.  Needs of panel k only the two early blocks H(k) = L[k+1][k] and R0(k) = L[k+2][k]."""
+            p = k + 1
+            s, s1 = k % NBUF, p % NBUF
+            pcp = p % Pc
+            with ops.queue(CH):
+                reuse(p)
+                if k >= 0 and not self.lookahead:
+                    ev_done[k].wait()
+                in_col = pc == pcp
+                urg = ev_urg.get(k - 1)
+                is_diag = in_col and pr == p % Pr
+                is_head = in_col and p + 1 < nblk and pr == (p + 1) % Pr
+                if (is_diag or is_head) and urg is not None:
+                    urg.wait()                                         # block column p is up to date with panel k - 1
+                if k >= 0:
+                    hk = arr_H.get(k)
+                    if is_diag or is_head:
+                        wait_all([hk])
+                    elif hk is not None:
+                        self._late.append(hk)                          # (receive side of a broadcast this queue does not read)
+                if is_diag:
+                    blk = self._blk(p, p)
+                    if k >= 0:
+                        ops.gemm_nt(nb, nb, nb, -1.0, self.H[s].data_ptr(), nb, self.H[s].data_ptr(), nb, 1.0, blk.data_ptr(), ld, 1,
+                                    q=CH)
+                    ops.potrf_panel(nb, nb, blk.data_ptr(), ld, self.invd, self.info, p * nb)
+                    ops.trinv(nb, blk.data_ptr(), ld, self.invd, self.W[s1].data_ptr(), nb)
+                    w = min(nb, N - p * nb)
+                    if w > 0:
+                        ops.panel_scalars(blk, w, N - p * nb if p == last else -1, self.red)
+                    self._mark(p, "W made")
+                if in_col:
+                    ev = None
+                    if is_diag:
+                        ev = ops.new_event()
+                        ev.record()
+                    arr_W[p] = _Arrival(self._xbcast("W", p, self.W[s1], (p % Pr, pcp), self.g_colw, Pr), ev)
+                if p + 1 < nblk:
+                    ev = None
+                    if is_head:
+                        hb = self._blk(p + 1, p)
+                        if k >= 0:
+                            wait_all([arr_R0.get(k)])
+                            li_r0 = (p + 1) // Pr                      # R0(k) = L[p+1][k] sits at its block row in R[s]
+                            ops.gemm_nt(nb, nb, nb, -1.0, _ptr(self.R[s], li_r0 * nb, 0), nb, self.H[s].data_ptr(), nb, 1.0,
+                                        hb.data_ptr(), ld, 0, q=CH)
+                        wait_all([arr_W[p]])
+                        ops.gemm_nt(nb, nb, nb, 1.0, hb.data_ptr(), ld, self.W[s1].data_ptr(), nb, 0.0, self.H[s1].data_ptr(), nb, 0,
+                                    q=CH)
+                        if p + 1 == last:
+                            ops.row_sumsq(self.H[s1][N - last * nb], self.red, q=CH)
+                        self._mark(p, "H made")
+                        ev = ops.new_event()
+                        ev.record()
+                    arr_H[p] = _Arrival(self._xbcast("H", p, self.H[s1], ((p + 1) % Pr, pcp), self.group, self.world), ev)
+                ev_ch[p] = ops.new_event()
+                ev_ch[p].record()
 
-        def exchange(k):
-            """Step 4 on the "recv" queue: the rank's columns J >= k + 2 of panel k, gathered from the process rows that hold
-            them.  Source process row q holds the blocks J = J_q0 + t * lcm(P_r, P_c); in its R they are ``lcm / P_r`` block rows
-            apart, in C ``lcm / P_c`` block columns."""
-            s = k % NBUF
-            lj0 = self.lj_ge(k + 2)
+        def bulk(k):
+            """Bulk queue, panel p = k + 1: the look-ahead update of block column p with panel k (rows p + 2 ..), the rank's rows of
+            panel p -- the early block R0(p) = L[p+2][p] first, on its own communicator -- and the column exchange."""
+            p = k + 1
+            s, s1 = k % NBUF, p % NBUF
+            pcp = p % Pc
+            lp = p // Pc
+            with ops.queue(BK):
+                reuse(p)
+                if k >= 0 and not self.lookahead:
+                    ev_done[k].wait()
+                in_col = pc == pcp
+                li0 = self.li_ge(p + 2)                                # first block row of the slices of panel p
+                rows0 = pr == (p + 2) % Pr and p + 2 < nblk            # this process row holds the early block R0(p)
+                if in_col and k >= 0:
+                    urg = ev_urg.get(k - 1)
+                    if urg is not None:
+                        urg.wait()
+                    lu = self.li_ge(p + 1)                             # look-ahead update: rows I >= p + 1 ...
+                    if pr == (p + 1) % Pr:
+                        lu += 1                                        # ... except the head block (the chain queue's)
+                    m = (self.nlr - lu) * nb
+                    if m > 0:
+                        wait_all([arr_H.get(k), arr_R0.get(k), arr_R.get(k)])
+                        first = nb if (rows0 and lu == li0 and m > nb) else 0      # the block R0(p) comes from: first, alone
+                        for (r0_, m_) in ((0, first), (first, m - first)):
+                            if m_ > 0:
+                                ops.gemm_nt(m_, nb, nb, -1.0, _ptr(self.R[s], lu * nb + r0_, 0), nb, self.H[s].data_ptr(), nb, 1.0,
+                                            _ptr(A, lu * nb + r0_, lp * nb), ld, 0, q=BK)
+                    self._mark(k, "LA done")
+                # the rank's rows of panel p: R0 first where this process row has it, then the rest
+                m = (self.nlr - li0) * nb
+                if in_col and m > 0:
+                    wait_all([arr_W[p]])
+                n0 = nb if (rows0 and m > 0) else 0
+                if n0:
+                    ev = None
+                    if in_col:
+                        ops.gemm_nt(nb, nb, nb, 1.0, _ptr(A, li0 * nb, lp * nb), ld, self.W[s1].data_ptr(), nb, 0.0,
+                                    _ptr(self.R[s1], li0 * nb, 0), nb, 0, q=BK)
+                        if p + 2 == last:
+                            ops.row_sumsq(self.R[s1][zrow_local], self.red_b, q=BK)
+                        ev = ops.new_event()
+                        ev.record()
+                    arr_R0[p] = _Arrival(self._xbcast("R0", p, self.R[s1][li0 * nb:(li0 + 1) * nb], (pr, pcp), self.g_row0, Pc), ev)
+                ev, works = None, []
+                if m - n0 > 0:
+                    if in_col:
+                        ops.gemm_nt(m - n0, nb, nb, 1.0, _ptr(A, li0 * nb + n0, lp * nb), ld, self.W[s1].data_ptr(), nb, 0.0,
+                                    _ptr(self.R[s1], li0 * nb + n0, 0), nb, 0, q=BK)
+                        if pr == last % Pr and last >= p + 2 and not (n0 and p + 2 == last):
+                            ops.row_sumsq(self.R[s1][zrow_local], self.red_b, q=BK)
+                        ev = ops.new_event()
+                        ev.record()
+                        self._mark(p, "R made")
+                    works = self._xbcast("R", p, self.R[s1][li0 * nb + n0:self.nlr * nb], (pr, pcp), self.g_row, Pc)
+                arr_R[p] = _Arrival(works, ev)
+                exchange(p)
+                ev_bk[p] = ops.new_event()
+                ev_bk[p].record()
+
+        def exchange(p):
+            """(bulk queue) The rank's columns J >= p + 2 of panel p, gathered from the process rows that hold them.  Source
+            process row q holds the blocks J = J_q0 + t * lcm(P_r, P_c); in its R they are ``lcm / P_r`` block rows apart, in C
+            ``lcm / P_c`` block columns."""
+            s1 = p % NBUF
+            lj0 = self.lj_ge(p + 2)
             if lj0 >= self.nlc:
-                arr_C[k] = _Arrival([], None)
+                arr_C[p] = _Arrival([], None)
                 return
             sc, sr = self.lcm // Pc, self.lcm // Pr
             bb = nb * nb
-            with ops.queue("recv"):
-                reuse_c(k)
-                arr_R[k].wait()
-                Cv = self.C[s]
-                qi = 0
-                for q in range(Pr):
-                    J0 = next((J for J in self.my_cols[lj0:lj0 + sc] if J % Pr == q), None)
-                    if J0 is None:
-                        continue
-                    nt = (nblk - 1 - J0) // self.lcm + 1
-                    ljq = J0 // Pc
-                    direct = sc == 1                       # one contributing process row: its share IS the rank's C
-                    dst = Cv[ljq * nb:(ljq + nt) * nb] if direct else self.piece[s][qi][:nt * nb]
-                    qi += 1
-                    if q == pr:
-                        liq = J0 // Pr
-                        src = torch.as_strided(self.R[s], (nt, bb), (sr * bb, 1), liq * bb)
-                        ops.copy2d(dst.view(nt, bb), src, q="recv")
-                    for w_ in self._xbcast("C", k, dst, (q, pc), self.g_colx, Pr):
-                        w_.wait()
-                    if not direct:
-                        ops.copy2d(torch.as_strided(Cv, (nt, bb), (sc * bb, 1), ljq * bb), dst.view(nt, bb), q="recv")
-                ev = ops.new_event()
-                ev.record()
-                self._mark(k, "C there")
-            arr_C[k] = _Arrival([], ev)
-
-        ev_cq = {}
-
-        def reuse_c(k):
-            if k - NBUF in ev_cq:
-                ev_cq.pop(k - NBUF).wait()
-
-        def step_panel(k):
-            """Panel / "recv" queues, after panel k is on its way: everything of panel k + 1 (steps 1-5)."""
-            s, nxt = k % NBUF, k + 1
-            with ops.queue("panel"):
-                reuse(nxt)
-                if not self.lookahead:
-                    ev_done[k].wait()                                  # nothing of step k+1 before update k is through
-                in_col = pc == nxt % Pc
-                urg = ev_urg.pop(k - 1, None)
-                if in_col and urg is not None:
-                    urg.wait()                                         # block column k+1 is up to date with panel k-1
-                hw = wH.pop(k, [])
-                if in_col:
-                    for w_ in hw:
-                        w_.wait()
-                    if pr == nxt % Pr:
-                        # the next diagonal block needs the head block only (step 2): update, factor, invert, send
-                        ops.gemm_nt(nb, nb, nb, -1.0, self.H[s].data_ptr(), nb, self.H[s].data_ptr(), nb, 1.0,
-                                    self._blk(nxt, nxt).data_ptr(), ld, 1, q="panel")
-                else:
-                    self._late_h += hw                                 # (receive side of a broadcast nobody here reads)
-                diag(nxt)
-                if in_col:
-                    # step 5: the rest of block column k+1 against this rank's rows of panel k
-                    li0 = self.li_ge(k + 2)
-                    m = (self.nlr - li0) * nb
-                    if m > 0:
-                        arr_R[k].wait()
-                        ops.gemm_nt(m, nb, nb, -1.0, _ptr(self.R[s], li0 * nb, 0), nb, self.H[s].data_ptr(), nb, 1.0,
-                                    _ptr(A, li0 * nb, (nxt // Pc) * nb), ld, 0, q="panel")
-                    ev_la[k] = ops.new_event()
-                    ev_la[k].record()
-                    self._mark(k, "LA done")
-                panel(nxt)
-            exchange(nxt)
+            wait_all([arr_R0.get(p), arr_R.get(p)])
+            Cv = self.C[s1]
+            qi = 0
+            for q in range(Pr):
+                J0 = next((J for J in self.my_cols[lj0:lj0 + sc] if J % Pr == q), None)
+                if J0 is None:
+                    continue
+                nt = (nblk - 1 - J0) // self.lcm + 1
+                ljq = J0 // Pc
+                direct = sc == 1                       # one contributing process row: its share IS the rank's C
+                dst = Cv[ljq * nb:(ljq + nt) * nb] if direct else self.piece[s1][qi][:nt * nb]
+                qi += 1
+                if q == pr:
+                    liq = J0 // Pr
+                    src = torch.as_strided(self.R[s1], (nt, bb), (sr * bb, 1), liq * bb)
+                    ops.copy2d(dst.view(nt, bb), src, q=BK)
+                for w_ in self._xbcast("C", p, dst, (q, pc), self.g_colx, Pr):
+                    w_.wait()
+                if not direct:
+                    ops.copy2d(torch.as_strided(Cv, (nt, bb), (sc * bb, 1), ljq * bb), dst.view(nt, bb), q=BK)
+            ev = ops.new_event()
+            ev.record()
+            self._mark(p, "C there")
+            arr_C[p] = _Arrival([], ev)
 
         def step_main(k):
-            """Step 6: panel k applied to the rank's blocks with I >= J >= k + 2."""
+            """Panel k applied to the rank's blocks with I >= J >= k + 2 (main queue), the column the next look-ahead touches
+            first."""
             s = k % NBUF
             with ops.queue("main"):
-                arr_R[k].wait()
-                arr_C[k].wait()
+                wait_all([arr_R0.get(k), arr_R.get(k), arr_C.get(k)])
                 self._mark(k, "arrived")
                 li0 = self.li_ge(k + 2)
                 lj0 = self.lj_ge(k + 2)
@@ -1013,27 +1066,28 @@ class GridLML(object):
                             ev_urg[k].record()
                 ev_done[k] = ops.new_event()
                 ev_done[k].record()
-                ev_cq[k] = ev_done[k]
                 self._mark(k, "applied")
 
-        # ---- the schedule.  Look-ahead: the chain (panel k + 1) is enqueued before update k and overlaps it; without it the
-        # same operations run one after the other.
-        self._late_h = []
-        with ops.queue("panel"):
-            diag(0)
-            panel(0)
-        exchange(0)
+        # ---- the schedule.  Look-ahead: the chain and the bulk of panel k + 1 are enqueued before update k and overlap it;
+        # without it the same operations run one after the other.
+        chain(-1)
+        bulk(-1)
         for k in range(nblk):
             if self.lookahead:
                 if k + 1 < nblk:
-                    step_panel(k)
+                    chain(k)
+                    bulk(k)
                 step_main(k)
             else:
                 step_main(k)
                 if k + 1 < nblk:
-                    step_panel(k)
-            arr_R.pop(k, None)
-            arr_C.pop(k, None)
+                    chain(k)
+                    bulk(k)
+            for d in (arr_W, arr_H, arr_R0, arr_R, arr_C, ev_urg, ev_done, ev_ch, ev_bk):
+                d.pop(k - NBUF - 2, None)
+        with ops.queue(BK):
+            self._ev_bulk_end = ops.new_event()
+            self._ev_bulk_end.record()
         return self._finish(t_host0)
 
     def _mark(self, k, tag):
@@ -1046,10 +1100,12 @@ class GridLML(object):
         ops, N = self.ops, self.N
         self.timings["host_enqueue_s"] = time.perf_counter() - t_host0
         with ops.queue("panel"):
-            for w_ in getattr(self, "_late_h", []):
+            for w_ in getattr(self, "_late", []):
                 w_.wait()
-            self._late_h = []
+            self._late = []
+            self._ev_bulk_end.wait()
             red = self.red
+            red[:2] += self.red_b[:2]
             red[2] = self.info.to(torch.float64)[0]
             if self.world > 1 or self.force_collectives or self._model:
                 info_t = red[2:3].clone()

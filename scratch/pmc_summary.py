@@ -71,6 +71,19 @@ def big_launch_bytes(path, counter):
                 and r['Queue_Id'] == mainq and int(r['Grid_Size']) >= MIN_GRID:
             per[r['Dispatch_Id']] += float(r['Counter_Value'])
     return len(per), sum(per.values()) * 1024.0
+# algorithmic flops / bytes of THE SAME launches: the library logged their shapes (GPT_GEMM_LOG, api.hip gemm_nt) during the
+# FETCH_SIZE pass, in launch order -- C read + written once (16 B per computed element) + the operand panel once (the B rows of a
+# trailing update are a subset of its A rows: 8 k max(m, n) bytes)
+ALG = {}
+try:
+    shapes = [l.split() for l in open(src + '/pmc_fetch_gemm_shapes.txt') if l.strip()]
+    fl = [float(x[4]) for x in shapes]
+    by = [16.0 * float(x[4]) / (2.0 * float(x[2])) + 8.0 * float(x[2]) * max(float(x[0]), float(x[1])) for x in shapes]
+    ALG = {"logged_launches": len(shapes), "flops_per_launch": sum(fl) / len(fl), "algorithmic_bytes_per_launch": sum(by) / len(by),
+           "algorithmic_note": "shapes of the measured launches themselves (GPT_GEMM_LOG during the FETCH_SIZE pass): 16 B per computed "
+                               "element of C + the operand panel once"}
+except Exception as e:
+    ALG = {"algorithmic_note": "no shape log: %r" % (e,)}
 nf, fb = big_launch_bytes(src + '/pmc_fetch/t_counter_collection.csv', 'FETCH_SIZE')
 nw, wb = big_launch_bytes(src + '/pmc_write/t_counter_collection.csv', 'WRITE_SIZE')
 tj = {"round": int(sys.argv[4]) if len(sys.argv) > 4 else 2, "kernel": "gemm_nt_kernel<64,64>",
@@ -78,6 +91,8 @@ tj = {"round": int(sys.argv[4]) if len(sys.argv) > 4 else 2, "kernel": "gemm_nt_
       "launches": nf, "launches_per_evaluation": round(nf / 3.0, 1),
       "note": "counter collection runs one kernel at a time, so the library falls back to event edges there (api.hip, EvalScope): these are the launches of the EVENT schedule (urgent and rest separate); the timed bench line runs the flag schedule with urgent + rest merged: bytes per launch scale with the flops per launch, the ratio to the algorithmic bytes is what carries over", "fetch_bytes_per_launch_x2_corrected": 2 * fb / nf, "write_bytes_per_launch": wb / nw,
       "hbm_bytes_per_launch": 2 * fb / nf + wb / nw,
+      **ALG, "ratio": ((2 * fb / nf + wb / nw) / ALG["algorithmic_bytes_per_launch"]) if "algorithmic_bytes_per_launch" in ALG else None,
+      "launch_count_matches_log": (ALG.get("logged_launches") == nf),
       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, scratch/prof_all.sh); FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md"}
 if len(sys.argv) > 3:
     json.dump(tj, open(sys.argv[3], 'w'), indent=1)

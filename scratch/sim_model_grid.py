@@ -98,10 +98,14 @@ class ModelRank(GridLML):
             buf.copy_(Winv[k])
         elif kind == "H":
             buf.copy_(P[nb:2 * nb])
-        elif kind == "R":
+        elif kind in ("R", "R0"):
+            # the rank's rows I >= k + 2 of panel k ("R0": the first of them alone, "R": the rest where an R0 exists, else all)
             li0 = self.li_ge(k + 2)
+            has0 = self.pr == (k + 2) % self.Pr and k + 2 < nblk
             rows = self.my_rows[li0:]
-            buf.view(len(rows), nb, nb).copy_(P.view(-1, nb, nb)[rows[0] - k::self.Pr][:len(rows)])
+            rows = rows[:1] if kind == "R0" else (rows[1:] if has0 else rows)
+            if rows:
+                buf.view(len(rows), nb, nb).copy_(P.view(-1, nb, nb)[rows[0] - k::self.Pr][:len(rows)])
         else:
             # process row src[0]'s share of this rank's columns J >= k + 2: J = J0 + t lcm
             lj0 = self.lj_ge(k + 2)
@@ -130,7 +134,7 @@ def members(kind, k, src):
         return [(r, src[1]) for r in range(Pr) if r != src[0]]
     if kind == "H":
         return [(r, c) for r in range(Pr) for c in range(Pc) if (r, c) != src]
-    if kind == "R":
+    if kind in ("R", "R0"):
         return [(src[0], c) for c in range(Pc) if c != src[1]]
     return [(r, src[1]) for r in range(Pr) if r != src[0]]
 
@@ -150,7 +154,11 @@ for r in range(W):
             p._payload("H", k, p.H[k], None)
         li0 = p.li_ge(k + 2)
         if p.pc != k % Pc and li0 < p.nlr:
-            p._payload("R", k, p.R[k][li0 * NB:p.nlr * NB], None)
+            has0 = p.pr == (k + 2) % Pr and k + 2 < nblk
+            if has0:
+                p._payload("R0", k, p.R[k][li0 * NB:(li0 + 1) * NB], None)
+            if p.nlr - li0 - int(has0) > 0:
+                p._payload("R", k, p.R[k][(li0 + int(has0)) * NB:p.nlr * NB], None)
         lj0 = p.lj_ge(k + 2)
         if lj0 < p.nlc:
             sc, qi = p.lcm // Pc, 0
