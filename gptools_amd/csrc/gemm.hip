@@ -777,13 +777,15 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
     // register file on every CU to the high-priority panel stream (whose own GEMMs and TRSMs need 32 / 9 KiB).
     const size_t dyn = (BM == 64) ? (size_t)lds_pad : 0;
     // Large ordered launches of the 64x64 kernel (the main stream's trailing updates, the staircases of the partitioned engines)
-    // walk the table with a tile loop (gemm_nt_loop_kernel): as many workgroups as are resident at once on the stream's CUs
-    // -- 4 per CU; a CU-masked stream has fewer CUs, the surplus workgroups of the last round simply start later -- each taking
-    // every G-th tile.  GPT_GEMM_LOOP=0 switches it off (A/B), =<n> sets the workgroups per CU.
+    // CAN walk the table with a tile loop (gemm_nt_loop_kernel): as many workgroups as are resident at once on the stream's CUs,
+    // each taking every G-th tile.  GPT_GEMM_LOOP=<workgroups per CU> switches it on; OFF by default: measured slower (round 4,
+    // same-box A/B: N = 8192 4.40 -> 4.72 ms, N = 16384 27.6 -> 33.6 ms at 4 per CU, 88 VGPRs, no spill) -- the one-tile kernel's
+    // prologue is already hidden by the three other workgroups of its CU and by the hardware's own re-dispatch, while the loop
+    // adds a wait for the previous tile's stores in front of every tile's first barrier (stores count in vmcnt on gfx9).
     if constexpr (BM == 64 && NSTAGE == 2) if (order != nullptr && !wait.word && nbatch == 1 && nwg >= 2048) {
         static int per_cu = -1, ncu = 0;
         if (per_cu < 0) {
-            per_cu = 4;
+            per_cu = 0;
             if (const char *e = getenv("GPT_GEMM_LOOP")) per_cu = atoi(e);
             int dev = 0;
             hipDeviceProp_t prop;

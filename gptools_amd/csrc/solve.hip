@@ -568,17 +568,24 @@ __global__ __launch_bounds__(256) void trsv_step_kernel(int64_t ncols, const dou
     __syncthreads();
     // rows [64 b, 64 b + 64) of x_prev = Uprev w_prev: a wave per row, sixteen rows per wave, 4 KB of the row per read
     const int64_t r0 = (int64_t)blockIdx.x * 64 + g * 16;
-    for (int rr = 0; rr < 16; rr++) {
-        const double *ur = Uprev + (r0 + rr) * TW_NB;
-        double s0 = 0.0, s1 = 0.0;
+    for (int rr = 0; rr < 16; rr += 4) {                        // four rows per pass: 32 loads in flight per lane
+        double u[4][TW_NB / 64];
 #pragma unroll
-        for (int q = 0; q < TW_NB / 64; q += 2) {
-            s0 = fma(ur[lane + 64 * q], xs[lane + 64 * q], s0);
-            s1 = fma(ur[lane + 64 * (q + 1)], xs[lane + 64 * (q + 1)], s1);
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int q = 0; q < TW_NB / 64; q++) u[a][q] = Uprev[(r0 + rr + a) * TW_NB + lane + 64 * q];
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int q = 0; q < TW_NB / 64; q += 2) {
+                s0 = fma(u[a][q], xs[lane + 64 * q], s0);
+                s1 = fma(u[a][q + 1], xs[lane + 64 * (q + 1)], s1);
+            }
+            double sum = s0 + s1;
+            for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+            if (lane == 0) xprev[r0 + rr + a] = sum;
         }
-        double sum = s0 + s1;
-        for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
-        if (lane == 0) xprev[r0 + rr] = sum;
     }
 }
 
