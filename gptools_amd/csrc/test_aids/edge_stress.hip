@@ -28,19 +28,38 @@ __global__ void xcc_probe_kernel(unsigned *out)
     if (threadIdx.x == 0) out[blockIdx.x] = xcc & 0xf;
 }
 
-__device__ __forceinline__ double payload_value(unsigned it, int64_t i) { return (double)it * 65536.0 + (double)(i & 0xffff); }
-
-__global__ __launch_bounds__(256) void producer_kernel(double *__restrict__ P, int64_t n, unsigned it, int mode, unsigned *flag,
-                                                       const unsigned *ready, unsigned *xcc_out, unsigned *err, int slot)
+// The first `nwork` workgroups of the launch that find themselves on XCD `want_xcc` take part (slot 0 .. nwork - 1); everybody
+// else leaves at once.  `claim` is zeroed by the host in front of every launch.
+__device__ __forceinline__ int64_t claim_slot(unsigned *claim, int want_xcc, int nwork, unsigned *xcc_out)
 {
-    if ((int)(blockIdx.x & 7) != slot) return;                   // (placement: see edge_stress_run)
-    const int64_t wb = blockIdx.x >> 3, nw = gridDim.x >> 3;
+    __shared__ int slot_s;
     if (threadIdx.x == 0) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        atomicOr(xcc_out, 1u << (xcc & 0xf));
-        edge_poll<2, false>(ready, it, err);                     // the consumer has cached the old payload and is spinning
+        xcc &= 0xf;
+        int sl = -1;
+        if ((int)xcc == want_xcc) {
+            const unsigned c = atomicAdd(claim, 1u);
+            if ((int)c < nwork) {
+                sl = (int)c;
+                atomicOr(xcc_out, 1u << xcc);
+            }
+        }
+        slot_s = sl;
     }
+    __syncthreads();
+    return slot_s;
+}
+
+__device__ __forceinline__ double payload_value(unsigned it, int64_t i) { return (double)it * 65536.0 + (double)(i & 0xffff); }
+
+__global__ __launch_bounds__(256) void producer_kernel(double *__restrict__ P, int64_t n, unsigned it, int mode, unsigned *flag,
+                                                       const unsigned *ready, unsigned *xcc_out, unsigned *err, int want_xcc,
+                                                       unsigned *claim, int nwork)
+{
+    const int64_t wb = claim_slot(claim, want_xcc, nwork, xcc_out), nw = nwork;      // (placement: see edge_stress_run)
+    if (wb < 0) return;
+    if (threadIdx.x == 0) edge_poll<2, false>(ready, it, err);   // the consumer has cached the old payload and is spinning
     __syncthreads();
     for (int64_t i = wb * 256 + threadIdx.x; i < n; i += nw * 256) {
         const double v = payload_value(it, i);
@@ -52,16 +71,12 @@ __global__ __launch_bounds__(256) void producer_kernel(double *__restrict__ P, i
 
 __global__ __launch_bounds__(256) void consumer_kernel(const double *__restrict__ P, int64_t n, unsigned it, int mode,
                                                        const unsigned *flag, unsigned *ready, unsigned *ready_count,
-                                                       unsigned long long *bad, double *sink, unsigned *xcc_out, int stage, unsigned *err, int slot)
+                                                       unsigned long long *bad, double *sink, unsigned *xcc_out, int stage, unsigned *err, int want_xcc,
+                                                       unsigned *claim, int nwork)
 {
     // stage 0: whole consumer; 1: pre-warm + ready only (mode 4, kernel 1); 2: verify only (mode 4, kernel 3)
-    if ((int)(blockIdx.x & 7) != slot) return;
-    const int64_t wb = blockIdx.x >> 3, nw = gridDim.x >> 3;
-    if (threadIdx.x == 0) {
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        atomicOr(xcc_out, 1u << (xcc & 0xf));
-    }
+    const int64_t wb = claim_slot(claim, want_xcc, nwork, xcc_out), nw = nwork;
+    if (wb < 0) return;
     if (stage != 2) {
         double s = 0.0;
         for (int64_t i = wb * 256 + threadIdx.x; i < n; i += nw * 256) s += P[i];   // plain: into this XCD's L2
@@ -96,10 +111,10 @@ __global__ void stress_wait_kernel(const unsigned *word, unsigned value, unsigne
 }
 
 // Placement.  CU masks cannot pin a stream to one XCD on this GPU (measured: every 32-CU mask, contiguous or strided, sees all
-// eight XCC ids -- the mask is applied inside every XCD), but the dispatcher deals the workgroups of a launch round robin over
-// the XCDs: workgroup b lands on XCD b % 8 (the rule the GEMM's tile order is built on).  So both kernels are launched with
-// 8 x wgs workgroups of which only those with b % 8 == slot work (producer: slot 0, consumer: slot 1); every working workgroup
-// records its XCC id, and an iteration in which producer and consumer did not sit on two different XCDs does not count.
+// eight XCC ids -- the mask is applied inside every XCD), and a small launch is not dealt round robin either (64 workgroups
+// all reported XCC 7).  So both kernels are launched LARGE (2048 workgroups, spread over all XCDs), every workgroup reads its
+// own XCC id, and only the first `wgs` that find themselves on the wanted XCD work (producer: XCD 0, consumer: XCD 1; a claim
+// counter zeroed in front of every launch); the XCC ids of the working workgroups are reported back.
 extern "C" int edge_stress_run(int mode, int iters, long long n_doubles, int wgs, long long *out)
 {
     int dev = 0;
@@ -120,17 +135,19 @@ extern "C" int edge_stress_run(int mode, int iters, long long n_doubles, int wgs
     long long bad_iters = 0, bad_words = 0;
     for (int it = 1; it <= iters; it++) {
         hipMemsetAsync(bad, 0, 8, sc);
+        hipMemsetAsync(words + 56, 0, 16, sc);                     // claim counters: [56] consumer kernel 1, [57] consumer kernel 2, [58] producer
+        hipStreamSynchronize(sc);
         if (mode == 4) {
-            hipLaunchKernelGGL(consumer_kernel, dim3(8 * wgs), dim3(256), 0, sc, P, (int64_t)n_doubles, (unsigned)it, mode, words, words + 16, words + 17, bad,
-                               sink, words + 33, 1, words + 48, 1);
+            hipLaunchKernelGGL(consumer_kernel, dim3(2048), dim3(256), 0, sc, P, (int64_t)n_doubles, (unsigned)it, mode, words, words + 16, words + 17, bad,
+                               sink, words + 33, 1, words + 48, 1, words + 56, wgs);
             hipLaunchKernelGGL(stress_wait_kernel, dim3(1), dim3(64), 0, sc, words, (unsigned)it, words + 48);
-            hipLaunchKernelGGL(consumer_kernel, dim3(8 * wgs), dim3(256), 0, sc, P, (int64_t)n_doubles, (unsigned)it, mode, words, words + 16, words + 17, bad,
-                               sink, words + 33, 2, words + 48, 1);
+            hipLaunchKernelGGL(consumer_kernel, dim3(2048), dim3(256), 0, sc, P, (int64_t)n_doubles, (unsigned)it, mode, words, words + 16, words + 17, bad,
+                               sink, words + 33, 2, words + 48, 1, words + 57, wgs);
         } else {
-            hipLaunchKernelGGL(consumer_kernel, dim3(8 * wgs), dim3(256), 0, sc, P, (int64_t)n_doubles, (unsigned)it, mode, words, words + 16, words + 17, bad,
-                               sink, words + 33, 0, words + 48, 1);
+            hipLaunchKernelGGL(consumer_kernel, dim3(2048), dim3(256), 0, sc, P, (int64_t)n_doubles, (unsigned)it, mode, words, words + 16, words + 17, bad,
+                               sink, words + 33, 0, words + 48, 1, words + 56, wgs);
         }
-        hipLaunchKernelGGL(producer_kernel, dim3(8 * wgs), dim3(256), 0, sp, P, (int64_t)n_doubles, (unsigned)it, mode, words, words + 16, words + 32, words + 48, 0);
+        hipLaunchKernelGGL(producer_kernel, dim3(2048), dim3(256), 0, sp, P, (int64_t)n_doubles, (unsigned)it, mode, words, words + 16, words + 32, words + 48, 0, words + 58, wgs);
         unsigned long long hb = 0;
         if (hipStreamSynchronize(sp) != hipSuccess || hipMemcpyAsync(&hb, bad, 8, hipMemcpyDeviceToHost, sc) != hipSuccess ||
             hipStreamSynchronize(sc) != hipSuccess)

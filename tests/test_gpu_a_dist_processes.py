@@ -483,8 +483,8 @@ def test_two_threads_without_the_concurrency_hint_do_not_crawl():
 
 def test_flag_edges_across_xcds_with_stale_l2_lines():
     """The flag-edge protocol of common.hpp ("memory model") under the conditions it is built for: producer
-    and waiter on DIFFERENT XCDs (workgroup b of a launch runs on XCD b % 8: only one residue class of either launch works; the
-    XCC ids are checked), the waiter's L2 pre-warmed with stale lines of the payload before
+    and waiter on DIFFERENT XCDs (both launches are large; only workgroups that find themselves on XCD 0 / XCD 1 take part; the
+    XCC ids of the working workgroups are checked), the waiter's L2 pre-warmed with stale lines of the payload before
     the flag goes up, 10^4 hand-overs per form, every word checked (gptools_amd/csrc/test_aids/edge_stress.hip, which uses the
     product's edge_signal / edge_poll and the product's store / load forms).  The three forms the library uses must never see a
     stale word; with the write-through stores or the acquire compiled out the same harness must SHOW stale words -- otherwise
