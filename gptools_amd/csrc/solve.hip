@@ -599,7 +599,10 @@ int launch_trsv_lt_wide(hipStream_t st, int64_t nwide, const double *L, int64_t 
         gpt_set_error("trsv_lt_wide: the extent must be a multiple of %d", TW_NB);
         return GPT_E_ARG;
     }
-    static const bool two_launches = getenv("GPT_ALPHA_TWO_LAUNCH") != nullptr;      // (measurement aid: round 4's first form)
+    // (the one-launch step -- trsv_step_kernel -- measured SLOWER than two launches per step: 0.36 against 0.26 ms at n = 8192
+    // with the inverses cached; eight workgroups forming 512 rows of U w after a hand-over cost more than a 512-workgroup launch.
+    // GPT_ALPHA_ONE_LAUNCH=1 selects it.)
+    static const bool two_launches = getenv("GPT_ALPHA_ONE_LAUNCH") == nullptr;
     int64_t j0 = nwide - TW_NB;
     GPT_TRY_RC_SOLVE(launch_gemv_n(st, TW_NB, TW_NB, U + j0 * TW_NB, TW_NB, w + j0, x + j0));
     for (; j0 > 0; j0 -= TW_NB) {

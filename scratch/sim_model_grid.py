@@ -60,21 +60,17 @@ Winv = {k: torch.linalg.solve_triangular(torch.tril(panels[k][:NB]), eye, upper=
 
 
 class Handle(object):
-    """Receive side of one modelled broadcast: delivered by the first queue that waits for it."""
+    """Receive side of one modelled broadcast: EVERY queue that waits for it is held, by a gate kernel of its own, until the
+    device clock reaches the arrival time (as every queue waits for the RCCL work by itself; a first version let the first
+    waiter gate and the others follow its event, which tied the queues of a rank to each other: the chain queue, stuck behind
+    a gate for an early block, held the bulk queue's wait for W back, and the sweeps ratcheted upwards instead of converging)."""
     def __init__(self, plan, kind, k, buf, src, t):
-        self.args = (plan, kind, k, buf, src, t)
-        self.done = None
+        self.plan, self.t = plan, t
 
     def wait(self):
-        cur = torch.cuda.current_stream()
-        if self.done is not None:
-            cur.wait_event(self.done)
-            return
-        plan, kind, k, buf, src, t = self.args
-        if t is not None and t > 0.0:
-            gate.gate_wait(ctypes.c_void_p(cur.cuda_stream), ctypes.c_void_p(plan.t0_dev.data_ptr()), int(t * 1e5))   # ms -> 10 ns ticks
-        self.done = torch.cuda.Event()
-        self.done.record(cur)
+        if self.t is not None and self.t > 0.0:
+            cur = torch.cuda.current_stream()
+            gate.gate_wait(ctypes.c_void_p(cur.cuda_stream), ctypes.c_void_p(self.plan.t0_dev.data_ptr()), int(self.t * 1e5))   # ms -> 10 ns ticks
 
 
 class ModelRank(GridLML):

@@ -189,9 +189,7 @@ def test_distributed_fit_matches_single_process_oracle(world, N, d, nb, kid, loo
     (8, (4, 2), 1900, 2, 128, 0, True),      # P_c | P_r: two process rows contribute to every rank's columns
     (8, (4, 2), 1900, 2, 128, 0, False),
     (6, (2, 3), 1500, 2, 128, 1, True),      # coprime: every process row contributes, uneven ownership
-    (6, (3, 2), 1500, 3, 128, 0, True),
     (4, (2, 2), 100, 2, 256, 0, True),       # one block: three idle ranks must still take part
-    (4, (2, 2), 500, 2, 256, 0, True),       # 2 x 2 blocks: every rank owns at most one block
     (2, (1, 2), 700, 3, 128, 1, True),       # the 1-D block-column layout as a grid
     (2, (2, 1), 700, 3, 128, 1, True),       # a block-row layout: the column exchange is an all-gather over all ranks
     (8, (2, 4), 1023, 2, 128, 0, True),      # N + 1 a multiple of nb: no padding rows beyond the augmented row
