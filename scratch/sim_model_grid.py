@@ -6,13 +6,13 @@ ranks and the links, is MODELLED:
   * a broadcast produced by another rank becomes readable here at  arrive = max(production, link free) + bytes / bw + latency,
     production = the time the OWNER's replay recorded behind the kernels that produce it; one FIFO per directed link
     (source -> destination: xGMI is point to point, a root feeds its peers over different links at the same time);
-  * the receiving side pays nothing for the data movement (an ideal DMA engine: every buffer a broadcast would fill exists up
-    front -- one slot per panel, NBUF = number of panels -- and holds the payload already, taken from a complete factor
-    computed first); it only may not read it earlier: the first queue that waits for the broadcast is held by a one-wave gate
-    kernel until the device clock reaches the arrival time, and an event releases the other queues that wait for the same
-    data.  (No extra streams: more busy streams than hardware queues alias, and a gate that spins on a shared queue would
-    hold the wrong work back.  A first version copied the payload at arrival time: the strided device-to-device copies --
-    50-100 MB per step on the receiving queues -- cost 15 ms per rank and evaluation, an artefact of the model.)
+  * the receiving side: the payload (taken from a complete factor computed first) is copied into the buffer the broadcast would
+    fill on a delivery stream of its own, as soon as that buffer may be written -- HBM traffic beside the compute, as a receive
+    is; every queue that waits for the broadcast waits for that copy and is then held by a one-wave gate kernel of its own until
+    the device clock reaches the arrival time.  (Versions that did not work: the copy on the waiting queue at arrival time -- 15 ms
+    of strided copies per rank on the critical queues; one buffer slot per panel, all payloads up front -- every step touches
+    fresh hundreds of MB, replays of 100+ ms; one gate on the first waiter with an event for the others -- ties a rank's queues
+    together, the sweeps ratchet upwards.)
 Production depends on arrivals and vice versa: the W replays are swept (Gauss-Seidel over the ranks) to the fixed point.
 NOT modelled: RCCL's own launch overhead and CU usage, contention between concurrent transfers on the fabric, host jitter.
 
@@ -59,17 +59,27 @@ eye = torch.eye(NB, dtype=torch.float64, device="cuda")
 Winv = {k: torch.linalg.solve_triangular(torch.tril(panels[k][:NB]), eye, upper=False) for k in range(nblk)}
 
 
+deliver = torch.cuda.Stream()          # the "DMA engine": payloads land on it, beside the compute queues
+
+
 class Handle(object):
-    """Receive side of one modelled broadcast: EVERY queue that waits for it is held, by a gate kernel of its own, until the
-    device clock reaches the arrival time (as every queue waits for the RCCL work by itself; a first version let the first
-    waiter gate and the others follow its event, which tied the queues of a rank to each other: the chain queue, stuck behind
-    a gate for an early block, held the bulk queue's wait for W back, and the sweeps ratcheted upwards instead of converging)."""
+    """Receive side of one modelled broadcast.  The payload is copied into the buffer on the delivery stream as soon as the
+    buffer may be written (the issue point of the broadcast on the rank's queue) -- HBM traffic beside the compute, as a
+    receive is; EVERY queue that waits for the broadcast then waits for that copy and is held, by a gate kernel of its own,
+    until the device clock reaches the arrival time (each queue waits for the RCCL work by itself)."""
     def __init__(self, plan, kind, k, buf, src, t):
         self.plan, self.t = plan, t
+        cur = torch.cuda.current_stream()
+        deliver.wait_stream(cur)
+        with torch.cuda.stream(deliver):
+            plan._payload(kind, k, buf, src)
+            self.copied = torch.cuda.Event()
+            self.copied.record(deliver)
 
     def wait(self):
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self.copied)
         if self.t is not None and self.t > 0.0:
-            cur = torch.cuda.current_stream()
             gate.gate_wait(ctypes.c_void_p(cur.cuda_stream), ctypes.c_void_p(self.plan.t0_dev.data_ptr()), int(self.t * 1e5))   # ms -> 10 ns ticks
 
 
@@ -136,37 +146,10 @@ def members(kind, k, src):
 
 
 plans = []
-ModelRank.NBUF = nblk                      # one slot per panel: nothing a broadcast would fill is ever written twice
 for r in range(W):
     p = ModelRank(X, n, (Pr, Pc), nb=NB, ops=ops, layout=r, lookahead=LA)
     p.t0_dev = torch.zeros(1, dtype=torch.int64, device="cuda")
     p.arrive, p.produced = {}, {}
-    # every foreign payload up front, where the broadcast would have put it
-    for k in range(nblk):
-        me = (p.pr, p.pc)
-        if p.pc == k % Pc and me != (k % Pr, k % Pc):
-            p._payload("W", k, p.W[k], None)
-        if k + 1 < nblk and me != ((k + 1) % Pr, k % Pc):
-            p._payload("H", k, p.H[k], None)
-        li0 = p.li_ge(k + 2)
-        if p.pc != k % Pc and li0 < p.nlr:
-            has0 = p.pr == (k + 2) % Pr and k + 2 < nblk
-            if has0:
-                p._payload("R0", k, p.R[k][li0 * NB:(li0 + 1) * NB], None)
-            if p.nlr - li0 - int(has0) > 0:
-                p._payload("R", k, p.R[k][(li0 + int(has0)) * NB:p.nlr * NB], None)
-        lj0 = p.lj_ge(k + 2)
-        if lj0 < p.nlc:
-            sc, qi = p.lcm // Pc, 0
-            for q in range(Pr):
-                J0 = next((J for J in p.my_cols[lj0:lj0 + sc] if J % Pr == q), None)
-                if J0 is None:
-                    continue
-                nt = (nblk - 1 - J0) // p.lcm + 1
-                dst = p.C[k][(J0 // Pc) * NB:(J0 // Pc + nt) * NB] if sc == 1 else p.piece[k][qi][:nt * NB]
-                qi += 1
-                if q != p.pr:
-                    p._payload("C", k, dst, (q, p.pc))
     plans.append(p)
 torch.cuda.synchronize()
 arrive, link_free_hist, hist = {}, None, []

@@ -510,10 +510,12 @@ def test_flag_edges_across_xcds_with_stale_l2_lines():
         assert xp and xc and xp & (xp - 1) == 0 and xc & (xc - 1) == 0 and xp != xc, "XCC id masks %#x / %#x" % (xp, xc)
     for mode in ("0", "1", "4"):            # the library's three consumer forms: never a stale word
         assert out[mode][3] == 0 and out[mode][4] == 0, (mode, out[mode])
-    # negative controls (acquire compiled out: 2; write-through stores compiled out: 3): reported, not asserted -- whether a stale
-    # line is OBSERVED depends on what the hardware happens to keep where (round 4, MI355X: mode 2 showed none in 2000 hand-overs;
-    # the protocol is argued from the memory model, DESIGN.md section 4.3, this test shows the product forms never fail under
-    # forced cross-XCD placement with a pre-warmed L2)
-    print("negative controls: no-acquire plain loads: %d stale words in %d hand-overs; plain stores: %d stale words"
-          % (out["2"][4], 2000, out["3"][4]))
+    # negative controls.  (3) the producer's write-through stores compiled out (plain stores, flag raised all the same): the
+    # harness MUST show stale words -- round 4: all 2000 hand-overs, 2.5 million words -- or it is not testing anything.  (2) the
+    # consumer's acquire compiled out (plain loads behind the poll): reported, not asserted -- on this MI355X no stale word was
+    # seen in 2000 hand-overs (a clean line pre-warmed in the waiter's L2 was not served stale); the acquire stays, argued
+    # from the memory model
+    assert out["3"][3] > 0 and out["3"][4] > 0, "plain (write-back) stores were visible across XCDs without a release: %r" % (out["3"],)
+    print("negative controls: no-acquire plain loads: %d stale words in 2000 hand-overs; plain stores: %d stale words in %d of 2000"
+          % (out["2"][4], out["3"][4], out["3"][3]))
     sys.stderr.write("edge stress result: %r\n" % (out,))
