@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r04
 rm -rf $O; mkdir -p $O
 cd $R
-git rev-parse HEAD > $O/HEAD.txt 2>/dev/null
+cp scratch/HEAD_for_collect.txt $O/HEAD.txt 2>/dev/null
 timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > $O/pytest.txt
 timeout 300 python bench.py --steps 20 --warmup 5 > $O/bench_c3_line.json 2> $O/bench_c3.err
 timeout 200 python bench.py --steps 10 --warmup 3 --workload c2 --no-batched > $O/bench_c2_line.json 2> $O/bench_c2.err

@@ -198,8 +198,9 @@ for name, fn in (("1-D, scatter+all-gather, 20 us", lambda s: model_1d(8, 20e-6,
                                                                    " / ".join("%.0f" % (100 * flops / (t * 1e-3) / (8 * 78.6e12)) for t in ts)))
 T, chain = model_grid(2, 4, 20e-6, 1.0)
 d = np.diff(np.array(chain))
-print("# grid 2x4, slow = 1: head block of panel p ready at (ms): p=0 %.2f, 16 %.2f, 32 %.2f, 48 %.2f, last %.2f; chain period in the "
-      "chain-bound tail (last 16 panels): %.3f ms" % (chain[0] * 1e3, chain[16] * 1e3, chain[32] * 1e3, chain[48] * 1e3, chain[-1] * 1e3, d[-16:].mean() * 1e3))
+q_ = [0, len(chain) // 4, len(chain) // 2, 3 * len(chain) // 4, len(chain) - 1]
+print("# grid 2x4, slow = 1: head block of panel p ready at (ms): " + ", ".join("p=%d %.2f" % (i, chain[i] * 1e3) for i in q_) +
+      "; chain period in the chain-bound tail (last quarter of the panels): %.3f ms" % (d[-len(chain) // 4:].mean() * 1e3))
 upd = sum(2.0 * nb ** 3 * sum(1 for J in range(p + 2, nblk) for I in range(J, nblk)) for p in range(nblk)) / 8 / UPD_RATE
 print("# per-rank trailing updates at %.0f TFLOP/s: %.1f ms; diagonal-block work alone: %d x %.0f us = %.1f ms" % (
     UPD_RATE * 1e-12, upd * 1e3, nblk, T_DIAG * 1e6, nblk * T_DIAG * 1e3))
