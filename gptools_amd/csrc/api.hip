@@ -350,15 +350,6 @@ static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, 
     // durations with the main stream's would count the same wall time twice)
     const bool on_main = (st == c->stream) || (c->early_stream && st == c->early_stream);
     const bool prof = c->prof_gemm && flops >= 1.0e9 && on_main;
-    // GPT_GEMM_LOG=<file> (evidence aid, scratch/collect_r04.sh): the shape of every >= 1 GFLOP main-stream launch, in launch order, so
-    // that a profiler's per-dispatch counters can be set against the algorithmic flops / bytes of THE SAME launches
-    {
-        static FILE *glog = getenv("GPT_GEMM_LOG") ? fopen(getenv("GPT_GEMM_LOG"), "a") : nullptr;
-        if (glog && flops >= 1.0e9 && on_main) {
-            fprintf(glog, "%lld %lld %lld %d %.6e\n", (long long)m, (long long)n, (long long)k, tri, flops);
-            fflush(glog);
-        }
-    }
     gpt_ctx::GemmProf *gp = nullptr;
     if (prof) {
         if (c->gprof_used == c->gprof.size()) {
@@ -385,6 +376,19 @@ static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, 
     } else if (prof) {
         gp->stop = gp->e1;
         GPT_HIP_CHECK(hipEventRecord(gp->e0, st));
+    }
+    // GPT_GEMM_LOG=<file> (evidence aid, scratch/collect_r04.sh): the shape of every >= 1 GFLOP main-stream launch, in launch order, and
+    // whether it runs the 64x64 kernel (launch_gemm_nt cuts launches under gemm_small_threshold() tiles into 32x32 tiles unless a
+    // start event or a partial edge rides on them), so that a profiler's per-dispatch counters of that kernel can be set against
+    // the algorithmic flops / bytes of THE SAME launches
+    {
+        static FILE *glog = getenv("GPT_GEMM_LOG") ? fopen(getenv("GPT_GEMM_LOG"), "a") : nullptr;
+        if (glog && flops >= 1.0e9 && on_main) {
+            const int64_t nt64 = ((m + 63) / 64) * ((n + 63) / 64);
+            const int k64 = (c->tile == 64) || !(c->tile == 0 && nt64 < gemm_small_threshold() && !e0 && edge_cols == 0);
+            fprintf(glog, "%lld %lld %lld %d %.6e %d\n", (long long)m, (long long)n, (long long)k, tri, flops, k64);
+            fflush(glog);
+        }
     }
     // the panel stream's updates keep a raised wave priority in their main loop (option panel_prio, see gemm.hip)
     // (option gemm_prio >= 0: every GEMM of this context -- the panel-side context of the block-cyclic engine, whose

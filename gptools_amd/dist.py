@@ -854,6 +854,8 @@ class GridLML(object):
                 self.err[:N] = torch.from_numpy(err_y)
             self.info.zero_()
             self.red.zero_()
+            self.red_b.zero_()          # (HERE, on the main queue in front of ev_asm: zeroed on the default stream it raced with the
+                                        #  bulk queue's accumulation -- one evaluation in 72 lost part of z.z under queue jitter)
             self._t0 = ops.new_timing_event() if self.trace else None
             if self._t0 is not None:
                 self._t0.record()
@@ -866,7 +868,6 @@ class GridLML(object):
                 ev_asm.wait()
         last = nblk - 1
         zrow_local = (last // Pr) * nb + (N - last * nb)       # local row of the augmented row on the ranks of its process row
-        self.red_b.zero_()
         CH, BK = "panel", "recv"                               # the CHAIN queue and the BULK queue (see the class docstring)
         ev_urg, ev_done, ev_ch, ev_bk = {}, {}, {}, {}
         arr_W, arr_H, arr_R0, arr_R, arr_C = {}, {}, {}, {}, {}

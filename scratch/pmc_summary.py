@@ -77,6 +77,7 @@ def big_launch_bytes(path, counter):
 ALG = {}
 try:
     shapes = [l.split() for l in open(src + '/pmc_fetch_gemm_shapes.txt') if l.strip()]
+    shapes = [x for x in shapes if len(x) < 6 or int(x[5]) == 1]       # (those that ran the 64x64 kernel the counter filter selects)
     fl = [float(x[4]) for x in shapes]
     by = [16.0 * float(x[4]) / (2.0 * float(x[2])) + 8.0 * float(x[2]) * max(float(x[0]), float(x[1])) for x in shapes]
     ALG = {"logged_launches": len(shapes), "flops_per_launch": sum(fl) / len(fl), "algorithmic_bytes_per_launch": sum(by) / len(by),
