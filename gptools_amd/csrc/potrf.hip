@@ -24,7 +24,7 @@
 #ifdef GPT_PD_STAMPS
 // cheap stamps: s_memtime into a small static LDS array (lane 0 of wave 0), dumped to global memory at the end of the kernel
 __device__ long long *g_pd_stamps;
-__shared__ long long pd_stamp_lds[96];
+__shared__ long long pd_stamp_lds[128];
 #define PD_STAMP(i)                                                             \
     do {                                                                        \
         if (wave == 0 && lane == 0) pd_stamp_lds[(i)] = (long long)__builtin_amdgcn_s_memtime(); \
@@ -40,9 +40,29 @@ __shared__ long long pd_stamp_lds[96];
 #define PD_STAMP_DUMP()                                                         \
     do {                                                                        \
         __syncthreads();                                                        \
-        if (threadIdx.x < 96) g_pd_stamps[threadIdx.x] = pd_stamp_lds[threadIdx.x]; \
+        if (threadIdx.x < 128) g_pd_stamps[threadIdx.x] = pd_stamp_lds[threadIdx.x]; \
+    } while (0)
+// event trace of every wave (look-ahead body; -DGPT_PD_TRACE on top of the stamps: every point costs several hundred cycles):
+// (time, code) pairs appended to a global array, lane 0 of the wave
+__device__ long long *g_pd_trace;
+#ifdef GPT_PD_TRACE
+#define PD_TRACE_DECL int pd_tr_n = 0
+#define PD_TRACE(code)                                                          \
+    do {                                                                        \
+        if (lane == 0 && g_pd_trace != nullptr && pd_tr_n < 250) {              \
+            long long *q_ = g_pd_trace + ((long long)wave * 256 + pd_tr_n) * 2; \
+            q_[0] = (long long)__builtin_amdgcn_s_memtime();                    \
+            q_[1] = (long long)(code);                                          \
+        }                                                                       \
+        pd_tr_n++;                                                              \
     } while (0)
 #else
+#define PD_TRACE_DECL do { } while (0)
+#define PD_TRACE(code) do { } while (0)
+#endif
+#else
+#define PD_TRACE_DECL do { } while (0)
+#define PD_TRACE(code) do { } while (0)
 #define PD_STAMP(i) do { } while (0)
 #define PD_STAMP1(i) do { } while (0)
 #define PD_STAMPW(i) do { } while (0)
@@ -185,6 +205,11 @@ __device__ __forceinline__ void pivot_col(double (&a)[16], double (&x)[16], RsqP
     }
 }
 
+// (Round 4: the same recurrence with EVERY instruction placed by hand -- volatile asm statements, the updates of column J - 1
+// spread over the gaps of column J's dependent chain, the new pivot read after the first update instead of two broadcasts and
+// an fma -- measured 2564-2612 cycles against 2492-2576 for what hipcc makes of the code above: no gain, not kept.  The block is
+// bound by the issue of its ~416 double-precision instructions on one SIMD, ~6 cycles each beside the store wave;
+// scratch/dpp_rate.hip has the issue and latency numbers, chain_slot below the hand-placed form.)
 // Factor the 16x16 pivot block jb of S with one wave: lane (l & 15) keeps ROW l of the block in a[0..15] and, at
 // the same time, COLUMN l of inv(L_jj) in x[0..15]; both recurrences consume the same broadcast L[c][j], so the
 // inverse costs one extra FMA per broadcast.  Writes L_jj back to S and inv(L_jj) to T (LDS; one buffer per pivot
@@ -461,6 +486,528 @@ __device__ __forceinline__ void potf2_body(double *__restrict__ A, int64_t lda, 
     PD_STAMP_DUMP();
 }
 
+// ------------------------------------------------------------------------------------------------
+// potf2_body_la: the same 128x128 block, "look-ahead" form (round 4).  potf2_body above is one lock-step loop: strip solve
+// (all waves) | barrier | tile updates + pivot block (wave 0) | barrier, 5200 cycles per 16 columns of which the pivot
+// recurrence is 2500 (profiles/r04_potf2_stamps.txt).  Here the waves are decoupled (flags in LDS, no workgroup barrier
+// inside the loop) and the chain wave does nothing but the chain:
+//   wave 0, CHAIN: the 16-column recurrence of the pivot tile ALONE (no inverse riding along: 120 instead of 240 DPP
+//           multiply-adds) and publishes every finished column (16 entries + 1/sqrt(pivot)) to LDS as it goes; then takes
+//           the next pivot tile: (jb+1, jb+1) -= X X^T with X = tile (jb+1, jb) as soon as wave 1 has stored it (4 MFMAs).
+//   waves 1, 2, RIDE-ALONG: 64 DIFFERENT rows each (lane = row: the up to seven 16-row tiles below the pivot tile, and the
+//           sixteen rows of the identity) follow the chain wave's columns a few hundred cycles behind with the same
+//           recurrence  v[C] -= L[C][J] v[J],  v[J] /= L[J][J]  (DPP broadcast out of the published column): when the pivot
+//           tile is done, so are the forward substitution of the whole strip -- no inverse, no strip phase, no barrier -- and
+//           inv(L_jj) (the identity rows; what the packed workspace / the TRSM consumers want).
+//   waves 3, 5, 6, 7, WORKERS: trailing tiles (a, b) -= X_a X_b^T; every tile has ONE owner for the whole kernel, so
+//           a tile's successive updates need no synchronisation; per step each worker takes the tiles the next step's
+//           chain / ride-along waves read FIRST (column jb+1 and tile (jb+2, jb+2)) and counts them in cF[jb].
+//   wave 4, STORE: as before (packed workspace, flag for the consumers of the fused kernel, info), paced by flags.
+// LDS is processed in order per wave and is one memory for the workgroup: "data stores, then the flag store" by the writer
+// and "flag load, then data loads" by the reader need no fence, only that the compiler keeps the order (volatile /
+// asm memory clobbers).  All flags only grow; nothing waits on a value a NaN could change (a block that is not positive
+// definite runs to the end and leaves NaN on its diagonal, found by the store wave as before).
+// ------------------------------------------------------------------------------------------------
+struct PdSync {
+    int colflag;        // chain: columns published so far (16 jb + J + 1)
+    int lflag;          // chain: L_jj rows of step jb are in S (jb + 1)
+    int x1flag, x2flag; // ride-along waves: strips (and inverse) of step jb stored (jb + 1)
+    int cstage;         // staging waves done (7)
+    int pad_[3];
+    int cF[8];          // workers: priority tiles of trailing step jb done
+};
+#define PD_LA_COLBUF (2 * 16 * 16)
+#define PD_LA_INVBUF (2 * 16)
+#define PD_LA_SMEM_BYTES ((size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP + PD_LA_COLBUF + PD_LA_INVBUF) * sizeof(double) + sizeof(PdSync))
+
+// (plain LDS accesses between compiler barriers, NOT volatile: a volatile access loses its address space here -- flat
+// instructions with sc0 sc1 and a vmcnt(0) wait behind each, 5500 instead of 1700 cycles per pivot block)
+__device__ __forceinline__ int lds_peek(const int *p)
+{
+    asm volatile("" ::: "memory");
+    const int v = *p;
+    asm volatile("" ::: "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+}
+template <bool SLEEP>
+__device__ __forceinline__ void lds_wait_ge(const int *p, int target)
+{
+    while (lds_peek(p) < target) {
+        if (SLEEP) __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void lds_post(int *p, int value)
+{
+    asm volatile("" ::: "memory");
+    *p = value;
+    asm volatile("" ::: "memory");
+}
+// tiles (a, s + 2), a = s + 2 .. 7: the workers' last step on them is s (cF[s] counts them)
+__device__ __forceinline__ int pd_prio_count(int s) { return (s <= 5) ? 6 - s : 0; }
+
+// ---- the chain recurrence, scheduled by hand ----
+// Numbers (scratch/dpp_rate.hip): a double-precision VALU instruction issues in ~4.5 cycles and its result is there after 8; v_rsq_f64
+// 20; a DPP read of a register a VALU instruction wrote needs two wait states (16 with the s_nop for a dependent v_mov_dpp).
+// One column's dependent chain is  scale (8) -> first update (8) -> broadcast of the new pivot (16) -> rsq (20) -> t (8) -> u (8)
+// -> 1/sqrt (8) = ~76 cycles; everything else (the column's other 14 - J updates, 4.8 cycles each) fits in its shadows IF it is
+// placed there -- left to the compiler the updates pile up between two chain steps and a block takes 2550 cycles (160 per
+// column, measured alone on a CU: scratch/chain_probe.hip).  Here every instruction of the recurrence is a volatile asm
+// statement (the compiler keeps their order) and slot J = the chain steps of column J with the updates of column J - 1 spread
+// over its gaps.  The new pivot is read AFTER the first update (lane J+1 of a[J+1] then IS a[J+1][J+1] - l^2, the same fused
+// operation as before), which saves the two broadcasts and the explicit fma.
+template <int JP, int C0, int N>
+__device__ __forceinline__ void chain_fill(double (&a)[16])
+{
+    if constexpr (JP >= 0 && N > 0 && C0 < 16) {
+        fnmac_bcast<C0>(a[C0], a[JP], a[JP]);
+        chain_fill<JP, C0 + 1, N - 1>(a);
+    }
+}
+template <int J>
+__device__ __forceinline__ void chain_slot(double (&a)[16], double &inv, double &inv_prev, double *colb, double *invb, int *colflag,
+                                           int flag0, int i)
+{
+    double d, y0, t, h, u;
+    asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a[J]) : "v"(inv));                       // column J of L (lane r: L[r][J])
+    chain_fill<J - 1, J + 1, 2>(a);
+    if constexpr (J + 1 < 16)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(a[J + 1]) : "v"(a[J]), "i"(J + 1));
+    // two columns per publication (an LDS store costs ~4 cycles of issue per register it reads: three stores per column were
+    // 50 of a column's ~170 cycles): after an odd column J the pair (J - 1, J) goes out as one 16-byte store per lane, the
+    // pair of 1/sqrt(pivot) as another, then the count
+    if constexpr (J & 1) {
+        f64x2 cw = {a[J - 1], a[J]}, iw = {inv_prev, inv};
+        *reinterpret_cast<f64x2 *>(colb + (J >> 1) * 32 + i * 2) = cw;
+        *reinterpret_cast<f64x2 *>(invb + (J >> 1) * 2) = iw;
+        asm volatile("" ::: "memory");
+        *colflag = flag0 + J + 1;
+        asm volatile("" ::: "memory");
+    } else {
+        inv_prev = inv;
+    }
+    if constexpr (J + 1 < 16) {
+        chain_fill<J - 1, J + 3, 1>(a);
+        asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(a[J + 1]), "i"(J + 1));
+        chain_fill<J - 1, J + 4, 3>(a);
+        asm volatile("s_nop 0\n\tv_rsq_f64 %0, %1" : "=v"(y0) : "v"(d));
+        chain_fill<J - 1, J + 7, 4>(a);
+        asm volatile("s_nop 0\n\tv_mul_f64 %0, %2, %3\n\tv_mul_f64 %1, %3, 0.5" : "=&v"(t), "=&v"(h) : "v"(d), "v"(y0));
+        chain_fill<J - 1, J + 11, 1>(a);
+        asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(u) : "v"(t), "v"(y0));
+        chain_fill<J - 1, J + 12, 2>(a);
+        asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(inv) : "v"(h), "v"(u), "v"(y0));
+        chain_fill<J - 1, J + 14, 16>(a);
+    }
+}
+__device__ __forceinline__ void chain_block(double (&a)[16], double *colb, double *invb, int *colflag, int flag0, int i)
+{
+    __builtin_amdgcn_sched_barrier(0);
+    double inv, inv_prev = 0.0;
+    {
+        RsqPipe rp;
+        rp.d = bcast_lane(a[0], 0);
+        rp.step(0);
+        rp.step(1);
+        rp.step(2);
+        rp.step(3);
+        inv = rp.inv;
+    }
+    chain_slot<0>(a, inv, inv_prev, colb, invb, colflag, flag0, i);
+    chain_slot<1>(a, inv, inv_prev, colb, invb, colflag, flag0, i);
+    chain_slot<2>(a, inv, inv_prev, colb, invb, colflag, flag0, i);
+    chain_slot<3>(a, inv, inv_prev, colb, invb, colflag, flag0, i);
+    chain_slot<4>(a, inv, inv_prev, colb, invb, colflag, flag0, i);
+    chain_slot<5>(a, inv, inv_prev, colb, invb, colflag, flag0, i);
+    chain_slot<6>(a, inv, inv_prev, colb, invb, colflag, flag0, i);
+    chain_slot<7>(a, inv, inv_prev, colb, invb, colflag, flag0, i);
+    chain_slot<8>(a, inv, inv_prev, colb, invb, colflag, flag0, i);
+    chain_slot<9>(a, inv, inv_prev, colb, invb, colflag, flag0, i);
+    chain_slot<10>(a, inv, inv_prev, colb, invb, colflag, flag0, i);
+    chain_slot<11>(a, inv, inv_prev, colb, invb, colflag, flag0, i);
+    chain_slot<12>(a, inv, inv_prev, colb, invb, colflag, flag0, i);
+    chain_slot<13>(a, inv, inv_prev, colb, invb, colflag, flag0, i);
+    chain_slot<14>(a, inv, inv_prev, colb, invb, colflag, flag0, i);
+    chain_slot<15>(a, inv, inv_prev, colb, invb, colflag, flag0, i);
+    asm volatile("" : "+v"(a[15]));
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// what a ride-along wave reads per PAIR of columns: the count first, then the data (returned in that order)
+struct ColIn {
+    int flag;
+    f64x2 col, inv;
+};
+__device__ __forceinline__ void col_read(ColIn &ci, const int *colflag, const double *colb, const double *invb, int P, int i)
+{
+    asm volatile("" ::: "memory");
+    ci.flag = *colflag;
+    asm volatile("" ::: "memory");
+    ci.col = *reinterpret_cast<const f64x2 *>(colb + P * 32 + i * 2);
+    ci.inv = *reinterpret_cast<const f64x2 *>(invb + P * 2);
+    asm volatile("" ::: "memory");
+}
+template <int J, int C>
+__device__ __forceinline__ void ride_group(double (&v)[16], double col)
+{
+    if constexpr (C < 16) {
+        fnmac_bcast<C>(v[C], col, v[J]);                   // v[row][C] -= L[C][J] * v[row][J]
+        ride_group<J, C + 1>(v, col);
+    }
+}
+template <int P>
+__device__ __forceinline__ void ride_pair(double (&v)[16], ColIn &cur, ColIn &pre, const int *colflag, const double *colb,
+                                          const double *invb, int flag0, int i)
+{
+    // `cur` was requested one pair ago (speculatively: re-read until its count covers column 2 P + 1); the next pair is
+    // requested into `pre` before the arithmetic of this one
+    while (__builtin_amdgcn_readfirstlane(cur.flag) < flag0 + 2 * P + 2) col_read(cur, colflag, colb, invb, P, i);
+    if constexpr (P + 1 < 8) col_read(pre, colflag, colb, invb, P + 1, i);
+    const double c0 = cur.col[0], c1 = cur.col[1];
+    v[2 * P] *= cur.inv[0];
+    ride_group<2 * P, 2 * P + 1>(v, c0);
+    v[2 * P + 1] *= cur.inv[1];
+    ride_group<2 * P + 1, 2 * P + 2>(v, c1);
+}
+__device__ __forceinline__ void ride_block(double (&v)[16], const int *colflag, const double *colb, const double *invb,
+                                           int flag0, int i)
+{
+    ColIn c0, c1;
+    col_read(c0, colflag, colb, invb, 0, i);
+    ride_pair<0>(v, c0, c1, colflag, colb, invb, flag0, i);
+    ride_pair<1>(v, c1, c0, colflag, colb, invb, flag0, i);
+    ride_pair<2>(v, c0, c1, colflag, colb, invb, flag0, i);
+    ride_pair<3>(v, c1, c0, colflag, colb, invb, flag0, i);
+    ride_pair<4>(v, c0, c1, colflag, colb, invb, flag0, i);
+    ride_pair<5>(v, c1, c0, colflag, colb, invb, flag0, i);
+    ride_pair<6>(v, c0, c1, colflag, colb, invb, flag0, i);
+    ride_pair<7>(v, c1, c0, colflag, colb, invb, flag0, i);
+}
+
+template <bool PUBLISH>
+__device__ __forceinline__ void potf2_body_la(double *__restrict__ A, int64_t lda, double *__restrict__ invd, int32_t *info,
+                                              int64_t info_col0, unsigned *flag, unsigned flag_base)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double (*S)[PD_PITCH] = reinterpret_cast<double (*)[PD_PITCH]>(smem);
+    typedef double TBuf[16][PD_TP];
+    TBuf *T = reinterpret_cast<TBuf *>(smem + PD_NB * PD_PITCH);
+    double *colbuf = smem + PD_NB * PD_PITCH + 8 * 16 * PD_TP;      // [parity][column][row]
+    double *invbuf = colbuf + PD_LA_COLBUF;                          // [parity][column]
+    PdSync *sy = reinterpret_cast<PdSync *>(invbuf + PD_LA_INVBUF);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    constexpr int NB16 = PD_NB / 16;
+
+    if (tid < (int)(sizeof(PdSync) / sizeof(int))) reinterpret_cast<int *>(sy)[tid] = 0;
+    __syncthreads();
+    PD_TRACE_DECL;
+    PD_TRACE(1);
+
+    if (wave == 0) {
+        // ================================ chain ================================
+        __builtin_amdgcn_s_setprio(3);
+        double a[16];
+        f64x4 acc;
+#pragma unroll
+        for (int c = 0; c < 16; c++) a[c] = A[(int64_t)fr * lda + c];
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] = A[(int64_t)(16 + fk + 4 * r) * lda + 16 + fr];      // tile (1, 1)
+        PD_STAMP(0);
+        for (int jb = 0; jb < NB16; jb++) {
+            PD_STAMP(8 + jb * 8 + 0);
+            PD_TRACE(100 + jb);
+            chain_block(a, colbuf + (jb & 1) * 256, invbuf + (jb & 1) * 16, &sy->colflag, jb * 16, fr);
+            PD_STAMP(8 + jb * 8 + 1);
+            PD_TRACE(110 + jb);
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; c += 2) {
+                    f64x2 w = {a[c], a[c + 1]};
+                    *reinterpret_cast<f64x2 *>(&S[jb * 16 + fr][jb * 16 + c]) = w;
+                }
+            }
+            lds_post(&sy->lflag, jb + 1);
+            if (jb + 1 == NB16) break;
+            // the next pivot tile: its updates of the steps before this one (its owner's), then this step's
+            const int t1 = (jb + 1) * 16;
+            if (jb > 0) {
+                lds_wait_ge<false>(&sy->cF[jb - 1], pd_prio_count(jb - 1));
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[r] = S[t1 + fk + 4 * r][t1 + fr];
+            }
+            PD_STAMP(8 + jb * 8 + 2);
+            PD_TRACE(120 + jb);
+            f64x4 acc2 = {0.0, 0.0, 0.0, 0.0};
+            lds_wait_ge<false>((jb + 1 <= 4) ? &sy->x1flag : &sy->x2flag, jb + 1);
+            PD_STAMP(8 + jb * 8 + 3);
+            PD_TRACE(130 + jb);
+            double xv[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) xv[kk] = S[t1 + fr][jb * 16 + fk + 4 * kk];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xv[0], xv[0], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xv[1], xv[1], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xv[2], xv[2], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xv[3], xv[3], acc2, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) S[t1 + fk + 4 * r][t1 + fr] = acc[r] + acc2[r];
+            PD_STAMP(8 + jb * 8 + 4);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int c = 0; c < 16; c += 2) {
+                const f64x2 w = *reinterpret_cast<const f64x2 *>(&S[t1 + fr][t1 + c]);
+                a[c] = w[0];
+                a[c + 1] = w[1];
+            }
+            PD_STAMP(8 + jb * 8 + 5);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    } else if (wave == 1 || wave == 2) {
+        // ================================ ride-along ================================
+        // Fixed rows: wave 1 the tiles 1..4, wave 2 the tiles 5..7 and the identity (quarter 3).  After the ride of step jb
+        // the wave stores its strips, applies step jb to ITS tiles of column jb+1 (what it rides next; the tiles' earlier
+        // steps are the workers': cF[jb-1]) and takes their rows back -- no other wave between two rides.
+        __builtin_amdgcn_s_setprio(2);
+        int *myflag = (wave == 1) ? &sy->x1flag : &sy->x2flag;
+        const int tq = (wave == 1) ? 1 + fk : 5 + fk;                   // this lane's tile (8: the identity)
+        const bool ident = (tq == NB16);
+        const int tfirst = (wave == 1) ? 1 : 5, tlast = (wave == 1) ? 4 : 7;
+        const int row = (ident ? NB16 - 1 : tq) * 16 + fr;
+        double v[16];
+#pragma unroll
+        for (int c = 0; c < 16; c += 2) {
+            const f64x2 w = *reinterpret_cast<const f64x2 *>(A + (int64_t)row * lda + c);
+            v[c] = ident ? ((c == fr) ? 1.0 : 0.0) : w[0];
+            v[c + 1] = ident ? ((c + 1 == fr) ? 1.0 : 0.0) : w[1];
+        }
+        // the wave's three tiles of the NEXT column (what it rides in the next step), C layout: before the first ride straight
+        // from global memory; later from LDS once the workers are through with them (cF)
+        const int tu0 = (wave == 1) ? 2 : 5;                            // tiles tu0 .. tu0 + 2
+        f64x4 accn[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) accn[q][r] = A[(int64_t)((tu0 + q) * 16 + fk + 4 * r) * lda + 16 + fr];
+        for (int jb = 0; jb < NB16; jb++) {
+            const bool valid = !ident && tq > jb;
+            const bool any = (wave == 2) || (jb < tlast);
+            const bool upd = (jb + 1 < NB16) && (tu0 + 2 >= jb + 2);   // (some tile of this wave lies below tile jb + 1)
+            const int t1 = (jb + 1) * 16;
+            if (any) {
+                PD_TRACE(200 + jb);
+                PD_STAMPW((wave == 1 ? 80 : 104) + jb);
+                ride_block(v, &sy->colflag, colbuf + (jb & 1) * 256, invbuf + (jb & 1) * 16, jb * 16, fr);
+                PD_STAMPW((wave == 1 ? 88 : 112) + jb);
+                PD_TRACE(210 + jb);
+                if (valid) {
+#pragma unroll
+                    for (int c = 0; c < 16; c += 2) {
+                        f64x2 w = {v[c], v[c + 1]};
+                        *reinterpret_cast<f64x2 *>(&S[row][jb * 16 + c]) = w;
+                    }
+                } else if (ident) {
+                    // the inverse goes out TRANSPOSED (T[l][c] = inv(L_jj)[c][l]; lane l holds column l of the inverse)
+#pragma unroll
+                    for (int c = 0; c < 16; c += 2) {
+                        f64x2 w = {v[c], v[c + 1]};
+                        *reinterpret_cast<f64x2 *>(&T[jb][fr][c]) = w;
+                    }
+                }
+                PD_STAMPW((wave == 1 ? 72 : 96) + jb);
+            }
+            lds_post(myflag, jb + 1);
+            PD_TRACE(220 + jb);
+            // ---- this wave's tiles of column jb + 1 take step jb (all three slots computed, the ones above tile jb + 2
+            // not stored); then their rows come back for the next ride
+            if (upd) {
+                // X(jb+1, jb) is the other wave's when tile jb+1 is (wave 1 owns 1..4)
+                if ((jb + 1 <= 4) != (wave == 1)) lds_wait_ge<false>((wave == 1) ? &sy->x2flag : &sy->x1flag, jb + 1);
+                if (jb > 0) {
+                    lds_wait_ge<false>(&sy->cF[jb - 1], pd_prio_count(jb - 1));
+#pragma unroll
+                    for (int q = 0; q < 3; q++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) accn[q][r] = S[(tu0 + q) * 16 + fk + 4 * r][t1 + fr];
+                }
+                double bv[4], av[3][4];
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) bv[kk] = S[t1 + fr][jb * 16 + fk + 4 * kk];
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) av[q][kk] = -S[(tu0 + q) * 16 + fr][jb * 16 + fk + 4 * kk];
+                f64x4 c1[3];
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    c1[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+                    accn[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][0], bv[0], accn[q], 0, 0, 0);
+                    c1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][1], bv[1], c1[q], 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    accn[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][2], bv[2], accn[q], 0, 0, 0);
+                    c1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][3], bv[3], c1[q], 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    if (tu0 + q >= jb + 2) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) S[(tu0 + q) * 16 + fk + 4 * r][t1 + fr] = accn[q][r] + c1[q][r];
+                    }
+                }
+                asm volatile("" ::: "memory");
+                const bool vnext = !ident && tq > jb + 1;
+#pragma unroll
+                for (int c = 0; c < 16; c += 2) {
+                    const f64x2 w = *reinterpret_cast<const f64x2 *>(&S[row][t1 + c]);
+                    v[c] = ident ? ((c == fr) ? 1.0 : 0.0) : (vnext ? w[0] : 0.0);
+                    v[c + 1] = ident ? ((c + 1 == fr) ? 1.0 : 0.0) : (vnext ? w[1] : 0.0);
+                }
+            } else if (wave == 2) {
+#pragma unroll
+                for (int c = 0; c < 16; c++) v[c] = (ident && c == fr) ? 1.0 : 0.0;
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    } else {
+        // ---- stage the columns from 32 on into LDS (waves 3..7): the first two column blocks are read from global memory by
+        // the waves that use them (chain: tiles (0, 0), (1, 1); ride-along: rows of column block 0, tiles (t, 1)) ----
+        {
+            // (the chain and ride-along waves' loads go first: the 73 KB requested here are not needed before the first strips)
+            __builtin_amdgcn_s_sleep(8);
+            constexpr int CW = (PD_NB - 32) / 2;                    // 16-byte chunks per row
+            constexpr int NCH = (PD_NB - 32) * CW;
+            constexpr int NT = PD_THREADS - 192;
+            constexpr int PER = (NCH + NT - 1) / NT;
+            f64x2 v[PER];
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const int idx = (tid - 192) + q * NT;
+                const int r = 32 + idx / CW, c2 = 32 + (idx % CW) * 2;
+                if (idx < NCH) v[q] = *reinterpret_cast<const f64x2 *>(A + (int64_t)r * lda + c2);
+            }
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const int idx = (tid - 192) + q * NT;
+                const int r = 32 + idx / CW, c2 = 32 + (idx % CW) * 2;
+                if (idx < NCH) *reinterpret_cast<f64x2 *>(&S[r][c2]) = v[q];
+            }
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&sy->cstage, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
+        }
+        if (wave == 4) {
+            // ================================ store ================================
+            for (int jb = 0; jb < NB16; jb++) {
+                lds_wait_ge<true>(&sy->lflag, jb + 1);
+                lds_wait_ge<true>(&sy->x1flag, jb + 1);
+                lds_wait_ge<true>(&sy->x2flag, jb + 1);
+                PD_TRACE(300 + jb);
+                double *ip = invd + jb * 256, *lp = invd + GPT_WS_LOFF;
+                {
+                    double tv[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) tv[kk] = T[jb][fk + 4 * kk][fr];             // packed element (fr, fk + 4kk)
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) ws_store<PUBLISH>(ip + kk * 64 + lane, tv[kk]);
+                }
+                for (int j0 = jb + 1; j0 < NB16; j0 += 3) {                                    // packed blocks (j, jb), j > jb
+                    double pv[3][4];
+#pragma unroll
+                    for (int jj = 0; jj < 3; jj++)
+                        if (j0 + jj < NB16) {
+#pragma unroll
+                            for (int kk = 0; kk < 4; kk++) pv[jj][kk] = S[(j0 + jj) * 16 + fr][jb * 16 + fk + 4 * kk];
+                        }
+#pragma unroll
+                    for (int jj = 0; jj < 3; jj++)
+                        if (j0 + jj < NB16) {
+                            const int j = j0 + jj, b = j * (j - 1) / 2 + jb;
+#pragma unroll
+                            for (int kk = 0; kk < 4; kk++) ws_store<PUBLISH>(lp + b * 256 + kk * 64 + lane, pv[jj][kk]);
+                        }
+                }
+                if (PUBLISH) {
+                    // (as in potf2_body: write-through stores of THIS wave, drained, then the flag)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(flag, flag_base + (unsigned)jb + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                {
+                    const double dg = S[jb * 16 + fr][jb * 16 + fr];
+                    const unsigned long long m = __ballot(!(dg > 0.0)) & 0xffffull;
+                    if (m != 0ull && lane == 0) atomicCAS(info, 0, (int32_t)(info_col0 + jb * 16 + __ffsll((long long)m)));
+                }
+            }
+        } else {
+            // ================================ workers ================================
+            // Unit of work: (column b >= 2, step s <= b - 2) = the worker's tiles (a, b), a >= b, take  -= X(a, s) X(b, s)^T.
+            // (Step b - 1 of column b is taken by the waves that use it next: the ride-along waves, the chain wave for (b, b).)
+            // A tile's steps go in order (one owner, program order): step-major, within a step the lowest column first.
+            // cF[s] counts the tiles of column s + 2 that have taken step s, their last one here.
+            // Ownership: the columns 2..4 -- 28 tile-steps, the early deadlines -- are waves 3 and 7's (one SIMD), the columns 5..7
+            // -- 28 tile-steps, late deadlines -- waves 5 and 6's: those share their SIMDs with the ride-along waves, and on gfx950
+            // a SIMD's fp64 MFMAs run at 32 flop per cycle (64 cycles per 16x16x4): a busy partner doubled the time of the
+            // ride-along waves' own tile updates between two rides (2000 against 1100 cycles), which are on the chain.
+            const int me = (wave == 3 || wave == 5) ? 0 : 1;        // tiles (a, b) with (a + b) & 1 == me
+            const int blo = (wave == 3 || wave == 7) ? 2 : 5, bhi = blo + 2;
+            lds_wait_ge<true>(&sy->cstage, PD_WAVES - 3);
+            for (int st = 0; st + 2 < NB16; st++) {                 // step-major, within a step the lowest column first
+                if (st + 2 > bhi) break;
+                lds_wait_ge<true>(&sy->x1flag, st + 1);
+                lds_wait_ge<true>(&sy->x2flag, st + 1);
+                for (int b = (st + 2 > blo ? st + 2 : blo); b <= bhi; b++) {
+                    int cnt = 0;
+                    for (int a0 = b + ((me + b + b) & 1); a0 < NB16; a0 += 4) {
+                        const int a1 = a0 + 2;
+                        PD_TRACE(1000 + b * 10 + st);
+                        const bool two = a1 < NB16;
+                        TileUpd u0, u1;
+                        u0.load(S, a0, b, st, fr, fk);
+                        if (two) u1.load(S, a1, b, st, fr, fk);
+                        u0.mma();
+                        if (two) u1.mma();
+                        u0.store(S, fr, fk);
+                        if (two) u1.store(S, fr, fk);
+                        cnt += two ? 2 : 1;
+                        PD_TRACE(2000 + b * 10 + st);
+                    }
+                    if (st == b - 2 && cnt) {
+                        asm volatile("" ::: "memory");
+                        if (lane == 0) __hip_atomic_fetch_add(&sy->cF[st], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        asm volatile("" ::: "memory");
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // L (lower triangle of S), row-major, 16 bytes per thread and store
+    {
+        const bool vec = (((uintptr_t)A & 15) == 0) && ((lda & 1) == 0);
+        constexpr int NCH2 = PD_NB * PD_NB / 2;
+        for (int idx = tid; idx < NCH2; idx += PD_THREADS) {
+            const int r = idx / (PD_NB / 2), c2 = (idx % (PD_NB / 2)) * 2;
+            if (c2 > r) continue;
+            const f64x2 w = *reinterpret_cast<const f64x2 *>(&S[r][c2]);
+            double *dst = A + (int64_t)r * lda + c2;
+            if (c2 + 1 <= r) {
+                if (vec) *reinterpret_cast<f64x2 *>(dst) = w;
+                else {
+                    dst[0] = w[0];
+                    dst[1] = w[1];
+                }
+            } else {
+                dst[0] = w[0];
+            }
+        }
+    }
+    PD_STAMP(2);
+    PD_STAMP_DUMP();
+}
+
+template <bool LA>
 __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restrict__ A, int64_t lda,
                                                                 double *__restrict__ invd, int32_t *info,
                                                                 int64_t info_col0, const unsigned *wait_word,
@@ -472,7 +1019,8 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restri
     A += (int64_t)blockIdx.y * bs_a;
     invd += (int64_t)blockIdx.y * bs_ws;
     info += blockIdx.y;
-    potf2_body<false>(A, lda, invd, info, info_col0, nullptr, 0u);
+    if (LA) potf2_body_la<false>(A, lda, invd, info, info_col0, nullptr, 0u);
+    else potf2_body<false>(A, lda, invd, info, info_col0, nullptr, 0u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -487,6 +1035,7 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restri
 // of the launch gets potf2's 135 KB of LDS, i.e. a CU to itself: used only while the panel is short (few workgroups,
 // idle chip); above that the two plain kernels run (host side, api.hip).
 // ------------------------------------------------------------------------------------------------
+template <bool LA>
 __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restrict__ A, int64_t lda,
                                                                 double *__restrict__ invd, int32_t *info,
                                                                 int64_t info_col0, int64_t m, double *__restrict__ B,
@@ -497,7 +1046,8 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
 {
     edge_wait(wait_word, wait_val, wait_err);
     if (blockIdx.x == 0) {
-        potf2_body<true>(A, lda, invd, info, info_col0, flag, flag_base);
+        if (LA) potf2_body_la<true>(A, lda, invd, info, info_col0, flag, flag_base);
+        else potf2_body<true>(A, lda, invd, info, info_col0, flag, flag_base);
         // (edge flag: "the panel is final" -- what the waiting update reads are the consumers' rows; this workgroup only
         // has to be counted)
         if (edge) edge_signal(edge, edge_val, gridDim.x);
@@ -832,10 +1382,18 @@ __global__ __launch_bounds__(PD_THREADS) void potf2x2_trsm_kernel(double *__rest
 // is a property of the function ON ONE DEVICE: set once per (kernel, device), thread-safe (ll_batch and bench.py drive
 // two contexts from two host threads; a process may hold contexts on several GPUs).
 #include <mutex>
+#include <cstdlib>
+// GPT_POTF2_LA=0 selects the lock-step body (potf2_body) for the 128-column kernels; the look-ahead body is the default
+// (same-box A/B, round 4: N = 4096 1.245 -> 1.207 ms, N = 8192 4.437 -> 4.402 ms; profiles/r04_potf2_la.txt)
+static bool potf2_lookahead()
+{
+    static const bool on = [] { const char *e = getenv("GPT_POTF2_LA"); return e == nullptr || atoi(e) != 0; }();
+    return on;
+}
 static int ensure_big_lds(const void *fn, int which, size_t shmem)
 {
     static std::mutex mu;
-    static bool done[3][64];
+    static bool done[5][64];
     int dev = 0;
     GPT_HIP_CHECK(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) dev = 63;
@@ -853,13 +1411,15 @@ int launch_potf2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int3
                       unsigned *flag, unsigned flag_base, hipEvent_t done, EdgeSig edge, EdgeSig wait)
 {
     gpt_jitter(st);
-    const size_t shmem = (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
-    { int rc_ = ensure_big_lds(reinterpret_cast<const void *>(potf2_trsm_kernel), 0, shmem); if (rc_ != GPT_OK) return rc_; }
+    const bool la = potf2_lookahead();
+    const size_t shmem = la ? PD_LA_SMEM_BYTES : (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
+    auto kern = la ? potf2_trsm_kernel<true> : potf2_trsm_kernel<false>;
+    { int rc_ = ensure_big_lds(reinterpret_cast<const void *>(kern), la ? 3 : 0, shmem); if (rc_ != GPT_OK) return rc_; }
     const unsigned grid = 1u + (unsigned)((m + 16 * PD_WAVES - 1) / (16 * PD_WAVES));
-    if (done) hipExtLaunchKernelGGL(potf2_trsm_kernel, dim3(grid), dim3(PD_THREADS), shmem, st, nullptr, done, 0, A, lda, invd,
+    if (done) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(PD_THREADS), shmem, st, nullptr, done, 0, A, lda, invd,
                                     info, info_base, m, A + 128 * lda, lda, flag, flag_base, edge.word, edge.value,
                                     wait.word, wait.value, wait.err);
-    else hipLaunchKernelGGL(potf2_trsm_kernel, dim3(grid), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base, m,
+    else hipLaunchKernelGGL(kern, dim3(grid), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base, m,
                             A + 128 * lda, lda, flag, flag_base, edge.word, edge.value, wait.word, wait.value, wait.err);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
@@ -888,9 +1448,11 @@ int launch_potf2_diag(hipStream_t st, double *A, int64_t lda, double *invd, int3
                       int64_t nbatch, int64_t bstride_a, int64_t bstride_ws)
 {
     gpt_jitter(st);
-    const size_t shmem = (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
-    { int rc_ = ensure_big_lds(reinterpret_cast<const void *>(potf2_diag_kernel), 1, shmem); if (rc_ != GPT_OK) return rc_; }
-    hipLaunchKernelGGL(potf2_diag_kernel, dim3(1, (unsigned)nbatch), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base, wait.word,
+    const bool la = potf2_lookahead();
+    const size_t shmem = la ? PD_LA_SMEM_BYTES : (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
+    auto kern = la ? potf2_diag_kernel<true> : potf2_diag_kernel<false>;
+    { int rc_ = ensure_big_lds(reinterpret_cast<const void *>(kern), la ? 4 : 1, shmem); if (rc_ != GPT_OK) return rc_; }
+    hipLaunchKernelGGL(kern, dim3(1, (unsigned)nbatch), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base, wait.word,
                        wait.value, wait.err, bstride_a, bstride_ws);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
