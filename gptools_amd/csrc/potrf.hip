@@ -512,8 +512,9 @@ struct PdSync {
     int colflag;        // chain: columns published so far (16 jb + J + 1)
     int lflag;          // chain: L_jj rows of step jb are in S (jb + 1)
     int x1flag, x2flag; // ride-along waves: strips (and inverse) of step jb stored (jb + 1)
-    int cstage;         // staging waves done (7)
-    int pad_[3];
+    int cstage;         // staging waves done with the columns from 32 on (5)
+    int cstage0;        // ... with the columns 0..31 (5)
+    int pad_[2];
     int cF[8];          // workers: priority tiles of trailing step jb done
 };
 #define PD_LA_COLBUF (2 * 16 * 16)
@@ -669,8 +670,10 @@ __device__ __forceinline__ void ride_pair(double (&v)[16], ColIn &cur, ColIn &pr
     v[2 * P + 1] *= cur.inv[1];
     ride_group<2 * P + 1, 2 * P + 2>(v, c1);
 }
+// (mid(): called after column 7 -- the columns 0..7 of the rows are final then and can be stored while the ride goes on)
+template <class F>
 __device__ __forceinline__ void ride_block(double (&v)[16], const int *colflag, const double *colb, const double *invb,
-                                           int flag0, int i)
+                                           int flag0, int i, F mid)
 {
     ColIn c0, c1;
     col_read(c0, colflag, colb, invb, 0, i);
@@ -678,6 +681,7 @@ __device__ __forceinline__ void ride_block(double (&v)[16], const int *colflag, 
     ride_pair<1>(v, c1, c0, colflag, colb, invb, flag0, i);
     ride_pair<2>(v, c0, c1, colflag, colb, invb, flag0, i);
     ride_pair<3>(v, c1, c0, colflag, colb, invb, flag0, i);
+    mid();
     ride_pair<4>(v, c0, c1, colflag, colb, invb, flag0, i);
     ride_pair<5>(v, c1, c0, colflag, colb, invb, flag0, i);
     ride_pair<6>(v, c0, c1, colflag, colb, invb, flag0, i);
@@ -775,21 +779,24 @@ __device__ __forceinline__ void potf2_body_la(double *__restrict__ A, int64_t ld
         const bool ident = (tq == NB16);
         const int tfirst = (wave == 1) ? 1 : 5, tlast = (wave == 1) ? 4 : 7;
         const int row = (ident ? NB16 - 1 : tq) * 16 + fr;
+        // the first two column blocks are staged first (coalesced; lane = row straight from global memory is 64 cache lines
+        // per load instruction: the rows arrived 2000 cycles after the chain wave's tile)
+        lds_wait_ge<false>(&sy->cstage0, PD_WAVES - 3);
         double v[16];
 #pragma unroll
         for (int c = 0; c < 16; c += 2) {
-            const f64x2 w = *reinterpret_cast<const f64x2 *>(A + (int64_t)row * lda + c);
+            const f64x2 w = *reinterpret_cast<const f64x2 *>(&S[row][c]);
             v[c] = ident ? ((c == fr) ? 1.0 : 0.0) : w[0];
             v[c + 1] = ident ? ((c + 1 == fr) ? 1.0 : 0.0) : w[1];
         }
-        // the wave's three tiles of the NEXT column (what it rides in the next step), C layout: before the first ride straight
-        // from global memory; later from LDS once the workers are through with them (cF)
+        // the wave's three tiles of the NEXT column (what it rides in the next step), C layout, once the workers are through
+        // with them (cF; before the first ride: as staged)
         const int tu0 = (wave == 1) ? 2 : 5;                            // tiles tu0 .. tu0 + 2
         f64x4 accn[3];
 #pragma unroll
         for (int q = 0; q < 3; q++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) accn[q][r] = A[(int64_t)((tu0 + q) * 16 + fk + 4 * r) * lda + 16 + fr];
+            for (int r = 0; r < 4; r++) accn[q][r] = S[(tu0 + q) * 16 + fk + 4 * r][16 + fr];
         for (int jb = 0; jb < NB16; jb++) {
             const bool valid = !ident && tq > jb;
             const bool any = (wave == 2) || (jb < tlast);
@@ -798,21 +805,25 @@ __device__ __forceinline__ void potf2_body_la(double *__restrict__ A, int64_t ld
             if (any) {
                 PD_TRACE(200 + jb);
                 PD_STAMPW((wave == 1 ? 80 : 104) + jb);
-                ride_block(v, &sy->colflag, colbuf + (jb & 1) * 256, invbuf + (jb & 1) * 16, jb * 16, fr);
+                // (the inverse goes out TRANSPOSED: T[l][c] = inv(L_jj)[c][l]; lane l holds column l of the inverse)
+                double *dst = ident ? &T[jb][fr][0] : &S[row][jb * 16];
+                const bool wr = valid || ident;
+                ride_block(v, &sy->colflag, colbuf + (jb & 1) * 256, invbuf + (jb & 1) * 16, jb * 16, fr, [&]() {
+                    if (wr) {
+#pragma unroll
+                        for (int c = 0; c < 8; c += 2) {
+                            f64x2 w = {v[c], v[c + 1]};
+                            *reinterpret_cast<f64x2 *>(dst + c) = w;
+                        }
+                    }
+                });
                 PD_STAMPW((wave == 1 ? 88 : 112) + jb);
                 PD_TRACE(210 + jb);
-                if (valid) {
+                if (wr) {
 #pragma unroll
-                    for (int c = 0; c < 16; c += 2) {
+                    for (int c = 8; c < 16; c += 2) {
                         f64x2 w = {v[c], v[c + 1]};
-                        *reinterpret_cast<f64x2 *>(&S[row][jb * 16 + c]) = w;
-                    }
-                } else if (ident) {
-                    // the inverse goes out TRANSPOSED (T[l][c] = inv(L_jj)[c][l]; lane l holds column l of the inverse)
-#pragma unroll
-                    for (int c = 0; c < 16; c += 2) {
-                        f64x2 w = {v[c], v[c + 1]};
-                        *reinterpret_cast<f64x2 *>(&T[jb][fr][c]) = w;
+                        *reinterpret_cast<f64x2 *>(dst + c) = w;
                     }
                 }
                 PD_STAMPW((wave == 1 ? 72 : 96) + jb);
@@ -875,24 +886,42 @@ __device__ __forceinline__ void potf2_body_la(double *__restrict__ A, int64_t ld
         // ---- stage the columns from 32 on into LDS (waves 3..7): the first two column blocks are read from global memory by
         // the waves that use them (chain: tiles (0, 0), (1, 1); ride-along: rows of column block 0, tiles (t, 1)) ----
         {
-            // (the chain and ride-along waves' loads go first: the 73 KB requested here are not needed before the first strips)
-            __builtin_amdgcn_s_sleep(8);
-            constexpr int CW = (PD_NB - 32) / 2;                    // 16-byte chunks per row
-            constexpr int NCH = (PD_NB - 32) * CW;
+            // phase 1: columns 0..31 of all rows (what the ride-along waves start from), without the chain wave's tiles (0, 0)
+            // and (1, 1); phase 2: the columns from 32 on of the rows from 32 on (the workers' tiles)
             constexpr int NT = PD_THREADS - 192;
-            constexpr int PER = (NCH + NT - 1) / NT;
-            f64x2 v[PER];
+            constexpr int NCH1 = PD_NB * 16, PER1 = (NCH1 + NT - 1) / NT;            // 16-byte chunks
+            constexpr int CW = (PD_NB - 32) / 2;                                      // 16-byte chunks per row of phase 2
+            constexpr int NCH2 = (PD_NB - 32) * CW, PER2 = (NCH2 + NT - 1) / NT;
+            {
+                f64x2 v1[PER1];
 #pragma unroll
-            for (int q = 0; q < PER; q++) {
+                for (int q = 0; q < PER1; q++) {
+                    const int idx = (tid - 192) + q * NT;
+                    const int r = idx / 16, c2 = (idx % 16) * 2;
+                    if (idx < NCH1) v1[q] = *reinterpret_cast<const f64x2 *>(A + (int64_t)r * lda + c2);
+                }
+#pragma unroll
+                for (int q = 0; q < PER1; q++) {
+                    const int idx = (tid - 192) + q * NT;
+                    const int r = idx / 16, c2 = (idx % 16) * 2;
+                    if (idx < NCH1 && r >= 16 && !(r < 32 && c2 >= 16)) *reinterpret_cast<f64x2 *>(&S[r][c2]) = v1[q];
+                }
+                asm volatile("" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(&sy->cstage0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                asm volatile("" ::: "memory");
+            }
+            f64x2 v2[PER2];
+#pragma unroll
+            for (int q = 0; q < PER2; q++) {
                 const int idx = (tid - 192) + q * NT;
                 const int r = 32 + idx / CW, c2 = 32 + (idx % CW) * 2;
-                if (idx < NCH) v[q] = *reinterpret_cast<const f64x2 *>(A + (int64_t)r * lda + c2);
+                if (idx < NCH2) v2[q] = *reinterpret_cast<const f64x2 *>(A + (int64_t)r * lda + c2);
             }
 #pragma unroll
-            for (int q = 0; q < PER; q++) {
+            for (int q = 0; q < PER2; q++) {
                 const int idx = (tid - 192) + q * NT;
                 const int r = 32 + idx / CW, c2 = 32 + (idx % CW) * 2;
-                if (idx < NCH) *reinterpret_cast<f64x2 *>(&S[r][c2]) = v[q];
+                if (idx < NCH2) *reinterpret_cast<f64x2 *>(&S[r][c2]) = v2[q];
             }
             asm volatile("" ::: "memory");
             if (lane == 0) __hip_atomic_fetch_add(&sy->cstage, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -946,21 +975,26 @@ __device__ __forceinline__ void potf2_body_la(double *__restrict__ A, int64_t ld
             // (Step b - 1 of column b is taken by the waves that use it next: the ride-along waves, the chain wave for (b, b).)
             // A tile's steps go in order (one owner, program order): step-major, within a step the lowest column first.
             // cF[s] counts the tiles of column s + 2 that have taken step s, their last one here.
-            // Ownership: the columns 2..4 -- 28 tile-steps, the early deadlines -- are waves 3 and 7's (one SIMD), the columns 5..7
-            // -- 28 tile-steps, late deadlines -- waves 5 and 6's: those share their SIMDs with the ride-along waves, and on gfx950
+            // Ownership: column 4 is waves 3 and 7's (one SIMD), the columns 5..7 -- late deadlines -- waves 5 and 6's: those share
+            // their SIMDs with the ride-along waves, and on gfx950
             // a SIMD's fp64 MFMAs run at 32 flop per cycle (64 cycles per 16x16x4): a busy partner doubled the time of the
             // ride-along waves' own tile updates between two rides (2000 against 1100 cycles), which are on the chain.
-            const int me = (wave == 3 || wave == 5) ? 0 : 1;        // tiles (a, b) with (a + b) & 1 == me
-            const int blo = (wave == 3 || wave == 7) ? 2 : 5, bhi = blo + 2;
+            // (columns 2 and 3 -- the first deadlines, 16 tile-steps in the first two steps -- go four ways all the same)
+            const int me2 = (wave == 3 || wave == 5) ? 0 : 1;       // columns >= 4: tiles (a, b) with (a + b) & 1 == me2
+            const int me4 = (wave == 3) ? 0 : wave - 4;             // columns 2, 3: (a + b) & 3 == me4 (waves 3, 5, 6, 7 -> 0 .. 3)
+            const int blo = (wave == 3 || wave == 7) ? 4 : 5, bhi = (wave == 3 || wave == 7) ? 4 : 7;
             lds_wait_ge<true>(&sy->cstage, PD_WAVES - 3);
             for (int st = 0; st + 2 < NB16; st++) {                 // step-major, within a step the lowest column first
                 if (st + 2 > bhi) break;
                 lds_wait_ge<true>(&sy->x1flag, st + 1);
                 lds_wait_ge<true>(&sy->x2flag, st + 1);
-                for (int b = (st + 2 > blo ? st + 2 : blo); b <= bhi; b++) {
+                for (int b = st + 2; b <= bhi; b++) {
+                    if (b > 3 && b < blo) continue;
+                    const bool four = b <= 3;
                     int cnt = 0;
-                    for (int a0 = b + ((me + b + b) & 1); a0 < NB16; a0 += 4) {
-                        const int a1 = a0 + 2;
+                    const int astep = four ? 8 : 4, apair = four ? 4 : 2;
+                    for (int a0 = four ? b + ((me4 - 2 * b) & 3) : b + ((me2 + b + b) & 1); a0 < NB16; a0 += astep) {
+                        const int a1 = a0 + apair;
                         PD_TRACE(1000 + b * 10 + st);
                         const bool two = a1 < NB16;
                         TileUpd u0, u1;

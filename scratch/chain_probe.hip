@@ -31,7 +31,7 @@ __global__ __launch_bounds__(512) void probe(const double *A, long long *out, do
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             long long r0 = __builtin_amdgcn_s_memtime();
 #ifndef CHAIN_NOPUB
-            ride_block(v, &flags[0], colbuf, invbuf, rep * 16, fr);
+            ride_block(v, &flags[0], colbuf, invbuf, rep * 16, fr, [] {});
 #endif
             long long r1 = __builtin_amdgcn_s_memtime();
             if (rep == 2) { t[6] = r0; t[7] = r1; }
