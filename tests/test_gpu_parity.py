@@ -715,6 +715,53 @@ def test_dense_kernels_against_numpy(ctx):
     assert "2-th leading minor" in str(ei.value)
 
 
+def test_diagonal_block_kernel_look_ahead_body(ctx):
+    """The 128-column leaf kernel's waves hand over through flags in LDS (potrf.hip, potf2_body_la: chain wave, ride-along
+    waves, workers, store wave -- no workgroup barrier inside its loop).  A missing hand-over would show as a result that
+    depends on the waves' timing: the same matrices factored 200 times must give the same bits every time, and LAPACK's factor
+    to rounding; the first column that is not positive definite is reported wherever it lies in the block (first / inner /
+    last column of a 16-column pivot block, first and last block, second 128-block behind a fused TRSM)."""
+    rs = np.random.RandomState(2024)
+    for N in (128, 640):
+        A = rs.randn(N, N)
+        A = A.dot(A.T) + N * np.eye(N)
+        ref = np.linalg.cholesky(A)
+        first = None
+        for rep in range(200 if N == 128 else 40):
+            L = ctx.potrf_host(A)
+            if first is None:
+                first = L.copy()
+                np.testing.assert_allclose(L, ref, rtol=1e-11, atol=1e-11)
+            else:
+                assert np.array_equal(L, first), "run %d of N = %d differs from the first" % (rep, N)
+        for col in (0, 1, 15, 16, 37, 111, 112, 127) + ((128, 200, 639) if N == 640 else ()):
+            B = A.copy()
+            B[col, col] = -1.0
+            with pytest.raises(np.linalg.LinAlgError) as ei:
+                ctx.potrf_host(B)
+            assert ("%d-th leading minor" % (col + 1)) in str(ei.value), (N, col, str(ei.value))
+    # the lock-step body (the 256-column leaf kernel keeps it) agrees to rounding: another process, GPT_POTF2_LA=0
+    import subprocess
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from gptools_amd import _lib\n"
+        "c = _lib.Context(0)\n"
+        "rs = np.random.RandomState(7)\n"
+        "A = rs.randn(384, 384); A = A.dot(A.T) + 384 * np.eye(384)\n"
+        "L = c.potrf_host(A)\n"
+        "print('RESULT', repr(float(np.abs(L - np.linalg.cholesky(A)).max())), repr(float(L.sum())))\n") % (ROOT,)
+    res = {}
+    for la in ("0", "1"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GPT_POTF2_LA=la), stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [l.split() for l in out.stdout.splitlines() if l.startswith("RESULT")][0]
+        res[la] = (float(line[1]), float(line[2]))
+        assert res[la][0] < 1e-11
+    assert abs(res["0"][1] - res["1"][1]) <= 1e-10 * abs(res["0"][1])
+
+
 def test_single_gpu_schedule_under_stream_jitter(ctx):
     """Missing-edge detector for the look-ahead schedule of gpt_fit (main / panel / helper streams): with GPT_JITTER set
     the library puts a delay kernel of random length in front of every dense launch.  Every dependency is an event, so
