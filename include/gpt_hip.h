@@ -108,7 +108,8 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
  * ("rows,cols,mode": supertile shape and deal of the GEMM's XCD-aware tile order, default 64,8,1), GPT_GRAD_TIMING,
  * GPT_EDGE_FLAGS=0 (event edges only: set it for jobs that share one GPU between several processes), GPT_GEMM_SMALL (64x64-tile count under which a GEMM launch uses 32x32 tiles, 512),
  * GPT_JITTER (test aid: random delay kernels in front of every dense launch), GPT_ALPHA_NARROW (measurement aid: gpt_get_alpha
- * by 128-wide substitution steps instead of the 512-wide block inverses). */
+ * by 128-wide substitution steps instead of the 512-wide block inverses), GPT_POTF2_LA=0 (the 128-column diagonal-block kernels
+ * with the lock-step body of rounds 1-3 instead of the look-ahead body; results agree to rounding, not bit for bit). */
 int gpt_ctx_set_option(gpt_ctx *ctx, const char *key, int64_t value);
 int gpt_ctx_synchronize(gpt_ctx *ctx);
 void *gpt_ctx_stream(gpt_ctx *ctx);
