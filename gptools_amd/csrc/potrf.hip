@@ -557,23 +557,18 @@ __device__ __forceinline__ int pd_prio_count(int s) { return (s <= 5) ? 6 - s : 
 // statement (the compiler keeps their order) and slot J = the chain steps of column J with the updates of column J - 1 spread
 // over its gaps.  The new pivot is read AFTER the first update (lane J+1 of a[J+1] then IS a[J+1][J+1] - l^2, the same fused
 // operation as before), which saves the two broadcasts and the explicit fma.
-template <int JP, int C0, int N>
-__device__ __forceinline__ void chain_fill(double (&a)[16])
-{
-    if constexpr (JP >= 0 && N > 0 && C0 < 16) {
-        fnmac_bcast<C0>(a[C0], a[JP], a[JP]);
-        chain_fill<JP, C0 + 1, N - 1>(a);
-    }
-}
+// (chain_slots.inc, generated by scratch/gen_chain_slots.py: per column two asm blocks with the instructions in exactly this order
+// -- A: scale, two updates of the column before, the first update of this column; B: the new pivot, rsq + Newton step with the other
+// updates of the column before in the gaps.  One statement per instruction left room for hipcc's conservative hazard s_nops: 9 of a
+// column's 33 instructions.)
+template <int J> __device__ __forceinline__ void chain_slot_a(double (&a)[16], double &inv);
+template <int J> __device__ __forceinline__ void chain_slot_b(double (&a)[16], double &inv);
+#include "chain_slots.inc"
 template <int J>
 __device__ __forceinline__ void chain_slot(double (&a)[16], double &inv, double &inv_prev, double *colb, double *invb, int *colflag,
                                            int flag0, int i)
 {
-    double d, y0, t, h, u;
-    asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a[J]) : "v"(inv));                       // column J of L (lane r: L[r][J])
-    chain_fill<J - 1, J + 1, 2>(a);
-    if constexpr (J + 1 < 16)
-        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(a[J + 1]) : "v"(a[J]), "i"(J + 1));
+    chain_slot_a<J>(a, inv);
     // two columns per publication (an LDS store costs ~4 cycles of issue per register it reads: three stores per column were
     // 50 of a column's ~170 cycles): after an odd column J the pair (J - 1, J) goes out as one 16-byte store per lane, the
     // pair of 1/sqrt(pivot) as another, then the count
@@ -587,19 +582,7 @@ __device__ __forceinline__ void chain_slot(double (&a)[16], double &inv, double 
     } else {
         inv_prev = inv;
     }
-    if constexpr (J + 1 < 16) {
-        chain_fill<J - 1, J + 3, 1>(a);
-        asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(a[J + 1]), "i"(J + 1));
-        chain_fill<J - 1, J + 4, 3>(a);
-        asm volatile("s_nop 0\n\tv_rsq_f64 %0, %1" : "=v"(y0) : "v"(d));
-        chain_fill<J - 1, J + 7, 4>(a);
-        asm volatile("s_nop 0\n\tv_mul_f64 %0, %2, %3\n\tv_mul_f64 %1, %3, 0.5" : "=&v"(t), "=&v"(h) : "v"(d), "v"(y0));
-        chain_fill<J - 1, J + 11, 1>(a);
-        asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(u) : "v"(t), "v"(y0));
-        chain_fill<J - 1, J + 12, 2>(a);
-        asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(inv) : "v"(h), "v"(u), "v"(y0));
-        chain_fill<J - 1, J + 14, 16>(a);
-    }
+    chain_slot_b<J>(a, inv);
 }
 __device__ __forceinline__ void chain_block(double (&a)[16], double *colb, double *invb, int *colflag, int flag0, int i)
 {
@@ -979,7 +962,8 @@ __device__ __forceinline__ void potf2_body_la(double *__restrict__ A, int64_t ld
             // their SIMDs with the ride-along waves, and on gfx950
             // a SIMD's fp64 MFMAs run at 32 flop per cycle (64 cycles per 16x16x4): a busy partner doubled the time of the
             // ride-along waves' own tile updates between two rides (2000 against 1100 cycles), which are on the chain.
-            // (columns 2 and 3 -- the first deadlines, 16 tile-steps in the first two steps -- go four ways all the same)
+            // (columns 2 and 3 -- the first deadlines, 16 tile-steps in the first two steps -- go four ways all the same: one SIMD
+            // cannot take the 36 tile updates of the first two steps; waves 3 and 7 with the columns 2..5: step 2 waits 4800 cycles)
             const int me2 = (wave == 3 || wave == 5) ? 0 : 1;       // columns >= 4: tiles (a, b) with (a + b) & 1 == me2
             const int me4 = (wave == 3) ? 0 : wave - 4;             // columns 2, 3: (a + b) & 3 == me4 (waves 3, 5, 6, 7 -> 0 .. 3)
             const int blo = (wave == 3 || wave == 7) ? 4 : 5, bhi = (wave == 3 || wave == 7) ? 4 : 7;
