@@ -671,6 +671,29 @@ __device__ __forceinline__ void ride_block(double (&v)[16], const int *colflag, 
     ride_pair<7>(v, c1, c0, colflag, colb, invb, flag0, i);
 }
 
+// Row-major copy of the columns [c_lo, c_hi) of L (lower triangle of S) to global memory by ONE wave, 16 bytes per lane and store
+// (c_lo, c_hi multiples of 16).  Called by waves that have run out of work, for column blocks that are final, while the chain goes on.
+__device__ __forceinline__ void pd_copy_out_cols(double (*S)[PD_PITCH], double *__restrict__ A, int64_t lda, int c_lo, int c_hi, int lane)
+{
+    const bool vec = (((uintptr_t)A & 15) == 0) && ((lda & 1) == 0);
+    const int cw = (c_hi - c_lo) / 2;                            // 16-byte chunks per row
+    for (int idx = lane; idx < (PD_NB - c_lo) * cw; idx += 64) {
+        const int r = c_lo + idx / cw, c2 = c_lo + (idx % cw) * 2;
+        if (c2 > r) continue;
+        const f64x2 w = *reinterpret_cast<const f64x2 *>(&S[r][c2]);
+        double *dst = A + (int64_t)r * lda + c2;
+        if (c2 + 1 <= r) {
+            if (vec) *reinterpret_cast<f64x2 *>(dst) = w;
+            else {
+                dst[0] = w[0];
+                dst[1] = w[1];
+            }
+        } else {
+            dst[0] = w[0];
+        }
+    }
+}
+
 template <bool PUBLISH>
 __device__ __forceinline__ void potf2_body_la(double *__restrict__ A, int64_t lda, double *__restrict__ invd, int32_t *info,
                                               int64_t info_col0, unsigned *flag, unsigned flag_base)
@@ -865,6 +888,14 @@ __device__ __forceinline__ void potf2_body_la(double *__restrict__ A, int64_t ld
             }
         }
         __builtin_amdgcn_s_setprio(0);
+        if (wave == 1) {
+            // wave 1 has no rows left after step 3: it writes the row-major copy of the columns 0..63 of L (final once the strips and
+            // the diagonal tiles of the steps 0..3 are stored) while the steps 4..7 run (the copy-out of the whole block after the
+            // loop was 2400 of the kernel's 46 000 cycles); waves 3 and 7 take the columns 64..111 when their tiles are done
+            lds_wait_ge<true>(&sy->x2flag, 4);
+            lds_wait_ge<true>(&sy->lflag, 4);
+            pd_copy_out_cols(S, A, lda, 0, 64, lane);
+        }
     } else {
         // ---- stage the columns from 32 on into LDS (waves 3..7): the first two column blocks are read from global memory by
         // the waves that use them (chain: tiles (0, 0), (1, 1); ride-along: rows of column block 0, tiles (t, 1)) ----
@@ -998,15 +1029,21 @@ __device__ __forceinline__ void potf2_body_la(double *__restrict__ A, int64_t ld
                     }
                 }
             }
+            if (wave == 3 || wave == 7) {                           // (done with their columns after step 2)
+                const int done = (wave == 3) ? 6 : 7;
+                lds_wait_ge<true>(&sy->x2flag, done);
+                lds_wait_ge<true>(&sy->lflag, done);
+                pd_copy_out_cols(S, A, lda, wave == 3 ? 64 : 96, wave == 3 ? 96 : 112, lane);
+            }
         }
     }
     __syncthreads();
-    // L (lower triangle of S), row-major, 16 bytes per thread and store
+    // L (lower triangle of S), row-major: what is left are the columns from 112 on (0..111: waves 1, 3 and 7, above)
     {
         const bool vec = (((uintptr_t)A & 15) == 0) && ((lda & 1) == 0);
-        constexpr int NCH2 = PD_NB * PD_NB / 2;
+        constexpr int NCH2 = (PD_NB - 112) * 8;
         for (int idx = tid; idx < NCH2; idx += PD_THREADS) {
-            const int r = idx / (PD_NB / 2), c2 = (idx % (PD_NB / 2)) * 2;
+            const int r = 112 + idx / 8, c2 = 112 + (idx % 8) * 2;
             if (c2 > r) continue;
             const f64x2 w = *reinterpret_cast<const f64x2 *>(&S[r][c2]);
             double *dst = A + (int64_t)r * lda + c2;
