@@ -1119,7 +1119,6 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
     const int64_t row0 = ((int64_t)(blockIdx.x - 1) * PD_WAVES + wave) * 16;
     const bool active = row0 < m;
     f64x4 bt[NB16];
-    double xa[NB16][4];
     if (active) {
 #pragma unroll
         for (int j = 0; j < NB16; j++)
@@ -1127,10 +1126,8 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
             for (int r = 0; r < 4; r++) bt[j][r] = B[(row0 + fk + 4 * r) * ldb + j * 16 + fr];
     }
     const double *lpk = invd + GPT_WS_LOFF;
-    // acc: right-hand side of step j with the earlier steps already folded in, bt[j] - sum_{c<j} x_c L_jc^T.  The blocks
-    // (j, c < j) were published in rounds c < j, i.e. they are covered by the flag value step j-1 has waited for: the
-    // folding for step j+1 is done right after step j, while workgroup 0 is still busy with pivot block j+1, and what
-    // remains behind flag j+1 is one load of inv(L_jj), four MFMAs, the re-layout and the store.
+    // acc: right-hand side of step j with the earlier steps already folded in, bt[j] - sum_{c<j} x_c L_jc^T (the folding is
+    // right-looking, see below): what remains behind flag j+1 is one load of inv(L_jj), four MFMAs, the re-layout and the store.
     f64x4 acc = bt[0];
 #pragma unroll
     for (int j = 0; j < NB16; j++) {
@@ -1161,19 +1158,26 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
             X[fk + 4 * r][fr] = res[r];
         }
         if (j + 1 < NB16) {
+            // right-looking: x_j goes into EVERY later right-hand side now (the blocks (j' > j, j) came with this round).  The
+            // left-looking form -- fold the blocks (j + 1, c <= j) right before step j + 1 -- put 28 dependent MFMAs (64 cycles
+            // each on gfx950, two waves per SIMD) between the last two flags: the consumers finished 2600 cycles behind the last
+            // publication instead of one step's 500.  Every accumulator sees the same operations in the same order: same bits.
+            double xj[4];
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) xa[j][kk] = -X[fr][fk + 4 * kk];
-            acc = bt[j + 1];
+            for (int kk = 0; kk < 4; kk++) xj[kk] = -X[fr][fk + 4 * kk];
+            double lv[NB16][4];
 #pragma unroll
-            for (int c = 0; c <= j; c++) {
-                double lv[4];
+            for (int jp = j + 1; jp < NB16; jp++)
 #pragma unroll
                 for (int kk = 0; kk < 4; kk++)
-                    lv[kk] = __hip_atomic_load(lpk + ((j + 1) * j / 2 + c) * 256 + kk * 64 + lane, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
+                    lv[jp][kk] = __hip_atomic_load(lpk + (jp * (jp - 1) / 2 + j) * 256 + kk * 64 + lane, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[c][kk], lv[kk], acc, 0, 0, 0);
-            }
+            for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+                for (int jp = j + 1; jp < NB16; jp++)
+                    bt[jp] = __builtin_amdgcn_mfma_f64_16x16x4f64(xj[kk], lv[jp][kk], bt[jp], 0, 0, 0);
+            acc = bt[j + 1];
         }
     }
     if (edge) edge_signal(edge, edge_val, gridDim.x);

@@ -32,8 +32,8 @@ int main()
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     long long *dtr;
-    CK(hipMalloc(&dtr, 8 * 256 * 2 * 8));
-    CK(hipMemset(dtr, 0, 8 * 256 * 2 * 8));
+    CK(hipMalloc(&dtr, 16 * 256 * 2 * 8));
+    CK(hipMemset(dtr, 0, 16 * 256 * 2 * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_pd_trace), &dtr, sizeof(dtr)));
     printf("body: %s\n", la ? "look-ahead (potf2_body_la)" : "lock-step (potf2_body)");
     for (int rep = 0; rep < 4; rep++) {
@@ -154,6 +154,19 @@ int main()
                 w2 = fmax(w2, fabs(s - P[(size_t)i * ld + j]));
             }
         printf("potf2_trsm m=%d: best event %.1f us; max |X L^T - B| over sampled rows %.3e\n", m, best * 1e3, w2);
+#ifdef GPT_PD_TRACE
+        if (m == 1024) {
+            std::vector<long long> tr(16 * 256 * 2);
+            CK(hipMemcpy(tr.data(), dtr, tr.size() * 8, hipMemcpyDeviceToHost));
+            long long t0 = tr[0];
+            FILE *f = fopen("gpurun_out/la/trace_fused.txt", "w");
+            for (int w = 0; w < 16; w++)
+                for (int k = 0; k < 250 && tr[(w * 256 + k) * 2 + 1] != 0; k++)
+                    fprintf(f, "%d %lld %lld\n", w, tr[(w * 256 + k) * 2] - t0, tr[(w * 256 + k) * 2 + 1]);
+            fclose(f);
+        }
+        CK(hipMemset(dtr, 0, 16 * 256 * 2 * 8));
+#endif
     }
     return 0;
 }
