@@ -1291,8 +1291,8 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "alpha_invalidate")) c->alpha_valid = false;          // (measurement aid: the next gpt_get_alpha recomputes)
     else if (!strcmp(key, "edge_test_stall")) c->edge_test_stall = value;
     else if (!strcmp(key, "tile")) {
-        if (value != 0 && value != 64 && value != 65 && value != 128 && value != 129) {
-            gpt_set_error("tile must be 0, 64 or 128");
+        if (value != 0 && value != 32 && value != 64 && value != 65 && value != 128 && value != 129) {
+            gpt_set_error("tile must be 0, 32, 64 or 128");
             return GPT_E_ARG;
         }
         c->tile = (int)value;

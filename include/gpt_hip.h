@@ -98,7 +98,7 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
  *   "graph"        0/1: replay the factorisation from a captured hipGraph
  *   "timing"       0/1: record per-phase HIP events (gpt_last_timings)
  *   "profile_gemm" 0/1: HIP-event timing of each large GEMM launch (gpt_gemm_profile_read)
- *   "tile"         0 auto, 64, 65 (4-stage), 128 (persistent), 129: force the GEMM macro-tile
+ *   "tile"         0 auto, 32, 64, 65 (4-stage), 128 (persistent), 129: force the GEMM macro-tile
  *   "debug_poison" 0/1 (test aid): gpt_ll_grad fills its scratch matrices with NaN before use
  *   "edge_test_stall" 1 (test aid): the next evaluation's first flag is withheld once, so that the bounded wait, the repeat on
  *                  event edges and the switch of the process to event edges can be tested
