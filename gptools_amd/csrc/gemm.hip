@@ -158,52 +158,19 @@ __device__ long long *g_gemm_stamps;
 #define GM_LOADC(p) (*(p))
 #define GM_STOREC(v, p) (*(p) = (v))
 #endif
-template <int BM, int BN, int WPS, int NSTAGE>
-__global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
+// The tile body (everything behind "this workgroup's tile starts at (row0, col0)"), force-inlined into the kernels below: the
+// one-tile kernel and the mixed-tile kernel (which calls it as a 64x64 tile or as one 32x32 quarter of one).
+template <int BM, int BN, int NSTAGE>
+__device__ __forceinline__ void gemm_tile_body(
+    int64_t row0, int64_t col0, int64_t tj, double *sA, double *sB,
     int64_t m, int64_t n, int64_t k, double alpha, const double *__restrict__ A, int64_t lda,
     const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
-    int tri, int64_t ntm, int64_t ntn, int64_t nwg, const int2 *__restrict__ order, int64_t seg_cols, int64_t bskip, int prio, unsigned *edge, unsigned edge_val,
-    unsigned edge_total, const unsigned *wait_word, unsigned wait_val, unsigned *wait_err, int edge_cols, int64_t bstride,
-    const unsigned *tail_word, unsigned tail_val, unsigned *tail_err, int64_t bstride_b, int64_t bstride_c)
+    int64_t seg_cols, int64_t bskip, int prio, unsigned *edge, unsigned edge_val,
+    unsigned edge_total, const unsigned *wait_word, unsigned wait_val, unsigned *wait_err, int edge_cols,
+    const unsigned *tail_word, unsigned tail_val, unsigned *tail_err)
 {
-    // batched launches (blockIdx.y = batch element).  gpt_fit_batch: independent small matrices, A, B and C all inside the
-    // element's own matrix, one stride; the batched block inverses (api.hip build_block_inverses): three operands in three
-    // different arrays, a stride each
-    A += (int64_t)blockIdx.y * bstride;
-    B += (int64_t)blockIdx.y * bstride_b;
-    C += (int64_t)blockIdx.y * bstride_c;
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int RM = WM / 16, RN = WN / 16;
-    // NSTAGE LDS buffers per operand: 2 for the large launches (four workgroups per CU hide the DMA latency for each
-    // other), 4 for the small, latency-bound launches of the panel (one workgroup per CU: the DMA of k-tile t+3 is
-    // in flight while k-tile t is multiplied, drained with a COUNTED s_waitcnt vmcnt).
-    __shared__ __attribute__((aligned(16))) double sA[NSTAGE][BM * GM_BK];
-    __shared__ __attribute__((aligned(16))) double sB[NSTAGE][BN * GM_BK];
-
-    // tile of this workgroup: from the host-built, XCD-aware order table (see tile_order()) or, without one, the
-    // closed-form enumeration
-    GM_STAMP(0);
-#ifndef GPT_GEMM_NOPRIO
-    // A new workgroup's waves are the YOUNGEST on their SIMDs and lose the issue arbitration to the three older
-    // workgroups' main loops: measured with per-workgroup stamps (scratch/gemm_stamps.hip) the prologue -- C tile and
-    // first operand tiles requested, then waited for -- took 20 us of a workgroup's 52 us at steady state against < 9 us
-    // when a launch starts on an empty chip, so only half of the resident workgroups were multiplying.  The prologue
-    // therefore runs at raised priority (its few dozen instructions go out at once; then the wave sleeps on memory).
-    __builtin_amdgcn_s_setprio(3);
-#endif
-    int64_t ti, tj;
-    if (order != nullptr) {
-        const int2 t = order[blockIdx.x];
-        if (t.x < 0) {
-            if (tail_word != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) edge_poll<16, false>(tail_word, tail_val, tail_err);
-            return;
-        }
-        ti = t.x;
-        tj = t.y;
-    } else {
-        tile_decode(xcd_remap(blockIdx.x, nwg), tri, ntn, &ti, &tj);
-    }
-    const int64_t row0 = ti * BM, col0 = tj * BN;
     GM_STAMP(6);
     const int tid = threadIdx.x, lane = tid & 63;
     // (edge_cols > 0: only the workgroups of the first edge_cols tile columns -- first in the order table -- write through
@@ -229,7 +196,7 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     // down per segment; plain launches have seg_cols == 0
     const int64_t brow0 = seg_cols ? col0 + (col0 / seg_cols) * bskip : col0;
     stage_ptrs<BN>(B, ldb, brow0, seg_cols ? (int64_t)1 << 62 : n, wave, lane, srcB);
-    const unsigned ldsA = lds_addr(&sA[0][0]), ldsB = lds_addr(&sB[0][0]);
+    const unsigned ldsA = lds_addr(sA), ldsB = lds_addr(sB);
     constexpr unsigned ABYTES = BM * GM_BK * sizeof(double), BBYTES = BN * GM_BK * sizeof(double);
     const int64_t nk = k / GM_BK;
     constexpr int PRE = NSTAGE - 1;                         // k-tiles requested ahead of the one being multiplied
@@ -287,7 +254,7 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
             stage_issue<BM>(srcA, (kt + PRE) * GM_BK, ldsA + nxt * ABYTES, wave);
             stage_issue<BN>(srcB, (kt + PRE) * GM_BK, ldsB + nxt * BBYTES, wave);
         }
-        mma_ktile<RM, RN>(sA[cur], sB[cur], wm * WM, wn * WN, fr, fk, acc);
+        mma_ktile<RM, RN>(sA + cur * (BM * GM_BK), sB + cur * (BN * GM_BK), wm * WM, wn * WN, fr, fk, acc);
         // k-tile kt+1 must be complete before the barrier; up to PRE-1 younger k-tiles may stay in flight
         if (NSTAGE == 2 || kt + PRE >= nk) dma_wait();
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PRE - 1) * PERSTAGE) : "memory");
@@ -319,6 +286,84 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
     // per panel while the updates set the pace; the word is then up long before this point and the poll is one load), and the
     // next launch still starts behind a kernel boundary, i.e. with the caches invalidated AFTER the word was seen.
     if (tail_word != nullptr && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && tid == 0) edge_poll<16, false>(tail_word, tail_val, tail_err);
+}
+
+template <int BM, int BN, int WPS, int NSTAGE>
+__global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
+    int64_t m, int64_t n, int64_t k, double alpha, const double *__restrict__ A, int64_t lda,
+    const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
+    int tri, int64_t ntm, int64_t ntn, int64_t nwg, const int2 *__restrict__ order, int64_t seg_cols, int64_t bskip, int prio, unsigned *edge, unsigned edge_val,
+    unsigned edge_total, const unsigned *wait_word, unsigned wait_val, unsigned *wait_err, int edge_cols, int64_t bstride,
+    const unsigned *tail_word, unsigned tail_val, unsigned *tail_err, int64_t bstride_b, int64_t bstride_c)
+{
+    // batched launches (blockIdx.y = batch element).  gpt_fit_batch: independent small matrices, A, B and C all inside the
+    // element's own matrix, one stride; the batched block inverses (api.hip build_block_inverses): three operands in three
+    // different arrays, a stride each
+    A += (int64_t)blockIdx.y * bstride;
+    B += (int64_t)blockIdx.y * bstride_b;
+    C += (int64_t)blockIdx.y * bstride_c;
+    // NSTAGE LDS buffers per operand: 2 for the large launches (four workgroups per CU hide the DMA latency for each
+    // other), 4 for the small, latency-bound launches of the panel (one workgroup per CU: the DMA of k-tile t+3 is
+    // in flight while k-tile t is multiplied, drained with a COUNTED s_waitcnt vmcnt).
+    __shared__ __attribute__((aligned(16))) double sA[NSTAGE * BM * GM_BK];
+    __shared__ __attribute__((aligned(16))) double sB[NSTAGE * BN * GM_BK];
+
+    // tile of this workgroup: from the host-built, XCD-aware order table (see tile_order()) or, without one, the
+    // closed-form enumeration
+    GM_STAMP(0);
+#ifndef GPT_GEMM_NOPRIO
+    // A new workgroup's waves are the YOUNGEST on their SIMDs and lose the issue arbitration to the three older
+    // workgroups' main loops: measured with per-workgroup stamps (scratch/gemm_stamps.hip) the prologue -- C tile and
+    // first operand tiles requested, then waited for -- took 20 us of a workgroup's 52 us at steady state against < 9 us
+    // when a launch starts on an empty chip, so only half of the resident workgroups were multiplying.  The prologue
+    // therefore runs at raised priority (its few dozen instructions go out at once; then the wave sleeps on memory).
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    int64_t ti, tj;
+    if (order != nullptr) {
+        const int2 t = order[blockIdx.x];
+        if (t.x < 0) {
+            if (tail_word != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) edge_poll<16, false>(tail_word, tail_val, tail_err);
+            return;
+        }
+        ti = t.x;
+        tj = t.y;
+    } else {
+        tile_decode(xcd_remap(blockIdx.x, nwg), tri, ntn, &ti, &tj);
+    }
+    gemm_tile_body<BM, BN, NSTAGE>(ti * BM, tj * BN, tj, sA, sB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, seg_cols, bskip, prio, edge,
+                                   edge_val, edge_total, wait_word, wait_val, wait_err, edge_cols, tail_word, tail_val, tail_err);
+}
+
+// Mixed tiles (round 4, opt-in: GPT_GEMM_MIXED): the order table's last partial round of every XCD list comes as 32x32 QUARTERS of
+// its 64x64 tiles (entry.x carries the quarter in bits 24..26: 1 + 2 qi + qj), so that the launch's tail -- half a tile time with
+// nothing behind it on an in-order stream -- is a quarter as long.  Same sums in the same order per element: same bits.
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void gemm_nt_mixed_kernel(
+    int64_t m, int64_t n, int64_t k, double alpha, const double *__restrict__ A, int64_t lda,
+    const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
+    const int2 *__restrict__ order, int prio, unsigned *edge, unsigned edge_val, unsigned edge_total, int edge_cols,
+    const unsigned *tail_word, unsigned tail_val, unsigned *tail_err)
+{
+    __shared__ __attribute__((aligned(16))) double sA[2 * 64 * GM_BK];
+    __shared__ __attribute__((aligned(16))) double sB[2 * 64 * GM_BK];
+#ifndef GPT_GEMM_NOPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    const int2 t = order[blockIdx.x];
+    if (t.x < 0) {
+        if (tail_word != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) edge_poll<16, false>(tail_word, tail_val, tail_err);
+        return;
+    }
+    const int qd = (t.x >> 24) & 7;
+    const int64_t ti = t.x & 0xffffff, tj = t.y;
+    if (edge_cols > 0 && tj >= edge_cols) edge = nullptr;
+    if (qd == 0)
+        gemm_tile_body<64, 64, 2>(ti * 64, tj * 64, tj, sA, sB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0, 0, prio, edge, edge_val,
+                                  edge_total, nullptr, 0u, nullptr, 0, tail_word, tail_val, tail_err);
+    else
+        gemm_tile_body<32, 32, 2>(ti * 64 + ((qd - 1) >> 1) * 32, tj * 64 + ((qd - 1) & 1) * 32, tj, sA, sB, m, n, k, alpha, A, lda, B, ldb,
+                                  beta, C, ldc, 0, 0, prio, edge, edge_val, edge_total, nullptr, 0u, nullptr, 0, tail_word, tail_val, tail_err);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -598,6 +643,8 @@ struct TileOrder {
     int64_t grid;
     int64_t ntiles;                // entries of the table that hold a tile (the rest are (-1, -1) padding)
     int64_t edge_cols, nedge;      // partial edge flag: the tiles of the first edge_cols columns come first; their number
+    int64_t mixed_slots;           // mixed-tile tables (gemm_nt_mixed_kernel): workgroup slots of the stream, 0 = plain table
+    int mixed_pct;
 };
 static std::vector<TileOrder> g_orders;
 static std::mutex g_orders_mu;
@@ -629,7 +676,7 @@ static inline bool tile_needed(int tri, int64_t i, int64_t j, int64_t seg_t, int
 
 static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64_t *grid, int64_t seg_t = 0,
                       int64_t rss_t = 0, int64_t *ntiles = nullptr, int64_t edge_cols = 0, int64_t *nedge = nullptr,
-                      const GridStair &gs = GridStair())
+                      const GridStair &gs = GridStair(), int64_t mixed_slots = 0, int mixed_pct = 0)
 {
     static int sgm = 0, sgn = 0, mode = 0;
     if (sgm == 0) {
@@ -644,7 +691,8 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
     std::lock_guard<std::mutex> lk(g_orders_mu);
     for (const auto &o : g_orders)
         if (o.ntm == ntm && o.ntn == ntn && o.tri == tri && o.dev == dev && o.seg_t == seg_t && o.rss_t == rss_t && o.edge_cols == edge_cols &&
-            o.g_off == gs.off && o.g_num == gs.num && o.g_den == gs.den && o.g_base == gs.base) {
+            o.g_off == gs.off && o.g_num == gs.num && o.g_den == gs.den && o.g_base == gs.base && o.mixed_slots == mixed_slots &&
+            o.mixed_pct == mixed_pct) {
             *tab = o.d_tab;
             *grid = o.grid;
             if (ntiles) *ntiles = o.ntiles;
@@ -678,6 +726,23 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
             }
         }
     }
+    if (mixed_slots >= 8 && (tri == 0 || tri == 1)) {
+        // mixed tiles: the last partial round of every XCD's list as 32x32 quarters (a diagonal tile of the trapezoid has no
+        // upper-right quarter), when that round is at most mixed_pct % full and lies behind the urgent tiles
+        const size_t ps = (size_t)(mixed_slots / 8), nu = sequ.size();
+        for (int x = 0; x < 8; x++) {
+            std::vector<int2> &v = per[x];
+            const size_t len = v.size(), r = len % ps, urgent = nu / 8 + ((size_t)x < nu % 8 ? 1 : 0);
+            if (len < ps || r == 0 || r * 100 > (size_t)mixed_pct * ps || len - r < urgent) continue;
+            std::vector<int2> tail(v.end() - r, v.end());
+            v.resize(len - r);
+            for (const int2 &t : tail)
+                for (int q = 0; q < 4; q++) {
+                    if (tri == 1 && t.x == t.y && q == 1) continue;
+                    v.push_back(make_int2(t.x | ((q + 1) << 24), t.y));
+                }
+        }
+    }
     size_t mx = 0;
     for (auto &v : per) mx = v.size() > mx ? v.size() : mx;
     std::vector<int2> flat(mx * 8, make_int2(-1, -1));
@@ -695,6 +760,8 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
     o.g_den = gs.den;
     o.g_base = gs.base;
     o.edge_cols = edge_cols;
+    o.mixed_slots = mixed_slots;
+    o.mixed_pct = mixed_pct;
     o.nedge = (int64_t)sequ.size();
     o.grid = (int64_t)flat.size();
     o.ntiles = 0;
@@ -782,6 +849,35 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
     // same-box A/B: N = 8192 4.40 -> 4.72 ms, N = 16384 27.6 -> 33.6 ms at 4 per CU, 88 VGPRs, no spill) -- the one-tile kernel's
     // prologue is already hidden by the three other workgroups of its CU and by the hardware's own re-dispatch, while the loop
     // adds a wait for the previous tile's stores in front of every tile's first barrier (stores count in vmcnt on gfx9).
+    // Mixed tiles (GPT_GEMM_MIXED=<percent>, off by default): see gemm_nt_mixed_kernel.  Plain and trapezoid launches of the
+    // 64x64 kernel with an order table and nobody waiting inside the kernel.
+    if constexpr (BM == 64 && NSTAGE == 2) if (order != nullptr && (tri == 0 || tri == 1) && !wait.word && nbatch == 1 && seg_cols == 0) {
+        static int pct = -1, ncu_m = 0;
+        if (pct < 0) {
+            pct = 0;
+            if (const char *e = getenv("GPT_GEMM_MIXED")) pct = atoi(e);
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu_m = prop.multiProcessorCount;
+            if (ncu_m <= 0) ncu_m = 256;
+        }
+        if (pct > 0) {
+            const int64_t slots = (int64_t)stream_cus(st, ncu_m) * 4;
+            const int2 *mo = nullptr;
+            int64_t grid = 0, nr = 0, ne = 0;
+            GPT_TRY_RC(tile_order(ntm, ntn, tri, &mo, &grid, 0, 0, &nr, edge_cols_elems / BN, &ne, GridStair(), slots, pct));
+            if (ev0 || ev1)
+                hipExtLaunchKernelGGL((gemm_nt_mixed_kernel<WPS>), dim3((unsigned)grid), dim3(256), dyn, st, ev0, ev1, 0, m, n, k, alpha, A, lda, B,
+                                      ldb, beta, C, ldc, mo, prio, edge.word, edge.value, (unsigned)(edge_cols_elems > 0 ? ne : nr),
+                                      (int)(edge_cols_elems / BN), tail.word, tail.value, tail.err);
+            else
+                hipLaunchKernelGGL((gemm_nt_mixed_kernel<WPS>), dim3((unsigned)grid), dim3(256), dyn, st, m, n, k, alpha, A, lda, B, ldb, beta, C,
+                                   ldc, mo, prio, edge.word, edge.value, (unsigned)(edge_cols_elems > 0 ? ne : nr),
+                                   (int)(edge_cols_elems / BN), tail.word, tail.value, tail.err);
+            GPT_LAUNCH_CHECK();
+            return GPT_OK;
+        }
+    }
     if constexpr (BM == 64 && NSTAGE == 2) if (order != nullptr && !wait.word && nbatch == 1 && nwg >= 2048) {
         static int per_cu = -1, ncu = 0;
         if (per_cu < 0) {

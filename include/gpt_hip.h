@@ -107,6 +107,7 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
  * Environment: GPT_RESERVE_CUS (CUs the main stream leaves to the panel stream, default 32), GPT_TILE_ORDER
  * ("rows,cols,mode": supertile shape and deal of the GEMM's XCD-aware tile order, default 64,8,1), GPT_GRAD_TIMING,
  * GPT_EDGE_FLAGS=0 (event edges only: set it for jobs that share one GPU between several processes), GPT_GEMM_SMALL (64x64-tile count under which a GEMM launch uses 32x32 tiles, 512),
+ * GPT_GEMM_MIXED=<percent> (measured, off: quarter tiles for the last partial round of a large GEMM launch),
  * GPT_JITTER (test aid: random delay kernels in front of every dense launch), GPT_ALPHA_NARROW (measurement aid: gpt_get_alpha
  * by 128-wide substitution steps instead of the 512-wide block inverses), GPT_POTF2_LA=0 (the 128-column diagonal-block kernels
  * with the lock-step body of rounds 1-3 instead of the look-ahead body; results agree to rounding, not bit for bit). */
