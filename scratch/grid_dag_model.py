@@ -4,7 +4,7 @@ section 5 and its sensitivities (what the modelled 8-rank time would be if the c
 cost, with a free interconnect, ...).
 
 Inputs (one idle MI355X, profiles/r04_chain_terms.txt; bench / replay traces for the rest):
-  diagonal block 512: update 12 + factor 113 + inverse 69 us;  512^3 product 12 us;
+  diagonal block 512: update 12 + factor 108 + inverse 69 us;  512^3 product 12 us;
   m x 512 x 512 GEMM (slices, look-ahead updates): 31 / 40 / 50 / 54 / 56 TFLOP/s at m = 1 / 2 / 4 / 8 / 16 k rows;
   trailing update of a rank: its flops at 50 TFLOP/s (staircase launches in situ on 224 CUs: 45-55) + 20 us per launch;
   links: bytes / 153 GB/s + latency per hop (xGMI, point to point; a root feeds its peers over different links at once).
@@ -21,8 +21,8 @@ nb = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 NP = (N + 1 + nb - 1) // nb * nb
 nblk = NP // nb
 BW = 153e9
-T_DIAG = (12 + 113 + 69) * 1e-6 * (nb / 512.0)
-T_FACT = 113e-6 * (nb / 512.0)
+T_DIAG = (12 + 108 + 69) * 1e-6 * (nb / 512.0)
+T_FACT = 108e-6 * (nb / 512.0)
 T_INV = 69e-6 * (nb / 512.0)
 T_G = 12e-6 * (nb / 512.0) ** 2
 UPD_RATE, UPD_LAUNCH = 50e12, 20e-6
