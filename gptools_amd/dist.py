@@ -765,7 +765,10 @@ class GridLML(object):
         # one contributing process row's share of C, where several rows contribute (lcm / P_c > 1): a buffer per slot and
         # contributing row (a single one would serialise consecutive exchanges on it)
         nq = (self.Pr // math.gcd(self.Pr, self.Pc)) if self.lcm // self.Pc > 1 else 0
-        self.piece = [[torch.empty((-(-cols // (self.lcm // self.Pc)), nb), **f64) for _ in range(nq)] for _ in range(self.NBUF)]
+        sc = self.lcm // self.Pc
+        # sized in whole blocks: one contributing row holds ceil(nlc / sc) of the rank's block columns (rows of
+        # ceil(cols / sc) are not a whole number of blocks when nlc % sc != 0)
+        self.piece = [[torch.empty((-(-max(self.nlc, 1) // sc) * nb, nb), **f64) for _ in range(nq)] for _ in range(self.NBUF)]
         self.invd = torch.empty(((nb // 128) * 9216,), **f64)
         self.info = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.y = torch.empty((self.NP,), **f64)

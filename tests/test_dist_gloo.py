@@ -194,6 +194,8 @@ def test_distributed_fit_matches_single_process_oracle(world, N, d, nb, kid, loo
     (2, (2, 1), 700, 3, 128, 1, True),       # a block-row layout: the column exchange is an all-gather over all ranks
     (8, (2, 4), 1023, 2, 128, 0, True),      # N + 1 a multiple of nb: no padding rows beyond the augmented row
     (4, (2, 2), 1024, 2, 128, 0, True),      # N a multiple of nb: the augmented row opens a block row of its own
+    (4, (4, 1), 1900, 2, 128, 0, True),      # nlc % (lcm / P_c) != 0 -- the exchange's staging piece in whole blocks
+    (12, (4, 3), 2000, 2, 128, 0, True),     # the same with three process columns
 ])
 def test_grid_fit_matches_single_process_oracle(world, grid, N, d, nb, kid, lookahead):
     """2-D block-cyclic layout (gptools_amd.dist.GridLML): every rank returns the oracle's ll / log-determinant
