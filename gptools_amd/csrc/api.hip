@@ -94,6 +94,12 @@ struct gpt_ctx {
     double *d_l10pk = nullptr;         // its scratch: the packed block between the two diagonal blocks (16384 doubles)
     unsigned *d_flag = nullptr;        // progress word of potf2_trsm_kernel (only ever raised)
     unsigned flag_epoch = 0;
+    unsigned x1_count = 0;             // value of d_flag[32..39], the producers' per-step counters of potf2_trsm_upd_kernel (only ever counted up)
+    int64_t fuse_upd = 0;              // 1: leaves with at most fuse_upd_rows rows below them apply their rank-128 update of the next
+    int64_t fuse_upd_rows = 4096;      //    128 / 256 columns inside the leaf's launch (potf2_trsm_upd_kernel); measured slower than
+                                       //    the separate update launch (profiles/r05_upd_ab.txt): off
+    int64_t fuse_rows64 = 2048;        // fused leaves with at most this many rows below them: 64 rows per consumer workgroup (one strip
+                                       // wave per SIMD, potf2_trsm_kernel<.., true>); 0 = always 128
     int64_t helper_min_n = 12288;      // the helper stream takes part only above this matrix size
     int helper_tf = 45;                // assumed rate of the helper stream, in 0.1 TFLOP/s per 24 CUs (0 = no helper);
                                        // measured: 0 / 25 / 35 / 50 -> 212 / 209 / 206 / 214 ms at N=32768, 30.8 / 30.6 / 30.2 / 32.0 at N=16384
@@ -424,7 +430,7 @@ static int leaf256_factor(gpt_ctx *c, hipStream_t st, double *Ad, int64_t lda, i
                           int32_t *info, int64_t info_base, hipEvent_t done_ev)
 {
     if (c->flag_epoch > 0x3fffff00u) {
-        GPT_HIP_CHECK(hipMemsetAsync(c->d_flag, 0, 64, st));
+        GPT_HIP_CHECK(hipMemsetAsync(c->d_flag, 0, 256, st)); c->x1_count = 0;
         c->flag_epoch = 0;
     }
     c->flag_epoch += 32;
@@ -572,11 +578,12 @@ static int panel_rec(gpt_ctx *c, hipStream_t st, double *Ap, int64_t lda, int64_
             // short panel (the head chunk of the row-chunked multi-GPU schedule, the last panels of a factorisation):
             // diagonal block and TRSM in one launch (potf2_trsm_kernel), as in panel_ext
             if (c->flag_epoch > 0x3fffff00u) {
-                GPT_HIP_CHECK(hipMemsetAsync(c->d_flag, 0, 64, st));
+                GPT_HIP_CHECK(hipMemsetAsync(c->d_flag, 0, 256, st)); c->x1_count = 0;
                 c->flag_epoch = 0;
             }
             c->flag_epoch += 32;           // (the 256-column leaf kernel raises the word by up to 17 per launch)
-            return launch_potf2_trsm(st, Ap, lda, invd, info, base, mb, c->d_flag, c->flag_epoch);
+            return launch_potf2_trsm(st, Ap, lda, invd, info, base, mb, c->d_flag, c->flag_epoch, nullptr, EdgeSig(), EdgeSig(),
+                                     mb <= c->fuse_rows64);
         }
         GPT_TRY(launch_potf2_diag(st, Ap, lda, invd, info, base));
         return launch_trsm_panel(st, m - 128, Ap, lda, invd, Ap + 128 * lda, lda);
@@ -601,11 +608,11 @@ static int leaf_factor(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64
     const int64_t m = n - (lc + 128);
     if (c->fuse_trsm > 0 && m >= 128 && m <= c->fuse_trsm && !c->use_graph) {
         if (c->flag_epoch > 0x3fffff00u) {
-            GPT_HIP_CHECK(hipMemsetAsync(c->d_flag, 0, 64, st));
+            GPT_HIP_CHECK(hipMemsetAsync(c->d_flag, 0, 256, st)); c->x1_count = 0;
             c->flag_epoch = 0;
         }
         c->flag_epoch += 32;           // (the 256-column leaf kernel raises the word by up to 17 per launch)
-        return launch_potf2_trsm(st, Ad, lda, ws, info, lc, m, c->d_flag, c->flag_epoch, done_ev);
+        return launch_potf2_trsm(st, Ad, lda, ws, info, lc, m, c->d_flag, c->flag_epoch, done_ev, EdgeSig(), EdgeSig(), m <= c->fuse_rows64);
     }
     GPT_TRY(launch_potf2_diag(st, Ad, lda, ws, info, lc));
     GPT_TRY(launch_trsm_panel(st, m, Ad, lda, ws, Ad + 128 * lda, lda, (done_ev && !c->use_graph) ? done_ev : nullptr));
@@ -685,27 +692,51 @@ static int panel_ext(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64_t
             // the fused kernel holds a whole CU (135 KB of LDS) while it spins, and beyond the reserved CUs they would be
             // taken from the K build the launch is waiting for.  Otherwise a one-wave wait kernel in front of it.
             const bool fused = c->fuse_trsm > 0 && m >= 128 && m <= c->fuse_trsm && !c->use_graph;
-            const int64_t wgs = fused ? 1 + (m + 127) / 128 : 1;
+            const bool r64 = fused && ((c->fuse_upd && m <= c->fuse_upd_rows && !first_ev) || m <= c->fuse_rows64);      // (64 rows per workgroup)
+            const int64_t wgs = r64 ? 1 + m / 64 : fused ? 1 + (m + 127) / 128 : 1;
             if (wgs > c->head_wait_wgs) {
                 GPT_TRY(stream_wait_flag(st, fw));
                 fw = EdgeSig();
             }
         }
+        int64_t upd_done = 0;                         // columns [r1, r1 + upd_done) updated inside the leaf's launch
         if (c->fuse_trsm > 0 && m >= 128 && m <= c->fuse_trsm && !c->use_graph) {
             // short panel: diagonal block and TRSM in one launch, the substitution trailing the pivots (potrf.hip)
             if (c->flag_epoch > 0x3fffff00u) {
-                GPT_HIP_CHECK(hipMemsetAsync(c->d_flag, 0, 64, st));
+                GPT_HIP_CHECK(hipMemsetAsync(c->d_flag, 0, 256, st)); c->x1_count = 0;
                 c->flag_epoch = 0;
             }
             c->flag_epoch += 32;           // (the 256-column leaf kernel raises the word by up to 17 per launch)
-            GPT_TRY(launch_potf2_trsm(st, Ad, lda, ws, info, lc, m, c->d_flag, c->flag_epoch, last ? done_ev : nullptr,
-                                      (r1 == c0 + w) ? done_edge : EdgeSig(), fw));
+            if (c->fuse_upd && m <= c->fuse_upd_rows && cend > r1 && !first_ev) {
+                // ... and the leaf's update of the next 128 / 256 columns as well (potf2_trsm_upd_kernel): the chain-bound end of
+                // the factorisation.  What those columns wait for -- the main stream's update of the columns this panel touches
+                // -- is awaited by the leaf's launch: inside the kernel, right before the accumulators are loaded (the word is
+                // long up there: the main stream is ahead of the chain), or in front of the launch when the edge is an event.
+                EdgeSig cw;
+                if (lc == c0 && wait_ev) GPT_HIP_CHECK(hipStreamWaitEvent(st, wait_ev, 0));
+                if (lc == c0 && wait_edge.word) cw = wait_edge;
+                upd_done = (cend - r1 >= 256) ? 256 : 128;
+                GPT_TRY(launch_potf2_trsm_upd(st, Ad, lda, ws, info, lc, m, c->d_flag, c->flag_epoch, c->x1_count, upd_done,
+                                              last ? done_ev : nullptr, (r1 == c0 + w) ? done_edge : EdgeSig(), fw, cw));
+                c->x1_count += (unsigned)(upd_done / 16);
+            } else {
+                GPT_TRY(launch_potf2_trsm(st, Ad, lda, ws, info, lc, m, c->d_flag, c->flag_epoch, last ? done_ev : nullptr,
+                                          (r1 == c0 + w) ? done_edge : EdgeSig(), fw, m <= c->fuse_rows64));
+            }
         } else {
             GPT_TRY(launch_potf2_diag(st, Ad, lda, ws, info, lc, fw));
             // (a stop event on the launch is not recorded by stream capture: under a graph use a plain record)
             GPT_TRY(launch_trsm_panel(st, m, Ad, lda, ws, Ad + 128 * lda, lda, (last && !c->use_graph) ? done_ev : nullptr,
                                       (r1 == c0 + w) ? done_edge : EdgeSig()));
             if (last && c->use_graph) GPT_HIP_CHECK(hipEventRecord(done_ev, st));
+        }
+        if (upd_done > 0) {
+            // the columns beyond the in-launch update (a 384-wide panel's first leaf): one narrower launch, rows from there on
+            const int64_t rr = r1 + upd_done;
+            if (cend > rr)
+                GPT_TRY(gemm_nt(c, st, n - rr, cend - rr, 128, -1.0, A + rr * lda + lc, lda, A + rr * lda + lc, lda, 1.0,
+                                A + rr * lda + rr, lda, 1));
+            continue;
         }
         if (lc == c0 && wait_ev) GPT_HIP_CHECK(hipStreamWaitEvent(st, wait_ev, 0));
         if (cend > r1) {
@@ -1183,13 +1214,13 @@ extern "C" int gpt_ctx_create(int device_id, void *stream, gpt_ctx **out)
     GPT_HIP_CHECK(hipStreamCreateWithPriority(&c->panel_stream, hipStreamNonBlocking, hi));
     for (int i = 0; i < 5; i++) GPT_HIP_CHECK(hipEventCreate(&c->tev[i]));
     GPT_HIP_CHECK(hipMalloc(&c->d_info, sizeof(int32_t)));
-    GPT_HIP_CHECK(hipMalloc((void **)&c->d_flag, 64));
+    GPT_HIP_CHECK(hipMalloc((void **)&c->d_flag, 256));
     GPT_HIP_CHECK(hipMalloc((void **)&c->d_l10pk, 16384 * sizeof(double)));
     GPT_HIP_CHECK(hipMalloc((void **)&c->d_edge, 256));
     // (hipMemsetAsync on the context's stream, never hipMemset: one call on the legacy null stream and from then on
     // every kernel of this process starts ~40 us late on every stream -- measured on the block-cyclic engine,
     // 31 -> 41 ms per rank at N=32768 over 8 ranks, potf2 26 -> 45..90 us in the trace)
-    GPT_HIP_CHECK(hipMemsetAsync(c->d_flag, 0, 64, c->stream));
+    GPT_HIP_CHECK(hipMemsetAsync(c->d_flag, 0, 256, c->stream));
     GPT_HIP_CHECK(hipMemsetAsync(c->d_edge, 0, 256, c->stream));
     GPT_HIP_CHECK(hipMalloc(&c->d_scal, 80 * sizeof(double)));     // logdet_dot's partial sums (64) + its counter
     GPT_HIP_CHECK(hipMemsetAsync(c->d_scal, 0, 80 * sizeof(double), c->stream));
@@ -1286,6 +1317,9 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "helper_tf")) c->helper_tf = (int)value;
     else if (!strcmp(key, "helper_min_n")) c->helper_min_n = value;
     else if (!strcmp(key, "fuse_trsm")) c->fuse_trsm = value;
+    else if (!strcmp(key, "fuse_rows64")) c->fuse_rows64 = value;
+    else if (!strcmp(key, "fuse_upd")) c->fuse_upd = value;
+    else if (!strcmp(key, "fuse_upd_rows")) c->fuse_upd_rows = value;
     else if (!strcmp(key, "leaf256")) c->leaf256 = value ? 1 : 0;
     else if (!strcmp(key, "debug_poison")) c->debug_poison = value;
     else if (!strcmp(key, "alpha_invalidate")) c->alpha_valid = false;          // (measurement aid: the next gpt_get_alpha recomputes)

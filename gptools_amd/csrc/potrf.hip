@@ -69,6 +69,15 @@ __device__ long long *g_pd_trace;
 #define PD_STAMP_DUMP() do { } while (0)
 #endif
 
+// wall-clock stamps of the consumer waves (scratch/r05_upd_stamps.hip compiles this file with -DGPT_PU_STAMPS; absent from the library):
+// g_pu_stamps[(workgroup * 8 + wave) * 32 + i], 100 MHz
+#ifdef GPT_PU_STAMPS
+__device__ long long *g_pu_stamps;
+#define PU_STAMP(i) do { if (lane == 0 && g_pu_stamps) g_pu_stamps[((long long)blockIdx.x * 8 + wave) * 32 + (i)] = (long long)wall_clock64(); } while (0)
+#else
+#define PU_STAMP(i) do { } while (0)
+#endif
+
 // linear index of a lower-triangle tile -> (row a, column b <= a); t is wave-uniform, so this is a scalar loop
 __device__ __forceinline__ void tri_decode(int t, int &a_, int &b_)
 {
@@ -729,7 +738,9 @@ __device__ __forceinline__ void potf2_body_la(double *__restrict__ A, int64_t ld
         for (int jb = 0; jb < NB16; jb++) {
             PD_STAMP(8 + jb * 8 + 0);
             PD_TRACE(100 + jb);
+            PU_STAMP(1 + 2 * jb);
             chain_block(a, colbuf + (jb & 1) * 256, invbuf + (jb & 1) * 16, &sy->colflag, jb * 16, fr);
+            PU_STAMP(2 + 2 * jb);
             PD_STAMP(8 + jb * 8 + 1);
             PD_TRACE(110 + jb);
             if (lane < 16) {
@@ -948,6 +959,7 @@ __device__ __forceinline__ void potf2_body_la(double *__restrict__ A, int64_t ld
                 lds_wait_ge<true>(&sy->x1flag, jb + 1);
                 lds_wait_ge<true>(&sy->x2flag, jb + 1);
                 PD_TRACE(300 + jb);
+                PU_STAMP(1 + 2 * jb);
                 double *ip = invd + jb * 256, *lp = invd + GPT_WS_LOFF;
                 {
                     double tv[4];
@@ -973,9 +985,28 @@ __device__ __forceinline__ void potf2_body_la(double *__restrict__ A, int64_t ld
                         }
                 }
                 if (PUBLISH) {
-                    // (as in potf2_body: write-through stores of THIS wave, drained, then the flag)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(flag, flag_base + (unsigned)jb + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // Write-through stores of THIS wave, acknowledged, then the flag -- PIPELINED (round 5): a write-through store
+                    // is acknowledged ~2.5 us after its issue, longer than a step of the chain (2 us), and draining every step
+                    // before the next one's stores were issued made the PUBLICATION the pace of every fused leaf (flags 3.06 us
+                    // apart, the last one 7 us behind the chain; profiles/r05_upd_stamps.txt).  Stores complete in issue order
+                    // (vmcnt), so once step jb's 32 - 4 jb store instructions are issued, vmcnt <= 32 - 4 jb means that everything
+                    // older -- step jb - 1 -- is in memory: its flag goes up then, and the last step drains.
+                    switch (jb) {
+                    case 0: break;
+                    case 1: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+                    case 2: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+                    case 3: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+                    case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+                    case 5: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+                    case 6: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                    }
+                    if (jb > 0 && lane == 0) __hip_atomic_store(flag, flag_base + (unsigned)jb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    PU_STAMP(2 + 2 * jb);
+                    if (jb + 1 == NB16) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lane == 0) __hip_atomic_store(flag, flag_base + (unsigned)NB16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
                 {
                     const double dg = S[jb * 16 + fr][jb * 16 + fr];
@@ -1078,6 +1109,123 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restri
     else potf2_body<false>(A, lda, invd, info, info_col0, nullptr, 0u);
 }
 
+// wave-level poll of a device word that only ever goes up (signed difference against `base`); returns the value seen
+template <int SLEEP>
+__device__ __forceinline__ unsigned pu_poll_ge(const unsigned *w, unsigned v, unsigned base, int target)
+{
+    while ((int)(v - base) < target) {
+        __builtin_amdgcn_s_sleep(SLEEP);
+        v = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    return v;
+}
+
+// ---- the forward substitution of ONE 16-row strip behind the chain's flags (the consumer waves of the fused leaf kernels) ----
+// Per step j: X_j = (B_j - sum_{c<j} X_c L_jc^T) inv(L_jj)^T; right-looking: x_j goes into every later right-hand side at
+// once (the left-looking form put 28 dependent MFMAs between the last two flags).  Everything a step reads -- inv(L_jj) and the
+// blocks (j', j) -- is published with flag j + 1 and read with agent-scope loads, ~1.5 us each way on this chip, so the memory
+// round trips are what a step costs (profiles/r05_upd_stamps.txt: 2.9-3.1 us per step against the chain's 2.1, the last x_7
+// stored 8 us behind the chain):
+//   * one BATCH per step: inv(L_jj), the fold's blocks and a sample of the flag word are requested together;
+//   * a wave that is BEHIND the chain (the sample taken with batch j already shows flag j + 2) requests batch j + 1 before
+//     the fold of step j, so that its round trip runs under the fold's MFMAs and the next step starts with its data there;
+//     a wave that has caught up polls, as before.  Every wave polls for itself: the strips share nothing (no barrier).
+// Same operations in the same order on every accumulator as the first form: same bits.
+struct StripBatch {
+    double dv[4];
+    double lv[7][4];
+    unsigned fn;
+};
+template <int J>
+__device__ __forceinline__ void strip_batch_issue(StripBatch &b, const double *__restrict__ ws, const unsigned *flag, int lane)
+{
+    const double *lpk = ws + GPT_WS_LOFF;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) b.dv[kk] = __hip_atomic_load(ws + J * 256 + kk * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int jp = J + 1; jp < 8; jp++)
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+            b.lv[jp - J - 1][kk] = __hip_atomic_load(lpk + (jp * (jp - 1) / 2 + J) * 256 + kk * 64 + lane, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+    b.fn = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// HIST: x_j also stays in LDS (Xh[j], which doubles as the re-layout scratch) and hprog counts the steps (potf2_trsm_upd_kernel);
+// otherwise Xh[0] is the wave's scratch.  through: write x_j through to memory (somebody reads it before this kernel ends).
+// post(j): called when x_j has been stored (the producers' counter).
+struct StripCtx {
+    const double *ws;
+    const unsigned *flag;
+    unsigned flag_base;
+    double *Brow;          // B + row0 * ldb
+    int64_t ldb;
+    bool through;
+    int lane, fr, fk;
+    unsigned fl;
+    bool have;
+};
+template <int J, bool HIST, class Post>
+__device__ __forceinline__ void strip_step(StripCtx &c, StripBatch &cur, StripBatch &nxt, f64x4 (&bt)[8], f64x4 &acc,
+                                           double (*Xh)[16][TP_SP], int *hprog, Post post)
+{
+    const int lane = c.lane, fr = c.fr, fk = c.fk;
+    if (!c.have) {
+        c.fl = pu_poll_ge<1>(c.flag, c.fl, c.flag_base, J + 1);      // (signed difference: an earlier launch's value lies below flag_base)
+        strip_batch_issue<J>(cur, c.ws, c.flag, lane);
+    }
+    double (*X)[TP_SP] = Xh[HIST ? J : 0];
+    // accumulator (C layout) -> A operand through the scratch
+#pragma unroll
+    for (int r = 0; r < 4; r++) X[fk + 4 * r][fr] = acc[r];
+    double av[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) av[kk] = X[fr][fk + 4 * kk];
+    f64x4 res = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) res = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], cur.dv[kk], res, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        double *dst = c.Brow + (int64_t)(fk + 4 * r) * c.ldb + J * 16 + fr;
+        if (c.through) __hip_atomic_store(dst, res[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = res[r];
+        X[fk + 4 * r][fr] = res[r];
+    }
+    if (HIST) lds_post(hprog, J + 1);
+    if constexpr (J + 1 < 8) {
+        double xj[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) xj[kk] = -X[fr][fk + 4 * kk];
+        // behind the chain?  then the next step's batch goes out now, under this step's fold
+        const unsigned f = (unsigned)__builtin_amdgcn_readfirstlane((int)cur.fn);
+        c.have = (int)(f - c.flag_base) >= J + 2;
+        if (c.have) strip_batch_issue<J + 1>(nxt, c.ws, c.flag, lane);
+        else c.fl = f;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+            for (int jp = J + 1; jp < 8; jp++)
+                bt[jp] = __builtin_amdgcn_mfma_f64_16x16x4f64(xj[kk], cur.lv[jp - J - 1][kk], bt[jp], 0, 0, 0);
+        acc = bt[J + 1];
+    }
+    post(J);
+}
+template <bool HIST, class Post>
+__device__ __forceinline__ void strip_substitution(StripCtx &c, f64x4 (&bt)[8], double (*Xh)[16][TP_SP], int *hprog, Post post)
+{
+    StripBatch a, b;
+    f64x4 acc = bt[0];
+    c.have = false;
+    c.fl = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(c.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    strip_step<0, HIST>(c, a, b, bt, acc, Xh, hprog, post);
+    strip_step<1, HIST>(c, b, a, bt, acc, Xh, hprog, post);
+    strip_step<2, HIST>(c, a, b, bt, acc, Xh, hprog, post);
+    strip_step<3, HIST>(c, b, a, bt, acc, Xh, hprog, post);
+    strip_step<4, HIST>(c, a, b, bt, acc, Xh, hprog, post);
+    strip_step<5, HIST>(c, b, a, bt, acc, Xh, hprog, post);
+    strip_step<6, HIST>(c, a, b, bt, acc, Xh, hprog, post);
+    strip_step<7, HIST>(c, b, a, bt, acc, Xh, hprog, post);
+}
+
 // ------------------------------------------------------------------------------------------------
 // potf2_trsm_kernel: the diagonal block AND the TRSM of the rows below it in one launch, for the latency-bound end of
 // the factorisation.  Workgroup 0 is potf2_body; it publishes the packed workspace block by block (agent-scope
@@ -1090,7 +1238,7 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_diag_kernel(double *__restri
 // of the launch gets potf2's 135 KB of LDS, i.e. a CU to itself: used only while the panel is short (few workgroups,
 // idle chip); above that the two plain kernels run (host side, api.hip).
 // ------------------------------------------------------------------------------------------------
-template <bool LA>
+template <bool LA, bool R64>
 __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restrict__ A, int64_t lda,
                                                                 double *__restrict__ invd, int32_t *info,
                                                                 int64_t info_col0, int64_t m, double *__restrict__ B,
@@ -1116,8 +1264,13 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
     const int fr = lane & 15, fk = lane >> 4;
     constexpr int NB16 = PD_NB / 16;
     double (*X)[TP_SP] = reinterpret_cast<double (*)[TP_SP]>(smem + wave * 16 * TP_SP);
-    const int64_t row0 = ((int64_t)(blockIdx.x - 1) * PD_WAVES + wave) * 16;
-    const bool active = row0 < m;
+    // R64 (round 5): 64 rows per workgroup -- ONE strip wave per SIMD (waves 4..7 idle).  On gfx950 a SIMD's fp64 MFMAs are 64
+    // cycles each: with two strips per SIMD the fold's 28 MFMAs of step 0 are 1.5 us and the strips finish 28 us after the
+    // launch; with one they follow the chain's flags (x_7 stored 20 us after the launch, m = 4096; profiles/r05_upd_stamps.txt)
+    // -- at twice the CUs, so only for the chain-bound end of a factorisation (api.hip: fuse_rows64).
+    constexpr int SWV = R64 ? 4 : PD_WAVES;
+    const int64_t row0 = ((int64_t)(blockIdx.x - 1) * SWV + wave) * 16;
+    const bool active = wave < SWV && row0 < m;
     f64x4 bt[NB16];
     if (active) {
 #pragma unroll
@@ -1125,62 +1278,257 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
 #pragma unroll
             for (int r = 0; r < 4; r++) bt[j][r] = B[(row0 + fk + 4 * r) * ldb + j * 16 + fr];
     }
-    const double *lpk = invd + GPT_WS_LOFF;
-    // acc: right-hand side of step j with the earlier steps already folded in, bt[j] - sum_{c<j} x_c L_jc^T (the folding is
-    // right-looking, see below): what remains behind flag j+1 is one load of inv(L_jj), four MFMAs, the re-layout and the store.
-    f64x4 acc = bt[0];
-#pragma unroll
-    for (int j = 0; j < NB16; j++) {
-        if (tid == 0) {
-            // (signed difference: a value left by an earlier launch lies below flag_base)
-            while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - flag_base) < j + 1)
-                __builtin_amdgcn_s_sleep(1);
-        }
-        __syncthreads();
-        if (!active) continue;
-        double dv[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++)
-            dv[kk] = __hip_atomic_load(invd + j * 256 + kk * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // accumulator (C layout) -> A operand through the per-wave scratch
-#pragma unroll
-        for (int r = 0; r < 4; r++) X[fk + 4 * r][fr] = acc[r];
-        double av[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) av[kk] = X[fr][fk + 4 * kk];
-        f64x4 res = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) res = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], dv[kk], res, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            if (edge) __hip_atomic_store(&B[(row0 + fk + 4 * r) * ldb + j * 16 + fr], res[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else B[(row0 + fk + 4 * r) * ldb + j * 16 + fr] = res[r];
-            X[fk + 4 * r][fr] = res[r];
-        }
-        if (j + 1 < NB16) {
-            // right-looking: x_j goes into EVERY later right-hand side now (the blocks (j' > j, j) came with this round).  The
-            // left-looking form -- fold the blocks (j + 1, c <= j) right before step j + 1 -- put 28 dependent MFMAs (64 cycles
-            // each on gfx950, two waves per SIMD) between the last two flags: the consumers finished 2600 cycles behind the last
-            // publication instead of one step's 500.  Every accumulator sees the same operations in the same order: same bits.
-            double xj[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) xj[kk] = -X[fr][fk + 4 * kk];
-            double lv[NB16][4];
-#pragma unroll
-            for (int jp = j + 1; jp < NB16; jp++)
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++)
-                    lv[jp][kk] = __hip_atomic_load(lpk + (jp * (jp - 1) / 2 + j) * 256 + kk * 64 + lane, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++)
-#pragma unroll
-                for (int jp = j + 1; jp < NB16; jp++)
-                    bt[jp] = __builtin_amdgcn_mfma_f64_16x16x4f64(xj[kk], lv[jp][kk], bt[jp], 0, 0, 0);
-            acc = bt[j + 1];
-        }
+    if (active) {
+        StripCtx sc;
+        sc.ws = invd;
+        sc.flag = flag;
+        sc.flag_base = flag_base;
+        sc.Brow = B + row0 * ldb;
+        sc.ldb = ldb;
+        sc.through = edge != nullptr;      // (a launch that raises an edge flag writes its rows through to memory, see EdgeSig)
+        sc.lane = lane;
+        sc.fr = fr;
+        sc.fk = fk;
+        typedef double XBlk[16][TP_SP];
+        strip_substitution<false>(sc, bt, reinterpret_cast<XBlk *>(&X[0][0]), nullptr, [](int) {});
     }
     if (edge) edge_signal(edge, edge_val, gridDim.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// potf2_trsm_upd_kernel (round 5): the diagonal block, the TRSM of the rows below it AND the leaf's rank-128 update of the
+// next 128 / 256 columns in ONE launch -- the separate update launch (a kernel boundary, ~5 us of dispatch, and an 8-28 us
+// GEMM on the chain of every leaf) disappears for those columns.
+//   Workgroup 0: potf2_body_la / potf2_body, unchanged (publishes the packed workspace block by block).
+//   Workgroups 1..: 64 rows each.  Waves 0..3 ("strip waves", one per SIMD: on gfx950 a SIMD's fp64 MFMAs are 64 cycles
+//     each, and a strip's 144 + 32 UT of them set the leaf's time) own 16 rows each as in potf2_trsm_kernel and keep the first
+//     TS tiles of those rows of the columns [r1, r1 + 16 UT) (r1 = the first row below the diagonal block) in accumulators,
+//     started from C itself; waves 4..7 ("helpers", wave w + 4 on the SIMD of wave w) keep the other UT - TS tiles of the same
+//     rows (A operand out of the strip wave's scratch).  The B operand of that update is X1 = the solved rows
+//     [r1, r1 + 16 UT) -- other workgroups' results.  Their owners ("producers") write x_j through to memory as they always
+//     did, drain, and count themselves in a per-context word (flag[32]); ONE step later every workgroup stages the
+//     16 UT x 16 block of x_j into its LDS with a coalesced agent-scope load (all 512 threads, latency under the step's own
+//     solve) and the waves read their B operands from there: the exchange is 16-32 KB per workgroup and step, once -- the
+//     first version of this kernel (round 4) read the operands straight from memory, 32 scattered loads per lane and step,
+//     and took 104 us per leaf.
+// Same sums in the same order as the separate launch (gemm.hip: accumulator from C, MFMA 2t+u of a 16-wide k-tile contracts
+// k = 8t + 2 (lane >> 4) + u, sign by negating one operand): the factor is bit-identical to the unfused schedule's.
+// Tiles above the diagonal (column tile > row tile of the strip) are neither read nor written.
+// Strip and helper waves run different code with the SAME sequence of workgroup barriers (two per step: "x_{j-1} staged
+// loads may start" and "x_{j-1} is in LDS / x_j is in the strip's scratch").
+// ------------------------------------------------------------------------------------------------
+#define PU_XS_PITCH 18
+#define PU_HIST (8 * 16 * TP_SP)                         // doubles of one strip's history: x_0 .. x_7, 16 x 16 each at pitch TP_SP
+#define PU_CONS_SMEM_DOUBLES (4 * PU_HIST + 2 * 256 * PU_XS_PITCH + 16)
+struct PuSync {
+    int hprog[4];        // strip wave w: x_0 .. x_{hprog - 1} are in its history
+    int stage_cnt[8];    // helper waves that have stored their part of the staged block of step s
+    int upd_cnt[8];      // helper waves that are through with the update of step s (its buffer may be overwritten)
+};
+
+// one step's update of a helper wave's UT tiles: A operand = the strip's x_s out of its history (negated), B operand = the
+// staged block of X1's x_s.  No validity test: a tile above the diagonal is computed like the others and never stored (a
+// branch per MFMA made hipcc keep two copies of the accumulators, 40 spilled registers).
+template <int TC>
+__device__ __forceinline__ void pu_update(f64x4 (&accU)[TC], const double (*Hs)[TP_SP], const double *Xsb, int fr, int fk)
+{
+    constexpr int G = (TC > 8) ? 8 : TC;                 // (operand pairs in groups of eight: 32 registers beside the accumulators)
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const f64x2 w = *reinterpret_cast<const f64x2 *>(&Hs[fr][8 * t + 2 * fk]);
+        const f64x2 xa = {-w[0], -w[1]};
+#pragma unroll
+        for (int q0 = 0; q0 < TC; q0 += G) {
+            f64x2 bf[G];
+#pragma unroll
+            for (int q = 0; q < G; q++) bf[q] = *reinterpret_cast<const f64x2 *>(Xsb + ((q0 + q) * 16 + fr) * PU_XS_PITCH + 8 * t + 2 * fk);
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int q = 0; q < G; q++) accU[q0 + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u], bf[q][u], accU[q0 + q], 0, 0, 0);
+        }
+    }
+}
+// The two kinds of wave are NOT in step with each other (no workgroup barrier after the prologue):
+//   strip waves 0..3: the substitution of potf2_trsm_kernel, every wave polling the chain's flag for itself (the next step's
+//     flag is requested while this step's fold runs); x_j also goes to the strip's history in LDS (hprog), and the producer
+//     strips count themselves in x1cnt[j] once their write-through stores are drained;
+//   helper waves 4..7: ALL update tiles of the strip of wave - 4.  Per step s, as soon as x1cnt[s] says the producers' x_s is
+//     in memory (~3 us behind the chain's flag s + 1: longer than a chain step, which is why nothing here waits for it in
+//     lock-step with the substitution -- the first build of this kernel did and ran 16 us per leaf behind the chain): the four
+//     helper waves load a quarter each of the 16 UT x 16 block into LDS (two buffers), count themselves (stage_cnt), and
+//     take their strip's 4 UT MFMAs against it.  The matrix pipe of SIMD w is shared by strip wave w and helper w + 4.
+template <int UT>
+__device__ __forceinline__ void trsm_upd_consumer(double *__restrict__ invd, int64_t m, double *__restrict__ B, int64_t ldb,
+                                                  unsigned *flag, unsigned flag_base, unsigned x1_base, unsigned *edge,
+                                                  unsigned edge_val, const unsigned *cwait_word, unsigned cwait_val,
+                                                  unsigned *cwait_err)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NB16 = PD_NB / 16;
+    constexpr int SW = 4;                                // strip waves per workgroup
+    constexpr int NSV = UT * 256 / 256;                  // staged doubles per helper thread and step
+    constexpr int XSB = 256 * PU_XS_PITCH;               // doubles of one staging buffer
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    const bool helper = wave >= SW;
+    const int sw = wave & 3;
+    typedef double HBlk[16][TP_SP];
+    HBlk *H = reinterpret_cast<HBlk *>(smem + sw * PU_HIST);       // H[s] = x_s of this strip (a helper wave: its strip wave's)
+    double *Xs = smem + SW * PU_HIST;                              // [2][16 UT][PU_XS_PITCH]
+    PuSync *sy = reinterpret_cast<PuSync *>(Xs + 2 * XSB);
+    const int64_t strip = (int64_t)(blockIdx.x - 1) * SW + sw;
+    const int64_t row0 = strip * 16;
+    const bool active = row0 < m;
+    unsigned *x1cnt = flag + 32;                         // x1cnt[s]: producer strips that have posted step s; only ever counted up, by UT per
+                                                         // launch: x1_base = their common value when this launch starts (host's count)
+    if (tid < (int)(sizeof(PuSync) / sizeof(int))) reinterpret_cast<int *>(sy)[tid] = 0;
+    __syncthreads();
+
+    if (helper) {
+        // ================================ helper waves ================================
+        __builtin_amdgcn_s_setprio(1);
+        const int nvalid = (strip + 1 > UT) ? UT : (int)(strip + 1);      // tiles on or below the diagonal of the trailing matrix
+        double *Cn = B + row0 * ldb + PD_NB;             // tile q, element (fk + 4r, fr): Cn[(fk + 4r) ldb + 16 q + fr]
+        f64x4 accU[UT];
+        if (active) {
+            // the C tiles of the update were last written by the main stream's update of the columns this panel touches
+            if (cwait_word != nullptr && lane == 0) edge_poll<1, false>(cwait_word, cwait_val, cwait_err);
+            // accumulators from C (agent-scope loads: behind an in-kernel wait they must not hit a stale line, EdgeSig form (b))
+#pragma unroll
+            for (int q = 0; q < UT; q++) {
+                if (q < nvalid) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        accU[q][r] = __hip_atomic_load(Cn + (int64_t)(fk + 4 * r) * ldb + 16 * q + fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    accU[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+                }
+            }
+        }
+        const int ht = tid - 256;                        // 0 .. 255 over the four helper waves
+        const unsigned ldb8 = (unsigned)ldb * 8u;        // (the launcher checks that these byte offsets fit 32 bits)
+        double sv[NSV];
+        auto block_load = [&](int s) {
+#pragma unroll
+            for (int q = 0; q < NSV; q++) {
+                // (uniform base + 32-bit byte offset: one address register per load)
+                const int idx = ht + q * 256;
+                const unsigned off = (unsigned)(idx >> 4) * ldb8 + (unsigned)(idx & 15) * 8u;
+                sv[q] = __hip_atomic_load(reinterpret_cast<const double *>(reinterpret_cast<const char *>(B + s * 16) + off),
+                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        };
+        auto cnt_load = [&](int s) -> unsigned {
+            return __hip_atomic_load(x1cnt + (s & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        PU_STAMP(0);
+        // Pipelined: the block of step s + 1 is requested BEFORE the update of step s when it has arrived by then (its counter was
+        // read one update earlier) -- a wave that is behind the producers, the normal case with 16 tiles, never waits for a load.
+        {
+            const unsigned c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)cnt_load(0));
+            pu_poll_ge<2>(x1cnt, c0, x1_base, UT);
+            block_load(0);
+        }
+        unsigned cn = cnt_load(1);                       // x1cnt[s + 1], requested one update ahead
+#pragma unroll 1
+        for (int s = 0; s < NB16; s++) {
+            PU_STAMP(1 + 3 * s);
+            double *Xsb = Xs + (s & 1) * XSB;
+            if (s >= 2) lds_wait_ge<false>(&sy->upd_cnt[s - 2], 4);          // everybody is through with this buffer's last block
+#pragma unroll
+            for (int q = 0; q < NSV; q++) {
+                const int idx = ht + q * 256;
+                Xsb[(idx >> 4) * PU_XS_PITCH + (idx & 15)] = sv[q];
+            }
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&sy->stage_cnt[s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
+            const unsigned cnow = (unsigned)__builtin_amdgcn_readfirstlane((int)cn);
+            const bool pre = (s + 1 < NB16) && (int)(cnow - x1_base) >= UT;
+            if (pre) block_load(s + 1);
+            cn = cnt_load(s + 2);
+            lds_wait_ge<false>(&sy->stage_cnt[s], 4);
+            PU_STAMP(2 + 3 * s);
+            if (active) {
+                lds_wait_ge<false>(&sy->hprog[sw], s + 1);
+                pu_update<UT>(accU, H[s], Xsb, fr, fk);
+            }
+            PU_STAMP(3 + 3 * s);
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&sy->upd_cnt[s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
+            if (s + 1 < NB16 && !pre) {
+                pu_poll_ge<2>(x1cnt + s + 1, cnow, x1_base, UT);
+                block_load(s + 1);
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int q = 0; q < UT; q++)
+                if (q < nvalid) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) Cn[(int64_t)(fk + 4 * r) * ldb + 16 * q + fr] = accU[q][r];
+                }
+        }
+        PU_STAMP(25);
+        if (edge) edge_signal(edge, edge_val, gridDim.x);
+        return;
+    }
+
+    // ================================ strip waves ================================
+    __builtin_amdgcn_s_setprio(2);
+    const bool producer = active && strip < UT;
+    f64x4 bt[NB16];
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < NB16; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) bt[j][r] = B[(row0 + fk + 4 * r) * ldb + j * 16 + fr];
+    }
+    PU_STAMP(0);
+    if (active) {
+        StripCtx sc;
+        sc.ws = invd;
+        sc.flag = flag;
+        sc.flag_base = flag_base;
+        sc.Brow = B + row0 * ldb;
+        sc.ldb = ldb;
+        sc.through = (edge != nullptr) || producer;
+        sc.lane = lane;
+        sc.fr = fr;
+        sc.fk = fk;
+        strip_substitution<true>(sc, bt, H, &sy->hprog[sw], [&](int j) {
+            PU_STAMP(1 + j);
+            if (producer) {
+                // (stores count in vmcnt on gfx9: drained = x_j is in memory)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(x1cnt + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        });
+    }
+    if (edge) edge_signal(edge, edge_val, gridDim.x);
+}
+
+template <bool LA, int UT>
+__global__ __launch_bounds__(PD_THREADS) void potf2_trsm_upd_kernel(double *__restrict__ A, int64_t lda,
+                                                                    double *__restrict__ invd, int32_t *info,
+                                                                    int64_t info_col0, int64_t m, double *__restrict__ B,
+                                                                    int64_t ldb, unsigned *flag, unsigned flag_base,
+                                                                    unsigned x1_base, unsigned *edge, unsigned edge_val,
+                                                                    const unsigned *wait_word, unsigned wait_val,
+                                                                    unsigned *wait_err, const unsigned *cwait_word,
+                                                                    unsigned cwait_val, unsigned *cwait_err)
+{
+    edge_wait(wait_word, wait_val, wait_err);
+    if (blockIdx.x == 0) {
+        if (LA) potf2_body_la<true>(A, lda, invd, info, info_col0, flag, flag_base);
+        else potf2_body<true>(A, lda, invd, info, info_col0, flag, flag_base);
+        if (edge) edge_signal(edge, edge_val, gridDim.x);
+        return;
+    }
+    trsm_upd_consumer<UT>(invd, m, B, ldb, flag, flag_base, x1_base, edge, edge_val, cwait_word, cwait_val, cwait_err);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1452,7 +1800,7 @@ static bool potf2_lookahead()
 static int ensure_big_lds(const void *fn, int which, size_t shmem)
 {
     static std::mutex mu;
-    static bool done[5][64];
+    static bool done[13][64];
     int dev = 0;
     GPT_HIP_CHECK(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) dev = 63;
@@ -1467,19 +1815,60 @@ static int ensure_big_lds(const void *fn, int which, size_t shmem)
 // m rows below the 128x128 diagonal block at A (B = A + 128 * lda).  `flag` is a device word only ever raised;
 // flag_base must exceed every value written to it before (the caller counts: 16 per launch).
 int launch_potf2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
-                      unsigned *flag, unsigned flag_base, hipEvent_t done, EdgeSig edge, EdgeSig wait)
+                      unsigned *flag, unsigned flag_base, hipEvent_t done, EdgeSig edge, EdgeSig wait, int rows64)
 {
     gpt_jitter(st);
     const bool la = potf2_lookahead();
     const size_t shmem = la ? PD_LA_SMEM_BYTES : (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
-    auto kern = la ? potf2_trsm_kernel<true> : potf2_trsm_kernel<false>;
-    { int rc_ = ensure_big_lds(reinterpret_cast<const void *>(kern), la ? 3 : 0, shmem); if (rc_ != GPT_OK) return rc_; }
-    const unsigned grid = 1u + (unsigned)((m + 16 * PD_WAVES - 1) / (16 * PD_WAVES));
+    auto kern = rows64 ? (la ? potf2_trsm_kernel<true, true> : potf2_trsm_kernel<false, true>)
+                       : (la ? potf2_trsm_kernel<true, false> : potf2_trsm_kernel<false, false>);
+    { int rc_ = ensure_big_lds(reinterpret_cast<const void *>(kern), (la ? 3 : 0) + (rows64 ? 9 : 0), shmem); if (rc_ != GPT_OK) return rc_; }
+    const int64_t rpw = rows64 ? 64 : 16 * PD_WAVES;
+    const unsigned grid = 1u + (unsigned)((m + rpw - 1) / rpw);
     if (done) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(PD_THREADS), shmem, st, nullptr, done, 0, A, lda, invd,
                                     info, info_base, m, A + 128 * lda, lda, flag, flag_base, edge.word, edge.value,
                                     wait.word, wait.value, wait.err);
     else hipLaunchKernelGGL(kern, dim3(grid), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base, m,
                             A + 128 * lda, lda, flag, flag_base, edge.word, edge.value, wait.word, wait.value, wait.err);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
+// The same with the leaf's update of the next `upd_cols` (128 or 256) columns inside the launch (potf2_trsm_upd_kernel; 64
+// rows per consumer workgroup).  flag[32..39] are the producers' counters, one per step: x1_base = their common value before
+// this launch; the launch raises each by upd_cols / 16.  cwait: the word the update's C tiles wait for (may be empty).
+int launch_potf2_trsm_upd(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
+                          unsigned *flag, unsigned flag_base, unsigned x1_base, int64_t upd_cols, hipEvent_t done,
+                          EdgeSig edge, EdgeSig wait, EdgeSig cwait)
+{
+    gpt_jitter(st);
+    if (!(upd_cols == 128 || upd_cols == 256) || m < upd_cols || m % 64 || lda >= (int64_t)1 << 21) {      // (32-bit byte offsets of the staged rows)
+        gpt_set_error("potf2_trsm_upd: bad shape (m=%lld, upd_cols=%lld)", (long long)m, (long long)upd_cols);
+        return GPT_E_ARG;
+    }
+    const bool la = potf2_lookahead();
+    size_t shmem = la ? PD_LA_SMEM_BYTES : (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
+    if (shmem < (size_t)PU_CONS_SMEM_DOUBLES * sizeof(double)) shmem = (size_t)PU_CONS_SMEM_DOUBLES * sizeof(double);
+    typedef void (*kern_t)(double *, int64_t, double *, int32_t *, int64_t, int64_t, double *, int64_t, unsigned *, unsigned,
+                           unsigned, unsigned *, unsigned, const unsigned *, unsigned, unsigned *, const unsigned *, unsigned,
+                           unsigned *);
+    kern_t kern;
+    int which;
+    if (upd_cols == 128) {
+        kern = la ? potf2_trsm_upd_kernel<true, 8> : potf2_trsm_upd_kernel<false, 8>;
+        which = la ? 5 : 6;
+    } else {
+        kern = la ? potf2_trsm_upd_kernel<true, 16> : potf2_trsm_upd_kernel<false, 16>;
+        which = la ? 7 : 8;
+    }
+    { int rc_ = ensure_big_lds(reinterpret_cast<const void *>(kern), which, shmem); if (rc_ != GPT_OK) return rc_; }
+    const unsigned grid = 1u + (unsigned)(m / 64);
+    if (done) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(PD_THREADS), shmem, st, nullptr, done, 0, A, lda, invd, info, info_base, m,
+                                    A + 128 * lda, lda, flag, flag_base, x1_base, edge.word, edge.value, wait.word, wait.value,
+                                    wait.err, cwait.word, cwait.value, cwait.err);
+    else hipLaunchKernelGGL(kern, dim3(grid), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base, m, A + 128 * lda, lda,
+                            flag, flag_base, x1_base, edge.word, edge.value, wait.word, wait.value, wait.err, cwait.word,
+                            cwait.value, cwait.err);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
