@@ -98,6 +98,10 @@ struct gpt_ctx {
     int64_t fuse_upd = 0;              // 1: leaves with at most fuse_upd_rows rows below them apply their rank-128 update of the next
     int64_t fuse_upd_rows = 4096;      //    128 / 256 columns inside the leaf's launch (potf2_trsm_upd_kernel); measured slower than
                                        //    the separate update launch (profiles/r05_upd_ab.txt): off
+    hipStream_t near_stream = nullptr;     // second main stream (same CU mask), created on first use: the rank-w "near" updates of paired panels
+    int64_t pair_rows = 0;                 // > 0: while more rows than this remain, panels are taken in PAIRS -- after the first one only the next
+                                           // panel's columns are updated (rank w, near_stream), after the second everything to the right in ONE
+                                           // rank-2w launch (potrf_enqueue "panel pairs")
     int64_t fuse_rows64 = 2048;        // fused leaves with at most this many rows below them: 64 rows per consumer workgroup (one strip
                                        // wave per SIMD, potf2_trsm_kernel<.., true>); 0 = always 128
     int64_t helper_min_n = 12288;      // the helper stream takes part only above this matrix size
@@ -370,7 +374,8 @@ static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, 
         gp->flops = flops;
     }
     // trailing updates on the main stream leave room on every CU for the panel stream (see gemm.hip)
-    const int lds_pad = (on_main && c->lookahead) ? (c->pad_now > 0 ? c->pad_now : c->gemm_pad) : 0;
+    const bool on_near = c->near_stream && st == c->near_stream;      // (shares the main stream's CUs: same room left for the panel stream)
+    const int lds_pad = ((on_main || on_near) && c->lookahead) ? (c->pad_now > 0 ? c->pad_now : c->gemm_pad) : 0;
     // `done` (a cross-stream edge) and the timing events ride on the dispatch packet itself where possible
     // (hipExtLaunchKernelGGL): a separate hipEventRecord is a barrier packet, ~6 us of command-processor time
     const bool ext = !c->use_graph && (c->tile == 0 || c->tile == 64);
@@ -399,7 +404,7 @@ static int gemm_nt(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, 
     // the panel stream's updates keep a raised wave priority in their main loop (option panel_prio, see gemm.hip)
     // (option gemm_prio >= 0: every GEMM of this context -- the panel-side context of the block-cyclic engine, whose
     // launches all sit on the chain)
-    const int prio = (c->gemm_prio >= 0) ? (int)c->gemm_prio : (!on_main && c->lookahead) ? (int)c->panel_prio : 0;
+    const int prio = (c->gemm_prio >= 0) ? (int)c->gemm_prio : (!on_main && !on_near && c->lookahead) ? (int)c->panel_prio : 0;
     int rc = launch_gemm_nt(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, c->tile, lds_pad, e0, e1, prio, edge, wait, edge_cols, 1, 0, tail);
     if (!ext) {
         if (prof) GPT_HIP_CHECK(hipEventRecord(gp->e1, st));
@@ -865,6 +870,8 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
     }
     EdgeSig cu_edge_prev, rest_edge_prev;
     EdgeSig next_panel_edge;      // the NEXT panel's edge, allocated early: the main stream's last launch of this panel awaits it at its end
+    bool pair_pending = false, near_synced = false;      // panel pairs (option pair_rows, see below)
+    int64_t pair_c0 = 0, pair_w = 0;
     struct PendingRest { bool on; int64_t c0, w, u1, split; hipStream_t S; } pend = {false, 0, 0, 0, 0, nullptr};
     auto launch_rest = [&](const PendingRest &r) -> int {
         return gemm_nt(c, r.S, n - r.u1, r.split - r.u1, r.w, -1.0, A + r.u1 * lda + r.c0, lda, A + r.u1 * lda + r.c0, lda,
@@ -1027,6 +1034,70 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
                 cu_edge.word = c->d_edge + 16;
                 cu_edge.value = ++c->edge_seq;
                 cu_edge = with_err(c, cu_edge);
+                // ---- panel pairs (round 5, option pair_rows): the trailing update with k = 2 w.  A rank-384 update spends ~20 % of
+                // a 64x64 tile's time in the C prologue / epilogue and the launch has a fixed cost of ~20 us; alone on the chip the
+                // same kernel runs at 48.2 / 51.8 / 53.5 TFLOP/s for k = 384 / 768 / 1152 (NOTES_r03).  First panel of a pair: only
+                // the columns the second panel touches get their rank-w update now -- on near_stream, a second main stream, because
+                // the main stream is still busy with the previous pair's large launch and this small one is on the chain.  Second
+                // panel: everything to the right of it gets both panels' updates in ONE launch with k = 2 w; its urgent columns --
+                // first in the launch, partial flag -- are the next TWO panels', so that the next pair's near update (which
+                // read-modify-writes the second one's columns on the other stream) comes after them by way of the panel stream.
+                // Every element still sums its products in the same order (k ascending, the accumulator carried through one
+                // store and load between the launches of the unpaired schedule): the factor is bit-identical.
+                if (pair_pending) {
+                    const int64_t K2 = pair_w + w;
+                    const int64_t u1p = (c0 + w + wn + wnn + GPT_PANEL_EXT < n) ? c0 + w + wn + wnn + GPT_PANEL_EXT : n;
+                    const int64_t mtn = (n - u0 + 63) / 64;
+                    const bool one = c->merge_urgent && u1p < n && mtn * (mtn + 1) / 2 >= c->merge_min_tiles && (u1p - u0) % 64 == 0;
+                    if (one) {
+                        GPT_TRY(gemm_nt(c, S, n - u0, n - u0, K2, -1.0, A + u0 * lda + pair_c0, lda, A + u0 * lda + pair_c0, lda, 1.0,
+                                        A + u0 * lda + u0, lda, 1, nullptr, cu_edge, EdgeSig(), u1p - u0));
+                    } else {
+                        GPT_TRY(gemm_nt(c, S, n - u0, u1p - u0, K2, -1.0, A + u0 * lda + pair_c0, lda, A + u0 * lda + pair_c0, lda, 1.0,
+                                        A + u0 * lda + u0, lda, 1, nullptr, cu_edge));
+                        if (u1p < n)
+                            GPT_TRY(gemm_nt(c, S, n - u1p, n - u1p, K2, -1.0, A + u1p * lda + pair_c0, lda, A + u1p * lda + pair_c0, lda,
+                                            1.0, A + u1p * lda + u1p, lda, 1));
+                    }
+                    cu_edge_prev = cu_edge;
+                    pair_pending = false;
+                    c0 += w;
+                    continue;
+                }
+                if (c->pair_rows > 0 && n - c0 > c->pair_rows && k + 1 < widths.size() && u1 < n && !tail.word && !panel_awaited) {
+                    if (!c->near_stream) {
+                        // (created on first use: every stream of a context costs, see gpt_ctx_create)
+                        std::vector<uint32_t> mm;
+                        int ncu = 0;
+                        if (c->reserve_cus > 0 && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess) {
+                            mm.assign((ncu + 31) / 32, 0u);
+                            for (int i = c->reserve_cus; i < ncu; i++) mm[i / 32] |= (1u << (i % 32));
+                        }
+                        if (mm.empty() || hipExtStreamCreateWithCUMask(&c->near_stream, (uint32_t)mm.size(), mm.data()) != hipSuccess) {
+                            (void)hipGetLastError();
+                            GPT_HIP_CHECK(hipStreamCreateWithFlags(&c->near_stream, hipStreamNonBlocking));
+                        }
+                    }
+                    if (!near_synced) {
+                        // the near stream's first launch of this factorisation: behind everything the main stream has enqueued so far
+                        // (the rest of the K build)
+                        hipEvent_t e_k = get_event(c, 12 + 6 * widths.size());
+                        if (!e_k) return GPT_E_HIP;
+                        GPT_HIP_CHECK(hipEventRecord(e_k, S));
+                        GPT_HIP_CHECK(hipStreamWaitEvent(c->near_stream, e_k, 0));
+                        near_synced = true;
+                    }
+                    // (the main stream was made to wait for this panel above -- harmless: its next launch needs the next panel anyway)
+                    GPT_TRY(stream_wait_flag(c->near_stream, panel_edge));
+                    GPT_TRY(gemm_nt(c, c->near_stream, n - u0, u1 - u0, w, -1.0, A + u0 * lda + c0, lda, A + u0 * lda + c0, lda, 1.0,
+                                    A + u0 * lda + u0, lda, 1, nullptr, cu_edge));
+                    cu_edge_prev = cu_edge;
+                    pair_pending = true;
+                    pair_c0 = c0;
+                    pair_w = w;
+                    c0 += w;
+                    continue;
+                }
                 // Urgent + rest as ONE launch (option merge_urgent) while the update is large enough for an order table: the
                 // tiles of the urgent columns come first on every XCD, write through and raise the flag when THEY are done;
                 // the rest follows in the same launch -- one drain and one ramp-up less per panel on the main stream, and
@@ -1077,6 +1148,13 @@ static int potrf_enqueue(gpt_ctx *c, int64_t n, double *A, int64_t lda, double *
         c0 += w;
     }
     if (pend.on) GPT_TRY(launch_rest(pend));
+    if (near_synced) {
+        // (every near launch was awaited by the panel stream through its flag; the join keeps the stream's work inside the evaluation)
+        hipEvent_t e_n = get_event(c, 13 + 6 * widths.size());
+        if (!e_n) return GPT_E_HIP;
+        GPT_HIP_CHECK(hipEventRecord(e_n, c->near_stream));
+        GPT_HIP_CHECK(hipStreamWaitEvent(S, e_n, 0));
+    }
     c->pad_now = 0;
     if (e_help_prev) GPT_HIP_CHECK(hipStreamWaitEvent(S, e_help_prev, 0));
     if (use_early && S_cur != S0) {
@@ -1275,6 +1353,7 @@ extern "C" int gpt_ctx_destroy(gpt_ctx *c)
     hipStreamDestroy(c->panel_stream);
     if (c->helper_stream) hipStreamDestroy(c->helper_stream);
     if (c->early_stream) hipStreamDestroy(c->early_stream);
+    if (c->near_stream) hipStreamDestroy(c->near_stream);
     if (c->late_panel_stream) hipStreamDestroy(c->late_panel_stream);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -1318,6 +1397,7 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "helper_min_n")) c->helper_min_n = value;
     else if (!strcmp(key, "fuse_trsm")) c->fuse_trsm = value;
     else if (!strcmp(key, "fuse_rows64")) c->fuse_rows64 = value;
+    else if (!strcmp(key, "pair_rows")) c->pair_rows = value;
     else if (!strcmp(key, "fuse_upd")) c->fuse_upd = value;
     else if (!strcmp(key, "fuse_upd_rows")) c->fuse_upd_rows = value;
     else if (!strcmp(key, "leaf256")) c->leaf256 = value ? 1 : 0;
