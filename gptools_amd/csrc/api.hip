@@ -218,7 +218,9 @@ static int make_kparams(int kernel_id, const double *params, int nparams, int D,
             kp->l[d] = l;
             kp->inv_l[d] = 1.0 / l;
             kp->inv_var[d] = 1.0 / (l * l);
-            if (l == 0.0) kp->zero_l = 1;
+            // (from the value the pair functions multiply by: a SUBNORMAL length scale has 1 / l = inf as well, and 0 * inf on the
+            // diagonal / for coincident points would be NaN where the reference divides 0 / l = 0, core.py:416 -- ADVICE r4)
+            if (l == 0.0 || std::isinf(kp->inv_l[d])) kp->zero_l = 1;
         }
     } else if (kernel_id == GPT_KERNEL_RQ) {
         // RationalQuadraticKernel: [sigma_f, alpha, l_1 .. l_D] (ref: rational_quadratic.py:30-45)
@@ -502,6 +504,13 @@ struct EvalScope {
         std::unique_lock<std::mutex> lk(g_eval_mu);
         const auto now = std::chrono::steady_clock::now();
         if (never_flags) {
+            // (a flag-mode evaluation must be alone: this work fills all 256 CUs from the unmasked panel stream, and kernels that
+            // spin on flags beside it would run into their bounded waits, repeat the evaluation and put the process on event edges
+            // for good -- so it WAITS for one in flight like any other evaluation; it only never takes the flag-mode slot.  ADVICE r4)
+            if (g_flag_evals != 0) {
+                g_contention_until = now + std::chrono::milliseconds(100);
+                g_eval_cv.wait(lk, [] { return g_flag_evals == 0; });
+            }
             if (g_evals != 0 && g_announced == 0) g_contention_until = now + std::chrono::milliseconds(100);
             g_evals++;
             c->flags_now = false;

@@ -509,86 +509,6 @@ __global__ __launch_bounds__(256) void gemv_t_sub_kernel(int64_t ncols, const do
     if (g == 0 && col < ncols) w[col] -= (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
-// One launch per 512-wide step (round 4): the update of step j AND the block solve of step j - 1.  The workgroups of the update
-// that own the LAST 512 columns -- the next block's right-hand side -- are dispatched first (blockIdx 0..7); when all eight
-// have written their columns (agent-scope stores, drained, a counter: the EdgeSig pattern of common.hpp inside one launch --
-// eight workgroups of <= 128, resident together by construction) each of them forms 64 rows of  x_(j-1) = U_(j-1) w_(j-1)
-// (w read back with agent-scope loads: the writers sit on other XCDs).  31 dependent launches at n = 8192 become 16.
-__global__ __launch_bounds__(256) void trsv_step_kernel(int64_t ncols, const double *__restrict__ M, int64_t ldm,
-                                                        const double *__restrict__ x, double *__restrict__ w,
-                                                        const double *__restrict__ Uprev, double *__restrict__ xprev,
-                                                        unsigned *counter, unsigned target)
-{
-    __shared__ double xs[TW_NB];
-    __shared__ double part[4][64];
-    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
-    const int64_t ncb = (ncols + 63) / 64;
-    const bool near = blockIdx.x < 8;                                   // ncols is a multiple of 512: the last eight column blocks
-    const int64_t cb = near ? ncb - 8 + blockIdx.x : (int64_t)blockIdx.x - 8;
-    for (int i = tid; i < TW_NB; i += 256) xs[i] = x[i];
-    __syncthreads();
-    const int64_t col = cb * 64 + lane;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    {
-        const double *p = M + (int64_t)(g * (TW_NB / 4)) * ldm + col;
-        const double *xv = xs + g * (TW_NB / 4);
-#pragma unroll 2
-        for (int r = 0; r < TW_NB / 4; r += 8) {
-            double v[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) v[q] = p[(int64_t)(r + q) * ldm];
-            a0 = fma(v[0], xv[r + 0], a0);
-            a1 = fma(v[1], xv[r + 1], a1);
-            a2 = fma(v[2], xv[r + 2], a2);
-            a3 = fma(v[3], xv[r + 3], a3);
-            a0 = fma(v[4], xv[r + 4], a0);
-            a1 = fma(v[5], xv[r + 5], a1);
-            a2 = fma(v[6], xv[r + 6], a2);
-            a3 = fma(v[7], xv[r + 7], a3);
-        }
-    }
-    part[g][lane] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (g == 0) {
-        const double nv = w[col] - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
-        if (near) __hip_atomic_store(&w[col], nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else w[col] = nv;
-    }
-    if (!near) return;
-    // the eight near workgroups: all of w[ncols - 512, ncols) is final once each has signalled
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(1);
-    }
-    __syncthreads();
-    double *wp = w + (ncols - TW_NB);
-    for (int i = tid; i < TW_NB; i += 256) xs[i] = __hip_atomic_load(&wp[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    // rows [64 b, 64 b + 64) of x_prev = Uprev w_prev: a wave per row, sixteen rows per wave, 4 KB of the row per read
-    const int64_t r0 = (int64_t)blockIdx.x * 64 + g * 16;
-    for (int rr = 0; rr < 16; rr += 4) {                        // four rows per pass: 32 loads in flight per lane
-        double u[4][TW_NB / 64];
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int q = 0; q < TW_NB / 64; q++) u[a][q] = Uprev[(r0 + rr + a) * TW_NB + lane + 64 * q];
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int q = 0; q < TW_NB / 64; q += 2) {
-                s0 = fma(u[a][q], xs[lane + 64 * q], s0);
-                s1 = fma(u[a][q + 1], xs[lane + 64 * (q + 1)], s1);
-            }
-            double sum = s0 + s1;
-            for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
-            if (lane == 0) xprev[r0 + rr + a] = sum;
-        }
-    }
-}
-
 // Blocks [0, nwide / 512) of  L^T x = w : U = the strip of the blocks' inverse transposes (block j at rows [512 j, 512 j + 512),
 // row stride 512), w (in: right-hand side, already updated by every block right of nwide; consumed) and x (out) distinct.
 // counter: a device word only ever raised (its value before the call in *counter_value, updated here).
@@ -599,21 +519,16 @@ int launch_trsv_lt_wide(hipStream_t st, int64_t nwide, const double *L, int64_t 
         gpt_set_error("trsv_lt_wide: the extent must be a multiple of %d", TW_NB);
         return GPT_E_ARG;
     }
-    // (the one-launch step -- trsv_step_kernel -- measured SLOWER than two launches per step: 0.36 against 0.26 ms at n = 8192
-    // with the inverses cached; eight workgroups forming 512 rows of U w after a hand-over cost more than a 512-workgroup launch.
-    // GPT_ALPHA_ONE_LAUNCH=1 selects it.)
-    static const bool two_launches = getenv("GPT_ALPHA_ONE_LAUNCH") == nullptr;
+    // (Round 4 also built a one-launch step -- update of step j and block solve of step j - 1 in one kernel, the eight workgroups that
+    // own the next block's columns dispatched first and handing over through a counter: 0.36 against 0.26 ms at n = 8192 with the
+    // inverses cached, and its wait was the one unbounded spin of the library.  Removed in round 5; `counter` is unused.)
+    (void)counter;
+    (void)counter_value;
     int64_t j0 = nwide - TW_NB;
     GPT_TRY_RC_SOLVE(launch_gemv_n(st, TW_NB, TW_NB, U + j0 * TW_NB, TW_NB, w + j0, x + j0));
     for (; j0 > 0; j0 -= TW_NB) {
-        if (two_launches || counter == nullptr) {
-            hipLaunchKernelGGL(gemv_t_sub_kernel, dim3((unsigned)(j0 / 64)), dim3(256), 0, st, j0, L + j0 * ldl, ldl, x + j0, w);
-            GPT_TRY_RC_SOLVE(launch_gemv_n(st, TW_NB, TW_NB, U + (j0 - TW_NB) * TW_NB, TW_NB, w + j0 - TW_NB, x + j0 - TW_NB));
-        } else {
-            *counter_value += 8u;
-            hipLaunchKernelGGL(trsv_step_kernel, dim3((unsigned)(j0 / 64)), dim3(256), 0, st, j0, L + j0 * ldl, ldl, x + j0, w,
-                               U + (j0 - TW_NB) * TW_NB, x + j0 - TW_NB, counter, *counter_value);
-        }
+        hipLaunchKernelGGL(gemv_t_sub_kernel, dim3((unsigned)(j0 / 64)), dim3(256), 0, st, j0, L + j0 * ldl, ldl, x + j0, w);
+        GPT_TRY_RC_SOLVE(launch_gemv_n(st, TW_NB, TW_NB, U + (j0 - TW_NB) * TW_NB, TW_NB, w + j0 - TW_NB, x + j0 - TW_NB));
     }
     GPT_LAUNCH_CHECK();
     return GPT_OK;

@@ -167,6 +167,30 @@ def test_kernel_error_contract(g):
     assert g.ZeroKernel(2)(Xr, Xr, n0, n0).tolist() == [0, 0, 0]
 
 
+@pytest.mark.parametrize("l0", [0.0, 1e-310])
+def test_se_zero_and_subnormal_length_scale(g, oracle, l0):
+    """core.py:416: a 0 / 0 term of the scaled distance counts as 0, and a SUBNORMAL length scale (1 / l = inf as well)
+    divides 0 / l = 0: coincident points give sigma_f^2, distinct ones exp(-inf) = 0 -- never NaN."""
+    rs = np.random.RandomState(3)
+    d = 2
+    Xi = rs.rand(40, d)
+    Xj = Xi.copy()
+    Xj[::3] = rs.rand(len(Xj[::3]), d)            # a third of the pairs distinct in both dimensions
+    Xj[1::3, 1] += 0.25                            # a third distinct in the dimension with the ordinary length scale only
+    z = np.zeros((40, d), int)
+    p = np.array([1.7, l0, 0.4])
+    k = make_kernel(g, "se", d, p)
+    got = k(Xi, Xj, z, z)
+    assert np.all(np.isfinite(got))
+    exp = np.where((Xi[:, 0] == Xj[:, 0]), p[0] ** 2 * np.exp(-0.5 * ((Xi[:, 1] - Xj[:, 1]) / p[2]) ** 2), 0.0)
+    assert_close(got, exp, rtol=1e-13, msg="se, l_1 = %g" % l0)
+    assert_close(got, oracle.kpairs("se", p, Xi, Xj, z, z), rtol=1e-13, msg="vs oracle")
+    # ... and on the diagonal of a Gram matrix
+    gp = g.GaussianProcess(k)
+    K = gp.compute_Kij(Xi, None, z, None)
+    assert np.all(np.isfinite(K)) and np.allclose(np.diag(K), p[0] ** 2, rtol=1e-15)
+
+
 def test_kernel_call_ragged_and_empty(g, oracle):
     rs = np.random.RandomState(5)
     for kern in KERNELS:
@@ -812,9 +836,15 @@ def test_schedule_options_agree_with_default(ctx, oracle):
                 {"leaf256": 1, "purg_rows": 1024, "defer_rows": 4608},
                 # a 128-wide first panel is factored before the rest of K is built: the panel stream's first update beyond
                 # the head columns has to wait for the build (it once did not: "8064-th leading minor ...")
-                {"ramp": 1, "purg_rows": 1024}, {"ramp": 1, "purg_rows": 0}, {"edge_flags": 0}, {"edge_flags": 0, "ramp": 1, "purg_rows": 512})
+                {"ramp": 1, "purg_rows": 1024}, {"ramp": 1, "purg_rows": 0}, {"edge_flags": 0}, {"edge_flags": 0, "ramp": 1, "purg_rows": 512},
+                # round 5: 128-row consumer workgroups everywhere / 64-row ones everywhere, the in-launch leaf update
+                # (potf2_trsm_upd_kernel) on flag and on event edges, panel pairs (rank-2w trailing updates on two main streams)
+                {"fuse_rows64": 0}, {"fuse_rows64": 8192}, {"fuse_upd": 1, "fuse_upd_rows": 8192}, {"fuse_upd": 1, "edge_flags": 0},
+                {"fuse_upd": 1, "nb_outer": 256}, {"pair_rows": 1}, {"pair_rows": 1024, "nb_outer": 256}, {"pair_rows": 1, "fuse_upd": 1})
     defaults = {"leaf256": 0, "nb_outer": 0, "inner": 0, "defer_rows": 0, "purg_rows": 6144, "nb_early": 0, "nb_switch_rows": 4608,
-                "ramp": 0, "edge_flags": 1}
+                "ramp": 0, "edge_flags": 1, "fuse_rows64": 2048, "fuse_upd": 0, "fuse_upd_rows": 4096, "pair_rows": 0}
+    # (the round-5 variants are bit-identical to the default schedule by construction: same sums in the same order)
+    exact = ("fuse_rows64", "fuse_upd", "pair_rows")
     try:
         for v in variants:
             for k_, d_ in defaults.items():
@@ -825,6 +855,8 @@ def test_schedule_options_agree_with_default(ctx, oracle):
                 got = ctx.fit(1, p, 0.0, y, err, 1e2 * EPS)
                 assert abs(got[0] - base[0]) <= 1e-11 * abs(base[0]), v
                 assert abs(got[1] - base[1]) <= 1e-12 * abs(base[1]), v
+                if all(k_ in exact or k_ == "fuse_upd_rows" for k_ in v):
+                    assert got == base, v
     finally:
         for k_, d_ in defaults.items():
             ctx.set_option(k_, d_)
@@ -1673,6 +1705,53 @@ def test_ll_batch_grid_path_and_thread_path_agree(g):
         gp = g.GaussianProcess(k, noise_k=nk, X=X2, y=y2, err_y=0.0, diag_factor=0.0)
         out = gp.ll_batch([[1.0, 0.4, 0.6, 0.05], [1.0, 0.4, 0.6, 0.0], [1.1, 0.5, 0.6, 0.02]])
         assert np.isfinite(out[0]) and np.isneginf(out[1]) and np.isfinite(out[2])
+
+
+def test_flag_mode_fit_beside_a_batch_on_another_thread_keeps_flag_edges():
+    """gpt_fit_batch (EvalScope never_flags) started while a flag-mode evaluation is in flight waits for it instead of
+    filling the chip beside its spinning kernels; afterwards a lone evaluation still runs on flag edges (no bounded wait tripped)
+    and every result is the sequential one."""
+    import threading
+    from gptools_amd import _lib
+    a, b = _lib.Context(0), _lib.Context(0)
+    N, d = 2500, 2
+    X, n, y = c3_inputs(N, d)
+    p = np.array([1.0, 0.3, 0.3])
+    err = 0.05 * np.ones(N)
+    a.set_data(X, n)
+    Nb = 700
+    b.set_data(X[:Nb], n[:Nb])
+    P = np.tile(np.array([1.0, 0.3, 0.4]), (16, 1)) * (1.0 + 0.01 * np.arange(16))[:, None]
+    Yb = np.tile(y[:Nb], (16, 1))
+    ref_a = a.fit(1, p, 0.0, y, err, 1e2 * EPS)
+    ref_b = b.fit_batch(1, P, np.zeros(16), Yb, err[:Nb], 1e2 * EPS)
+    out, errs = {"a": [], "b": []}, []
+
+    def run_a():
+        try:
+            for _ in range(40):
+                out["a"].append(a.fit(1, p, 0.0, y, err, 1e2 * EPS))
+        except Exception as e:          # noqa
+            errs.append(e)
+
+    def run_b():
+        try:
+            for _ in range(40):
+                out["b"].append(b.fit_batch(1, P, np.zeros(16), Yb, err[:Nb], 1e2 * EPS))
+        except Exception as e:          # noqa
+            errs.append(e)
+
+    ta, tb = threading.Thread(target=run_a), threading.Thread(target=run_b)
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert not errs, errs
+    assert all(r == ref_a for r in out["a"])
+    assert all(all(np.array_equal(u, v) for u, v in zip(r, ref_b)) for r in out["b"])
+    import time
+    time.sleep(0.15)                                  # (the contention window of un-announced overlap)
+    e0 = a.edge_count
+    assert a.fit(1, p, 0.0, y, err, 1e2 * EPS) == ref_a
+    assert a.edge_count > e0, "the process left flag edges for good"
+    a.close(); b.close()
 
 
 @pytest.mark.parametrize("kern,N,d", [("m52", 1408, 3), ("se", 2047, 2), ("se", 3000, 2), ("m52", 1024, 3), ("se", 1100, 2)])
