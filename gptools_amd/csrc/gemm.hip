@@ -778,6 +778,13 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
         GPT_HIP_CHECK(e1);
         GPT_HIP_CHECK(e2);
     }
+    // (a cap: the block-cyclic engines and the experiments behind options make a table per shape -- ADVICE r4.  Tables may be in use
+    // by launches in flight, so the oldest half goes only behind a device-wide synchronisation; rare by construction)
+    if (g_orders.size() >= 1024) {
+        GPT_HIP_CHECK(hipDeviceSynchronize());
+        for (size_t q = 0; q < 512; q++) hipFree(g_orders[q].d_tab);
+        g_orders.erase(g_orders.begin(), g_orders.begin() + 512);
+    }
     g_orders.push_back(o);
     *tab = o.d_tab;
     *grid = o.grid;

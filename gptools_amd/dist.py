@@ -215,12 +215,9 @@ class HipPanelOps(PanelOps):
 
     def copy2d(self, dst, src, q="panel"):
         assert dst.shape == src.shape and dst.stride(1) == 1 and src.stride(1) == 1
-        if q in self._ctx:
-            _lib.check(self.lib.gpt_dev_copy2d(self._ctx[q].handle, src.shape[0], src.shape[1], src.data_ptr(), src.stride(0),
-                                               dst.data_ptr(), dst.stride(0)))
-        else:       # a queue without a library context of its own ("recv"): the library's kernel on that queue's stream
-            _lib.check(self.lib.gpt_dev_copy2d_on(self.ctx_panel.handle, self._stream[q].cuda_stream, src.shape[0], src.shape[1],
-                                                  src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0)))
+        # (every queue has a library context of its own, "recv" included)
+        _lib.check(self.lib.gpt_dev_copy2d(self._ctx[q].handle, src.shape[0], src.shape[1], src.data_ptr(), src.stride(0),
+                                           dst.data_ptr(), dst.stride(0)))
 
     def pad_block(self, A, lj, c0, nb, N, NP, y, big, row_shift=0):
         # (row_shift: the library addresses row r of the block column as base + r * lda; a shifted base makes that the local row)
@@ -711,7 +708,6 @@ class GridLML(object):
         self.device = getattr(ops, "device", torch.device("cpu"))
         self.force_collectives = bool(int(os.environ.get("GPT_DIST_FORCE_COLLECTIVES", "0"))) and inited
         self.lookahead = bool(lookahead)
-        self._stream_ordered = inited and dist.get_backend(group) == "nccl"
         # communicators: one per process row (panel rows), two per process column (the inverse of the diagonal block / the
         # column exchange: the latter must never queue behind a diagonal block that is still being factored), the whole grid
         # for the head blocks and the final reduction.  Every rank creates every group, in the same order.
