@@ -69,7 +69,7 @@ def flops_fit(N, alpha=True):
     return N ** 3 / 3.0 + N ** 2 / 2.0 + N / 6.0 + (2.0 if alpha else 1.0) * N ** 2
 
 
-def cpu_baseline(kernel, X, n, y, err, params, budget_s=20.0, max_reps=5, sweep_budget_s=15.0):
+def cpu_baseline(kernel, X, n, y, err, params, budget_s=20.0, max_reps=5, sweep_budget_s=25.0):
     """Oracle K-build (all host cores, OpenMP) + LAPACK Cholesky / solve through scipy, like the reference's
     scipy.linalg.cholesky + cho_solve (gaussian_process.py:1452,1462).  K-build and factorisation are timed
     separately."""
@@ -99,7 +99,7 @@ def cpu_baseline(kernel, X, n, y, err, params, budget_s=20.0, max_reps=5, sweep_
         idx = np.arange(N)
         K[idx, idx] = (K[idx, idx] + err ** 2.0) + 1e2 * sys.float_info.epsilon
         spent = 0.0
-        for th in (16, 32, 8):
+        for th in (8, 4, 16, 32):      # (the settings most likely to be sane -- one NUMA node's worth of threads -- first)
             if th >= blas_threads or th > cores or spent + tp > sweep_budget_s:
                 continue
             with threadpool_limits(limits=th, user_api="blas"):

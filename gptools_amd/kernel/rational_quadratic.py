@@ -4,8 +4,8 @@ ref: gptools/kernel/rational_quadratic.py:30-164 (RationalQuadraticKernel) throu
 gptools/kernel/core.py:691-816.  Hyperparameters ``[sigma_f, alpha, l_1 .. l_D]``:
 ``k = sigma_f^2 (1 + 1/(2 alpha) sum_d tau_d^2 / l_d^2)^-alpha``.  Derivative observations follow the reference's
 Faa di Bruno sum over set partitions, regrouped on the device (gptools_amd/csrc/kpair.hpp, ``rq_pair``): the
-derivative orders of a pair (``ni[m] + nj[m]`` summed over the dimensions) may reach ``GPT_RQ_MAXORD`` = 8, a
-``ValueError`` beyond (the reference has no limit; its cost grows with the Bell numbers).  Hyperparameter
+derivative orders of a pair (``ni[m] + nj[m]`` summed over the dimensions) may reach ``GPT_RQ_MAXORD`` = 16, a
+``ValueError`` beyond (the reference has no limit, but its cost grows with the Bell numbers: order 12 takes it minutes per pair).  Hyperparameter
 derivatives raise ``NotImplementedError`` like the reference (core.py:723-726).
 """
 from .core import Kernel

@@ -48,8 +48,9 @@ extern "C" {
 #define GPT_KERNEL_RQ 4          /* RationalQuadraticKernel, params [sigma_f, alpha, l_1 .. l_D]
                                   * (ref: gptools/kernel/rational_quadratic.py:30-164 through ChainRuleKernel.__call__,
                                   * kernel/core.py:691-816); derivative orders of a pair may sum to GPT_RQ_MAXORD at most
-                                  * (GPT_E_VALUE beyond; the reference has no limit); no hyper-parameter derivatives */
-#define GPT_RQ_MAXORD 8
+                                  * (GPT_E_VALUE beyond; the reference has no limit, but walks every set partition of the
+                                  * derivative multiset: Bell(12) = 4.2 million per pair); no hyper-parameter derivatives */
+#define GPT_RQ_MAXORD 16
 #define GPT_KERNEL_MATERN 5      /* MaternKernel (general order nu), params [sigma_f, nu, l_1 .. l_D] (ref: kernel/matern.py:251-465
                                   * through ChainRuleKernel.__call__); same limit on the derivative orders of a pair; nu must
                                   * lie in (0, 60) (GPT_E_VALUE otherwise: beyond it the closed form the device evaluates,

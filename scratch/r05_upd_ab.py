@@ -60,7 +60,7 @@ if "check" in what:
             print("fuse_upd %d: %s" % (v, str(e)[:100]))
     print("check:", "OK" if bad == 0 else "%d MISMATCHES" % bad, flush=True)
 
-CONFIGS = {0: dict(fuse_upd=0, fuse_rows64=0), 1: dict(fuse_upd=0, fuse_rows64=4096), 2: dict(fuse_upd=0, fuse_rows64=2048), 3: dict(fuse_upd=0, fuse_rows64=1024)}
+CONFIGS = {0: dict(fuse_upd=0, fuse_rows64=0), 1: dict(fuse_upd=0, fuse_rows64=2048), 2: dict(fuse_upd=0, fuse_rows64=4096), 3: dict(fuse_upd=1, fuse_rows64=2048)}
 if "time" in what:
     for (kid, N, d, deriv) in ((0, 1024, 2, False), (0, 2048, 2, False), (0, 4096, 2, False), (1, 8192, 3, True), (0, 16384, 2, False)):
         X, n, y, p, err = data(N, d, deriv)

@@ -36,7 +36,7 @@ gate.gate_wait.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong]
 
 class TimedOps(HipPanelOps):
     def new_event(self):
-        return _StreamEvent(timing=True)
+        return _StreamEvent(self, timing=True)
 
 
 ops = TimedOps(0)

@@ -17,6 +17,7 @@ Fixture groups follow SURVEY.md section 8(c):
   G8 RationalQuadraticKernel: pairs, Gram, fit, predict (kernel/rational_quadratic.py:30-164, kernel/core.py:691-816)
   G10 MaternKernel (general nu): pairs, Gram, fit, predict (kernel/matern.py:251-465, utils.py:1369-1527)
   G9 ProductKernel (k1 * k2) with derivative orders: pairs, fit, predict (kernel/core.py:587-671)
+  G11 RQ / general Matern / product pairs at combined derivative orders 9 .. 12 (not in the default list: ~15 minutes)
 """
 import os
 import pickle
@@ -666,8 +667,59 @@ def gen_g10():
     save("g10_matern", **out)
 
 
+# ----------------------------------------------------------------------------
+# G11 (round 5): combined derivative orders 9 .. 12 of a pair -- the device builder's limit went from 8 to 16 (GPT_RQ_MAXORD);
+# the reference walks every set partition of the derivative multiset (core.py:752-816: Bell(12) = 4.2 million per pair), so a
+# handful of pairs per order is what a generation run affords (RQ order 12: ~3 minutes per pair)
+# ----------------------------------------------------------------------------
+def orders_with_sum(rs, d, tot):
+    """ni, nj (d,) with ni.sum() + nj.sum() == tot, spread over both points and all dimensions."""
+    v = np.zeros(2 * d, dtype=int)
+    for _ in range(tot):
+        v[rs.randint(2 * d)] += 1
+    return v[:d], v[d:]
+
+
+def gen_g11():
+    rs = np.random.RandomState(1111)
+    out = {}
+    plans = (("rq", 2, ((9, 5), (10, 3), (11, 2), (12, 1))), ("rq", 3, ((9, 4), (10, 2))),
+             ("matern", 2, ((9, 3), (10, 2))), ("prod", 2, ((9, 3), (10, 1))))
+    for name, d, plan in plans:
+        Xi, Xj, ni, nj = [], [], [], []
+        for tot, cnt in plan:
+            for _ in range(cnt):
+                a, b = orders_with_sum(rs, d, tot)
+                Xi.append(rs.rand(d)); Xj.append(rs.rand(d)); ni.append(a); nj.append(b)
+        Xi, Xj, ni, nj = np.array(Xi), np.array(Xj), np.array(ni), np.array(nj)
+        if name == "rq":
+            params = np.concatenate(([1.3, 1.7], 0.3 + 0.5 * rs.rand(d)))
+            k = rq_kernel(d, params)
+        elif name == "matern":
+            params = np.concatenate(([1.1, 3.2], 0.4 + 0.4 * rs.rand(d)))
+            k = gptools.MaternKernel(num_dim=d, initial_params=list(params), param_bounds=[(0.0, 1e3)] * (d + 2))
+        else:
+            p1 = np.concatenate(([1.1], 0.4 + 0.4 * rs.rand(d)))
+            p2 = np.concatenate(([0.9, 1.7], 0.3 + 0.5 * rs.rand(d)))
+            params = np.concatenate((p1, p2))
+            k = se_kernel(d, p1) * rq_kernel(d, p2)
+            out["prod_d%d_p1" % d], out["prod_d%d_p2" % d] = p1, p2
+        key = "%s_d%d_" % (name, d)
+        out[key + "Xi"], out[key + "Xj"] = Xi, Xj
+        out[key + "ni"], out[key + "nj"] = ni.astype(np.int32), nj.astype(np.int32)
+        out[key + "params"] = params
+        vals = []
+        for m in range(len(Xi)):                       # one pair per call: the progress shows, a run can be interrupted
+            vals.append(float(np.asarray(k(Xi[m:m + 1], Xj[m:m + 1], ni[m:m + 1], nj[m:m + 1]))[0]))
+            print("  %s order %d: %.15g" % (key, ni[m].sum() + nj[m].sum(), vals[-1]), flush=True)
+        out[key + "k"] = np.array(vals)
+    save("g11_high_orders", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["g1", "g2", "g34", "g5", "g6", "g7", "g8", "g9", "g10"]
+    if "g11" in which:
+        gen_g11()
     if "g10" in which:
         gen_g10()
     if "g1" in which:

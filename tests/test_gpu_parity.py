@@ -269,15 +269,43 @@ def test_g8_rational_quadratic_kernel_call(g, golden, oracle, d):
     M = 300
     Xi, Xj = rs.rand(M, d), rs.rand(M, d)
     ni, nj = np.zeros((M, d), int), np.zeros((M, d), int)
-    for m in range(M):                       # combined order exactly 8, spread at random
-        for _ in range(8):
-            (ni if rs.rand() < 0.5 else nj)[m, rs.randint(d)] += 1
-    assert_close(k(Xi, Xj, ni, nj), oracle.kpairs("rq", p, Xi, Xj, ni, nj), rtol=1e-10, atol_scale=1e-13, msg="order 8")
+    for tot in (8, 12, 16):                  # combined order exactly 8 / 12 / 16 (the device builder's limit), spread at random
+        ni[:], nj[:] = 0, 0
+        for m in range(M):
+            for _ in range(tot):
+                (ni if rs.rand() < 0.5 else nj)[m, rs.randint(d)] += 1
+        assert_close(k(Xi, Xj, ni, nj), oracle.kpairs("rq", p, Xi, Xj, ni, nj), rtol=1e-10, atol_scale=1e-13, msg="order %d" % tot)
     ni[0, 0] += 1
     with pytest.raises(ValueError):          # beyond what the device builder carries
         k(Xi, Xj, ni, nj)
     with pytest.raises(NotImplementedError):  # ref: core.py:723-726
         k(Xi, Xj, 0 * ni, 0 * nj, hyper_deriv=1)
+
+
+def test_g11_high_derivative_orders(g, golden, oracle):
+    """Combined derivative orders 9 .. 12 of a pair (round 5: GPT_RQ_MAXORD 8 -> 16) against outputs of the reference itself
+    (golden g11: the reference walks every set partition, minutes per pair at order 12): rational-quadratic, general-order
+    Matern and the product SE * RQ.  The reference's Matern sums lose digits with the order (Bell polynomials of kvp with
+    alternating signs): there the device is held to the oracle's closed form and to the reference at what it delivers."""
+    G = golden("g11_high_orders")
+    for d in (2, 3):
+        key = "rq_d%d_" % d
+        p = G[key + "params"]
+        k = g.RationalQuadraticKernel(num_dim=d, initial_params=list(p), param_bounds=[(0.0, 1e3)] * (d + 2))
+        got = k(G[key + "Xi"], G[key + "Xj"], G[key + "ni"], G[key + "nj"])
+        assert_close(got, G[key + "k"], rtol=1e-9, atol_scale=1e-13, msg=key)
+        assert_close(got, oracle.kpairs("rq", p, G[key + "Xi"], G[key + "Xj"], G[key + "ni"], G[key + "nj"]), rtol=1e-10, msg=key + "oracle")
+    key = "matern_d2_"
+    p = G[key + "params"]
+    k = g.MaternKernel(num_dim=2, initial_params=list(p), param_bounds=[(0.0, 1e3)] * 4)
+    got = k(G[key + "Xi"], G[key + "Xj"], G[key + "ni"], G[key + "nj"])
+    assert_close(got, oracle.kpairs("matern", p, G[key + "Xi"], G[key + "Xj"], G[key + "ni"], G[key + "nj"]), rtol=1e-9, msg=key + "oracle")
+    assert_close(got, G[key + "k"], rtol=1e-4, msg=key)
+    key = "prod_d2_"
+    k = (g.SquaredExponentialKernel(num_dim=2, initial_params=list(G["prod_d2_p1"]), param_bounds=[(0.0, 1e3)] * 3) *
+         g.RationalQuadraticKernel(num_dim=2, initial_params=list(G["prod_d2_p2"]), param_bounds=[(0.0, 1e3)] * 4))
+    got = k(G[key + "Xi"], G[key + "Xj"], G[key + "ni"], G[key + "nj"])
+    assert_close(got, G[key + "k"], rtol=1e-9, atol_scale=1e-13, msg=key)
 
 
 @pytest.mark.parametrize("d", [1, 2, 3])
@@ -313,7 +341,7 @@ def test_g10_matern_general_nu_pairs(g, golden, oracle, d):
         assert keep.sum() > 280
         assert_close_nan(k(Xi, Xj, ni, nj)[keep], oracle.kpairs("matern", p, Xi, Xj, ni, nj)[keep], rtol=1e-9,
                          atol_scale=1e-12, msg="nu %g, orders <= 8" % nu)
-    ni[0, 0] += 9
+    ni[0, 0] += 17
     with pytest.raises(ValueError):          # beyond what the device builder carries
         k(Xi, Xj, ni, nj)
     with pytest.raises(NotImplementedError):  # ref: core.py:723-726

@@ -51,6 +51,21 @@ def test_g1_pairs_m52_bit_exact_and_ref(oracle, golden, d):
         assert np.array_equal(p[0] ** 2 * oracle.ref_matern52(Xi, Xj, ni, nj, p[1:] ** 2), want)
 
 
+def test_g11_high_derivative_orders(oracle, golden):
+    """Combined derivative orders 9 .. 12 of a pair against the reference's own outputs (golden g11; core.py:752-816 walks every
+    set partition of the derivative multiset): the restatement's regrouped sums agree for the rational-quadratic kernel; for the
+    general-order Matern kernel the reference's Bell-polynomial sums of kvp lose digits with the order, the closed form does not."""
+    g = golden("g11_high_orders")
+    for d in (2, 3):
+        key = "rq_d%d_" % d
+        got = oracle.kpairs("rq", g[key + "params"], g[key + "Xi"], g[key + "Xj"], g[key + "ni"], g[key + "nj"])
+        assert (g[key + "ni"].sum(1) + g[key + "nj"].sum(1)).min() >= 9
+        assert_close(got, g[key + "k"], rtol=1e-9, atol_scale=1e-14, msg=key)
+    key = "matern_d2_"
+    got = oracle.kpairs("matern", g[key + "params"], g[key + "Xi"], g[key + "Xj"], g[key + "ni"], g[key + "nj"])
+    assert_close(got, g[key + "k"], rtol=1e-4, msg=key)
+
+
 @pytest.mark.parametrize("d", [1, 2, 3, 4])
 def test_g8_rational_quadratic_pairs(oracle, golden, d):
     """RationalQuadraticKernel (ref kernel/rational_quadratic.py:30-164 via ChainRuleKernel, core.py:691-816): derivative
