@@ -86,6 +86,8 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
  *   "panel_prio"   wave priority (0..3) of the panel stream's GEMM main loops (2); "gemm_prio" >= 0 forces one priority
  *                  for every GEMM of the context (the panel-side context of gptools_amd/dist.py)
  *   "fuse_trsm"    panels with at most this many rows under a leaf use the fused diagonal-block + TRSM kernel (8192)
+ *   "fuse_rows64"  fused leaves with at most this many rows under them run 64-row consumer workgroups, one substitution
+ *                  strip per SIMD (2048 = what fits the CUs reserved for the panel stream; 0 = always 128-row workgroups)
  *   "merge_urgent" 1 (default, with edge_flags): the two trailing updates per panel are one launch with a partial edge flag
  *   "edge_flags"   1 (default): the per-panel dependencies of the look-ahead are flag words in device memory (last workgroup
  *                  of the producer raises it; a bounded in-kernel wait or a one-wave wait kernel on the consumer side)
@@ -104,7 +106,10 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
  *   "edge_test_stall" 1 (test aid): the next evaluation's first flag is withheld once, so that the bounded wait, the repeat on
  *                  event edges and the switch of the process to event edges can be tested
  *   measured and off by default: "ramp", "inner", "inner_rows", "leaf256", "defer_rows", "late_rows",
- *   "early_rows", "nb_early", "nb_switch_rows", "late_pad", "late_pad_rows"
+ *   "early_rows", "nb_early", "nb_switch_rows", "late_pad", "late_pad_rows"; round 5 (NOTES_r05.md; both bit-identical to the
+ *   default schedule and slower): "fuse_upd" / "fuse_upd_rows" (the leaf's rank-128 update of the next 128 / 256 columns inside
+ *   the leaf's launch, potf2_trsm_upd_kernel), "pair_rows" (panels in pairs: one rank-2w trailing update per pair, the near
+ *   update on a second main stream)
  * Environment: GPT_RESERVE_CUS (CUs the main stream leaves to the panel stream, default 32), GPT_TILE_ORDER
  * ("rows,cols,mode": supertile shape and deal of the GEMM's XCD-aware tile order, default 64,8,1), GPT_GRAD_TIMING,
  * GPT_EDGE_FLAGS=0 (event edges only: set it for jobs that share one GPU between several processes), GPT_GEMM_SMALL (64x64-tile count under which a GEMM launch uses 32x32 tiles, 512),
