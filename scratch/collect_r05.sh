@@ -20,7 +20,7 @@ timeout 300 python -m pytest tests/test_gpu_a_dist_processes.py -x -q -s -k "xcd
 timeout 200 python scratch/predict_bench.py c3 64 256 1024 > $O/predict.txt 2>&1
 timeout 300 python scratch/c5_map_grad.py 16384 > $O/c5_map_gradient.txt 2>&1
 ROUND_TAG=r05/prof timeout 2400 bash scratch/prof_all.sh > $O/prof_all.log 2>&1
-python scratch/pmc_summary.py $O/prof $O/rocprof_summary.txt $O/gemm_traffic.json 4 > $O/pmc_summary.log 2>&1
+python scratch/pmc_summary.py $O/prof $O/rocprof_summary.txt $O/gemm_traffic.json 5 > $O/pmc_summary.log 2>&1
 rm -rf $O/prof/*/t_*trace.csv $O/prof/*/t_counter_collection.csv
 if [ -x scratch/r05_upd_stamps ]; then (timeout 60 scratch/r05_upd_stamps 4096 128; timeout 60 scratch/r05_upd_stamps 4096 256) > $O/upd_stamps.txt 2>&1; fi
 timeout 300 python scratch/r05_upd_ab.py time > $O/upd_ab.txt 2>&1
