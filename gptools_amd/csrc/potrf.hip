@@ -1296,26 +1296,27 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// potf2_trsm_upd_kernel (round 5): the diagonal block, the TRSM of the rows below it AND the leaf's rank-128 update of the
-// next 128 / 256 columns in ONE launch -- the separate update launch (a kernel boundary, ~5 us of dispatch, and an 8-28 us
-// GEMM on the chain of every leaf) disappears for those columns.
+// potf2_trsm_upd_kernel (round 5, option "fuse_upd", OFF by default): the diagonal block, the TRSM of the rows below it AND the
+// leaf's rank-128 update of the next 128 / 256 columns in ONE launch -- the separate update launch on the chain of every leaf
+// (7-15 us) disappears for those columns.  Built because VERDICT r4 asked for it; bit-identical to the separate launch; measured
+// SLOWER (N = 4096: 1.16 -> 1.62 ms): behind the chain's last pivot block the update is a chain of memory hand-overs between CUs
+// (write-through store acknowledged after 2.6 us, count, poll, staging load 1.5 us, then the MFMAs) that costs 8-10 us where the
+// separate GEMM costs 7-8 (NOTES_r05.md section 1, profiles/r05_upd_stamps.txt).
 //   Workgroup 0: potf2_body_la / potf2_body, unchanged (publishes the packed workspace block by block).
-//   Workgroups 1..: 64 rows each.  Waves 0..3 ("strip waves", one per SIMD: on gfx950 a SIMD's fp64 MFMAs are 64 cycles
-//     each, and a strip's 144 + 32 UT of them set the leaf's time) own 16 rows each as in potf2_trsm_kernel and keep the first
-//     TS tiles of those rows of the columns [r1, r1 + 16 UT) (r1 = the first row below the diagonal block) in accumulators,
-//     started from C itself; waves 4..7 ("helpers", wave w + 4 on the SIMD of wave w) keep the other UT - TS tiles of the same
-//     rows (A operand out of the strip wave's scratch).  The B operand of that update is X1 = the solved rows
-//     [r1, r1 + 16 UT) -- other workgroups' results.  Their owners ("producers") write x_j through to memory as they always
-//     did, drain, and count themselves in a per-context word (flag[32]); ONE step later every workgroup stages the
-//     16 UT x 16 block of x_j into its LDS with a coalesced agent-scope load (all 512 threads, latency under the step's own
-//     solve) and the waves read their B operands from there: the exchange is 16-32 KB per workgroup and step, once -- the
-//     first version of this kernel (round 4) read the operands straight from memory, 32 scattered loads per lane and step,
-//     and took 104 us per leaf.
+//   Workgroups 1..: 64 rows each.  Waves 0..3 ("strip waves", one per SIMD) run the substitution of potf2_trsm_kernel
+//     (strip_substitution) and also leave every x_j in LDS (the strip's "history"); waves 4..7 ("helpers", wave w + 4 on the
+//     SIMD of wave w) keep ALL UT tiles of the strip's rows of the columns [r1, r1 + 16 UT) (r1 = the first row below the
+//     diagonal block) in accumulators, started from C itself.  The B operand of that update is X1 = the solved rows
+//     [r1, r1 + 16 UT) -- other workgroups' results: their owners ("producers") write x_j through to memory as they always did,
+//     drain, and count themselves in a per-step word (flag[32 + j]); the four helper waves of every workgroup stage the
+//     16 UT x 16 block of x_s into LDS (two buffers, a quarter each, one block ahead of the update when it has arrived) and take
+//     4 UT MFMAs per wave against it.  No workgroup barrier after the prologue: strip -> helper and helper <-> helper hand-overs
+//     are counters in LDS (the potf2_body_la style), so the substitution is never held up by the exchange.
+//     (First build, round 4: operands straight from memory, 104 us per leaf.  Round 5 (a): lock-step exchange, three memory round
+//     trips per step; (b): lagged exchange behind two workgroup barriers per step, solve and update alternating; this is (c).)
 // Same sums in the same order as the separate launch (gemm.hip: accumulator from C, MFMA 2t+u of a 16-wide k-tile contracts
 // k = 8t + 2 (lane >> 4) + u, sign by negating one operand): the factor is bit-identical to the unfused schedule's.
-// Tiles above the diagonal (column tile > row tile of the strip) are neither read nor written.
-// Strip and helper waves run different code with the SAME sequence of workgroup barriers (two per step: "x_{j-1} staged
-// loads may start" and "x_{j-1} is in LDS / x_j is in the strip's scratch").
+// Tiles above the diagonal (column tile > row tile of the strip) are computed like the others and never stored.
 // ------------------------------------------------------------------------------------------------
 #define PU_XS_PITCH 18
 #define PU_HIST (8 * 16 * TP_SP)                         // doubles of one strip's history: x_0 .. x_7, 16 x 16 each at pitch TP_SP
