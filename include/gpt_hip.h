@@ -95,6 +95,12 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
  *                  process (idle contexts do not count; see gpt_concurrency_hint) on a context that owns its streams; off by
  *                  itself under rocprofv3 counter collection, for n > 12288, and for the rest of the process once a wait has
  *                  timed out (250 ms: the evaluation is then repeated on events)
+ *   "head_wait_wgs" the first leaf of a factorisation waits for the K build's head columns inside its own kernel while its launch has
+ *                  at most this many workgroups (33 = what fits the reserved CUs), else a one-wave wait kernel in front of it
+ *   "merge_min_tiles" smallest merged trailing update, in 64x64 tiles (512: the launch needs an order table)
+ *   "purg_rows_flags" "purg_rows" while flag edges and merged launches are in use (0: never -- measured)
+ *   "tail_wait"    1: the main stream's last launch of a panel awaits the NEXT panel's flag at its end (measured the same, 0)
+ *   "alpha_invalidate" (measurement aid) the next gpt_get_alpha recomputes alpha
  *   "helper_tf"    assumed rate of the helper stream (0.1 TFLOP/s per 24 CUs, 45) that takes a slice of the large trailing
  *                  updates on the reserved CUs when n > "helper_min_n" (12288); 0 = off
  *   "gemm_pad"     bytes of dummy dynamic LDS of the main-stream GEMM (residency cap)
