@@ -41,7 +41,7 @@ struct DevBuf {
 
 enum { SLOT_XI = 0, SLOT_XJ, SLOT_NI, SLOT_NJ, SLOT_OUT, SLOT_KST, SLOT_KSS, SLOT_XS, SLOT_NS, SLOT_VEC, SLOT_VEC2,
        SLOT_RHS, SLOT_LOW, SLOT_KFULL, SLOT_TK, SLOT_ZERO, SLOT_UINV, SLOT_WINV, SLOT_GPART, SLOT_BINV, SLOT_BTMP,
-       SLOT_BINV2, SLOT_BINV3, SLOT_BINV3U, SLOT_BINVU, SLOT_BATCH_A, SLOT_BATCH_WS, SLOT_BATCH_MISC, SLOT_COUNT };
+       SLOT_BINV2, SLOT_BINV3, SLOT_BINV3U, SLOT_BINVU, SLOT_BATCH_A, SLOT_BATCH_WS, SLOT_BATCH_MISC, SLOT_SPLITK, SLOT_COUNT };
 
 struct gpt_ctx {
     int device = 0;
@@ -99,6 +99,7 @@ struct gpt_ctx {
     int64_t fuse_upd_rows = 4096;      //    128 / 256 columns inside the leaf's launch (potf2_trsm_upd_kernel); measured slower than
                                        //    the separate update launch (profiles/r05_upd_ab.txt): off
     hipStream_t near_stream = nullptr;     // second main stream (same CU mask), created on first use: the rank-w "near" updates of paired panels
+    int64_t splitk = 512;                  // few-rows solves: GEMMs with k >= 1024 of fewer 32x32 tiles than this are split along k until they reach it (0: never)
     int64_t pair_rows = 0;                 // > 0: while more rows than this remain, panels are taken in PAIRS -- after the first one only the next
                                            // panel's columns are updated (rank w, near_stream), after the second everything to the right in ONE
                                            // rank-2w launch (potrf_enqueue "panel pairs")
@@ -1407,6 +1408,7 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "fuse_trsm")) c->fuse_trsm = value;
     else if (!strcmp(key, "fuse_rows64")) c->fuse_rows64 = value;
     else if (!strcmp(key, "pair_rows")) c->pair_rows = value;
+    else if (!strcmp(key, "splitk")) c->splitk = value;
     else if (!strcmp(key, "fuse_upd")) c->fuse_upd = value;
     else if (!strcmp(key, "fuse_upd_rows")) c->fuse_upd_rows = value;
     else if (!strcmp(key, "leaf256")) c->leaf256 = value ? 1 : 0;
@@ -2800,6 +2802,59 @@ static int trsm_rlt_binv(gpt_ctx *c, hipStream_t st, int64_t m, int64_t nb, int6
 }
 
 // V (m x n128, ldv) <- B L^-T for the resident factor (n128 = N rounded up to 128); B (m x n128, ldb) is consumed.
+// C = beta * C + P_0 + P_1 + ... + P_{S-1} (each m x n, row stride n, `pstride` doubles apart), summed in that order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(int64_t m, int64_t n2, int S, const double2 *__restrict__ P, int64_t pstride2,
+                                                            double beta, double *__restrict__ C, int64_t ldc)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m * n2) return;
+    const int64_t r = i / n2, q = i - r * n2;
+    double2 *cp = reinterpret_cast<double2 *>(C + r * ldc) + q;
+    double2 acc = make_double2(0.0, 0.0);
+    if (beta != 0.0) {
+        acc = *cp;
+        acc.x *= beta;
+        acc.y *= beta;
+    }
+    for (int s = 0; s < S; ++s) {
+        const double2 p = P[(int64_t)s * pstride2 + i];
+        acc.x += p.x;
+        acc.y += p.y;
+    }
+    *cp = acc;
+}
+
+// A GEMM of a few-rows solve: m <= 256 rows against k in the thousands is a handful of 32x32 tiles (128 at m = 64, n = 2048: half the
+// chip idle) each walking a long k loop at ~0.3 us per 16-wide k-tile -- 37 us for 0.5 GFLOP.  Split along k instead: S chunks as the
+// batch dimension of ONE launch (chunk s reads columns [s k/S, (s+1) k/S) of A and B and writes alpha * A_s B_s^T to its own m x n slab),
+// then one pass adds the slabs to C in chunk order -- a fixed summation order, so results repeat bit for bit run to run (they differ in
+// rounding from the unsplit sum; option `splitk` 0 restores that).  Measured (scratch/r05_splitk_ab.py, N = 8192, predict with std):
+// 16 / 64 / 128 points 0.352 / 0.352 / 0.467 -> 0.281 / 0.280 / 0.424 ms; the leaf GEMM 37 -> 22 us + 4.8 us for the sum.  A split
+// launch is bound by the 32x32 kernel's throughput with four workgroups per CU (~25 TFLOP/s), no longer by one workgroup's k loop.
+// Not for k = 512 (the blocks of solves with 129..256 rows): one launch is 11 us there against 7.6 + 4.8 split in two.
+// `tri`: the caller needs the lower triangle of C only (the predictive covariance: k = N against at most 256 x 256 outputs -- a
+// dozen tiles walking 512 k-tiles each, 150 us at N = 8192); a split launch computes all of C, an unsplit one the lower tiles.
+static int gemm_nt_few(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A, int64_t lda,
+                       const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri = 0)
+{
+    const int64_t tiles = ((m + 31) / 32) * ((n + 31) / 32);
+    int64_t S = 1;
+    if (c->splitk && !c->use_graph && c->tile == 0 && k >= 1024 && (n % 2) == 0 && (ldc % 2) == 0)
+        while (S < 32 && tiles * S < c->splitk && (k / (2 * S)) >= 256 && (k % (2 * S * 16)) == 0) S *= 2;
+    if (S == 1) return gemm_nt(c, st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri);
+    double *P;
+    const int64_t pstride = ((m + 31) / 32) * 32 * n;
+    GPT_TRY(ensure(c, SLOT_SPLITK, (size_t)S * pstride * sizeof(double), (void **)&P));
+    const int64_t kc = k / S;
+    GPT_TRY(launch_gemm_nt(st, m, n, kc, alpha, A, lda, B, ldb, 0.0, P, n, 0, 0, 0, nullptr, nullptr, 0, EdgeSig(), EdgeSig(), 0, S, kc,
+                           EdgeSig(), kc, pstride));
+    const int64_t n2 = n / 2, tot = m * n2;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m, n2, (int)S,
+                       reinterpret_cast<const double2 *>(P), pstride / 2, beta, C, ldc);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
 static int solve_rows_resident(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n128, double *B, int64_t ldb, double *V, int64_t ldv)
 {
     const int64_t nfull = (n128 / GPT_BINV_NB) * GPT_BINV_NB;
@@ -2829,10 +2884,10 @@ static int solve_rows_resident(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n1
         while (j < nfull) {
             const int64_t nb = (j + GPT_BINV_NB3 <= n3) ? GPT_BINV_NB3 : (j + GPT_BINV_NB2 <= n2) ? GPT_BINV_NB2 : GPT_BINV_NB;
             const double *Wj = (nb == GPT_BINV_NB3) ? W3 + j * nb : (nb == GPT_BINV_NB2) ? W2 + j * nb : W + j * nb;
-            GPT_TRY(gemm_nt(c, st, m, nb, nb, 1.0, B + j, ldb, Wj, nb, 0.0, V + j, ldv, 0));
+            GPT_TRY(gemm_nt_few(c, st, m, nb, nb, 1.0, B + j, ldb, Wj, nb, 0.0, V + j, ldv));
             const int64_t r0 = j + nb;
             if (r0 < n128)
-                GPT_TRY(gemm_nt(c, st, m, n128 - r0, nb, -1.0, V + j, ldv, c->dA + r0 * c->NP + j, c->NP, 1.0, B + r0, ldb, 0));
+                GPT_TRY(gemm_nt_few(c, st, m, n128 - r0, nb, -1.0, V + j, ldv, c->dA + r0 * c->NP + j, c->NP, 1.0, B + r0, ldb));
             j = r0;
         }
     } else {
@@ -3081,7 +3136,10 @@ extern "C" int gpt_predict(gpt_ctx *c, const double *Xstar, const int32_t *nstar
         }
         for (int64_t q = 0; q < nblk; q++) {
             const int64_t c0 = q * CB, w = (MP - c0 < CB) ? MP - c0 : CB;
-            GPT_TRY(gemm_nt(c, st, MP - c0, w, n128, -1.0, dV + c0 * n128, n128, dV + c0 * n128, n128, 1.0, dcov + c0 * LDC + c0, LDC, 1));
+            if (MP <= 256)
+                GPT_TRY(gemm_nt_few(c, st, MP, MP, n128, -1.0, dV, n128, dV, n128, 1.0, dcov, LDC, 1));
+            else
+                GPT_TRY(gemm_nt(c, st, MP - c0, w, n128, -1.0, dV + c0 * n128, n128, dV + c0 * n128, n128, 1.0, dcov + c0 * LDC + c0, LDC, 1));
             if (!cov_out) continue;
             GPT_TRY(launch_mirror_rows(st, dcov, LDC, c0, w, MP));
             hipEvent_t e = get_event(c, 100 + (size_t)q);

@@ -101,6 +101,10 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
  *   "purg_rows_flags" "purg_rows" while flag edges and merged launches are in use (0: never -- measured)
  *   "tail_wait"    1: the main stream's last launch of a panel awaits the NEXT panel's flag at its end (measured the same, 0)
  *   "alpha_invalidate" (measurement aid) the next gpt_get_alpha recomputes alpha
+ *   "splitk"       gpt_predict with std / cov at few points: the GEMMs of a triangular solve with at most 128 right-hand sides
+ *                  and the V V^T of a covariance of at most 256 points, when k >= 1024 and they have fewer 32x32 tiles than this
+ *                  (512), are split along k into up to 32 chunks of at least 256, summed in chunk order by a second kernel --
+ *                  repeatable bit for bit, rounding differs from the unsplit sum; 0 = never split
  *   "helper_tf"    assumed rate of the helper stream (0.1 TFLOP/s per 24 CUs, 45) that takes a slice of the large trailing
  *                  updates on the reserved CUs when n > "helper_min_n" (12288); 0 = off
  *   "gemm_pad"     bytes of dummy dynamic LDS of the main-stream GEMM (residency cap)
