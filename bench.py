@@ -545,6 +545,8 @@ def main():
             a_gpu_ = np.array(gp_.alpha).ravel()
             # alpha alone, device side, on the resident factor: block inverses cached (what predict / gp.alpha pay after a
             # fit) and rebuilt (what every eager evaluation pays)
+            ctx.set_option("eager_alpha", 0)
+
             def alpha_ms(rebuild):
                 ts = []
                 for _ in range(5):
@@ -562,8 +564,10 @@ def main():
                                    "alpha_extra_ms": (ta_ - tg_) * 1e3,
                                    "alpha_alone_ms": alpha_ms(True), "alpha_alone_cached_inverses_ms": alpha_ms(False),
                                    "alpha_max_abs_diff_vs_lazy": float(np.abs(a_gpu_ - ctx.get_alpha(N)).max()),
-                                   "note": "alpha = L^-T z in 2 N / 512 steps against the batched 512-wide block inverses, incl. "
-                                           "building them (15 launches) and the N doubles over PCIe"}
+                                   "note": "alpha = L^-T z in 2 N / 512 steps against the 512-wide block inverses (one launch, trinv512_kernel), "
+                                           "enqueued by the fit itself behind the factorisation (context option eager_alpha), the N doubles "
+                                           "landing in pinned memory under the fit's own sync; alpha_alone_*: a separate gpt_get_alpha call "
+                                           "after a plain fit"}
             gp_._ctx_obj = gp_._ctx_pool = None
             del gp_
             ctx.set_option("timing", 1)

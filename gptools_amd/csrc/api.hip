@@ -99,6 +99,7 @@ struct gpt_ctx {
     int64_t fuse_upd_rows = 4096;      //    128 / 256 columns inside the leaf's launch (potf2_trsm_upd_kernel); measured slower than
                                        //    the separate update launch (profiles/r05_upd_ab.txt): off
     hipStream_t near_stream = nullptr;     // second main stream (same CU mask), created on first use: the rank-w "near" updates of paired panels
+    int64_t binv_launches = 0;             // 1: the 512-wide block inverses by the recursion over 15 launches of rounds 2-4 instead of trinv512_kernel
     int64_t splitk = 512;                  // few-rows solves: GEMMs with k >= 1024 of fewer 32x32 tiles than this are split along k until they reach it (0: never)
     int64_t pair_rows = 0;                 // > 0: while more rows than this remain, panels are taken in PAIRS -- after the first one only the next
                                            // panel's columns are updated (rank w, near_stream), after the second everything to the right in ONE
@@ -128,11 +129,14 @@ struct gpt_ctx {
     double *d_y = nullptr, *d_erry = nullptr, *d_scal = nullptr, *d_alpha = nullptr;
     double *h_scal = nullptr;  // pinned
     double *h_yerr = nullptr;  // pinned staging for y | err_y (a pageable source would make the upload synchronous)
+    double *h_alpha = nullptr; // pinned landing place of alpha (a pageable destination costs a staged, synchronous copy: ~70 us for 64 KB)
+    bool h_alpha_valid = false;
     int32_t *h_info = nullptr; // pinned
     bool factored = false, alpha_valid = false, have_kernel = false;
     bool binv_valid = false;           // SLOT_BINV holds the inverses of the 512x512 diagonal blocks of the resident factor
     bool binv2_valid = false;          // SLOT_BINV2 those of its 1024x1024 diagonal blocks (solves with very few rows)
     bool binv3_valid = false;          // SLOT_BINV3 those of its 2048x2048 diagonal blocks (the same, large factors)
+    int64_t eager_alpha = 0;           // 1: every evaluation also enqueues alpha = L^-T z behind the factorisation (no second host round trip)
     // (all three are always built for the whole padded order, floor(NP / width) blocks, whatever extent the caller needs:
     // gpt_ll_grad and the solves ask for different extents at N = 512 k - 128, and a valid flag says nothing about how far)
     unsigned alpha_counter = 0;        // value of the step counter of the wide back-substitution (d_edge[40], only ever raised)
@@ -1326,10 +1330,13 @@ static void free_factor(gpt_ctx *c)
     if (c->d_y) hipFree(c->d_y);
     if (c->h_yerr) hipHostFree(c->h_yerr);
     c->h_yerr = nullptr;
+    if (c->h_alpha) hipHostFree(c->h_alpha);
+    c->h_alpha = nullptr;
+    c->h_alpha_valid = false;
     if (c->d_alpha) hipFree(c->d_alpha);
     c->dA = c->d_invd = c->d_y = c->d_erry = c->d_alpha = nullptr;
     c->NP = 0;
-    c->factored = c->alpha_valid = c->binv_valid = c->binv2_valid = c->binv3_valid = false;
+    c->factored = c->h_alpha_valid = c->alpha_valid = c->binv_valid = c->binv2_valid = c->binv3_valid = false;
 }
 
 extern "C" int gpt_ctx_destroy(gpt_ctx *c)
@@ -1409,11 +1416,13 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "fuse_rows64")) c->fuse_rows64 = value;
     else if (!strcmp(key, "pair_rows")) c->pair_rows = value;
     else if (!strcmp(key, "splitk")) c->splitk = value;
+    else if (!strcmp(key, "eager_alpha")) c->eager_alpha = value;
+    else if (!strcmp(key, "binv_launches")) { c->binv_launches = value; c->binv_valid = c->binv2_valid = c->binv3_valid = false; c->h_alpha_valid = c->alpha_valid = false; }
     else if (!strcmp(key, "fuse_upd")) c->fuse_upd = value;
     else if (!strcmp(key, "fuse_upd_rows")) c->fuse_upd_rows = value;
     else if (!strcmp(key, "leaf256")) c->leaf256 = value ? 1 : 0;
     else if (!strcmp(key, "debug_poison")) c->debug_poison = value;
-    else if (!strcmp(key, "alpha_invalidate")) c->alpha_valid = false;          // (measurement aid: the next gpt_get_alpha recomputes)
+    else if (!strcmp(key, "alpha_invalidate")) c->h_alpha_valid = c->alpha_valid = false;          // (measurement aid: the next gpt_get_alpha recomputes)
     else if (!strcmp(key, "edge_test_stall")) c->edge_test_stall = value;
     else if (!strcmp(key, "tile")) {
         if (value != 0 && value != 32 && value != 64 && value != 65 && value != 128 && value != 129) {
@@ -1638,7 +1647,7 @@ extern "C" int gpt_set_data(gpt_ctx *c, const double *X, const int32_t *n, int64
         if (sn > c->n_maxsum) c->n_maxsum = sn;
     }
     c->factored = false;
-    c->alpha_valid = c->binv_valid = c->binv2_valid = c->binv3_valid = false;
+    c->h_alpha_valid = c->alpha_valid = c->binv_valid = c->binv2_valid = c->binv3_valid = false;
     c->have_kernel = false;
     if (c->dT) hipFree(c->dT);          // a transform belongs to one data set
     c->dT = nullptr;
@@ -1661,7 +1670,7 @@ extern "C" int gpt_set_T(gpt_ctx *c, const double *T, int64_t Ny)
     c->dT = nullptr;
     c->Ny = 0;
     c->factored = false;
-    c->alpha_valid = c->binv_valid = c->binv2_valid = c->binv3_valid = false;
+    c->h_alpha_valid = c->alpha_valid = c->binv_valid = c->binv2_valid = c->binv3_valid = false;
     c->have_kernel = false;
     if (!T || Ny <= 0) return GPT_OK;
     const int64_t NyP = round_up(Ny, 64), NxP = round_up(c->Nx, 16);
@@ -1686,6 +1695,7 @@ static int ensure_factor_storage(gpt_ctx *c, int64_t N)
     GPT_HIP_CHECK(hipMalloc(&c->d_y, (size_t)2 * NP * sizeof(double)));          // y | err_y, one upload per evaluation
     c->d_erry = c->d_y + NP;
     GPT_HIP_CHECK(hipHostMalloc((void **)&c->h_yerr, (size_t)2 * NP * sizeof(double), hipHostMallocDefault));
+    GPT_HIP_CHECK(hipHostMalloc((void **)&c->h_alpha, (size_t)NP * sizeof(double), hipHostMallocDefault));
     GPT_HIP_CHECK(hipMalloc(&c->d_alpha, (size_t)2 * NP * sizeof(double)));      // alpha | work vector of its substitution
     c->NP = NP;
     return GPT_OK;
@@ -1693,6 +1703,7 @@ static int ensure_factor_storage(gpt_ctx *c, int64_t N)
 
 // Factor the (already assembled, lower) N x N matrix in dA, with y in d_y; produce ll terms.
 static int harvest_gemm_profile(gpt_ctx *c);
+static int alpha_to_host(gpt_ctx *c);
 
 static int factor_and_ll(gpt_ctx *c, int64_t N, double *ll_data_out, double *logdet_half_out, bool padded = false)
 {
@@ -1718,13 +1729,17 @@ static int factor_and_ll(gpt_ctx *c, int64_t N, double *ll_data_out, double *log
     // (only a STOP event: a start event on the packet holds the kernel back ~7 us like a barrier packet would)
     GPT_TRY(launch_logdet_dot(tl, c->dA, NP, N, c->d_info, c->d_scal, c->h_scal, nullptr, c->timing ? c->tev[4] : nullptr,
                               c->flags_now ? c->d_edge + 60 : nullptr));
+    c->h_alpha_valid = c->alpha_valid = c->binv_valid = c->binv2_valid = c->binv3_valid = false;
     if (tl != st) {
         hipEvent_t e_end = get_event(c, 1);
         if (!e_end) return GPT_E_HIP;
         GPT_HIP_CHECK(hipEventRecord(e_end, tl));
         GPT_HIP_CHECK(hipStreamWaitEvent(st, e_end, 0));
-        GPT_HIP_CHECK(hipStreamSynchronize(tl));
     }
+    // option eager_alpha (the reference computes alpha in every evaluation, gaussian_process.py:1462): the block inverses and the
+    // substitution go behind the factorisation at once -- no host round trip between the two, and gpt_get_alpha is a copy
+    if (c->eager_alpha) GPT_TRY(alpha_to_host(c));          // (on a failed factorisation: finite work on garbage, flags reset below)
+    if (tl != st) GPT_HIP_CHECK(hipStreamSynchronize(tl));
     GPT_HIP_CHECK(hipStreamSynchronize(st));
     if (c->gprof_used) GPT_TRY(harvest_gemm_profile(c));
     if (c->timing) {
@@ -1739,8 +1754,8 @@ static int factor_and_ll(gpt_ctx *c, int64_t N, double *ll_data_out, double *log
         hipEventElapsedTime(&ms, c->tev[0], c->tev[4]);
         c->timings[4] = ms;
     }
-    c->alpha_valid = c->binv_valid = c->binv2_valid = c->binv3_valid = false;
     if (c->flags_now && c->h_scal[3] != 0.0) {
+        c->h_alpha_valid = c->alpha_valid = c->binv_valid = c->binv2_valid = c->binv3_valid = false;
         // a flag wait of this evaluation timed out (common.hpp): its numbers mean nothing; the caller repeats it on events
         c->factored = false;
         return GPT_I_EDGE_TIMEOUT;
@@ -1748,6 +1763,7 @@ static int factor_and_ll(gpt_ctx *c, int64_t N, double *ll_data_out, double *log
     const int32_t info = (int32_t)c->h_scal[2];
     if (info != 0) {
         c->factored = false;
+        c->h_alpha_valid = c->alpha_valid = c->binv_valid = c->binv2_valid = c->binv3_valid = false;
         if (info > N) {          // only the augmented / padding pivots failed: z.z overflowed
             gpt_set_error("factorisation failed in the augmented row (non-finite data?)");
             return (int)N;
@@ -2295,10 +2311,13 @@ extern "C" int gpt_get_L(gpt_ctx *c, double *L_out)
 
 // alpha = L^-T z with z = the augmented row (z = L^-1 y)   (ref: gaussian_process.py:1462, the second half of cho_solve)
 // In 512-wide steps against the inverse transposes of the factor's 512 x 512 diagonal blocks (solve.hip launch_trsv_lt_wide;
-// the blocks' inverses are the ones predict and the gradient use, built once per factorisation by a dozen batched launches):
-// 2 N / 512 dependent launches instead of 2 N / 128 -- N = 8192: ~1.0 -> ~0.3 ms including the inverses, ~0.2 ms with them
-// cached.  What is left of the order beyond the last whole 512-block falls in 128-wide steps first (last rows first).
-// GPT_ALPHA_NARROW=1 (measurement aid): the 128-wide form throughout.
+// the blocks' inverses are the ones predict and the gradient use, built once per factorisation -- by ONE launch since round 5,
+// trinv512_kernel): 2 N / 512 dependent launches instead of 2 N / 128.  N = 8192: 128-wide 1.0 ms; 512-wide with the inverses
+// from 15 batched launches (rounds 2-4) 0.43 ms; now 0.34 ms, 0.24 of them the 31 launches of the substitution.  What is left of
+// the order beyond the last whole 512-block falls in 128-wide steps first (last rows first).
+// (Round 5 also built 1024-wide steps -- the off-diagonal quadrant of a 1024-block's inverse transpose, U12 = -(U11 L21^T) U22,
+// from two batched GEMMs: 15 launches instead of 31 save 95 us, the two GEMMs are 2 x 2.1 GFLOP = 119 us.  Removed.)
+// GPT_ALPHA_NARROW=1 (measurement aid): the 128-wide form throughout.  Option binv_launches = 1: the inverses by rounds 2-4's launches.
 static int ensure_block_inverses(gpt_ctx *c, int64_t nb, int64_t nfull, double **out, double **out_u = nullptr);
 static int ensure_alpha(gpt_ctx *c)
 {
@@ -2321,8 +2340,18 @@ static int ensure_alpha(gpt_ctx *c)
         GPT_TRY(launch_trsv_lt(st, n128, c->dA, NP, c->d_invd, w, nwide / 128));
         GPT_HIP_CHECK(hipMemcpyAsync(c->d_alpha + nwide, w + nwide, (size_t)(n128 - nwide) * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
-    GPT_TRY(launch_trsv_lt_wide(st, nwide, c->dA, NP, U, w, c->d_alpha, c->d_edge + 40, &c->alpha_counter));
+    GPT_TRY(launch_trsv_lt_wide(st, nwide, c->dA, NP, U, w, c->d_alpha));
     c->alpha_valid = true;
+    return GPT_OK;
+}
+
+// alpha to the pinned landing buffer, behind whatever computes it on the main stream (valid for the host after the stream's next sync)
+static int alpha_to_host(gpt_ctx *c)
+{
+    GPT_TRY(ensure_alpha(c));
+    if (c->h_alpha_valid) return GPT_OK;
+    GPT_HIP_CHECK(hipMemcpyAsync(c->h_alpha, c->d_alpha, (size_t)c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    c->h_alpha_valid = true;
     return GPT_OK;
 }
 
@@ -2331,9 +2360,12 @@ extern "C" int gpt_get_alpha(gpt_ctx *c, double *alpha_out)
     CTX_ENTER(c);
     NEED_FACTOR(c);
     if (!alpha_out) return GPT_E_ARG;
-    GPT_TRY(ensure_alpha(c));
-    GPT_HIP_CHECK(hipMemcpyAsync(alpha_out, c->d_alpha, (size_t)c->N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    GPT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    const bool landed = c->alpha_valid && c->h_alpha_valid;      // (an eager evaluation: the fit's own sync covered the copy)
+    if (!landed) {
+        GPT_TRY(alpha_to_host(c));
+        GPT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    memcpy(alpha_out, c->h_alpha, (size_t)c->N * sizeof(double));
     return GPT_OK;
 }
 
@@ -2738,7 +2770,8 @@ static int ensure_block_inverses(gpt_ctx *c, int64_t nb, int64_t nfull, double *
     if (valid) return GPT_OK;
     hipStream_t st = c->stream;
     if (!big) {
-        GPT_TRY(build_block_inverses_512(c, st, nall / nb, Us, W));
+        if (c->binv_launches) GPT_TRY(build_block_inverses_512(c, st, nall / nb, Us, W));
+        else GPT_TRY(launch_trinv512(st, nall / nb, c->dA, c->NP, c->d_invd, Us, W));      // one launch (solve.hip)
         valid = true;
         return GPT_OK;
     }

@@ -5,6 +5,7 @@
 // ref: gptools/gaussian_process.py:1462-1467 (alpha, ll), :971 (mean = Kstar^T alpha),
 //      :987,1006 (cov diagonal / std).
 #include "common.hpp"
+#include <type_traits>
 #define GPT_TRY_RC_SOLVE(expr) do { int rc_ = (expr); if (rc_ != GPT_OK) return rc_; } while (0)
 
 // Rows [n_valid, n_pad) of the padded matrix: zero, unit diagonal.  If dy != NULL row n_valid
@@ -469,51 +470,192 @@ int launch_trsv_lt(hipStream_t st, int64_t n, const double *L, int64_t ldl, cons
     return GPT_OK;
 }
 
+// ---- inverses of the 512 x 512 diagonal blocks of the factor, all of them in ONE launch ------------------------------------------
+// Rounds 2-4 built them by recursion over launches (identity through the panel TRSM, 128 -> 256 -> 512 by batched GEMMs and TRSMs,
+// one transpose: 15 dependent launches, 205 us at N = 8192 whatever the block count -- half of what alpha costs after a
+// factorisation).  Here a workgroup owns 16 ROWS of one block's X = L_bb^-1 (strip s = rows [16 s, 16 s + 16), non-zero in columns
+// [0, 16 s + 16)) and solves X L_bb = I for them from the diagonal leftwards, right-looking, in 16-column steps against the inverted
+// 16x16 diagonal blocks the factorisation left in its workspace:
+//   step k = s, s - 1, .. :  X_k = R_k D_k^-1          (the wave that owns column block k; R = the running right-hand side, I at start)
+//                            R_j -= X_k L_kj           for every column block j < k   (eight waves; wave w owns the j = w mod 8)
+// so that a step reads ONE row block of L (16 rows, contiguous bytes along each) -- a first version that owned 16 columns read a
+// 128-byte column slice of every row below k per step: 512 rows, 64 KB apart, 512 pages per step, 1.4 us per step in address
+// translation alone (75 us per launch at N = 4096).  Everything is kept TRANSPOSED in the accumulators (acc = R_j^T): with the
+// contraction index of MFMA u taken as g + 4u (g = lane / 16) the B operand of X_k^T = D_k^-T R_k^T IS the accumulator of R_k, and
+// the solver's result registers ARE the B operand (X_k^T) of the updates R_j^T -= L_kj^T X_k^T -- the other waves fetch the same 32
+// bytes per lane from a 2 KB LDS tile (two tiles, by step parity: one barrier per step).  The L fragments of step k - 2 are requested
+// when step k has consumed their registers.  The wave that owns column block k - 1 updates it first and solves it at once; its other
+// column blocks follow while the rest of the workgroup is already reading X_{k-1}.  Heavy strips (large s) are dealt first.
+// No load of the step loop sits inside a branch (with loads inside branches hipcc waits vmcnt(0) in front of each of them and of
+// every MFMA group): the loop is compiled once per number of live column blocks of a wave, the D_k^-1 come from LDS.
+// Out: W = X (lower, rows of 512), U = X^T (upper), both with their zero halves.
+#define TI_NB 512
+#define TI_XS 513                                            // row pitch of the strip in LDS (odd: conflict-free column reads)
+__global__ __launch_bounds__(512, 2) void trinv512_kernel(int nblk, const double *__restrict__ L, int64_t ldl, const double *__restrict__ invd,
+                                                          double *__restrict__ U, double *__restrict__ W)
+{
+    __shared__ double xs[16 * TI_XS];                        // the strip of X, 16 rows (columns >= 16 s + 16 never touched)
+    __shared__ double xt[2][256];                            // X_k^T in the solver's lane order: [lane][u]
+    __shared__ double dl[32 * 256];                          // D_k^-1, k <= s, as the workspace holds them
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fk = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // eight waves: wave w owns the column blocks j = w mod 8
+    const int s = 31 - (int)blockIdx.x / nblk, b = (int)blockIdx.x % nblk;
+    const double *Lb = L + (int64_t)b * TI_NB * (ldl + 1);
+    const double *wsb = invd + (int64_t)b * 4 * GPT_WS_BLOCK;
+
+    f64x4 acc[4];                                            // acc[t][q] = R_j[fr][fk + 4 q], j = 8 t + w
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+        if (8 * t + w == s) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[t][q] = (fk + 4 * q == fr) ? 1.0 : 0.0;      // R_s = I
+        }
+    }
+    f64x4 la[2][4];
+    // A operand of the update of column block j with row block k: L_kj^T, lane (fr, fk), MFMA u: L[16 k + fk + 4 u][16 j + fr].
+    // What bounds a step is the CU's rate of vector-memory requests (a 64-lane 8-byte load every ~16 cycles whatever it hits), so only
+    // the NL column blocks of this wave that are still being updated are requested: the step is compiled once per NL (below).
+    auto request = [&](f64x4 (&dst)[4], int k, auto nl) {
+        const int kc = k > 0 ? k : 0;
+#pragma unroll
+        for (int t = 0; t < decltype(nl)::value; t++) {
+            const double *p = Lb + (int64_t)(16 * kc + fk) * ldl + 16 * (8 * t + w) + fr;
+#pragma unroll
+            for (int u = 0; u < 4; u++) dst[t][u] = p[(int64_t)(4 * u) * ldl];
+        }
+    };
+    // X_k^T = D_k^-T R_k^T by the owner of column block k: x[q] = X[fr][16 k + fk + 4 q]
+    // (A operand: D_k^-T, lane (fr, fk), MFMA u: D_k^-1[fk + 4 u][fr]; workspace order: element (r, c) at 64 (c / 4) + 16 (c % 4) + r)
+    auto solve = [&](const f64x4 &r, int k) {
+        const double *dk = dl + k * 256 + 64 * (fr >> 2) + 16 * (fr & 3) + fk;
+        f64x4 x = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 4; u++) x = __builtin_amdgcn_mfma_f64_16x16x4f64(dk[4 * u], r[u], x, 0, 0, 0);
+        *reinterpret_cast<f64x4 *>(&xt[k & 1][4 * lane]) = x;
+#pragma unroll
+        for (int q = 0; q < 4; q++) xs[fr * TI_XS + 16 * k + fk + 4 * q] = x[q];
+    };
+    // the slots of this wave that are live at step k: j = 8 t + w < k
+    auto nlive = [&](int k) { const int n = (k - w + 7) >> 3; return n < 0 ? 0 : (n > 4 ? 4 : n); };
+
+    for (int e = tid; e < 256 * (s + 1); e += 512) dl[e] = wsb[(int64_t)(e >> 11) * GPT_WS_BLOCK + (e & 2047)];
+    request(la[0], s, std::integral_constant<int, 4>());
+    request(la[1], s - 1, std::integral_constant<int, 4>());
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        if (8 * t + w == s) solve(acc[t], s);
+    __syncthreads();
+    // step k: lk = the L fragments of row block k (requested two steps ago)
+    auto step = [&](f64x4 (&lk)[4], int k, auto nl) {
+        constexpr int NL = decltype(nl)::value;
+        f64x4 xb = *reinterpret_cast<const f64x4 *>(&xt[k & 1][4 * lane]);
+        xb = -xb;
+        const int tn = (k - 1) >> 3;
+        const bool next_owner = (w == ((k - 1) & 7));
+        if (next_owner) {
+#pragma unroll
+            for (int t = 0; t < NL; t++)
+                if (t == tn) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(lk[t][u], xb[u], acc[t], 0, 0, 0);
+                    solve(acc[t], k - 1);
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < NL; t++) {
+            if (!(next_owner && t == tn)) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(lk[t][u], xb[u], acc[t], 0, 0, 0);
+            }
+        }
+        request(lk, k - 2, nl);
+        __syncthreads();
+    };
+    // (a phase ends on an even step count, so that la[0] / la[1] keep their turns: its last step may carry one slot that has just died --
+    // the block it solved in the step before; updating that accumulator further is harmless)
+    int k = s;
+    auto phase = [&](auto nl) {
+        while (k > 0 && nlive(k) == decltype(nl)::value) {
+            step(la[0], k, nl);
+            if (k - 1 > 0) step(la[1], k - 1, nl);
+            k -= 2;
+        }
+    };
+    phase(std::integral_constant<int, 4>());
+    phase(std::integral_constant<int, 3>());
+    phase(std::integral_constant<int, 2>());
+    phase(std::integral_constant<int, 1>());
+    phase(std::integral_constant<int, 0>());
+
+    // the strip goes out: W = its 16 rows of X (zeros right of column 16 s + 15), U = its 16 columns of X^T
+    double *Ub = U + (int64_t)b * TI_NB * TI_NB, *Wb = W + (int64_t)b * TI_NB * TI_NB;
+    const int nz = 16 * s + 16;
+    for (int e = tid; e < 16 * TI_NB; e += 512) {
+        const int r = e >> 9, c = e & 511;
+        Wb[(int64_t)(16 * s + r) * TI_NB + c] = (c < nz) ? xs[r * TI_XS + c] : 0.0;
+    }
+    for (int e = tid; e < 16 * TI_NB; e += 512) {
+        const int c = e >> 4, r = e & 15;
+        Ub[(int64_t)c * TI_NB + 16 * s + r] = (c < nz) ? xs[r * TI_XS + c] : 0.0;
+    }
+}
+
+int launch_trinv512(hipStream_t st, int64_t nblk, const double *L, int64_t ldl, const double *invd, double *U, double *W)
+{
+    if (nblk <= 0) return GPT_OK;
+    hipLaunchKernelGGL(trinv512_kernel, dim3((unsigned)(32 * nblk)), dim3(512), 0, st, (int)nblk, L, ldl, invd, U, W);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
 // ---- the same substitution in 512-wide steps against explicit inverses of the diagonal blocks -------------------------------
 // 127 dependent launches of ~8 us are what the 128-wide form costs at n = 8192 (1 ms, a fifth of an evaluation).  With
-// U_j = L_jj^-T of the 512 x 512 diagonal blocks at hand (api.hip build_block_inverses: a dozen batched launches for all of
-// them) a step is  x_j = U_j w_j  (launch_gemv_n: one workgroup per row)  and  w[0 : j0) -= L[j0 : j0 + 512, 0 : j0)^T x_j
-// (this kernel): 2 n / 512 launches.  A workgroup takes 64 columns; its four waves split the 512 rows and walk them with
-// eight loads in flight per lane (a row segment is 512 contiguous bytes); the four partial sums meet in LDS in a fixed order.
+// U_j = L_jj^-T of the 512 x 512 diagonal blocks at hand (trinv512_kernel above) a step is  x_j = U_j w_j  (launch_gemv_n: one
+// workgroup per row)  and  w[0 : j0) -= L[j0 : j0 + 512, 0 : j0)^T x_j  (this kernel): 2 n / 512 launches.
+// A workgroup takes 16 columns: a CU turns out ~32 bytes of vector loads per cycle whatever they hit, so the 256 KB of the 64-column
+// workgroups of rounds 2-4 were 3.9 us of requests alone (8-10 us per launch whatever ncols was); 16 columns are 64 KB, and j0 / 16
+// workgroups fill the chip four times sooner.  Lane = (column, row mod 4); the eight waves split the 512 rows, sixteen loads in flight
+// per lane (a load instruction covers four rows of 128 bytes); the 32 partial sums of a column meet in LDS in a fixed order.
 #define TW_NB 512
-__global__ __launch_bounds__(256) void gemv_t_sub_kernel(int64_t ncols, const double *__restrict__ M, int64_t ldm,
+__global__ __launch_bounds__(512) void gemv_t_sub_kernel(int64_t ncols, const double *__restrict__ M, int64_t ldm,
                                                          const double *__restrict__ x, double *__restrict__ w)
 {
     __shared__ double xs[TW_NB];
-    __shared__ double part[4][64];
-    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
-    for (int i = tid; i < TW_NB; i += 256) xs[i] = x[i];
+    __shared__ double part[32][17];
+    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6, c = lane & 15, rs = lane >> 4;
+    xs[tid] = x[tid];
     __syncthreads();
-    const int64_t col = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t col = (int64_t)blockIdx.x * 16 + c;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     if (col < ncols) {
-        const double *p = M + (int64_t)(g * (TW_NB / 4)) * ldm + col;
-        const double *xv = xs + g * (TW_NB / 4);
-#pragma unroll 2
-        for (int r = 0; r < TW_NB / 4; r += 8) {
-            double v[8];
+        const int r0 = g * (TW_NB / 8) + rs;                  // rows r0 + 4 i, i < 16
+        const double *p = M + (int64_t)r0 * ldm + col;
+        double v[16];
 #pragma unroll
-            for (int q = 0; q < 8; q++) v[q] = p[(int64_t)(r + q) * ldm];
-            a0 = fma(v[0], xv[r + 0], a0);
-            a1 = fma(v[1], xv[r + 1], a1);
-            a2 = fma(v[2], xv[r + 2], a2);
-            a3 = fma(v[3], xv[r + 3], a3);
-            a0 = fma(v[4], xv[r + 4], a0);
-            a1 = fma(v[5], xv[r + 5], a1);
-            a2 = fma(v[6], xv[r + 6], a2);
-            a3 = fma(v[7], xv[r + 7], a3);
+        for (int i = 0; i < 16; i++) v[i] = p[(int64_t)(4 * i) * ldm];
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) {
+            a0 = fma(v[i + 0], xs[r0 + 4 * (i + 0)], a0);
+            a1 = fma(v[i + 1], xs[r0 + 4 * (i + 1)], a1);
+            a2 = fma(v[i + 2], xs[r0 + 4 * (i + 2)], a2);
+            a3 = fma(v[i + 3], xs[r0 + 4 * (i + 3)], a3);
         }
     }
-    part[g][lane] = (a0 + a1) + (a2 + a3);
+    part[g * 4 + rs][c] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (g == 0 && col < ncols) w[col] -= (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (tid < 16 && col < ncols) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 32; q++) t += part[q][tid];
+        w[col] -= t;
+    }
 }
 
 // Blocks [0, nwide / 512) of  L^T x = w : U = the strip of the blocks' inverse transposes (block j at rows [512 j, 512 j + 512),
 // row stride 512), w (in: right-hand side, already updated by every block right of nwide; consumed) and x (out) distinct.
-// counter: a device word only ever raised (its value before the call in *counter_value, updated here).
-int launch_trsv_lt_wide(hipStream_t st, int64_t nwide, const double *L, int64_t ldl, const double *U, double *w, double *x,
-                        unsigned *counter, unsigned *counter_value)
+int launch_trsv_lt_wide(hipStream_t st, int64_t nwide, const double *L, int64_t ldl, const double *U, double *w, double *x)
 {
     if (nwide % TW_NB) {
         gpt_set_error("trsv_lt_wide: the extent must be a multiple of %d", TW_NB);
@@ -521,14 +663,11 @@ int launch_trsv_lt_wide(hipStream_t st, int64_t nwide, const double *L, int64_t 
     }
     // (Round 4 also built a one-launch step -- update of step j and block solve of step j - 1 in one kernel, the eight workgroups that
     // own the next block's columns dispatched first and handing over through a counter: 0.36 against 0.26 ms at n = 8192 with the
-    // inverses cached, and its wait was the one unbounded spin of the library.  Removed in round 5; `counter` is unused.)
-    (void)counter;
-    (void)counter_value;
-    int64_t j0 = nwide - TW_NB;
-    GPT_TRY_RC_SOLVE(launch_gemv_n(st, TW_NB, TW_NB, U + j0 * TW_NB, TW_NB, w + j0, x + j0));
-    for (; j0 > 0; j0 -= TW_NB) {
-        hipLaunchKernelGGL(gemv_t_sub_kernel, dim3((unsigned)(j0 / 64)), dim3(256), 0, st, j0, L + j0 * ldl, ldl, x + j0, w);
-        GPT_TRY_RC_SOLVE(launch_gemv_n(st, TW_NB, TW_NB, U + (j0 - TW_NB) * TW_NB, TW_NB, w + j0 - TW_NB, x + j0 - TW_NB));
+    // inverses cached, and its wait was the one unbounded spin of the library.  Removed in round 5.)
+    for (int64_t j0 = nwide - TW_NB; j0 >= 0; j0 -= TW_NB) {
+        GPT_TRY_RC_SOLVE(launch_gemv_n(st, TW_NB, TW_NB, U + j0 * TW_NB, TW_NB, w + j0, x + j0));
+        if (j0 > 0)
+            hipLaunchKernelGGL(gemv_t_sub_kernel, dim3((unsigned)(j0 / 16)), dim3(512), 0, st, j0, L + j0 * ldl, ldl, x + j0, w);
     }
     GPT_LAUNCH_CHECK();
     return GPT_OK;

@@ -426,6 +426,8 @@ class GaussianProcess(object):
             self.K_up_to_date = True
             return
         ctx = self._ctx
+        # (eager: the device enqueues alpha behind the factorisation of the same call; get_alpha below is then a copy)
+        ctx.set_option("eager_alpha", 1 if self.eager_alpha else 0)
         if self._fast_fit_possible():
             if not self._data_on_device:
                 self._upload_data(ctx)

@@ -101,6 +101,11 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
  *   "purg_rows_flags" "purg_rows" while flag edges and merged launches are in use (0: never -- measured)
  *   "tail_wait"    1: the main stream's last launch of a panel awaits the NEXT panel's flag at its end (measured the same, 0)
  *   "alpha_invalidate" (measurement aid) the next gpt_get_alpha recomputes alpha
+ *   "eager_alpha"  1: every gpt_fit* also enqueues alpha = K_tot^-1 y behind its factorisation (the reference computes alpha in every
+ *                  evaluation, gaussian_process.py:1462) and lands it in pinned memory under the call's own synchronisation;
+ *                  gpt_get_alpha is then a host copy.  0 (default): alpha on first use (gpt_get_alpha, gpt_predict, gpt_ll_grad)
+ *   "binv_launches" 1 (measurement aid): the 512-wide block inverses by rounds 2-4's recursion over 15 launches instead of the one
+ *                  launch of trinv512_kernel (solve.hip); results agree to rounding
  *   "splitk"       gpt_predict with std / cov at few points: the GEMMs of a triangular solve with at most 128 right-hand sides
  *                  and the V V^T of a covariance of at most 256 points, when k >= 1024 and they have fewer 32x32 tiles than this
  *                  (512), are split along k into up to 32 chunks of at least 256, summed in chunk order by a second kernel --

@@ -1841,6 +1841,49 @@ def test_alpha_by_wide_steps_matches_the_oracle_and_the_narrow_form(oracle, kern
         c.close()
 
 
+@pytest.mark.parametrize("N", [1408, 3000, 4608])
+def test_eager_alpha_and_the_one_launch_block_inverses(oracle, N):
+    """Option eager_alpha: the fit itself enqueues alpha behind the factorisation and lands it in pinned memory (ref
+    gaussian_process.py:1462 computes alpha in every evaluation) -- the same bits as gpt_get_alpha after a plain fit, also when a
+    non-positive-definite evaluation came in between.  The 512-wide block inverses behind it come out of one launch
+    (solve.hip trinv512_kernel; N = 4608: nine blocks, 288 workgroups): against rounds 2-4's recursion over 15 launches (option
+    binv_launches) alpha, a solve and a many-points predict agree to rounding, and alpha matches the oracle."""
+    from gptools_amd import _lib
+    d = 2
+    X, n, y = c3_inputs(N, d)
+    p = np.array([1.0, 0.3, 0.3])
+    err = 0.05 * np.ones(N)
+    ref = oracle.fit("m52", p, X, n, y, err, chol="scipy")
+    scale = np.abs(ref["alpha"]).max()
+    rs = np.random.RandomState(N)
+    Xs, ns = rs.rand(300, d), np.zeros((300, d), dtype=np.int32)
+    B = rs.randn(N, 2)
+    c = _lib.Context(0)
+    try:
+        c.set_data(X, n)
+        out = {}
+        for mode in (0, 1):
+            c.set_option("binv_launches", mode)
+            c.fit(KID["m52"], p, 0.0, y, err, 1e2 * EPS)
+            out[mode] = (c.get_alpha(N), c.cho_solve(B.copy()), c.predict(Xs, ns, 1)[1])
+        np.testing.assert_allclose(out[0][0], ref["alpha"], rtol=0, atol=2e-7 * scale)
+        for u, v in zip(out[0], out[1]):
+            assert np.abs(u - v).max() <= 1e-10 * max(1.0, np.abs(v).max())
+        c.set_option("binv_launches", 0)
+        c.set_option("eager_alpha", 1)
+        ll = c.fit(KID["m52"], p, 0.0, y, err, 1e2 * EPS)
+        assert np.array_equal(c.get_alpha(N), out[0][0])
+        with pytest.raises(np.linalg.LinAlgError):
+            c.fit(KID["m52"], p, 0.0, y, 0.0 * err, -2.0)          # K - 2 I: not positive definite
+        with pytest.raises(Exception):
+            c.get_alpha(N)                                        # (no factor, no alpha)
+        assert c.fit(KID["m52"], p, 0.0, y, err, 1e2 * EPS) == ll
+        assert np.array_equal(c.get_alpha(N), out[0][0])
+        assert np.array_equal(c.predict(Xs, ns, 1)[1], out[0][2])
+    finally:
+        c.close()
+
+
 def test_block_inverse_extents_fit_predict_then_gradient(g):
     """at N = 512 k - 128 the solves (predict with std) and gpt_ll_grad ask for block inverses over different
     extents; fit -> predict(std) -> ll_grad must give the gradient ll_grad gives straight after the fit."""
