@@ -2431,6 +2431,9 @@ extern "C" int gpt_dev_trinv(gpt_ctx *c, int64_t n, const double *dL, int64_t ld
     hipStream_t st = c->stream;
     double *U;
     GPT_TRY(ensure(c, SLOT_UINV, (size_t)n * n * sizeof(double), (void **)&U));
+    // (the partitioned engines' block size: one launch instead of ten -- 69 -> ~43 us on the panel chain and nine launches less of
+    // host enqueue per panel; solve.hip trinv512_kernel)
+    if (n == 512 && ldw == 512 && !c->binv_launches) return launch_trinv512(st, 1, dL, ldl, d_invd, U, dW);
     GPT_HIP_CHECK(hipMemsetAsync(U, 0, (size_t)n * n * sizeof(double), st));
     hipLaunchKernelGGL(eye_blocks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, U, n, n);
     GPT_LAUNCH_CHECK();
@@ -2753,39 +2756,25 @@ static int build_block_inverses_512(gpt_ctx *c, hipStream_t st, int64_t nblk, do
 // (the inverses are always built for the WHOLE padded order -- floor(NP / nb) blocks -- whatever extent `nfull` the
 // caller is going to use: gpt_ll_grad asks for floor(NP / 512) blocks, the solves for floor(round_up(N, 128) / 512), one block
 // less at N = 512 k - 128; a strip sized for the smaller request used to be reallocated, and not rebuilt, by the larger one)
+static int ensure_block_inverses_wide(gpt_ctx *c, int64_t nb, int64_t nfull, double **out);
 static int ensure_block_inverses(gpt_ctx *c, int64_t nb, int64_t nfull, double **out, double **out_u)
 {
-    const bool big = (nb == GPT_BINV_NB2);
+    if (nb == GPT_BINV_NB2) return ensure_block_inverses_wide(c, nb, nfull, out);
     const int64_t nall = (c->NP / nb) * nb;
     if (nfull > nall || nall <= 0) {
         gpt_set_error("block inverses: extent %lld exceeds the padded order %lld", (long long)nfull, (long long)c->NP);
         return GPT_E_ARG;
     }
     double *W, *Us = nullptr;
-    GPT_TRY(ensure(c, big ? SLOT_BINV2 : SLOT_BINV, (size_t)nall * nb * sizeof(double), (void **)&W));
-    if (!big) GPT_TRY(ensure(c, SLOT_BINVU, (size_t)nall * nb * sizeof(double), (void **)&Us));
+    GPT_TRY(ensure(c, SLOT_BINV, (size_t)nall * nb * sizeof(double), (void **)&W));
+    GPT_TRY(ensure(c, SLOT_BINVU, (size_t)nall * nb * sizeof(double), (void **)&Us));
     *out = W;
     if (out_u) *out_u = Us;
-    bool &valid = big ? c->binv2_valid : c->binv_valid;
-    if (valid) return GPT_OK;
+    if (c->binv_valid) return GPT_OK;
     hipStream_t st = c->stream;
-    if (!big) {
-        if (c->binv_launches) GPT_TRY(build_block_inverses_512(c, st, nall / nb, Us, W));
-        else GPT_TRY(launch_trinv512(st, nall / nb, c->dA, c->NP, c->d_invd, Us, W));      // one launch (solve.hip)
-        valid = true;
-        return GPT_OK;
-    }
-    double *U;
-    GPT_TRY(ensure(c, SLOT_UINV, (size_t)nb * nb * sizeof(double), (void **)&U));
-    for (int64_t j = 0; j < nall; j += nb) {
-        GPT_HIP_CHECK(hipMemsetAsync(U, 0, (size_t)nb * nb * sizeof(double), st));
-        hipLaunchKernelGGL(eye_blocks_kernel, dim3((unsigned)(nb / 256)), dim3(256), 0, st, U, nb, nb);
-        GPT_LAUNCH_CHECK();
-        GPT_TRY(trsm_rlt(c, st, nb, nb, c->dA + j * c->NP + j, c->NP, c->d_invd + (j / 128) * GPT_WS_BLOCK, U, nb));
-        hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)(nb / 32), (unsigned)(nb / 32)), dim3(256), 0, st, U, nb, W + j * nb, nb, nb);
-        GPT_LAUNCH_CHECK();
-    }
-    valid = true;
+    if (c->binv_launches) GPT_TRY(build_block_inverses_512(c, st, nall / nb, Us, W));
+    else GPT_TRY(launch_trinv512(st, nall / nb, c->dA, c->NP, c->d_invd, Us, W));      // one launch (solve.hip)
+    c->binv_valid = true;
     return GPT_OK;
 }
 
@@ -2794,15 +2783,21 @@ static int ensure_block_inverses(gpt_ctx *c, int64_t nb, int64_t nfull, double *
 // 512-wide inverses by the GEMM-only triangular inverse of the gradient path (trtri_u_gemm: U = L^-T of the block, N^3/3 flop
 // with the block's zeros skipped -- the identity pushed through the panel TRSM would cost 6 x that), then transposed.
 #define GPT_BINV_NB3 2048
-static int ensure_block_inverses_big(gpt_ctx *c, int64_t nfull, double **out)
+static int ensure_block_inverses_wide(gpt_ctx *c, int64_t nb, int64_t nfull, double **out)
 {
-    const int64_t nb = GPT_BINV_NB3;
+    // (nb = 1024 -- solves with very few rows against factors of 4096 <= n < 8192 -- went through the substitution leaves block
+    // by block until round 5: a dozen dependent launches per block)
+    const bool w3 = (nb == GPT_BINV_NB3);
     double *W, *U, *T, *Wb;
-    if (nfull > (c->NP / nb) * nb) return GPT_E_ARG;
+    if (nfull > (c->NP / nb) * nb) {
+        gpt_set_error("block inverses: extent %lld exceeds the padded order %lld", (long long)nfull, (long long)c->NP);
+        return GPT_E_ARG;
+    }
     nfull = (c->NP / nb) * nb;                                  // (always the whole padded order, see ensure_block_inverses)
-    GPT_TRY(ensure(c, SLOT_BINV3, (size_t)nfull * nb * sizeof(double), (void **)&W));
+    GPT_TRY(ensure(c, w3 ? SLOT_BINV3 : SLOT_BINV2, (size_t)nfull * nb * sizeof(double), (void **)&W));
     *out = W;
-    if (c->binv3_valid) return GPT_OK;
+    bool &valid = w3 ? c->binv3_valid : c->binv2_valid;
+    if (valid) return GPT_OK;
     GPT_TRY(ensure_block_inverses(c, GPT_BINV_NB, nfull, &Wb));
     // U strip (nfull x nb, block j at rows [j, j + nb)) followed by one nb x nb scratch block for the products
     GPT_TRY(ensure(c, SLOT_BINV3U, ((size_t)nfull * nb + (size_t)nb * nb) * sizeof(double), (void **)&U));
@@ -2816,7 +2811,7 @@ static int ensure_block_inverses_big(gpt_ctx *c, int64_t nfull, double **out)
                            W + j * nb, nb, nb, nb);
         GPT_LAUNCH_CHECK();
     }
-    c->binv3_valid = true;
+    valid = true;
     return GPT_OK;
 }
 
@@ -2908,7 +2903,7 @@ static int solve_rows_resident(gpt_ctx *c, hipStream_t st, int64_t m, int64_t n1
         int64_t n3 = 0, n2 = 0;
         if (m <= GPT_FEW_ROWS && n128 >= 4 * GPT_BINV_NB3) {
             n3 = (n128 / GPT_BINV_NB3) * GPT_BINV_NB3;
-            GPT_TRY(ensure_block_inverses_big(c, n3, &W3));
+            GPT_TRY(ensure_block_inverses_wide(c, GPT_BINV_NB3, n3, &W3));
         } else if (m <= GPT_FEW_ROWS && n128 >= 4 * GPT_BINV_NB2) {
             n2 = (n128 / GPT_BINV_NB2) * GPT_BINV_NB2;
             GPT_TRY(ensure_block_inverses(c, GPT_BINV_NB2, n2, &W2));
