@@ -2453,9 +2453,12 @@ static int trsm_rlt_binv(gpt_ctx *c, hipStream_t st, int64_t m, int64_t nb, int6
 
 // dst (rows x cols, ldd) = src (cols x rows, lds)^T through a 32x33 LDS tile
 __global__ __launch_bounds__(256) void transpose_rect_kernel(const double *__restrict__ src, int64_t lds, double *__restrict__ dst,
-                                                             int64_t ldd, int64_t rows, int64_t cols)
+                                                             int64_t ldd, int64_t rows, int64_t cols, int64_t sstride = 0,
+                                                             int64_t dstride = 0)
 {
     __shared__ double t[32][33];
+    src += (int64_t)blockIdx.z * sstride;                   // (blockIdx.z: a batch of equal blocks)
+    dst += (int64_t)blockIdx.z * dstride;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;      // tile of dst
     for (int i = ty; i < 32; i += 8)
@@ -2494,6 +2497,50 @@ static int trtri_u_gemm(gpt_ctx *c, hipStream_t st, int64_t lo, int64_t hi, cons
                         T + (lo + o) * ldt + mid, ldt, 0));
     }
     return trsm_rlt_binv(c, st, h, nb, mid, hi, Wb, T + lo * ldt, ldt, U + lo * ldu, ldu);
+}
+
+// The same for `nbatch` equal diagonal blocks at once (the nb-wide inverses of few-rows solves: nb = 1024 / 2048, block J at
+// factor rows [J nb, J nb + nb)): every GEMM and transpose of the recursion is ONE launch with the blocks as its batch dimension
+// (round 5; block by block the 2048-wide inverses of N = 8192 were 64 dependent launches, 0.9 ms of the first predict after a fit).
+// Indices are those of block 0; U and T are strips of nb-wide blocks (block J at rows [J nb, J nb + nb), row stride nb).
+struct WideBatch { int64_t n, sU, sT, sL, sW; };
+static int gemm_b(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A, int64_t lda, int64_t sA, const double *B,
+                  int64_t ldb, int64_t sB, double beta, double *C, int64_t ldc, int64_t sC, int64_t nbatch)
+{
+    return launch_gemm_nt(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0, 0, 0, nullptr, nullptr, 0, EdgeSig(), EdgeSig(), 0, nbatch, sA,
+                          EdgeSig(), sB, sC);
+}
+static int trsm_rlt_binv_b(gpt_ctx *c, hipStream_t st, int64_t m, int64_t nb, int64_t lo, int64_t hi, const double *W, double *B, int64_t ldb,
+                           double *V, int64_t ldv, const WideBatch &wb)
+{
+    const int64_t n = hi - lo;
+    if (n == nb) return gemm_b(st, m, nb, nb, 1.0, B + lo, ldb, wb.sT, W + lo * nb, nb, wb.sW, 0.0, V + lo, ldv, wb.sU, wb.n);
+    const int64_t h = (n / (2 * nb)) * nb > 0 ? (n / (2 * nb)) * nb : nb;
+    const int64_t mid = lo + h;
+    GPT_TRY(trsm_rlt_binv_b(c, st, m, nb, lo, mid, W, B, ldb, V, ldv, wb));
+    GPT_TRY(gemm_b(st, m, hi - mid, h, -1.0, V + lo, ldv, wb.sU, c->dA + mid * c->NP + lo, c->NP, wb.sL, 1.0, B + mid, ldb, wb.sT, wb.n));
+    return trsm_rlt_binv_b(c, st, m, nb, mid, hi, W, B, ldb, V, ldv, wb);
+}
+static int trtri_u_gemm_b(gpt_ctx *c, hipStream_t st, int64_t lo, int64_t hi, const double *Wb, double *U, int64_t ldu, double *T, int64_t ldt,
+                          const WideBatch &wb)
+{
+    const int64_t nb = GPT_BINV_NB, n = hi - lo;
+    if (n == nb) {
+        hipLaunchKernelGGL(transpose_rect_kernel, dim3((unsigned)(nb / 32), (unsigned)(nb / 32), (unsigned)wb.n), dim3(256), 0, st,
+                           Wb + lo * nb, nb, U + lo * ldu + lo, ldu, nb, nb, wb.sW, wb.sU);
+        GPT_LAUNCH_CHECK();
+        return GPT_OK;
+    }
+    const int64_t h = (n / (2 * nb)) * nb > 0 ? (n / (2 * nb)) * nb : nb, mid = lo + h;
+    GPT_TRY(trtri_u_gemm_b(c, st, lo, mid, Wb, U, ldu, T, ldt, wb));
+    GPT_TRY(trtri_u_gemm_b(c, st, mid, hi, Wb, U, ldu, T, ldt, wb));
+    const int64_t nq = (h >= 1024) ? 2 : 1, hc = h / nq;          // (row chunks of U11 start their k range at their own first column)
+    for (int64_t q = 0; q < nq; q++) {
+        const int64_t o = q * hc;
+        GPT_TRY(gemm_b(st, hc, hi - mid, h - o, -1.0, U + (lo + o) * ldu + lo + o, ldu, wb.sU, c->dA + mid * c->NP + lo + o, c->NP, wb.sL, 0.0,
+                       T + (lo + o) * ldt + mid, ldt, wb.sT, wb.n));
+    }
+    return trsm_rlt_binv_b(c, st, h, nb, mid, hi, Wb, T + lo * ldt, ldt, U + lo * ldu, ldu, wb);
 }
 
 extern "C" int gpt_ll_grad(gpt_ctx *c, int nh, const int *term_idx, const int *local_idx, double *out)
@@ -2799,18 +2846,16 @@ static int ensure_block_inverses_wide(gpt_ctx *c, int64_t nb, int64_t nfull, dou
     bool &valid = w3 ? c->binv3_valid : c->binv2_valid;
     if (valid) return GPT_OK;
     GPT_TRY(ensure_block_inverses(c, GPT_BINV_NB, nfull, &Wb));
-    // U strip (nfull x nb, block j at rows [j, j + nb)) followed by one nb x nb scratch block for the products
-    GPT_TRY(ensure(c, SLOT_BINV3U, ((size_t)nfull * nb + (size_t)nb * nb) * sizeof(double), (void **)&U));
+    // U strip (nfull x nb, block J at rows [J nb, J nb + nb)) followed by a strip of the same shape for the products
+    GPT_TRY(ensure(c, SLOT_BINV3U, (size_t)2 * nfull * nb * sizeof(double), (void **)&U));
     T = U + nfull * nb;
     hipStream_t st = c->stream;
     GPT_HIP_CHECK(hipMemsetAsync(U, 0, (size_t)nfull * nb * sizeof(double), st));
-    for (int64_t j = 0; j < nfull; j += nb) {
-        // (trtri_u_gemm indexes U and T by ABSOLUTE factor rows / columns: bases shifted so that (j, j) is the block's origin)
-        GPT_TRY(trtri_u_gemm(c, st, j, j + nb, Wb, U + j * nb - j * nb - j, nb, T - j * nb - j, nb));
-        hipLaunchKernelGGL(transpose_rect_kernel, dim3((unsigned)(nb / 32), (unsigned)(nb / 32)), dim3(256), 0, st, U + j * nb, nb,
-                           W + j * nb, nb, nb, nb);
-        GPT_LAUNCH_CHECK();
-    }
+    const WideBatch wb = {nfull / nb, nb * nb, nb * nb, nb * (c->NP + 1), nb * GPT_BINV_NB};
+    GPT_TRY(trtri_u_gemm_b(c, st, 0, nb, Wb, U, nb, T, nb, wb));
+    hipLaunchKernelGGL(transpose_rect_kernel, dim3((unsigned)(nb / 32), (unsigned)(nb / 32), (unsigned)wb.n), dim3(256), 0, st, U, nb, W, nb, nb,
+                       nb, nb * nb, nb * nb);
+    GPT_LAUNCH_CHECK();
     valid = true;
     return GPT_OK;
 }
