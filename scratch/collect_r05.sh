@@ -32,6 +32,7 @@ timeout 300 python scratch/r05_binv_ab.py c3 >> $O/alpha_ab.txt 2>&1
 timeout 300 python scratch/r05_splitk_ab.py c3 16 64 128 256 > $O/splitk_ab.txt 2>&1
 timeout 300 python scratch/r05_splitk_ab.py c2 16 64 >> $O/splitk_ab.txt 2>&1
 timeout 300 python scratch/r05_first_predict.py c2 c3 > $O/first_predict.txt 2>&1
+timeout 900 python scratch/r05_fuzz_alpha.py 300 11 > $O/fuzz_alpha.txt 2>&1
 bash scratch/trace_any.sh scratch/alpha_one.py c3 > /dev/null 2>&1; awk '/logdet_dot/{f=1} f' gpurun_out/tla/timeline.txt > $O/timeline_alpha_c3.txt
 bash scratch/trace_any.sh scratch/predict_one.py c3 64 1 > /dev/null 2>&1; cp gpurun_out/tla/timeline.txt $O/timeline_predict_m64.txt
 bash scratch/trace_fit.sh c3 6 > /dev/null 2>&1; cp gpurun_out/tl/timeline.txt $O/timeline_c3.txt
