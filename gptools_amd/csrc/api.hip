@@ -2889,10 +2889,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int64_t m, int64_t n
         acc.x *= beta;
         acc.y *= beta;
     }
-    for (int s = 0; s < S; ++s) {
-        const double2 p = P[(int64_t)s * pstride2 + i];
-        acc.x += p.x;
-        acc.y += p.y;
+    // (S is a power of two >= 2: pairs, fours or eights of loads in flight, added in slab order)
+    if (S % 8 == 0) {
+        for (int s = 0; s < S; s += 8) {
+            double2 p[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) p[q] = P[(int64_t)(s + q) * pstride2 + i];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                acc.x += p[q].x;
+                acc.y += p[q].y;
+            }
+        }
+    } else {
+        for (int s = 0; s < S; s += 2) {
+            const double2 p0 = P[(int64_t)s * pstride2 + i], p1 = P[(int64_t)(s + 1) * pstride2 + i];
+            acc.x = (acc.x + p0.x) + p1.x;
+            acc.y = (acc.y + p0.y) + p1.y;
+        }
     }
     *cp = acc;
 }

@@ -539,7 +539,21 @@ __global__ __launch_bounds__(512, 2) void trinv512_kernel(int nblk, const double
     // the slots of this wave that are live at step k: j = 8 t + w < k
     auto nlive = [&](int k) { const int n = (k - w + 7) >> 3; return n < 0 ? 0 : (n > 4 ? 4 : n); };
 
-    for (int e = tid; e < 256 * (s + 1); e += 512) dl[e] = wsb[(int64_t)(e >> 11) * GPT_WS_BLOCK + (e & 2047)];
+    {   // (sixteen loads in flight per thread, then sixteen LDS stores: as a plain loop hipcc waits for every load before its store,
+        // sixteen dependent round trips = 13 us of the launch)
+        double v[16];
+        const int lim = 256 * (s + 1);
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int e = tid + 512 * i, ec = e < lim ? e : 0;
+            v[i] = wsb[(int64_t)(ec >> 11) * GPT_WS_BLOCK + (ec & 2047)];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int e = tid + 512 * i;
+            if (e < lim) dl[e] = v[i];
+        }
+    }
     request(la[0], s, std::integral_constant<int, 4>());
     request(la[1], s - 1, std::integral_constant<int, 4>());
     __syncthreads();
@@ -592,13 +606,28 @@ __global__ __launch_bounds__(512, 2) void trinv512_kernel(int nblk, const double
     // the strip goes out: W = its 16 rows of X (zeros right of column 16 s + 15), U = its 16 columns of X^T
     double *Ub = U + (int64_t)b * TI_NB * TI_NB, *Wb = W + (int64_t)b * TI_NB * TI_NB;
     const int nz = 16 * s + 16;
-    for (int e = tid; e < 16 * TI_NB; e += 512) {
-        const int r = e >> 9, c = e & 511;
-        Wb[(int64_t)(16 * s + r) * TI_NB + c] = (c < nz) ? xs[r * TI_XS + c] : 0.0;
-    }
-    for (int e = tid; e < 16 * TI_NB; e += 512) {
-        const int c = e >> 4, r = e & 15;
-        Ub[(int64_t)c * TI_NB + 16 * s + r] = (c < nz) ? xs[r * TI_XS + c] : 0.0;
+    {   // (all sixteen LDS reads of a thread before its sixteen stores, for the same reason)
+        double v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int e = tid + 512 * i, r = e >> 9, c = e & 511;
+            v[i] = (c < nz) ? xs[r * TI_XS + c] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int e = tid + 512 * i, r = e >> 9, c = e & 511;
+            Wb[(int64_t)(16 * s + r) * TI_NB + c] = v[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int e = tid + 512 * i, c = e >> 4, r = e & 15;
+            v[i] = (c < nz) ? xs[r * TI_XS + c] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int e = tid + 512 * i, c = e >> 4, r = e & 15;
+            Ub[(int64_t)c * TI_NB + 16 * s + r] = v[i];
+        }
     }
 }
 
