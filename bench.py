@@ -532,7 +532,7 @@ def main():
                                                                  or abs((-v_ - gp_.hyperprior(gp_.params)) - ll) <= 1e-12 * abs(ll))}
             # The evaluation the reference's compute_K_L_alpha_ll performs (ref gaussian_process.py:1462: alpha = cho_solve(L, y)
             # in EVERY evaluation): the same call with eager_alpha -- K build, factorisation, ll, alpha = L^-T z computed on
-            # the device (512-wide steps against the batched block inverses) and returned to the host.  Full LAPACK flop count.
+            # the device (512-wide steps against the block inverses of trinv512_kernel) and returned to the host.  Full LAPACK flop count.
             gp_.eager_alpha = True
             for _ in range(2):
                 v_ = gp_.update_hyperparameters(params)

@@ -2772,6 +2772,8 @@ __global__ __launch_bounds__(256) void transpose_strip_kernel(const double *__re
 // U12 = -(U11 L21^T) L22^-T per level -- with every launch BATCHED over the blocks (blockIdx.y; the three operands of the
 // GEMMs lie in three arrays with a stride each): 2 + 4 + 4 + 4 + 1 = 15 launches whatever the order, where the per-block
 // loop of round 3 needed 10 per block (N = 8192: 160 launches, ~1.3 ms before the first predict / gradient / alpha).
+// (Rounds 2-4's builder: since round 5 only behind option binv_launches = 1 -- the default is ONE launch, solve.hip trinv512_kernel,
+// 205 -> 59 us at N = 8192 -- kept as the same-process A/B baseline and as a second implementation for the tests.)
 static int build_block_inverses_512(gpt_ctx *c, hipStream_t st, int64_t nblk, double *U, double *W)
 {
     const int64_t nb = 512, bs = nb * nb, NP = c->NP, bsl = nb * (NP + 1), WS = GPT_WS_BLOCK;
