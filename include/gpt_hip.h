@@ -55,7 +55,10 @@ extern "C" {
                                   * through ChainRuleKernel.__call__); same limit on the derivative orders of a pair; nu must
                                   * lie in (0, 60) (GPT_E_VALUE otherwise: beyond it the closed form the device evaluates,
                                   * 2^(1-nu)/Gamma(nu) y^((nu-m)/2) K_(nu-m)(sqrt y), overflows in its factors before the
-                                  * product is formed; the reference accepts any nu) */
+                                  * product is formed.  The reference accepts any nu and evaluates the same form through
+                                  * scipy.special.kv, with the same fate: run here (round 5), MaternKernel(nu = 70) already returns nan for
+                                  * a pair 1e-6 apart at l = 0.3 (50: still 1.0), nu = 130 nan / inf for every pair closer than
+                                  * 0.02, nu = 160 nan throughout) */
 
 #define GPT_KERNEL_PRODUCT 6     /* k1 * k2 of two of the kernels above (SE, Matern52, RQ, Matern), ref: kernel/core.py:587-671: the product
                                   * rule over the derivative orders of a pair, sum over sub-multi-indices a of prod_slots C(n, a)
