@@ -104,6 +104,8 @@ struct gpt_ctx {
     int64_t pair_rows = 0;                 // > 0: while more rows than this remain, panels are taken in PAIRS -- after the first one only the next
                                            // panel's columns are updated (rank w, near_stream), after the second everything to the right in ONE
                                            // rank-2w launch (potrf_enqueue "panel pairs")
+    int64_t fuse_rows32 = 2048, fuse_rows16 = 0;   // ... 32 / 16 rows per consumer workgroup: two / one strip waves per CU (same-box A/B, bit-identical: N = 4096
+                                                   // 1.158 -> 1.152 ms, N = 8192 4.346 -> 4.31 ms with 32 rows below 2048; 16 rows: no further gain)
     int64_t fuse_rows64 = 2048;        // fused leaves with at most this many rows below them: 64 rows per consumer workgroup (one strip
                                        // wave per SIMD, potf2_trsm_kernel<.., true>); 0 = always 128
     int64_t helper_min_n = 12288;      // the helper stream takes part only above this matrix size
@@ -165,6 +167,9 @@ struct gpt_ctx {
     double *g_A = nullptr;
     DevBuf slots[SLOT_COUNT];
 };
+
+// rows per consumer workgroup of a fused leaf with m rows below it, as launch_potf2_trsm's code: 0 = 128, 1 = 64, 2 = 32, 3 = 16
+static int strip_rows_code(const gpt_ctx *c, int64_t m) { return m <= c->fuse_rows16 ? 3 : m <= c->fuse_rows32 ? 2 : m <= c->fuse_rows64 ? 1 : 0; }
 
 static int ensure(gpt_ctx *c, int slot, size_t bytes, void **out)
 {
@@ -602,7 +607,7 @@ static int panel_rec(gpt_ctx *c, hipStream_t st, double *Ap, int64_t lda, int64_
             }
             c->flag_epoch += 32;           // (the 256-column leaf kernel raises the word by up to 17 per launch)
             return launch_potf2_trsm(st, Ap, lda, invd, info, base, mb, c->d_flag, c->flag_epoch, nullptr, EdgeSig(), EdgeSig(),
-                                     mb <= c->fuse_rows64);
+                                     strip_rows_code(c, mb));
         }
         GPT_TRY(launch_potf2_diag(st, Ap, lda, invd, info, base));
         return launch_trsm_panel(st, m - 128, Ap, lda, invd, Ap + 128 * lda, lda);
@@ -631,7 +636,7 @@ static int leaf_factor(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64
             c->flag_epoch = 0;
         }
         c->flag_epoch += 32;           // (the 256-column leaf kernel raises the word by up to 17 per launch)
-        return launch_potf2_trsm(st, Ad, lda, ws, info, lc, m, c->d_flag, c->flag_epoch, done_ev, EdgeSig(), EdgeSig(), m <= c->fuse_rows64);
+        return launch_potf2_trsm(st, Ad, lda, ws, info, lc, m, c->d_flag, c->flag_epoch, done_ev, EdgeSig(), EdgeSig(), strip_rows_code(c, m));
     }
     GPT_TRY(launch_potf2_diag(st, Ad, lda, ws, info, lc));
     GPT_TRY(launch_trsm_panel(st, m, Ad, lda, ws, Ad + 128 * lda, lda, (done_ev && !c->use_graph) ? done_ev : nullptr));
@@ -712,7 +717,7 @@ static int panel_ext(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64_t
             // taken from the K build the launch is waiting for.  Otherwise a one-wave wait kernel in front of it.
             const bool fused = c->fuse_trsm > 0 && m >= 128 && m <= c->fuse_trsm && !c->use_graph;
             const bool r64 = fused && ((c->fuse_upd && m <= c->fuse_upd_rows && !first_ev) || m <= c->fuse_rows64);      // (64 rows per workgroup)
-            const int64_t wgs = r64 ? 1 + m / 64 : fused ? 1 + (m + 127) / 128 : 1;
+            const int64_t wgs = (fused && strip_rows_code(c, m) > 1) ? 1 + m / (128 >> strip_rows_code(c, m)) : r64 ? 1 + m / 64 : fused ? 1 + (m + 127) / 128 : 1;
             if (wgs > c->head_wait_wgs) {
                 GPT_TRY(stream_wait_flag(st, fw));
                 fw = EdgeSig();
@@ -740,7 +745,7 @@ static int panel_ext(gpt_ctx *c, hipStream_t st, double *A, int64_t lda, int64_t
                 c->x1_count += (unsigned)(upd_done / 16);
             } else {
                 GPT_TRY(launch_potf2_trsm(st, Ad, lda, ws, info, lc, m, c->d_flag, c->flag_epoch, last ? done_ev : nullptr,
-                                          (r1 == c0 + w) ? done_edge : EdgeSig(), fw, m <= c->fuse_rows64));
+                                          (r1 == c0 + w) ? done_edge : EdgeSig(), fw, strip_rows_code(c, m)));
             }
         } else {
             GPT_TRY(launch_potf2_diag(st, Ad, lda, ws, info, lc, fw));
@@ -1414,6 +1419,8 @@ extern "C" int gpt_ctx_set_option(gpt_ctx *c, const char *key, int64_t value)
     else if (!strcmp(key, "helper_min_n")) c->helper_min_n = value;
     else if (!strcmp(key, "fuse_trsm")) c->fuse_trsm = value;
     else if (!strcmp(key, "fuse_rows64")) c->fuse_rows64 = value;
+    else if (!strcmp(key, "fuse_rows32")) c->fuse_rows32 = value;
+    else if (!strcmp(key, "fuse_rows16")) c->fuse_rows16 = value;
     else if (!strcmp(key, "pair_rows")) c->pair_rows = value;
     else if (!strcmp(key, "splitk")) c->splitk = value;
     else if (!strcmp(key, "eager_alpha")) c->eager_alpha = value;

@@ -1238,7 +1238,7 @@ __device__ __forceinline__ void strip_substitution(StripCtx &c, f64x4 (&bt)[8], 
 // of the launch gets potf2's 135 KB of LDS, i.e. a CU to itself: used only while the panel is short (few workgroups,
 // idle chip); above that the two plain kernels run (host side, api.hip).
 // ------------------------------------------------------------------------------------------------
-template <bool LA, bool R64>
+template <bool LA, int SWV>
 __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restrict__ A, int64_t lda,
                                                                 double *__restrict__ invd, int32_t *info,
                                                                 int64_t info_col0, int64_t m, double *__restrict__ B,
@@ -1268,7 +1268,8 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
     // cycles each: with two strips per SIMD the fold's 28 MFMAs of step 0 are 1.5 us and the strips finish 28 us after the
     // launch; with one they follow the chain's flags (x_7 stored 20 us after the launch, m = 4096; profiles/r05_upd_stamps.txt)
     // -- at twice the CUs, so only for the chain-bound end of a factorisation (api.hip: fuse_rows64).
-    constexpr int SWV = R64 ? 4 : PD_WAVES;
+    // (SWV = 2 / 1, option fuse_rows32 / fuse_rows16: 32 / 16 rows per workgroup -- a CU's vector loads are ~32 bytes of requests per
+    // cycle whatever they hit, and every strip wave requests the same 5 + 4 j fragments per step)
     const int64_t row0 = ((int64_t)(blockIdx.x - 1) * SWV + wave) * 16;
     const bool active = wave < SWV && row0 < m;
     f64x4 bt[NB16];
@@ -1801,7 +1802,7 @@ static bool potf2_lookahead()
 static int ensure_big_lds(const void *fn, int which, size_t shmem)
 {
     static std::mutex mu;
-    static bool done[13][64];
+    static bool done[21][64];
     int dev = 0;
     GPT_HIP_CHECK(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) dev = 63;
@@ -1821,10 +1822,13 @@ int launch_potf2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int3
     gpt_jitter(st);
     const bool la = potf2_lookahead();
     const size_t shmem = la ? PD_LA_SMEM_BYTES : (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
-    auto kern = rows64 ? (la ? potf2_trsm_kernel<true, true> : potf2_trsm_kernel<false, true>)
-                       : (la ? potf2_trsm_kernel<true, false> : potf2_trsm_kernel<false, false>);
-    { int rc_ = ensure_big_lds(reinterpret_cast<const void *>(kern), (la ? 3 : 0) + (rows64 ? 9 : 0), shmem); if (rc_ != GPT_OK) return rc_; }
-    const int64_t rpw = rows64 ? 64 : 16 * PD_WAVES;
+    // rows64: 0 = 128 rows per consumer workgroup, 1 = 64, 2 = 32, 3 = 16
+    auto kern = rows64 == 3 ? (la ? potf2_trsm_kernel<true, 1> : potf2_trsm_kernel<false, 1>)
+              : rows64 == 2 ? (la ? potf2_trsm_kernel<true, 2> : potf2_trsm_kernel<false, 2>)
+              : rows64 == 1 ? (la ? potf2_trsm_kernel<true, 4> : potf2_trsm_kernel<false, 4>)
+                            : (la ? potf2_trsm_kernel<true, PD_WAVES> : potf2_trsm_kernel<false, PD_WAVES>);
+    { int rc_ = ensure_big_lds(reinterpret_cast<const void *>(kern), (la ? 3 : 0) + (rows64 == 1 ? 9 : rows64 == 2 ? 13 : rows64 == 3 ? 17 : 0), shmem); if (rc_ != GPT_OK) return rc_; }
+    const int64_t rpw = 128 >> rows64;
     const unsigned grid = 1u + (unsigned)((m + rpw - 1) / rpw);
     if (done) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(PD_THREADS), shmem, st, nullptr, done, 0, A, lda, invd,
                                     info, info_base, m, A + 128 * lda, lda, flag, flag_base, edge.word, edge.value,

@@ -91,6 +91,9 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
  *   "fuse_trsm"    panels with at most this many rows under a leaf use the fused diagonal-block + TRSM kernel (8192)
  *   "fuse_rows64"  fused leaves with at most this many rows under them run 64-row consumer workgroups, one substitution
  *                  strip per SIMD (2048 = what fits the CUs reserved for the panel stream; 0 = always 128-row workgroups)
+ *   "fuse_rows32", "fuse_rows16"  ... 32-row (2048) / 16-row (0 = never) consumer workgroups below that many rows: two / one strip
+ *                  waves per CU -- every strip wave requests the same fragments of the diagonal block and a CU turns out ~32 bytes of
+ *                  vector-load requests per cycle (round 5, bit-identical: N = 4096 1.158 -> 1.152 ms, N = 8192 4.346 -> 4.31 ms)
  *   "merge_urgent" 1 (default, with edge_flags): the two trailing updates per panel are one launch with a partial edge flag
  *   "edge_flags"   1 (default): the per-panel dependencies of the look-ahead are flag words in device memory (last workgroup
  *                  of the producer raises it; a bounded in-kernel wait or a one-wave wait kernel on the consumer side)

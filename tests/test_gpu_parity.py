@@ -868,11 +868,14 @@ def test_schedule_options_agree_with_default(ctx, oracle):
                 # round 5: 128-row consumer workgroups everywhere / 64-row ones everywhere, the in-launch leaf update
                 # (potf2_trsm_upd_kernel) on flag and on event edges, panel pairs (rank-2w trailing updates on two main streams)
                 {"fuse_rows64": 0}, {"fuse_rows64": 8192}, {"fuse_upd": 1, "fuse_upd_rows": 8192}, {"fuse_upd": 1, "edge_flags": 0},
-                {"fuse_upd": 1, "nb_outer": 256}, {"pair_rows": 1}, {"pair_rows": 1024, "nb_outer": 256}, {"pair_rows": 1, "fuse_upd": 1})
+                {"fuse_upd": 1, "nb_outer": 256}, {"pair_rows": 1}, {"pair_rows": 1024, "nb_outer": 256}, {"pair_rows": 1, "fuse_upd": 1},
+                # ... 64-row workgroups where the default has 32-row ones, 32-row ones everywhere, 16-row ones, a mix
+                {"fuse_rows32": 0}, {"fuse_rows32": 8192}, {"fuse_rows16": 8192}, {"fuse_rows32": 3000, "fuse_rows16": 1000, "fuse_rows64": 5000})
     defaults = {"leaf256": 0, "nb_outer": 0, "inner": 0, "defer_rows": 0, "purg_rows": 6144, "nb_early": 0, "nb_switch_rows": 4608,
-                "ramp": 0, "edge_flags": 1, "fuse_rows64": 2048, "fuse_upd": 0, "fuse_upd_rows": 4096, "pair_rows": 0}
+                "ramp": 0, "edge_flags": 1, "fuse_rows64": 2048, "fuse_rows32": 2048, "fuse_rows16": 0, "fuse_upd": 0, "fuse_upd_rows": 4096,
+                "pair_rows": 0}
     # (the round-5 variants are bit-identical to the default schedule by construction: same sums in the same order)
-    exact = ("fuse_rows64", "fuse_upd", "pair_rows")
+    exact = ("fuse_rows64", "fuse_rows32", "fuse_rows16", "fuse_upd", "pair_rows")
     try:
         for v in variants:
             for k_, d_ in defaults.items():
