@@ -917,6 +917,8 @@ __device__ __forceinline__ void potf2_body_la(double *__restrict__ A, int64_t ld
             constexpr int NCH1 = PD_NB * 16, PER1 = (NCH1 + NT - 1) / NT;            // 16-byte chunks
             constexpr int CW = (PD_NB - 32) / 2;                                      // 16-byte chunks per row of phase 2
             constexpr int NCH2 = (PD_NB - 32) * CW, PER2 = (NCH2 + NT - 1) / NT;
+            // (phase 2's loads only behind phase 1's LDS writes: issued together with phase 1's -- one memory round trip less for the
+            // workers' tiles -- the ride-along waves get their columns later: N = 8192 4.316 -> 4.358 ms, N = 4096 1.151 -> 1.168, same box)
             {
                 f64x2 v1[PER1];
 #pragma unroll
@@ -1148,6 +1150,8 @@ __device__ __forceinline__ void strip_batch_issue(StripBatch &b, const double *_
         for (int kk = 0; kk < 4; kk++)
             b.lv[jp - J - 1][kk] = __hip_atomic_load(lpk + (jp * (jp - 1) / 2 + J) * 256 + kk * 64 + lane, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_AGENT);
+    // (the flag sample LAST: sampled first -- readable without waiting for the fold blocks -- it sees the next step's publication less
+    // often and the strips prefetch less: N = 8192 4.328 -> 4.360 ms, N = 4096 1.153 -> 1.164, same box)
     b.fn = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // HIST: x_j also stays in LDS (Xh[j], which doubles as the re-layout scratch) and hprog counts the steps (potf2_trsm_upd_kernel);
@@ -1164,7 +1168,7 @@ struct StripCtx {
     unsigned fl;
     bool have;
 };
-template <int J, bool HIST, class Post>
+template <int J, bool HIST, bool THROUGH, class Post>
 __device__ __forceinline__ void strip_step(StripCtx &c, StripBatch &cur, StripBatch &nxt, f64x4 (&bt)[8], f64x4 &acc,
                                            double (*Xh)[16][TP_SP], int *hprog, Post post)
 {
@@ -1186,7 +1190,9 @@ __device__ __forceinline__ void strip_step(StripCtx &c, StripBatch &cur, StripBa
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         double *dst = c.Brow + (int64_t)(fk + 4 * r) * c.ldb + J * 16 + fr;
-        if (c.through) __hip_atomic_store(dst, res[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (THROUGH is a template parameter: with the two kinds of store in a run-time branch hipcc cannot count them and waits
+        // vmcnt(0) -- for the acknowledgement of THESE stores, 1-2.5 us -- in front of the flag sample below, in every step)
+        if (THROUGH) __hip_atomic_store(dst, res[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *dst = res[r];
         X[fk + 4 * r][fr] = res[r];
     }
@@ -1209,21 +1215,27 @@ __device__ __forceinline__ void strip_step(StripCtx &c, StripBatch &cur, StripBa
     }
     post(J);
 }
-template <bool HIST, class Post>
-__device__ __forceinline__ void strip_substitution(StripCtx &c, f64x4 (&bt)[8], double (*Xh)[16][TP_SP], int *hprog, Post post)
+template <bool HIST, bool THROUGH, class Post>
+__device__ __forceinline__ void strip_substitution_t(StripCtx &c, f64x4 (&bt)[8], double (*Xh)[16][TP_SP], int *hprog, Post post)
 {
     StripBatch a, b;
     f64x4 acc = bt[0];
     c.have = false;
     c.fl = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(c.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    strip_step<0, HIST>(c, a, b, bt, acc, Xh, hprog, post);
-    strip_step<1, HIST>(c, b, a, bt, acc, Xh, hprog, post);
-    strip_step<2, HIST>(c, a, b, bt, acc, Xh, hprog, post);
-    strip_step<3, HIST>(c, b, a, bt, acc, Xh, hprog, post);
-    strip_step<4, HIST>(c, a, b, bt, acc, Xh, hprog, post);
-    strip_step<5, HIST>(c, b, a, bt, acc, Xh, hprog, post);
-    strip_step<6, HIST>(c, a, b, bt, acc, Xh, hprog, post);
-    strip_step<7, HIST>(c, b, a, bt, acc, Xh, hprog, post);
+    strip_step<0, HIST, THROUGH>(c, a, b, bt, acc, Xh, hprog, post);
+    strip_step<1, HIST, THROUGH>(c, b, a, bt, acc, Xh, hprog, post);
+    strip_step<2, HIST, THROUGH>(c, a, b, bt, acc, Xh, hprog, post);
+    strip_step<3, HIST, THROUGH>(c, b, a, bt, acc, Xh, hprog, post);
+    strip_step<4, HIST, THROUGH>(c, a, b, bt, acc, Xh, hprog, post);
+    strip_step<5, HIST, THROUGH>(c, b, a, bt, acc, Xh, hprog, post);
+    strip_step<6, HIST, THROUGH>(c, a, b, bt, acc, Xh, hprog, post);
+    strip_step<7, HIST, THROUGH>(c, b, a, bt, acc, Xh, hprog, post);
+}
+template <bool HIST, class Post>
+__device__ __forceinline__ void strip_substitution(StripCtx &c, f64x4 (&bt)[8], double (*Xh)[16][TP_SP], int *hprog, Post post)
+{
+    if (c.through) strip_substitution_t<HIST, true>(c, bt, Xh, hprog, post);
+    else strip_substitution_t<HIST, false>(c, bt, Xh, hprog, post);
 }
 
 // ------------------------------------------------------------------------------------------------
