@@ -1168,6 +1168,12 @@ struct StripCtx {
     unsigned fl;
     bool have;
 };
+// The first step that may request the NEXT step's batch under its own fold.  Step 0 does not: with both batches, seven accumulators and the
+// store addresses live the strip code needed 272 VGPRs (16 spilled, their reloads in every step); without it 254, no spill.  Same box,
+// separate processes: N = 4096 1.163 -> 1.129 ms, N = 8192 4.302 / 4.303; from step 2 on (232 VGPRs): 1.131 -> 1.141, 4.348 -> 4.365.
+#ifndef STRIP_PREFETCH_FROM
+#define STRIP_PREFETCH_FROM 1
+#endif
 template <int J, bool HIST, bool THROUGH, class Post>
 __device__ __forceinline__ void strip_step(StripCtx &c, StripBatch &cur, StripBatch &nxt, f64x4 (&bt)[8], f64x4 &acc,
                                            double (*Xh)[16][TP_SP], int *hprog, Post post)
@@ -1203,7 +1209,7 @@ __device__ __forceinline__ void strip_step(StripCtx &c, StripBatch &cur, StripBa
         for (int kk = 0; kk < 4; kk++) xj[kk] = -X[fr][fk + 4 * kk];
         // behind the chain?  then the next step's batch goes out now, under this step's fold
         const unsigned f = (unsigned)__builtin_amdgcn_readfirstlane((int)cur.fn);
-        c.have = (int)(f - c.flag_base) >= J + 2;
+        c.have = (J >= STRIP_PREFETCH_FROM) && (int)(f - c.flag_base) >= J + 2;
         if (c.have) strip_batch_issue<J + 1>(nxt, c.ws, c.flag, lane);
         else c.fl = f;
 #pragma unroll
