@@ -18,6 +18,8 @@ Fixture groups follow SURVEY.md section 8(c):
   G10 MaternKernel (general nu): pairs, Gram, fit, predict (kernel/matern.py:251-465, utils.py:1369-1527)
   G9 ProductKernel (k1 * k2) with derivative orders: pairs, fit, predict (kernel/core.py:587-671)
   G11 RQ / general Matern / product pairs at combined derivative orders 9 .. 12 (not in the default list: ~15 minutes)
+  G12 independent evaluations and samples: ``compute_ll_matrix`` grids (gaussian_process.py:1607-1692), random starts
+      of ``optimize_hyperparameters`` (:689-735, :2443-2486), ``draw_sample`` / ``predict(return_samples=True)`` (:1155-1330, :990-1005)
 """
 import os
 import pickle
@@ -716,10 +718,117 @@ def gen_g11():
     save("g11_high_orders", **out)
 
 
+# ----------------------------------------------------------------------------
+# G12 (round 6): the reference's independent-evaluation consumers and its posterior samples (8f-4)
+# ----------------------------------------------------------------------------
+def gen_g12():
+    out = {}
+    rs = np.random.RandomState(1212)
+    # --- (a) compute_ll_matrix: 2 free parameters (l_2 fixed), grid reaching beyond the bounds of sigma_f -> -inf row;
+    #         a Gamma hyperprior so that the prior term is not a constant over the grid
+    N, d = 72, 2
+    n = deriv_pattern(rs, N, d, 0.25, 1)
+    X, y = synth(rs, N, d, n)
+    out["grid_X"], out["grid_y"], out["grid_n"] = X, y, n.astype(np.int32)
+    for kname, cls in (("se", gptools.SquaredExponentialKernel), ("m52", gptools.Matern52Kernel)):
+        k = cls(num_dim=d, initial_params=[1.2, 0.35, 0.4], param_bounds=[(1e-3, 10.0)] * 3,
+                fixed_params=[False, False, True])
+        gp = gptools.GaussianProcess(k, X=X, y=y, err_y=0.05, n=n)
+        before = np.array(gp.free_params[:], dtype=float)
+        ll, pv = gp.compute_ll_matrix([(0.4, 12.0), (0.1, 0.9)], [5, 4])       # sigma_f = 12 is out of bounds
+        out["grid_%s_ll" % kname] = np.asarray(ll, dtype=float)
+        out["grid_%s_p0" % kname], out["grid_%s_p1" % kname] = np.asarray(pv[0]), np.asarray(pv[1])
+        out["grid_%s_free_after" % kname] = np.array(gp.free_params[:], dtype=float)
+        out["grid_%s_ll_after" % kname] = np.float64(gp.ll)
+        assert np.array_equal(before, out["grid_%s_free_after" % kname])
+    # three free parameters incl. the noise kernel's, one (bounds, num_pts) pair for all of them; Gamma hyperpriors
+    k = gptools.SquaredExponentialKernel(
+        num_dim=d, initial_params=[1.0, 0.3, 0.5], fixed_params=[False, False, True],
+        hyperprior=gptools.GammaJointPriorAlt([1.0, 0.4, 0.5], [0.5, 0.2, 0.3]))
+    nk = gptools.DiagonalNoiseKernel(num_dim=d, initial_noise=0.1, fixed_noise=False, noise_bound=(1e-3, 1.0))
+    gp = gptools.GaussianProcess(k, noise_k=nk, X=X, y=y, err_y=0.02, n=n)
+    ll, pv = gp.compute_ll_matrix((0.05, 0.8), 3)
+    out["grid3_ll"] = np.asarray(ll, dtype=float)
+    out["grid3_p"] = np.asarray(pv, dtype=float)
+    # --- (b) random starts: the draws of the hyperprior (global numpy state), one minimize per draw, the best one kept
+    N = 40
+    nb = deriv_pattern(rs, N, 1, 0.2, 1)
+    Xb = rs.rand(N, 1)
+    yb = np.sin(4.0 * Xb[:, 0]) + 0.05 * rs.randn(N)
+    yb[nb[:, 0] == 1] = 4.0 * np.cos(4.0 * Xb[nb[:, 0] == 1, 0])
+    out["rs_X"], out["rs_y"], out["rs_n"] = Xb, yb, nb.astype(np.int32)
+    for tag, deriv in (("fd", False), ("hd", True)):
+        k = gptools.SquaredExponentialKernel(num_dim=1, initial_params=[1.0, 0.3], param_bounds=[(0.05, 20.0), (0.02, 3.0)])
+        gp = gptools.GaussianProcess(k, X=Xb, y=yb, err_y=0.05, n=nb, use_hyper_deriv=deriv)
+        np.random.seed(4242)
+        draws = gp.hyperprior.random_draw(size=5).T[:, ~np.asarray(gp.fixed_params, dtype=bool)]   # (:702-703)
+        out["rs_%s_draws" % tag] = np.asarray(draws, dtype=float)
+        per = []
+        for s in draws:       # what _OptimizeHyperparametersEval does per start (gaussian_process.py:2459-2466)
+            import scipy.optimize
+            r = scipy.optimize.minimize(gp.update_hyperparameters, s, method="SLSQP", jac=deriv,
+                                        bounds=np.asarray(gp.free_param_bounds, dtype=float))
+            per.append(np.concatenate((r.x, [r.fun, float(r.success)])))
+        out["rs_%s_per_start" % tag] = np.asarray(per)
+        np.random.seed(4242)
+        res, count = gp.optimize_hyperparameters(method="SLSQP", random_starts=5, num_proc=0)
+        out["rs_%s_x" % tag], out["rs_%s_fun" % tag] = np.asarray(res.x, dtype=float), np.float64(res.fun)
+        out["rs_%s_count" % tag] = np.int64(count)
+        out["rs_%s_params_after" % tag] = np.array(gp.params[:], dtype=float)
+        out["rs_%s_ll_after" % tag] = np.float64(gp.ll)
+    # --- (c) draw_sample / predict(return_samples=True)
+    N, d, M = 48, 2, 12
+    n = deriv_pattern(rs, N, d, 0.25, 1)
+    X, y = synth(rs, N, d, n)
+    Xs = rs.rand(M, d)
+    ns = np.zeros((M, d), dtype=int)
+    ns[M - 4:, 0] = 1
+    out["samp_X"], out["samp_y"], out["samp_n"] = X, y, n.astype(np.int32)
+    out["samp_Xs"], out["samp_ns"] = Xs, ns.astype(np.int32)
+    u = rs.randn(M, 3)
+    uu = rs.rand(M, 2)
+    u6 = rs.randn(M, 6)
+    out["samp_u"], out["samp_uu"], out["samp_u6"] = u, uu, u6
+    for kname, cls in (("se", gptools.SquaredExponentialKernel), ("m52", gptools.Matern52Kernel)):
+        k = cls(num_dim=d, initial_params=[1.1, 0.4, 0.3], param_bounds=[(1e-3, 10.0)] * 3)
+        nk = gptools.DiagonalNoiseKernel(num_dim=d, initial_noise=0.07, fixed_noise=True)
+        gp = gptools.GaussianProcess(k, noise_k=nk, X=X, y=y, err_y=0.05, n=n)
+        key = "samp_%s_" % kname
+        out[key + "chol"] = np.asarray(gp.draw_sample(Xs, n=ns, rand_vars=u))
+        out[key + "chol_noise"] = np.asarray(gp.draw_sample(Xs, n=ns, rand_vars=u, noise=True))
+        out[key + "chol_df"] = np.asarray(gp.draw_sample(Xs, n=ns, rand_vars=u, diag_factor=1e6))
+        out[key + "chol_uniform"] = np.asarray(gp.draw_sample(Xs, n=ns, rand_vars=uu, rand_type="uniform"))
+        out[key + "chol_scalar_n"] = np.asarray(gp.draw_sample(Xs, n=0, rand_vars=u))
+        # eig: ascending eigenvalues; noise=True keeps them well separated from zero so that Q is reproducible
+        for ms in (None, "left value", "right value", "left slope", "right slope", "left concavity", "right concavity"):
+            tagm = "none" if ms is None else ms.replace(" ", "_")
+            out[key + "eig_" + tagm] = np.asarray(
+                gp.draw_sample(Xs, n=0, rand_vars=u, method="eig", modify_sign=ms, noise=True))
+        out[key + "eig_num5"] = np.asarray(
+            gp.draw_sample(Xs, n=0, rand_vars=u, method="eig", num_eig=5, modify_sign="left value", noise=True))
+        # predict(return_samples=True): samples through samp_kwargs (deterministic), and full_output's other entries
+        o = gp.predict(Xs, n=ns, full_output=True, return_samples=True, samp_kwargs={"rand_vars": u})
+        out[key + "pred_mean"], out[key + "pred_std"] = np.asarray(o["mean"]), np.asarray(o["std"])
+        out[key + "pred_cov"], out[key + "pred_samp"] = np.asarray(o["cov"]), np.asarray(o["samp"])
+        # the seeded multivariate_normal route (no rand_vars): noise=True keeps the SVD's vectors well defined
+        np.random.seed(99)
+        o = gp.predict(Xs, n=0, noise=True, full_output=True, return_samples=True, num_samples=4)
+        out[key + "pred_mvn_samp"] = np.asarray(o["samp"])
+        out[key + "pred_mvn_cov"] = np.asarray(o["cov"])
+        # full_MC: mean / covariance estimated from the samples (gaussian_process.py:1003-1005)
+        o = gp.predict(Xs, n=0, noise=True, full_output=True, full_MC=True, num_samples=6,
+                       samp_kwargs={"rand_vars": u6}, ddof=1)
+        out[key + "mc_mean"], out[key + "mc_cov"], out[key + "mc_samp"] = (
+            np.asarray(o["mean"]), np.asarray(o["cov"]), np.asarray(o["samp"]))
+    save("g12_batch_samples", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g34", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g34", "g5", "g6", "g7", "g8", "g9", "g10", "g12"]
     if "g11" in which:
         gen_g11()
+    if "g12" in which:
+        gen_g12()
     if "g10" in which:
         gen_g10()
     if "g1" in which:

@@ -2,7 +2,7 @@
 
 Used only by ``gen_golden.py`` to produce the committed ``*.npz`` fixtures.  It
 (1) restores the numpy aliases that modern scipy no longer re-exports (the
-reference calls ``scipy.asarray``, ``scipy.tile`` ... everywhere), (2) builds the
+reference calls ``scipy.asarray``, ``scipy.tile`` ... everywhere; ``eigh(eigvals=...)``), (2) builds the
 reference's own Cython/C Matern-5/2 extension *out of tree* in a temp dir from
 the sources where they lie under /root/reference, and (3) imports
 ``/root/reference/gptools`` unchanged.  Nothing from the reference is copied
@@ -51,6 +51,15 @@ def import_reference():
                 setattr(scipy, name, getattr(numpy, name))
             except Exception:
                 pass
+    # scipy >= 1.14 dropped eigh's ``eigvals=(lo, hi)`` keyword, which draw_sample(method='eig') passes
+    # (gaussian_process.py:1304-1307); same meaning under its new name
+    _eigh = scipy.linalg.eigh
+
+    def eigh_compat(a, *args, **kw):
+        if "eigvals" in kw:
+            kw["subset_by_index"] = kw.pop("eigvals")
+        return _eigh(a, *args, **kw)
+    scipy.linalg.eigh = eigh_compat
     tmp = tempfile.mkdtemp(prefix="gptools_ref_matern_")
     _build_matern(tmp)
     sys.path.insert(0, tmp)

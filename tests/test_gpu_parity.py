@@ -1627,11 +1627,12 @@ def test_device_ll_gradient_with_transform_mixed_sum_and_block_inverses(g, case)
 
 @pytest.mark.parametrize("kern,N,d,deriv", [("m52", 700, 3, True), ("se", 1100, 2, False), ("se", 130, 1, False),
                                             ("m52", 2700, 2, True)])
-def test_fit_batch_is_bit_identical_to_single_fits(kern, N, d, deriv):
+def test_fit_batch_is_bit_identical_to_single_fits(oracle, kern, N, d, deriv):
     """gpt_fit_batch (every kernel of the small-N factorisation carries the batch in a grid dimension; SURVEY 8f-2, ref
     gaussian_process.py:1607-1692 / :723-735) against one gpt_fit per hyperparameter vector: ll and log-determinant
     bit for bit (same kernels, same tile choice, same summation orders), per-element targets and noise variances, an element
-    that is not positive definite reported through info without disturbing the others."""
+    that is not positive definite reported through info without disturbing the others; elements of the batch also against
+    the CPU oracle (ll 1e-9, log-determinant 1e-10)."""
     from gptools_amd import _lib
     X, n, y = c3_inputs(N, d)
     if not deriv:
@@ -1654,6 +1655,10 @@ def test_fit_batch_is_bit_identical_to_single_fits(kern, N, d, deriv):
             continue
         l1, d1 = c.fit(KID[kern], P[b], nv[b], Y[b], err, 1e2 * EPS)
         assert (l1, d1) == (ll[b], ld[b]), (b, l1 - ll[b], d1 - ld[b])
+        if b % 4 == 0 or N <= 600:           # ... and every (N <= 600) / every fourth element against the CPU oracle
+            ref = oracle.fit(kern, P[b], X, n, Y[b], err, noise_var=nv[b], chol="c" if N <= 600 else "scipy")
+            assert abs(ll[b] - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"]), (b, ll[b], ref["ll_data"])
+            assert abs(ld[b] - ref["logdet_half"]) <= 1e-10 * max(1.0, abs(ref["logdet_half"])), b
     # a second batch of another size on the same context, after single fits
     ll2, ld2, info2 = c.fit_batch(KID[kern], P[:3], nv[:3], Y[:3], err, 1e2 * EPS)
     assert np.array_equal(ll2, ll[:3]) and np.array_equal(ld2, ld[:3]) and not info2.any()
@@ -1993,3 +1998,175 @@ def test_fit_batch_terms_products_and_transform_bit_identical(g, case):
         assert calls, "ll_batch did not take the batched evaluator for case %s" % case
         one = np.array([-gp.update_hyperparameters(p) for p in pts])
         np.testing.assert_array_equal(vals, one)
+
+
+
+# ---------------------------------------------------------------- G12: independent evaluations and samples against the reference
+def _g12_grid_gp(g, G, kern):
+    cls = g.SquaredExponentialKernel if kern == "se" else g.Matern52Kernel
+    k = cls(num_dim=2, initial_params=[1.2, 0.35, 0.4], param_bounds=[(1e-3, 10.0)] * 3, fixed_params=[False, False, True])
+    return g.GaussianProcess(k, X=G["grid_X"], y=G["grid_y"], err_y=0.05, n=G["grid_n"])
+
+
+@pytest.mark.parametrize("kern", KERNELS)
+def test_g12_compute_ll_matrix_against_the_reference(g, golden, oracle, kern):
+    """compute_ll_matrix (ref gaussian_process.py:1607-1692) on the grid the REFERENCE walked (tests/golden/gen_golden.py g12):
+    same grid axes, same shape (first free parameter = first axis), the out-of-bounds row -inf, the log-posterior at every
+    other point to 1e-9, the GP left at its hyperparameters with its own ll -- through each of the three evaluators
+    (one launch sequence for the batch = gpt_fit_batch_terms, two contexts in flight, one call per point), and the C-ABI
+    batch entry itself (gpt_fit_batch) against the fixture's data term and the CPU oracle."""
+    G = golden("g12_batch_samples")
+    want = G["grid_%s_ll" % kern]
+    for mode in ("grid", "threads", "sequential"):
+        gp = _g12_grid_gp(g, G, kern)
+        if mode == "threads":
+            gp.batch_grid = 1
+        elif mode == "sequential":
+            gp.batch_concurrency = 1
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ll, pv = gp.compute_ll_matrix([(0.4, 12.0), (0.1, 0.9)], [5, 4])
+        assert ll.shape == want.shape == (5, 4)
+        np.testing.assert_array_equal(pv[0], G["grid_%s_p0" % kern])
+        np.testing.assert_array_equal(pv[1], G["grid_%s_p1" % kern])
+        np.testing.assert_array_equal(np.isneginf(ll), np.isneginf(want), err_msg=mode)
+        assert np.isneginf(want[4]).all() and np.isfinite(want[:4]).all()
+        assert_close(ll, want, rtol=1e-9, atol_scale=0.0, msg=mode)
+        np.testing.assert_array_equal(gp.free_params[:], G["grid_%s_free_after" % kern])
+        assert abs(gp.ll - G["grid_%s_ll_after" % kern]) <= 1e-9 * abs(G["grid_%s_ll_after" % kern])
+    # the C ABI's batch entry on the same grid: data term = fixture - log prior (uniform over the bounds: a constant)
+    gp = _g12_grid_gp(g, G, kern)
+    prior = gp.hyperprior(gp.params)
+    pts = [(a, b) for a in G["grid_%s_p0" % kern][:4] for b in G["grid_%s_p1" % kern]]
+    P = np.array([[a, b, 0.4] for a, b in pts])
+    X, n, y = G["grid_X"], G["grid_n"], G["grid_y"]
+    from gptools_amd import _lib
+    c = _lib.Context(0)
+    c.set_data(X, n)
+    ll, ld, info = c.fit_batch(KID[kern], P, np.zeros(len(P)), np.tile(y, (len(P), 1)), np.full(len(y), 0.05), 1e2 * EPS)
+    c.close()
+    assert not info.any()
+    assert_close(ll + prior, want[:4].ravel(), rtol=1e-9, atol_scale=0.0, msg="gpt_fit_batch vs reference")
+    for b in range(len(P)):
+        ref = oracle.fit(kern, P[b], X, n, y, np.full(len(y), 0.05))
+        assert abs(ll[b] - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"])
+        assert abs(ld[b] - ref["logdet_half"]) <= 1e-10 * max(1.0, abs(ref["logdet_half"]))
+
+
+def test_g12_ll_matrix_three_free_parameters_noise_kernel_gamma_prior(g, golden):
+    """compute_ll_matrix with ONE (bounds, num_pts) pair for three free parameters -- sigma_f, l_1 and the noise kernel's
+    sigma_n -- under a Gamma hyperprior (the prior term varies over the grid): reference fixture, 1e-9."""
+    G = golden("g12_batch_samples")
+    k = g.SquaredExponentialKernel(num_dim=2, initial_params=[1.0, 0.3, 0.5], fixed_params=[False, False, True],
+                                   hyperprior=g.GammaJointPriorAlt([1.0, 0.4, 0.5], [0.5, 0.2, 0.3]))
+    nk = g.DiagonalNoiseKernel(num_dim=2, initial_noise=0.1, fixed_noise=False, noise_bound=(1e-3, 1.0))
+    for conc in (2, 1):
+        gp = g.GaussianProcess(k, noise_k=nk, X=G["grid_X"], y=G["grid_y"], err_y=0.02, n=G["grid_n"])
+        gp.batch_concurrency = conc
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ll, pv = gp.compute_ll_matrix((0.05, 0.8), 3)
+        assert ll.shape == (3, 3, 3)
+        np.testing.assert_array_equal(np.asarray(pv), G["grid3_p"])
+        assert_close(ll, G["grid3_ll"], rtol=1e-9, atol_scale=0.0)
+
+
+@pytest.mark.parametrize("tag", ["fd", "hd"])
+def test_g12_random_starts_against_the_reference(g, golden, tag):
+    """optimize_hyperparameters(random_starts=5) (ref gaussian_process.py:689-735, :2443-2486): with numpy's global state
+    seeded like the generator's, the starts drawn from the hyperprior are the reference's draws bit for bit; each start's
+    SLSQP run ends where the reference's did; the start with the lowest objective is the one returned, all five count as
+    completed, and the GP is left at that optimum.  'fd': scipy's finite differences (through the batched evaluator
+    here), 'hd': use_hyper_deriv=True (the analytic gradient, gpt_ll_grad).  Tolerances: objective 2e-6 absolute -- SLSQP's own
+    stopping rule is ftol = 1e-6 on the objective, and forward differences with h = 1.5e-8 turn the 1e-12 agreement of two ll
+    values into 1e-4 of gradient, so two correct implementations stop within that of each other, not closer -- and location
+    2e-3 relative (the objective is flat to ~1e-6 over that range)."""
+    G = golden("g12_batch_samples")
+
+    def make():
+        k = g.SquaredExponentialKernel(num_dim=1, initial_params=[1.0, 0.3], param_bounds=[(0.05, 20.0), (0.02, 3.0)])
+        return g.GaussianProcess(k, X=G["rs_X"], y=G["rs_y"], err_y=0.05, n=G["rs_n"], use_hyper_deriv=(tag == "hd"))
+    gp = make()
+    np.random.seed(4242)
+    free = ~np.asarray(gp.fixed_params[:], dtype=bool)
+    draws = np.atleast_2d(gp.hyperprior.random_draw(size=5).T)[:, free]
+    np.testing.assert_array_equal(draws, G["rs_%s_draws" % tag])
+    per = G["rs_%s_per_start" % tag]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for s, want in zip(draws, per):                     # one start at a time: where each of them ends
+            gp1 = make()
+            gp1.free_params = s
+            r, cnt = gp1.optimize_hyperparameters(method="SLSQP", random_starts=0)
+            assert cnt == 1 and bool(r.success) == bool(want[3])
+            assert abs(r.fun - want[2]) <= 2e-6, (s, r.fun, want[2])
+            np.testing.assert_allclose(r.x, want[:2], rtol=2e-3)
+        np.random.seed(4242)
+        res, count = gp.optimize_hyperparameters(method="SLSQP", random_starts=5, num_proc=0)
+    assert count == int(G["rs_%s_count" % tag]) == 5
+    assert abs(res.fun - G["rs_%s_fun" % tag]) <= 2e-6
+    np.testing.assert_allclose(res.x, G["rs_%s_x" % tag], rtol=2e-3)
+    assert res.fun <= per[:, 2].min() + 2e-6                                   # the best start is the one returned
+    np.testing.assert_array_equal(gp.free_params[:], res.x)                     # ... and the GP is left there
+    assert abs(gp.ll - G["rs_%s_ll_after" % tag]) <= 2e-6
+    assert abs(gp.ll + res.fun) <= 1e-12 * abs(res.fun)
+
+
+@pytest.mark.parametrize("kern", KERNELS)
+def test_g12_draw_sample_and_predict_samples_against_the_reference(g, golden, kern):
+    """draw_sample(rand_vars=u) (ref gaussian_process.py:1155-1330) and predict(return_samples / full_MC) (:990-1005)
+    against samples the REFERENCE produced from the same u: Cholesky route (device: gpt_predict with the covariance left in
+    HBM + gpt_cov_sample; host route with mean= / cov=), diag_factor, noise=True, uniform variates through the normal
+    quantile, scalar n, the eigen route with every modify_sign option and num_eig, the full_output dict, the seeded
+    multivariate_normal route and full_MC's sample moments.  Tolerances: the Cholesky factor of cov + 1e3 eps I amplifies the
+    1e-13 agreement of the covariances by the factor's condition -- 1e-7 absolute without the noise term, 1e-10 with it."""
+    G = golden("g12_batch_samples")
+    cls = g.SquaredExponentialKernel if kern == "se" else g.Matern52Kernel
+    k = cls(num_dim=2, initial_params=[1.1, 0.4, 0.3], param_bounds=[(1e-3, 10.0)] * 3)
+    nk = g.DiagonalNoiseKernel(num_dim=2, initial_noise=0.07, fixed_noise=True)
+    gp = g.GaussianProcess(k, noise_k=nk, X=G["samp_X"], y=G["samp_y"], err_y=0.05, n=G["samp_n"])
+    Xs, ns, u, uu, u6 = G["samp_Xs"], G["samp_ns"], G["samp_u"], G["samp_uu"], G["samp_u6"]
+    key = "samp_%s_" % kern
+
+    def close(a, b, atol, msg):
+        a = np.asarray(a)
+        assert a.shape == b.shape, msg
+        np.testing.assert_allclose(a, b, rtol=0, atol=atol, err_msg=msg)
+    o = gp.predict(Xs, n=ns, full_output=True, return_samples=True, samp_kwargs={"rand_vars": u})
+    assert set(o) == {"mean", "std", "cov", "samp"}
+    close(o["mean"], G[key + "pred_mean"], 1e-9, "mean")
+    close(o["cov"], G[key + "pred_cov"], 1e-10, "cov")
+    close(o["std"] ** 2, G[key + "pred_std"] ** 2, 1e-10, "std")
+    close(o["samp"], G[key + "pred_samp"], 1e-7, "predict(return_samples) host route")
+    np.testing.assert_array_equal(G[key + "pred_samp"], G[key + "chol"])        # (the reference's two spellings agree)
+    close(gp.draw_sample(Xs, n=ns, rand_vars=u), G[key + "chol"], 1e-7, "device route")
+    close(gp.draw_sample(Xs, n=ns, rand_vars=u, mean=o["mean"], cov=o["cov"]), G[key + "chol"], 1e-7, "host route")
+    close(gp.draw_sample(Xs, n=ns, rand_vars=u, noise=True), G[key + "chol_noise"], 1e-10, "noise")
+    close(gp.draw_sample(Xs, n=ns, rand_vars=u, diag_factor=1e6), G[key + "chol_df"], 1e-7, "diag_factor")
+    close(gp.draw_sample(Xs, n=ns, rand_vars=uu, rand_type="uniform"), G[key + "chol_uniform"], 1e-7, "uniform")
+    close(gp.draw_sample(Xs, n=0, rand_vars=u), G[key + "chol_scalar_n"], 1e-7, "scalar n")
+    for ms in (None, "left value", "right value", "left slope", "right slope", "left concavity", "right concavity"):
+        tagm = "none" if ms is None else ms.replace(" ", "_")
+        got = gp.draw_sample(Xs, n=0, rand_vars=u, method="eig", modify_sign=ms, noise=True)
+        if ms is None:
+            # LAPACK leaves the sign of an eigenvector open; the reference does not fix it either: compare the sample's
+            # deviation from the mean mode by mode only through what IS determined -- L L^T
+            pm = gp.predict(Xs, n=0, noise=True, full_output=True)
+            dev_g, dev_w = got - pm["mean"][:, None], G[key + "eig_none"] - pm["mean"][:, None]
+            lam, Q = np.linalg.eigh(pm["cov"] + 1e3 * EPS * np.eye(len(Xs)))
+            cg, cw = Q.T.dot(dev_g), Q.T.dot(dev_w)                 # = +- sqrt(lam_i) u_i row by row
+            np.testing.assert_allclose(np.abs(cg), np.abs(cw), rtol=0, atol=1e-9)
+            np.testing.assert_allclose(np.abs(cw), np.sqrt(lam)[:, None] * np.abs(u), rtol=0, atol=1e-9)
+        else:
+            close(got, G[key + "eig_" + tagm], 1e-9, "eig " + tagm)
+    close(gp.draw_sample(Xs, n=0, rand_vars=u, method="eig", num_eig=5, modify_sign="left value", noise=True),
+          G[key + "eig_num5"], 1e-9, "num_eig")
+    np.random.seed(99)
+    o = gp.predict(Xs, n=0, noise=True, full_output=True, return_samples=True, num_samples=4)
+    close(o["cov"], G[key + "pred_mvn_cov"], 1e-10, "mvn cov")
+    close(o["samp"], G[key + "pred_mvn_samp"], 1e-8, "seeded multivariate_normal route")
+    o = gp.predict(Xs, n=0, noise=True, full_output=True, full_MC=True, num_samples=6, samp_kwargs={"rand_vars": u6}, ddof=1)
+    close(o["samp"], G[key + "mc_samp"], 1e-10, "full_MC samples")
+    close(o["mean"], G[key + "mc_mean"], 1e-10, "full_MC mean")
+    close(o["cov"], G[key + "mc_cov"], 1e-10, "full_MC cov")
+    close(o["std"], np.sqrt(np.diag(G[key + "mc_cov"])), 1e-10, "full_MC std")
