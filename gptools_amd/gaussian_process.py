@@ -25,7 +25,7 @@ import numpy as np
 import scipy.linalg
 import scipy.optimize
 
-from . import _lib
+from . import _lib, _ingest
 from . import replicas
 from .error_handling import GPArgumentError, GPImpossibleParamsError
 from .kernel import Kernel, ZeroKernel, DiagonalNoiseKernel, SumKernel, ProductKernel
@@ -34,6 +34,21 @@ from .utils import CombinedBounds
 __all__ = ["GaussianProcess"]
 
 _NATIVE_FIT = (_lib.KERNEL_SE, _lib.KERNEL_M52, _lib.KERNEL_RQ, _lib.KERNEL_MATERN)
+
+
+def _uniform_to_normal(u):
+    from scipy.stats import norm
+    return norm.ppf(u)
+
+
+# draw_sample: how the given variates are distributed -> what turns them into standard normals
+_VARIATE_KINDS = {"standard normal": lambda u: u, "uniform": _uniform_to_normal}
+# draw_sample(modify_sign=...): e = the three entries of every eigenvector at the chosen end, in index order
+_SIGN_FEATURES = {
+    "value": lambda e, where: e[0] if where == "left" else e[-1],
+    "slope": lambda e, where: (e[1] - e[0]) if where == "left" else (e[-1] - e[-2]),
+    "concavity": lambda e, where: e[2] - 2.0 * e[1] + e[0],
+}
 
 
 def _combine(a, b, c=None):
@@ -229,59 +244,26 @@ class GaussianProcess(object):
 
     # ---- data ingest (ref: gptools/gaussian_process.py:376-503) ------------------------------
     def add_data(self, X, y, err_y=0, n=0, T=None):
-        """Append observations.  ``X`` (M, D), ``y`` (M,), ``err_y`` scalar or (M,) standard
-        deviations, ``n`` scalar or (M, D) derivative orders, ``T`` optional (M, N) transform."""
-        y = np.atleast_1d(np.asarray(y, dtype=float))
-        if y.ndim != 1:
-            raise ValueError("Training targets y must have only one dimension with length greater than one! "
-                             "Shape of y given is {}".format(y.shape))
-        try:
-            iter(err_y)
-        except TypeError:
-            err_y = err_y * np.ones_like(y, dtype=float)
-        else:
-            err_y = np.asarray(err_y, dtype=float)
-            if err_y.shape != y.shape:
-                raise ValueError("When using array-like err_y, shape must match shape of y! Shape of err_y given is "
-                                 "{}, shape of y given is {}.".format(err_y.shape, y.shape))
-        if (err_y < 0).any():
-            raise ValueError("All elements of err_y must be non-negative!")
-        X = np.atleast_2d(np.asarray(X, dtype=float))
-        if self.num_dim == 1 and X.shape[0] == 1:
-            X = X.T
-        if T is None and X.shape != (len(y), self.num_dim):
-            raise ValueError("Shape of training inputs must be (len(y), k.num_dim)! X given has shape {}, shape of "
-                             "y is {} and num_dim={:d}.".format(X.shape, y.shape, self.num_dim))
-        try:
-            iter(n)
-        except TypeError:
-            n = n * np.ones_like(X, dtype=int)
-        else:
-            n = np.atleast_2d(np.asarray(n, dtype=int))
-            if self.num_dim == 1 and n.shape[1] != 1:
-                n = n.T
-            if n.shape != X.shape:
-                raise ValueError("When using array-like n, shape must be (len(y), k.num_dim)! Shape of n given is "
-                                 "{}, shape of y given is {} and num_dim={:d}.".format(n.shape, y.shape, self.num_dim))
-        if (n < 0).any():
-            raise ValueError("All elements of n must be non-negative integers!")
-        if T is None and self.T is not None:
-            T = np.eye(len(y))
-        if T is not None:
-            T = np.atleast_2d(np.asarray(T, dtype=float))
-            if T.ndim != 2:
-                raise ValueError("T must have exactly 2 dimensions!")
-            if T.shape[0] != len(y):
-                raise ValueError("T must have as many rows are there are elements in y!")
-            if T.shape[1] != X.shape[0]:
-                raise ValueError("There must be as many columns in T as there are rows in X!")
+        """Append observations: ``y`` (M,) observed at ``X`` (M, D) with standard deviations ``err_y`` (scalar or (M,))
+        and derivative orders ``n`` (scalar or (M, D)).  With ``T`` (M, N') the observations are linear combinations
+        ``T f(X)`` of the process at N' points ``X`` (line integrals); once any block has a transform, blocks without one
+        get the identity and the blocks sit on the diagonal of ``self.T``.  Forms accepted: ``gptools_amd._ingest``."""
+        y = _ingest.targets(y)
+        err_y = _ingest.noise_levels(err_y, y)
+        X = _ingest.points(X, self.num_dim)
+        if T is None and X.shape[0] != y.size:
+            raise ValueError("%d points for %d observations (without a transform T there is one point per observation)"
+                             % (X.shape[0], y.size))
+        n = _ingest.derivative_orders(n, X, self.num_dim, column_rule="not-column")
+        if T is not None or self.T is not None:
+            block = np.eye(y.size) if T is None else _ingest.linear_map(T, y.size, X.shape[0])
             if self.T is None and self.X is not None:
-                self.T = np.eye(len(self.y))
-            self.T = T if self.T is None else scipy.linalg.block_diag(self.T, T)
-        self.X = X if self.X is None else np.vstack((self.X, X))
-        self.y = np.append(self.y, y)
-        self.err_y = np.append(self.err_y, err_y)
-        self.n = n if self.n is None else np.vstack((self.n, n))
+                self.T = np.eye(self.y.size)               # what was there so far was observed directly
+            self.T = block if self.T is None else scipy.linalg.block_diag(self.T, block)
+        self.X = X if self.X is None else np.concatenate((self.X, X), axis=0)
+        self.n = n if self.n is None else np.concatenate((self.n, n), axis=0)
+        self.y = np.concatenate((self.y, y))
+        self.err_y = np.concatenate((self.err_y, err_y))
         self.K_up_to_date = False
         self._data_on_device = False
         self._dist_plan = None
@@ -523,44 +505,48 @@ class GaussianProcess(object):
         self.ll_deriv = ll_deriv
 
     # ---- hyperparameter update (ref: gptools/gaussian_process.py:1332-1416) -------------------
+    def _assign_free(self, values):
+        """Distribute a vector of FREE hyperparameters over the kernel, the noise kernel and the mean function, in the
+        order ``free_params`` lists them (ref: gaussian_process.py:1377-1384)."""
+        values = np.asarray(values, dtype=float)
+        at = 0
+        for part in self._parts():
+            cnt = len(part.free_params)
+            part.set_hyperparams(values[at:at + cnt])
+            at += cnt
+        self.K_up_to_date = False
+
     def update_hyperparameters(self, new_params, hyper_deriv_handling="default", exit_on_bounds=True,
                                inf_on_error=True):
-        """Set the free hyperparameters and refit; returns ``-ll`` (and ``-ll_deriv``).  Impossible
-        parameters and linear-algebra failures give ``+inf`` when ``inf_on_error``."""
-        use_hyper_deriv = self.use_hyper_deriv
-        if hyper_deriv_handling == "value":
-            self.use_hyper_deriv = False
-        elif hyper_deriv_handling == "deriv":
-            self.use_hyper_deriv = True
-        new_params = np.asarray(new_params, dtype=float)
-        nk, nn = len(self.k.free_params), len(self.noise_k.free_params)
-        self.k.set_hyperparams(new_params[:nk])
-        self.noise_k.set_hyperparams(new_params[nk:nk + nn])
-        if self.mu is not None:
-            self.mu.set_hyperparams(new_params[nk + nn:])
-        self.K_up_to_date = False
+        """Set the free hyperparameters and evaluate the negative log-posterior there -- the objective an optimiser
+        minimises (ref: gptools/gaussian_process.py:1332-1416).
+
+        Returns ``-ll``; ``(-ll, -ll_deriv)`` when the GP uses hyperparameter derivatives; ``hyper_deriv_handling`` =
+        ``'value'`` / ``'deriv'`` asks for one of the two alone whatever the GP's setting.  Hyperparameters the prior
+        rules out (``exit_on_bounds``) and any failure of the evaluation -- a covariance matrix that is not positive
+        definite above all -- count as ``+inf`` (gradient: zeros) while ``inf_on_error`` is set; otherwise they raise."""
+        want_value = hyper_deriv_handling != "deriv"
+        want_deriv = hyper_deriv_handling == "deriv" or (hyper_deriv_handling == "default" and self.use_hyper_deriv)
+        configured = self.use_hyper_deriv
+        self.use_hyper_deriv = want_deriv
         try:
+            self._assign_free(new_params)
             if exit_on_bounds and np.isinf(self.hyperprior(self.params)):
-                raise GPImpossibleParamsError("Impossible values for params!")
+                raise GPImpossibleParamsError("the hyperprior excludes these hyperparameters")
             self.compute_K_L_alpha_ll(need_factor=False)
-        except Exception as e:
-            self.use_hyper_deriv = use_hyper_deriv
+            value, deriv = -1.0 * self.ll, (-1.0 * self.ll_deriv if want_deriv else None)
+        except Exception as exc:
             if not inf_on_error:
-                raise e
-            if not isinstance(e, GPImpossibleParamsError) and self.verbose:
-                warnings.warn("Unhandled exception when updating GP! Exception was:\n{:s}\nState of params is: "
-                              "{:s}".format(traceback.format_exc(), str(self.free_params[:])))
-            if use_hyper_deriv and hyper_deriv_handling == "default":
-                return (np.inf, np.zeros(len(self.free_params)))
-            if hyper_deriv_handling == "deriv":
-                return np.zeros(len(self.free_params))
-            return np.inf
-        self.use_hyper_deriv = use_hyper_deriv
-        if use_hyper_deriv and hyper_deriv_handling == "default":
-            return (-1.0 * self.ll, -1.0 * self.ll_deriv)
-        if hyper_deriv_handling == "deriv":
-            return -1.0 * self.ll_deriv
-        return -1.0 * self.ll
+                raise
+            if self.verbose and not isinstance(exc, GPImpossibleParamsError):
+                warnings.warn("evaluation failed at free hyperparameters %s and counts as +inf:\n%s"
+                              % (self.free_params[:], traceback.format_exc()))
+            value, deriv = np.inf, np.zeros(len(self.free_params))
+        finally:
+            self.use_hyper_deriv = configured
+        if want_value and want_deriv:
+            return (value, deriv)
+        return value if want_value else deriv
 
     # ---- independent evaluations (ref: gptools/gaussian_process.py:1607-1692; SURVEY.md 8f-2) ----
     #: independent LML evaluations kept in flight on one GPU.  While one factorisation is in its latency-bound tail
@@ -608,12 +594,7 @@ class GaussianProcess(object):
                 return out
             return self._ll_batch_local(param_list, exit_on_bounds)
         finally:
-            nk, nn = len(self.k.free_params), len(self.noise_k.free_params)
-            self.k.set_hyperparams(keep[:nk])
-            self.noise_k.set_hyperparams(keep[nk:nk + nn])
-            if self.mu is not None:
-                self.mu.set_hyperparams(keep[nk + nn:])
-            self.K_up_to_date = False
+            self._assign_free(keep)
             self.partitioned = keep_partitioned
 
     def _ll_batch_local(self, param_list, exit_on_bounds):
@@ -630,14 +611,10 @@ class GaussianProcess(object):
             return out
         # host part, in order: the kernel / mean objects are shared, so the numeric inputs of every evaluation are
         # extracted one after another; only the GPU work overlaps
-        nk, nn = len(self.k.free_params), len(self.noise_k.free_params)
         diag_add = self.diag_factor * sys.float_info.epsilon
         jobs = []
         for i, p in enumerate(param_list):
-            self.k.set_hyperparams(p[:nk])
-            self.noise_k.set_hyperparams(p[nk:nk + nn])
-            if self.mu is not None:
-                self.mu.set_hyperparams(p[nk + nn:])
+            self._assign_free(p)
             prior = self.hyperprior(self.params)
             if exit_on_bounds and np.isinf(prior):
                 continue                                            # impossible parameters: stays -inf
@@ -748,39 +725,39 @@ class GaussianProcess(object):
             pts = []
             approx_derivative(lambda z: (pts.append(np.array(z, dtype=float)), 0.0)[1], x, **kw)
             vals = -1.0 * self._ll_batch_local(pts, True)
-            nk, nn = len(self.k.free_params), len(self.noise_k.free_params)
-            self.k.set_hyperparams(x[:nk])                       # back to the expansion point
-            self.noise_k.set_hyperparams(x[nk:nk + nn])
-            if self.mu is not None:
-                self.mu.set_hyperparams(x[nk + nn:])
-            self.K_up_to_date = False
+            self._assign_free(x)                                 # back to the expansion point
             table = {p.tobytes(): v for p, v in zip(pts, vals)}
             return approx_derivative(lambda z: table[np.array(z, dtype=float).tobytes()], x, **kw)
         return fun, jac
 
     def compute_ll_matrix(self, bounds, num_pts):
-        """Log-posterior over a regular grid of the free hyperparameters (ref: gptools/gaussian_process.py:1607-1692):
-        returns ``(ll_vals, param_vals)`` with ``ll_vals.shape == num_pts``.  The reference walks the grid
-        recursively, one evaluation at a time; here the grid points go through :meth:`ll_batch`."""
-        present_free_params = self.free_params[:]
-        bounds = np.atleast_2d(np.asarray(bounds, dtype=float))
-        if bounds.shape[1] != 2:
-            raise ValueError("Argument bounds must have shape (n, 2)!")
-        if bounds.shape[0] == 1:
-            bounds = np.tile(bounds, (len(present_free_params), 1))
-        try:
-            iter(num_pts)
-        except TypeError:
-            num_pts = num_pts * np.ones(bounds.shape[0], dtype=int)
-        else:
-            num_pts = np.asarray(num_pts, dtype=int)
-            if len(num_pts) != len(present_free_params):
-                raise ValueError("Length of num_pts must match the number of free parameters!")
-        param_vals = [np.linspace(bounds[k, 0], bounds[k, 1], num_pts[k]) for k in range(len(present_free_params))]
-        grid = np.stack([g.ravel() for g in np.meshgrid(*param_vals, indexing="ij")], axis=1)
-        ll_vals = self.ll_batch(list(grid)).reshape(tuple(int(v) for v in num_pts))
-        self.update_hyperparameters(np.asarray(present_free_params, dtype=float))
-        return (ll_vals, param_vals)
+        """Log-posterior on a regular grid over the free hyperparameters (ref: gptools/gaussian_process.py:1607-1692).
+
+        ``bounds``: one ``(low, high)`` pair for all free hyperparameters or one pair each; ``num_pts``: one count or
+        one per hyperparameter.  Returns ``(ll_vals, param_vals)``: the grid axes ``param_vals[i] = linspace(low_i,
+        high_i, num_pts[i])`` and ``ll_vals`` of shape ``num_pts`` (axis i = free hyperparameter i; ``-inf`` where the
+        prior excludes the point or the evaluation fails).  The reference walks the grid recursively, one evaluation
+        at a time; here all points go through :meth:`ll_batch`.  The GP is left at its present hyperparameters."""
+        here = np.array(self.free_params[:], dtype=float)
+        nfree = here.size
+        box = np.asarray(bounds, dtype=float)
+        if box.ndim == 1:
+            box = box[None, :]
+        if box.ndim != 2 or box.shape[1] != 2:
+            raise ValueError("bounds must be a (low, high) pair or one pair per free hyperparameter")
+        if box.shape[0] == 1:
+            box = np.repeat(box, nfree, axis=0)
+        counts = np.asarray(num_pts, dtype=int)
+        if counts.ndim == 0:
+            counts = np.full(box.shape[0], int(counts))
+        elif counts.size != nfree:
+            raise ValueError("num_pts lists %d counts for %d free hyperparameters" % (counts.size, nfree))
+        axes = [np.linspace(lo, hi, c) for (lo, hi), c in zip(box[:nfree], counts)]
+        mesh = np.meshgrid(*axes, indexing="ij")
+        points = np.column_stack([m.ravel() for m in mesh])
+        ll_vals = self.ll_batch(list(points)).reshape([int(c) for c in counts[:nfree]])
+        self.update_hyperparameters(here)
+        return (ll_vals, axes)
 
     # ---- MAP estimate (ref: gptools/gaussian_process.py:623-783, :2443-2486) ------------------
     def optimize_hyperparameters(self, method="SLSQP", opt_kwargs={}, verbose=False, random_starts=None,
@@ -833,80 +810,58 @@ class GaussianProcess(object):
                 return scipy.optimize.minimize(objective, samp, **opt_kwargs)
             except Exception:
                 if self.verbose:
-                    warnings.warn("Minimizer failed, skipping sample. Error is: {:s}. State of params is: "
-                                  "{:s}".format(traceback.format_exc(), str(self.free_params[:])), RuntimeWarning)
+                    warnings.warn("start %s dropped, the optimiser raised (free hyperparameters now %s):\n%s"
+                                  % (samp, self.free_params[:], traceback.format_exc()), RuntimeWarning)
                 return None
 
-        trial, res_min, res = 0, None, []
-        while trial < max_tries and res_min is None:
-            if trial >= 1 and random_starts != 0:
-                param_samples = draw()
-            trial += 1
+        best, finished = None, []
+        for attempt in range(max(int(max_tries), 0)):
+            if attempt > 0 and random_starts != 0:
+                param_samples = draw()                        # nothing usable last time: fresh draws
             if partitioned and replicas.world_size() > 1:
                 # ... and every rank walks all the starts (rank 0's draws), in the same order
                 param_samples = list(replicas.shared(np.asarray(param_samples)))
-                res = [r for r in (run(s) for s in param_samples) if r is not None]
+                outcomes = [run(s) for s in param_samples]
             elif replicas.world_size() > 1 and len(param_samples) > 1:
                 # one start per GPU: the ranks of the torch.distributed job replace the reference's process pool
                 param_samples = replicas.shared(np.asarray(param_samples))
-                res = [r for r in replicas.distributed_map(run, list(param_samples)) if r is not None]
+                outcomes = replicas.distributed_map(run, list(param_samples))
             else:
-                res = [r for r in (run(s) for s in param_samples) if r is not None]
-            finite = [r for r in res if np.isfinite(r.fun)]
-            res_min = min(finite, key=lambda r: r.fun) if finite else None
-        if res_min is None:
-            raise ValueError("Optimizer failed to find a valid solution. Try changing the parameter bounds, "
-                             "picking a new initial guess or increasing the number of random starts.")
-        self.update_hyperparameters(res_min.x)
+                outcomes = [run(s) for s in param_samples]
+            finished = [r for r in outcomes if r is not None]
+            usable = [r for r in finished if np.isfinite(r.fun)]
+            if usable:
+                best = min(usable, key=lambda r: r.fun)
+                break
+        if best is None:
+            raise ValueError("no start of the optimiser ended at a finite log-posterior; widen or shift the parameter "
+                             "bounds, start elsewhere or use more random starts")
+        self.update_hyperparameters(best.x)
         if verbose:
-            print("Got {:d} completed starts, optimal result is:".format(len(res)))
-            print(res_min)
-            print("\nLL\t{:.3g}".format(-1 * res_min.fun))
-            for v, l in zip(res_min.x, self.free_param_names[:]):
-                print("{:s}\t{:.3g}".format(str(l).replace("\\", ""), v))
-        if not res_min.success:
-            warnings.warn("Optimizer {:s} reports failure, selected hyperparameters are likely NOT optimal. Status: "
-                          "{:d}, Message: '{:s}'. Try adjusting bounds, initial guesses or the number of random "
-                          "starts used.".format(method, res_min.status, str(res_min.message)), RuntimeWarning)
-        bounds = np.asarray(self.free_param_bounds[:], dtype=float)
-        if (res_min.x <= 1.001 * bounds[:, 0]).any() or (res_min.x >= 0.999 * bounds[:, 1]).any():
-            warnings.warn("Optimizer appears to have hit/exceeded the bounds. Bounds are:\n{:s}\n, solution is:\n"
-                          "{:s}. Try adjusting bounds, initial guesses or the number of random starts "
-                          "used.".format(str(bounds), str(res_min.x)))
-        return (res_min, len(res))
+            print("%d starts completed; the best one:" % len(finished))
+            print(best)
+            print("log-posterior %.6g" % (-best.fun))
+            for name, v in zip(self.free_param_names[:], best.x):
+                print("  %s = %.6g" % (str(name).replace("\\", ""), v))
+        if not best.success:
+            warnings.warn("%s stopped without converging (status %s: %s); the hyperparameters it ended at are kept but "
+                          "are probably not the optimum -- other bounds, starting points or more random starts may help"
+                          % (method, best.status, best.message), RuntimeWarning)
+        box = np.asarray(self.free_param_bounds[:], dtype=float)
+        # (within 0.1 % of an edge counts as on it, as in the reference)
+        if np.any(best.x <= 1.001 * box[:, 0]) or np.any(best.x >= 0.999 * box[:, 1]):
+            warnings.warn("the optimum sits on the edge of the parameter bounds\n%s\nat %s: the bounds, not the data, "
+                          "decided it" % (box, best.x))
+        return (best, len(finished))
 
     # ---- prediction (ref: gptools/gaussian_process.py:785-1034) ------------------------------
     def _check_predict_args(self, Xstar, n, output_transform=None):
-        """Shapes and types of ``predict``'s inputs as the reference checks them (ref: gaussian_process.py:913-963)."""
-        Xstar = np.atleast_2d(np.asarray(Xstar, dtype=float))
-        if self.num_dim == 1 and Xstar.shape[0] == 1:
-            Xstar = Xstar.T
-        if Xstar.shape[1] != self.num_dim:
-            raise ValueError("Second dimension of Xstar must be equal to self.num_dim! Shape of Xstar given is "
-                             "{:s}, num_dim is {:d}.".format(str(Xstar.shape), self.num_dim))
+        """Test points, their derivative orders and the optional output transform in the layout ``gpt_predict`` takes
+        (forms accepted: ``gptools_amd._ingest``; ref: gaussian_process.py:913-963)."""
+        Xstar = _ingest.points(Xstar, self.num_dim, "Xstar")
+        n = _ingest.derivative_orders(n, Xstar, self.num_dim, column_rule="row")
         if output_transform is not None:
-            output_transform = np.atleast_2d(np.asarray(output_transform, dtype=float))
-            if output_transform.ndim != 2:
-                raise ValueError("output_transform must have exactly 2 dimensions! Shape of output_transform given "
-                                 "is {:s}.".format(str(output_transform.shape)))
-            if output_transform.shape[1] != Xstar.shape[0]:
-                raise ValueError("output_transform must have the same number of columns the number of rows in "
-                                 "Xstar! Shape of output_transform given is {:s}, shape of Xstar is "
-                                 "{:s}.".format(str(output_transform.shape), str(Xstar.shape)))
-        try:
-            iter(n)
-        except TypeError:
-            n = n * np.ones(Xstar.shape, dtype=int)
-        else:
-            n = np.atleast_2d(np.asarray(n, dtype=int))
-            if self.num_dim == 1 and n.shape[0] == 1:
-                n = n.T
-            if n.shape != Xstar.shape:
-                raise ValueError("When using array-like n, shape must match shape of Xstar! Shape of n given is "
-                                 "{:s}, shape of Xstar given is {:s}.".format(str(n.shape), str(Xstar.shape)))
-        if (n < 0).any():
-            raise ValueError("All elements of n must be non-negative integers!")
-
+            output_transform = _ingest.linear_map(output_transform, None, Xstar.shape[0], "output_transform")
         return Xstar, n, output_transform
 
     def predict(self, Xstar, n=0, noise=False, return_std=True, return_cov=False, full_output=False,
@@ -1006,52 +961,47 @@ class GaussianProcess(object):
                         rv = _norm.ppf(rv)
                     return np.atleast_2d(mean_d).T + self._ctx.cov_sample(diag_factor * sys.float_info.epsilon, rv)
         if mean is None or cov is None:
-            out = self.predict(Xstar, n=n, full_output=True, **kwargs)
-            mean, cov = out["mean"], out["cov"]
+            both = self.predict(Xstar, n=n, full_output=True, **kwargs)
+            mean, cov = both["mean"], both["cov"]
         mean, cov = np.asarray(mean, dtype=float), np.asarray(cov, dtype=float)
+        M = mean.size
         if rand_vars is None and method != "eig":
+            # no variates given: numpy's own multivariate normal (global random state), the eigen route as its fallback
             try:
                 return np.random.multivariate_normal(mean, cov, num_samp).T
-            except np.linalg.LinAlgError as e:
+            except np.linalg.LinAlgError as exc:
                 if self.verbose:
-                    warnings.warn("Failure when drawing from MVN! Falling back on eig. Exception was:\n{:s}".format(
-                        str(e)), RuntimeWarning)
+                    warnings.warn("multivariate_normal failed (%s); using the eigendecomposition instead" % exc, RuntimeWarning)
                 method = "eig"
-        if num_eig is None or num_eig > len(mean):
-            num_eig = len(mean)
-        elif num_eig < 1:
-            num_eig = 1
-        if rand_vars is None:
-            rand_vars = np.random.standard_normal((num_eig, num_samp))
-        valid_types = ("standard normal", "uniform")
-        if rand_type not in valid_types:
-            raise ValueError("rand_type {:s} not recognized! Valid options are: {}.".format(rand_type, valid_types))
-        rand_vars = np.asarray(rand_vars, dtype=float)
-        if rand_type == "uniform":
-            from scipy.stats import norm as _norm
-            rand_vars = _norm.ppf(rand_vars)
-        loaded = cov + diag_factor * sys.float_info.epsilon * np.eye(cov.shape[0])
+        if rand_type not in _VARIATE_KINDS:
+            raise ValueError("rand_type %r is not one of %s" % (rand_type, sorted(_VARIATE_KINDS)))
+        modes = M if (num_eig is None or num_eig > M) else max(int(num_eig), 1)
+        u = np.random.standard_normal((modes, num_samp)) if rand_vars is None else np.asarray(rand_vars, dtype=float)
+        u = _VARIATE_KINDS[rand_type](u)
+        root = self._covariance_root(cov + diag_factor * sys.float_info.epsilon * np.eye(M), method, modes, modify_sign)
+        return mean[:, None] + root.dot(u[:modes, :])
+
+    def _covariance_root(self, loaded, method, modes, modify_sign):
+        """A matrix ``R`` with ``R R^T`` = the (jittered) predictive covariance: its lower Cholesky factor (computed on the
+        GPU), or ``Q sqrt(Lambda)`` over the ``modes`` largest eigenpairs, eigenvalues ascending like ``eigh`` returns them
+        (ref: gaussian_process.py:1295-1329)."""
         if method == "cholesky":
             # a context of its own: factoring here must not disturb the resident factor of the fit
             if getattr(self, "_scratch_ctx", None) is None:
                 self._scratch_ctx = _lib.Context(self.device)
-            L = np.tril(self._scratch_ctx.potrf_host(loaded))
-        elif method == "eig":
-            M = len(mean)
-            eig, Q = scipy.linalg.eigh(loaded, subset_by_index=(M - 1 - (num_eig - 1), M - 1))
-            if modify_sign is not None:
-                masks = {"left value": lambda q: q[0, :] < 0.0, "right value": lambda q: q[-1, :] < 0.0,
-                         "left slope": lambda q: (q[1, :] - q[0, :]) < 0.0,
-                         "right slope": lambda q: (q[-1, :] - q[-2, :]) < 0.0,
-                         "left concavity": lambda q: (q[2, :] - 2 * q[1, :] + q[0, :]) < 0.0,
-                         "right concavity": lambda q: (q[-1, :] - 2 * q[-2, :] + q[-3, :]) < 0.0}
-                if modify_sign not in masks:
-                    raise ValueError("modify_sign {:s} not recognized!".format(modify_sign))
-                Q[:, masks[modify_sign](Q)] *= -1.0
-            L = Q.dot(np.diag(np.sqrt(eig)))
-        else:
-            raise ValueError("method {:s} not recognized!".format(method))
-        return np.atleast_2d(mean).T + L.dot(rand_vars[:num_eig, :])
+            return np.tril(self._scratch_ctx.potrf_host(loaded))
+        if method != "eig":
+            raise ValueError("method %r is neither 'cholesky' nor 'eig'" % (method,))
+        M = loaded.shape[0]
+        lam, Q = scipy.linalg.eigh(loaded, subset_by_index=(M - modes, M - 1))
+        if modify_sign is not None:
+            # the sign of an eigenvector is arbitrary; these rules pin it by a feature of the vector's first / last entries
+            where, feature = (str(modify_sign).split(" ") + [""])[:2]
+            if where not in ("left", "right") or feature not in _SIGN_FEATURES:
+                raise ValueError("modify_sign %r is not '<left|right> <value|slope|concavity>'" % (modify_sign,))
+            ends = Q[:3, :] if where == "left" else Q[-3:, :]
+            Q[:, _SIGN_FEATURES[feature](ends, where) < 0.0] *= -1.0
+        return Q * np.sqrt(lam)[None, :]
 
     def _predict_general(self, Xstar, n, noise, need_std):
         """predict for fits that went through ``gpt_fit_matrix`` (``T`` present or a Python kernel):

@@ -9,129 +9,35 @@ Covariance kernels are evaluated element-wise on a pair list: row m of the four 
 in Python keep working through the same interface (``GaussianProcess.compute_Kij`` then feeds them
 the tiled pair list exactly like ref: gptools/gaussian_process.py:1591-1603).
 """
-import warnings
-
 import numpy as np
 
 from ..error_handling import GPArgumentError
-from ..utils import UniformJointPrior, IndependentJointPrior, MaskedBounds
+from .._hyper import HyperparameterSet
 from .. import _lib
 
 __all__ = ["ProductKernel", "Kernel", "BinaryKernel", "SumKernel"]
 
 
-class Kernel(object):
+class Kernel(HyperparameterSet):
     """Covariance kernel base class (not meant to be instantiated directly).
 
-    Parameters follow ref: gptools/kernel/core.py:136-210: ``num_dim``, ``num_params``,
+    Constructor arguments as in ref: gptools/kernel/core.py:136-210 -- ``num_dim``, ``num_params``,
     ``initial_params``, ``fixed_params``, ``param_bounds``, ``param_names``, ``enforce_bounds``,
-    ``hyperprior``.  Length scales of stationary kernels are the last ``num_dim`` parameters.
+    ``hyperprior``; the hyperparameter storage and the free-parameter views (``free_params``,
+    ``free_param_bounds``, ``set_hyperparams`` ...) come from :class:`gptools_amd._hyper.HyperparameterSet`.
+    Length scales of stationary kernels are the last ``num_dim`` parameters.
     """
 
     _gpt_kernel_id = None     # set by the kernels the HIP library implements natively
 
     def __init__(self, num_dim=1, num_params=0, initial_params=None, fixed_params=None, param_bounds=None,
                  param_names=None, enforce_bounds=False, hyperprior=None):
-        if not isinstance(num_params, (int, np.integer)) or num_params < 0:
-            raise ValueError("num_params must be an integer >= 0!")
-        self.num_params = int(num_params)
-        if param_names is None:
-            param_names = [""] * self.num_params
-        elif len(param_names) != self.num_params:
-            raise ValueError("param_names must be a list of length num_params!")
-        self.param_names = np.asarray(param_names, dtype=str)
-        if not isinstance(num_dim, (int, np.integer)) or num_dim < 1:
+        if isinstance(num_dim, bool) or not isinstance(num_dim, (int, np.integer)) or num_dim < 1:
             raise ValueError("num_dim must be an integer > 0!")
         self.num_dim = int(num_dim)
-        self.enforce_bounds = enforce_bounds
-
-        if initial_params is None:
-            if fixed_params is not None:
-                raise GPArgumentError("Must pass explicit parameter values if fixing parameters!")
-            initial_params = np.ones(self.num_params, dtype=float)
-            fixed_params = np.zeros(self.num_params, dtype=bool)
-        else:
-            if len(initial_params) != self.num_params:
-                raise ValueError("Length of initial_params must be equal to num_params!")
-            if fixed_params is None:
-                fixed_params = np.zeros(self.num_params, dtype=bool)
-            elif len(fixed_params) != self.num_params:
-                raise ValueError("Length of fixed_params must be equal to num_params!")
-        self.fixed_params = np.asarray(fixed_params, dtype=bool)
-
-        if param_bounds is None and hyperprior is None:
-            if (~self.fixed_params).any():
-                warnings.warn("Neither param_bounds nor hyperprior were specified when creating the kernel, "
-                              "defaults may not be appropriate for your data.")
-            param_bounds = self.num_params * [(0.0, 1e16)]
-        elif param_bounds is not None and len(param_bounds) != self.num_params:
-            raise ValueError("Length of param_bounds must be equal to num_params!")
-
-        if hyperprior is None:
-            hyperprior = UniformJointPrior(param_bounds)
-        elif not callable(hyperprior) or isinstance(hyperprior, (list, tuple)):
-            if len(hyperprior) != self.num_params:
-                raise ValueError("If hyperprior is a list its length must be equal to num_params!")
-            hyperprior = IndependentJointPrior(hyperprior)
-        self.params = np.array(initial_params, dtype=float)
-        self.hyperprior = hyperprior
-
-    # ---- bounds / free-parameter views (ref: gptools/kernel/core.py:212-352) ----
-    @property
-    def param_bounds(self):
-        return self.hyperprior.bounds
-
-    @param_bounds.setter
-    def param_bounds(self, value):
-        self.hyperprior.bounds = value
-
-    @property
-    def num_free_params(self):
-        return int(np.sum(~self.fixed_params))
-
-    @property
-    def free_param_idxs(self):
-        return np.arange(0, self.num_params)[~self.fixed_params]
-
-    @property
-    def free_params(self):
-        return MaskedBounds(self.params, self.free_param_idxs)
-
-    @free_params.setter
-    def free_params(self, value):
-        self.params[self.free_param_idxs] = np.asarray(value, dtype=float)
-
-    @property
-    def free_param_bounds(self):
-        return MaskedBounds(self.hyperprior.bounds, self.free_param_idxs)
-
-    @free_param_bounds.setter
-    def free_param_bounds(self, value):
-        for i, v in zip(self.free_param_idxs, value):
-            self.hyperprior.bounds[i] = v
-
-    @property
-    def free_param_names(self):
-        return MaskedBounds(self.param_names, self.free_param_idxs)
-
-    @free_param_names.setter
-    def free_param_names(self, value):
-        self.param_names = np.asarray(self.param_names, dtype=str)
-        self.param_names[~self.fixed_params] = value
-
-    def set_hyperparams(self, new_params):
-        """Set the free hyperparameters, clamping to the bounds if ``enforce_bounds``
-        (ref: gptools/kernel/core.py:259-287)."""
-        new_params = np.array(new_params, dtype=float)
-        if len(new_params) != len(self.free_params):
-            raise ValueError("Length of new_params must be {:d}!".format(len(self.free_params)))
-        if self.enforce_bounds:
-            for idx, (p, b) in enumerate(zip(new_params, self.free_param_bounds)):
-                if b[0] is not None and p < b[0]:
-                    new_params[idx] = b[0]
-                elif b[1] is not None and p > b[1]:
-                    new_params[idx] = b[1]
-        self.params[~self.fixed_params] = new_params
+        self._init_hyperparameters(num_params, values=initial_params, fixed=fixed_params, bounds=param_bounds,
+                                   names=param_names, prior=hyperprior, clamp=enforce_bounds,
+                                   fixing_error=GPArgumentError, warn_if_unbounded=True)
 
     # ---- evaluation ----
     def __call__(self, Xi, Xj, ni, nj, hyper_deriv=None, symmetric=False):
