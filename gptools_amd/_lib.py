@@ -60,6 +60,13 @@ SIGNATURES = {
     "gpt_cho_solve": (C.c_int, [_vp, _dp, _i64]),
     "gpt_last_timings": (C.c_int, [_vp, _dp, C.c_int]),
     "gpt_gemm_profile_read": (C.c_int, [_vp, _dp]),
+    "gpt_gemm_profile_read4": (C.c_int, [_vp, _dp]),
+    "gpt_plan_unique_id": (C.c_int, [_vp]),
+    "gpt_plan_create": (C.c_int, [C.c_int, C.POINTER(_vp), C.POINTER(_i64), _i64, C.c_int, _vp, _vp, C.c_int, _vp, C.POINTER(_vp)]),
+    "gpt_plan_set_comm": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "gpt_plan_run": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, C.c_double]),
+    "gpt_plan_last_enqueue_ms": (C.c_double, [_vp]),
+    "gpt_plan_destroy": (C.c_int, [_vp]),
     "gpt_potrf_host": (C.c_int, [_vp, _dp, _i64]),
     "gpt_gemm_nt_host": (C.c_int, [_vp, _i64, _i64, _i64, C.c_double, _dp, _dp, C.c_double, _dp]),
     "gpt_dev_kbuild": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _vp, _vp, _i64, _vp, _vp, _i64, C.c_int, C.c_int, C.c_int,
@@ -491,10 +498,12 @@ class Context(object):
         self._lib.gpt_last_timings(self.handle, dptr(out), 5)
         return dict(upload=out[0], kbuild=out[1], potrf=out[2], tail=out[3], total=out[4])
 
-    def gemm_profile_read(self):
-        """(algorithmic flops, summed launch ms, launches) of the profiled GEMM launches since the last read."""
-        out = np.zeros(3)
-        check(self._lib.gpt_gemm_profile_read(self.handle, dptr(out)))
+    def gemm_profile_read(self, with_bytes=False):
+        """(algorithmic flops, summed launch ms, launches[, algorithmic bytes]) of the profiled GEMM launches since the last read."""
+        out = np.zeros(4)
+        check(self._lib.gpt_gemm_profile_read4(self.handle, dptr(out)))
+        if with_bytes:
+            return float(out[0]), float(out[1]), int(out[2]), float(out[3])
         return float(out[0]), float(out[1]), int(out[2])
 
     def potrf_host(self, A):

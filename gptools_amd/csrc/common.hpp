@@ -157,11 +157,6 @@ int launch_gemm_nt_gridstair(hipStream_t st, int64_t m, int64_t nseg, int64_t se
 int launch_potf2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
                       unsigned *flag, unsigned flag_base, hipEvent_t done = nullptr, EdgeSig edge = EdgeSig(),
                       EdgeSig wait = EdgeSig(), int rows64 = 0);
-int launch_potf2_trsm_upd(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
-                          unsigned *flag, unsigned flag_base, unsigned x1_base, int64_t upd_cols,
-                          hipEvent_t done = nullptr, EdgeSig edge = EdgeSig(), EdgeSig wait = EdgeSig(), EdgeSig cwait = EdgeSig());
-int launch_potf2x2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
-                        double *l10pk, unsigned *flag, unsigned flag_base, hipEvent_t done = nullptr);
 int launch_trsm_panel(hipStream_t st, int64_t m, const double *L, int64_t ldl, const double *invd,
                       double *B, int64_t ldb, hipEvent_t done = nullptr, EdgeSig edge = EdgeSig(), int64_t nbatch = 1,
                       int64_t bstride_a = 0, int64_t bstride_ws = 0);

@@ -18,8 +18,8 @@
 //     MFMA step 2t+u of a k-tile contracts k = 8t + 2*(lane>>4) + u for A and B alike.
 //   * The accumulators start from (beta/alpha)*C: the C tile is fetched in the prologue next to the
 //     first operand tiles, the epilogue only stores.
-//   * Large updates use a persistent variant: one workgroup per CU walks a static, XCD-aware tile list and
-//     pipelines ACROSS tiles (next tile's C and first k-tile are fetched under the current MFMAs).
+//   * One output tile per workgroup, four workgroups per CU: the other three cover a workgroup's prologue and its DMA waits.
+//     (A tile loop inside the launch, a persistent 128x128 variant and mixed tile sizes were built, measured slower and removed.)
 //   * `tri` enumerates only the lower tiles of a SYRK-style update.
 #include "common.hpp"
 
@@ -158,8 +158,7 @@ __device__ long long *g_gemm_stamps;
 #define GM_LOADC(p) (*(p))
 #define GM_STOREC(v, p) (*(p) = (v))
 #endif
-// The tile body (everything behind "this workgroup's tile starts at (row0, col0)"), force-inlined into the kernels below: the
-// one-tile kernel and the mixed-tile kernel (which calls it as a 64x64 tile or as one 32x32 quarter of one).
+// The tile body (everything behind "this workgroup's tile starts at (row0, col0)"), force-inlined into the kernel below.
 template <int BM, int BN, int NSTAGE>
 __device__ __forceinline__ void gemm_tile_body(
     int64_t row0, int64_t col0, int64_t tj, double *sA, double *sB,
@@ -335,290 +334,6 @@ __global__ __launch_bounds__(256, WPS) void gemm_nt_kernel(
                                    edge_val, edge_total, wait_word, wait_val, wait_err, edge_cols, tail_word, tail_val, tail_err);
 }
 
-// Mixed tiles (round 4, opt-in: GPT_GEMM_MIXED): the order table's last partial round of every XCD list comes as 32x32 QUARTERS of
-// its 64x64 tiles (entry.x carries the quarter in bits 24..26: 1 + 2 qi + qj), so that the launch's tail -- half a tile time with
-// nothing behind it on an in-order stream -- is a quarter as long.  Same sums in the same order per element: same bits.
-template <int WPS>
-__global__ __launch_bounds__(256, WPS) void gemm_nt_mixed_kernel(
-    int64_t m, int64_t n, int64_t k, double alpha, const double *__restrict__ A, int64_t lda,
-    const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
-    const int2 *__restrict__ order, int prio, unsigned *edge, unsigned edge_val, unsigned edge_total, int edge_cols,
-    const unsigned *tail_word, unsigned tail_val, unsigned *tail_err)
-{
-    __shared__ __attribute__((aligned(16))) double sA[2 * 64 * GM_BK];
-    __shared__ __attribute__((aligned(16))) double sB[2 * 64 * GM_BK];
-#ifndef GPT_GEMM_NOPRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
-    const int2 t = order[blockIdx.x];
-    if (t.x < 0) {
-        if (tail_word != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) edge_poll<16, false>(tail_word, tail_val, tail_err);
-        return;
-    }
-    const int qd = (t.x >> 24) & 7;
-    const int64_t ti = t.x & 0xffffff, tj = t.y;
-    if (edge_cols > 0 && tj >= edge_cols) edge = nullptr;
-    if (qd == 0)
-        gemm_tile_body<64, 64, 2>(ti * 64, tj * 64, tj, sA, sB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0, 0, prio, edge, edge_val,
-                                  edge_total, nullptr, 0u, nullptr, 0, tail_word, tail_val, tail_err);
-    else
-        gemm_tile_body<32, 32, 2>(ti * 64 + ((qd - 1) >> 1) * 32, tj * 64 + ((qd - 1) & 1) * 32, tj, sA, sB, m, n, k, alpha, A, lda, B, ldb,
-                                  beta, C, ldc, 0, 0, prio, edge, edge_val, edge_total, nullptr, 0u, nullptr, 0, tail_word, tail_val, tail_err);
-}
-
-// ------------------------------------------------------------------------------------------------
-// The same 64x64 tile kernel with a TILE LOOP (round 4, VERDICT r3 #4: "remove the per-launch / per-tile fixed cost"): a
-// workgroup walks every G-th entry of the order table instead of one, and pipelines ACROSS tiles -- the k-tile counter runs
-// on through the tile boundary, so the first operand tile of the next output tile is requested by the LDS-DMA of the last
-// k-tile of this one; the next C tile follows the stores straight into the accumulators.  What a fresh workgroup spends before
-// its first MFMA (per-workgroup stamps, profiles/r02_gemm_stamps.txt: 10.1 of its 53.5 us -- table entry, addresses, C and
-// the first operand tiles requested and waited for) happens under the previous tile's MFMAs; at any time 73 % of the
-// resident workgroups were in their main loop, now all of them are except in the tile's first / last k-tile.
-// Workgroup b keeps to the entries b, b + G, ... of the table: G is a multiple of 8, so it stays on the tile list of ITS XCD
-// (same L2 reuse as the one-tile kernel), and the tiles of the urgent columns (partial edge flag) are still the first ones.
-// Launched for the large main-stream updates only (an order table exists, nobody waits inside the kernel, no batch).
-template <int BM, int BN, int WPS>
-__global__ __launch_bounds__(256, 4) void gemm_nt_loop_kernel(
-    int64_t m, int64_t n, int64_t k, double alpha, const double *__restrict__ A, int64_t lda,
-    const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
-    const int2 *__restrict__ order, int64_t order_len, int64_t seg_cols, int64_t bskip, int prio, unsigned *edge_word, unsigned edge_val,
-    unsigned edge_total, int edge_cols, const unsigned *tail_word, unsigned tail_val, unsigned *tail_err)
-{
-    constexpr int WM = BM / 2, WN = BN / 2;
-    constexpr int RM = WM / 16, RN = WN / 16;
-    __shared__ __attribute__((aligned(16))) double sA[2][BM * GM_BK];
-    __shared__ __attribute__((aligned(16))) double sB[2][BN * GM_BK];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int fr = lane & 15, fk = lane >> 4;
-    const int64_t G = gridDim.x;
-    const unsigned ldsA = lds_addr(&sA[0][0]), ldsB = lds_addr(&sB[0][0]);
-    constexpr unsigned ABYTES = BM * GM_BK * sizeof(double), BBYTES = BN * GM_BK * sizeof(double);
-    const int64_t nk = k / GM_BK;
-    const double cs = (beta != 0.0) ? beta / alpha : 0.0;
-    const bool is_last_wg = blockIdx.x == gridDim.x - 1;
-
-    // first tile of this workgroup
-    int64_t e = blockIdx.x;
-    int2 t = (e < order_len) ? order[e] : make_int2(-1, -1);
-    if (t.x < 0) {
-        if (tail_word != nullptr && is_last_wg && tid == 0) edge_poll<16, false>(tail_word, tail_val, tail_err);
-        return;
-    }
-#ifndef GPT_GEMM_NOPRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
-    int64_t row0 = (int64_t)t.x * BM, col0 = (int64_t)t.y * BN;
-    const double *srcA[BM / 32], *srcB[BN / 32];
-    stage_ptrs<BM>(A, lda, row0, m, wave, lane, srcA);
-    {
-        const int64_t brow0 = seg_cols ? col0 + (col0 / seg_cols) * bskip : col0;
-        stage_ptrs<BN>(B, ldb, brow0, seg_cols ? (int64_t)1 << 62 : n, wave, lane, srcB);
-    }
-    f64x4 acc[RM][RN];
-#define GL_LOADC(DST, R0, C0)                                                                              \
-    _Pragma("unroll") for (int i = 0; i < RM; i++)                                                         \
-    _Pragma("unroll") for (int j = 0; j < RN; j++) {                                                       \
-        const int64_t col = (C0) + wn * WN + j * 16 + fr;                                                  \
-        _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                    \
-            const int64_t row = (R0) + wm * WM + i * 16 + fk + 4 * r;                                      \
-            DST[i][j][r] = (beta != 0.0 && row < m && col < n) ? GM_LOADC(&C[row * ldc + col]) : 0.0;       \
-        }                                                                                                  \
-    }
-    GL_LOADC(acc, row0, col0);
-    stage_issue<BM>(srcA, 0, ldsA, wave);
-    stage_issue<BN>(srcB, 0, ldsB, wave);
-#pragma unroll
-    for (int i = 0; i < RM; i++)
-#pragma unroll
-        for (int j = 0; j < RN; j++) acc[i][j] = acc[i][j] * cs;
-    dma_wait();
-    __syncthreads();
-#ifndef GPT_GEMM_NOPRIO
-    if (prio == 0) __builtin_amdgcn_s_setprio(0);
-    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
-    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
-#endif
-    int cur = 0;                                    // LDS buffer of the k-tile being multiplied (the counter runs across tiles)
-    for (;;) {
-        // the next tile of this workgroup is known before the k loop (one table load under the first MFMAs)
-        const int64_t ne = e + G;
-        const int2 nt = (ne < order_len) ? order[ne] : make_int2(-1, -1);
-        const bool has_next = nt.x >= 0;
-        const int64_t nrow0 = (int64_t)nt.x * BM, ncol0 = (int64_t)nt.y * BN;
-        for (int64_t kt = 0; kt < nk; kt++) {
-            if (kt + 1 < nk) {
-                stage_issue<BM>(srcA, (kt + 1) * GM_BK, ldsA + (cur ^ 1) * ABYTES, wave);
-                stage_issue<BN>(srcB, (kt + 1) * GM_BK, ldsB + (cur ^ 1) * BBYTES, wave);
-            } else if (has_next) {
-                // last k-tile: this tile's operand pointers are spent -- they become the next tile's, whose first operand
-                // tile is requested here, under this k-tile's MFMAs
-                stage_ptrs<BM>(A, lda, nrow0, m, wave, lane, srcA);
-                const int64_t nbrow0 = seg_cols ? ncol0 + (ncol0 / seg_cols) * bskip : ncol0;
-                stage_ptrs<BN>(B, ldb, nbrow0, seg_cols ? (int64_t)1 << 62 : n, wave, lane, srcB);
-                stage_issue<BM>(srcA, 0, ldsA + (cur ^ 1) * ABYTES, wave);
-                stage_issue<BN>(srcB, 0, ldsB + (cur ^ 1) * BBYTES, wave);
-            }
-            mma_ktile<RM, RN>(sA[cur], sB[cur], wm * WM, wn * WN, fr, fk, acc);
-            dma_wait();
-            __syncthreads();
-            cur ^= 1;
-        }
-        // results of this tile: fire-and-forget stores (an edge tile: written through, counted, see gemm_nt_kernel)
-        unsigned *edge = edge_word;
-        if (edge_cols > 0 && t.y >= edge_cols) edge = nullptr;
-#pragma unroll
-        for (int i = 0; i < RM; i++)
-#pragma unroll
-            for (int j = 0; j < RN; j++) {
-                const int64_t col = col0 + wn * WN + j * 16 + fr;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int64_t row = row0 + wm * WM + i * 16 + fk + 4 * r;
-                    if (row < m && col < n) {
-                        if (edge) __hip_atomic_store(&C[row * ldc + col], alpha * acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        else GM_STOREC(alpha * acc[i][j][r], &C[row * ldc + col]);
-                    }
-                }
-            }
-        if (edge) edge_signal(edge, edge_val, edge_total);
-        if (!has_next) break;
-        // the next C tile straight into the accumulators (its operand tile is already on its way; the wait for C sits in front
-        // of the first MFMA, where the other three workgroups of the CU cover it)
-        e = ne;
-        t = nt;
-        row0 = nrow0;
-        col0 = ncol0;
-        GL_LOADC(acc, row0, col0);
-#pragma unroll
-        for (int i = 0; i < RM; i++)
-#pragma unroll
-            for (int j = 0; j < RN; j++) acc[i][j] = acc[i][j] * cs;
-    }
-#undef GL_LOADC
-    if (tail_word != nullptr && is_last_wg && tid == 0) edge_poll<16, false>(tail_word, tail_val, tail_err);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Persistent 128x128 variant: one workgroup per CU, static XCD-aware tile list, cross-tile pipelining.
-// 128 accumulator + 128 next-C registers per lane (one wave per SIMD).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void gemm_nt_persist_kernel(
-    int64_t m, int64_t n, int64_t k, double alpha, const double *__restrict__ A, int64_t lda,
-    const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
-    int tri, int64_t ntn, int64_t ntiles)
-{
-    constexpr int BM = 128, BN = 128, WM = 64, WN = 64, RM = 4, RN = 4;
-    __shared__ __attribute__((aligned(16))) double sA[2][BM * GM_BK];
-    __shared__ __attribute__((aligned(16))) double sB[2][BN * GM_BK];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int fr = lane & 15, fk = lane >> 4;
-    const int64_t G = gridDim.x;
-    // block b runs on XCD b % 8: give each XCD a contiguous run of G/8 tiles per sweep (shared A row-panels)
-    const int64_t slot = (G % 8 == 0) ? (int64_t)(blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
-    const int64_t nk = k / GM_BK;
-    const double cs = (beta != 0.0) ? beta / alpha : 0.0;
-
-    int64_t lid = slot;
-    if (lid >= ntiles) return;
-    int64_t ti, tj;
-    tile_decode(lid, tri, ntn, &ti, &tj);
-    int64_t row0 = ti * BM, col0 = tj * BN;
-
-    const double *srcA[4], *srcB[4], *nsrcA[4], *nsrcB[4];
-    stage_ptrs<BM>(A, lda, row0, m, wave, lane, srcA);
-    stage_ptrs<BN>(B, ldb, col0, n, wave, lane, srcB);
-    const unsigned ldsA = lds_addr(&sA[0][0]), ldsB = lds_addr(&sB[0][0]);
-    constexpr unsigned TBYTES = 128 * GM_BK * sizeof(double);
-    stage_issue<BM>(srcA, 0, ldsA, wave);
-    stage_issue<BN>(srcB, 0, ldsB, wave);
-
-    f64x4 acc[RM][RN], cn[RM][RN];
-#define GP_LOADC(DST, R0, C0, SCALE)                                                              \
-    do {                                                                                          \
-        const bool full_ = (beta != 0.0) && ((R0) + BM <= m) && ((C0) + BN <= n);                 \
-        const double *cb_ = C + ((R0) + wm * WM + fk) * ldc + (C0) + wn * WN + fr;                \
-        if (full_) {                                                                              \
-            _Pragma("unroll") for (int i = 0; i < RM; i++)                                        \
-            _Pragma("unroll") for (int j = 0; j < RN; j++)                                        \
-            _Pragma("unroll") for (int r = 0; r < 4; r++)                                         \
-                DST[i][j][r] = (SCALE) * cb_[(i * 16 + 4 * r) * ldc + j * 16];                    \
-        } else {                                                                                  \
-            _Pragma("unroll") for (int i = 0; i < RM; i++)                                        \
-            _Pragma("unroll") for (int j = 0; j < RN; j++) {                                      \
-                const int64_t col = (C0) + wn * WN + j * 16 + fr;                                 \
-                _Pragma("unroll") for (int r = 0; r < 4; r++) {                                   \
-                    const int64_t row = (R0) + wm * WM + i * 16 + fk + 4 * r;                     \
-                    DST[i][j][r] = (beta != 0.0 && row < m && col < n) ? (SCALE) * C[row * ldc + col] : 0.0; \
-                }                                                                                 \
-            }                                                                                     \
-        }                                                                                         \
-    } while (0)
-    GP_LOADC(acc, row0, col0, cs);
-    dma_wait();
-    __syncthreads();
-    int cur = 0;
-    const int64_t ctrig = (nk >= 4) ? nk - 4 : 0;
-
-    for (;;) {
-        const int64_t nlid = lid + G;
-        const bool has_next = nlid < ntiles;
-        int64_t nrow0 = 0, ncol0 = 0;
-        if (has_next) {
-            int64_t nti, ntj;
-            tile_decode(nlid, tri, ntn, &nti, &ntj);
-            nrow0 = nti * BM;
-            ncol0 = ntj * BN;
-            stage_ptrs<BM>(A, lda, nrow0, m, wave, lane, nsrcA);
-            stage_ptrs<BN>(B, ldb, ncol0, n, wave, lane, nsrcB);
-        }
-        for (int64_t kt = 0; kt < nk; kt++) {
-            if (kt + 1 < nk) {
-                stage_issue<BM>(srcA, (kt + 1) * GM_BK, ldsA + (cur ^ 1) * TBYTES, wave);
-                stage_issue<BN>(srcB, (kt + 1) * GM_BK, ldsB + (cur ^ 1) * TBYTES, wave);
-            } else if (has_next) {
-                stage_issue<BM>(nsrcA, 0, ldsA + (cur ^ 1) * TBYTES, wave);
-                stage_issue<BN>(nsrcB, 0, ldsB + (cur ^ 1) * TBYTES, wave);
-            }
-            if (has_next && kt == ctrig) GP_LOADC(cn, nrow0, ncol0, 1.0);
-            mma_ktile<RM, RN>(sA[cur], sB[cur], wm * WM, wn * WN, fr, fk, acc);
-            dma_wait();
-            __syncthreads();
-            cur ^= 1;
-        }
-        // results of this tile: fire-and-forget stores
-#pragma unroll
-        for (int i = 0; i < RM; i++)
-#pragma unroll
-            for (int j = 0; j < RN; j++) {
-                const int64_t col = col0 + wn * WN + j * 16 + fr;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int64_t row = row0 + wm * WM + i * 16 + fk + 4 * r;
-                    if (row < m && col < n) C[row * ldc + col] = alpha * acc[i][j][r];
-                }
-            }
-        if (!has_next) break;
-#pragma unroll
-        for (int i = 0; i < RM; i++)
-#pragma unroll
-            for (int j = 0; j < RN; j++) acc[i][j] = cs * cn[i][j];
-        lid = nlid;
-        row0 = nrow0;
-        col0 = ncol0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            srcA[q] = nsrcA[q];
-            srcB[q] = nsrcB[q];
-        }
-    }
-#undef GP_LOADC
-}
-
 // ---- XCD-aware tile order ------------------------------------------------------------------------------------
 // Workgroup b runs on XCD b % 8 and the workgroups of one XCD start in the order of b / 8.  The needed tiles are put
 // in ONE sequence -- supertiles of 64 x 8 tiles (rows x columns) in row-major order, each walked row by row -- and the
@@ -630,6 +345,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_persist_kernel(
 // 404 us, 16 x 16 846 MB (the streamed C tiles leave the panels well under the L2's 4 MB).  GPT_TILE_ORDER="rows,cols,mode"
 // overrides (mode 0 = round-robin deal).  Tables are built once per (ntm, ntn, tri) and cached on the device; slots past
 // an XCD's list hold (-1, -1).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -643,11 +359,12 @@ struct TileOrder {
     int64_t grid;
     int64_t ntiles;                // entries of the table that hold a tile (the rest are (-1, -1) padding)
     int64_t edge_cols, nedge;      // partial edge flag: the tiles of the first edge_cols columns come first; their number
-    int64_t mixed_slots;           // mixed-tile tables (gemm_nt_mixed_kernel): workgroup slots of the stream, 0 = plain table
-    int mixed_pct;
+    uint64_t last_use;             // tick of the last look-up (eviction takes the least recently used tables)
+    bool pinned;                   // looked up during a stream capture: a captured graph holds d_tab, never evicted
 };
 static std::vector<TileOrder> g_orders;
 static std::mutex g_orders_mu;
+static uint64_t g_orders_tick = 0;
 
 // tri == 2: staircase.  Column segment q = j / seg_t starts (its diagonal block) at tile row q * rss_t; tile (i, j) is
 // needed iff i >= q * rss_t + (j - q * seg_t).
@@ -676,7 +393,7 @@ static inline bool tile_needed(int tri, int64_t i, int64_t j, int64_t seg_t, int
 
 static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64_t *grid, int64_t seg_t = 0,
                       int64_t rss_t = 0, int64_t *ntiles = nullptr, int64_t edge_cols = 0, int64_t *nedge = nullptr,
-                      const GridStair &gs = GridStair(), int64_t mixed_slots = 0, int mixed_pct = 0)
+                      const GridStair &gs = GridStair(), hipStream_t st = nullptr)
 {
     static int sgm = 0, sgn = 0, mode = 0;
     if (sgm == 0) {
@@ -688,17 +405,48 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
     }
     int dev = 0;
     GPT_HIP_CHECK(hipGetDevice(&dev));
+    // (a look-up under stream capture: the captured launch keeps the table's address for every replay)
+    bool capturing = false;
+    if (st != nullptr) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess) capturing = (cs != hipStreamCaptureStatusNone);
+        else (void)hipGetLastError();
+    }
     std::lock_guard<std::mutex> lk(g_orders_mu);
-    for (const auto &o : g_orders)
+    for (auto &o : g_orders)
         if (o.ntm == ntm && o.ntn == ntn && o.tri == tri && o.dev == dev && o.seg_t == seg_t && o.rss_t == rss_t && o.edge_cols == edge_cols &&
-            o.g_off == gs.off && o.g_num == gs.num && o.g_den == gs.den && o.g_base == gs.base && o.mixed_slots == mixed_slots &&
-            o.mixed_pct == mixed_pct) {
+            o.g_off == gs.off && o.g_num == gs.num && o.g_den == gs.den && o.g_base == gs.base) {
+            o.last_use = ++g_orders_tick;
+            o.pinned = o.pinned || capturing;
             *tab = o.d_tab;
             *grid = o.grid;
             if (ntiles) *ntiles = o.ntiles;
             if (nedge) *nedge = o.nedge;
             return GPT_OK;
         }
+    // A cap (the block-cyclic engines make a table per shape -- ADVICE r4): at 1024 tables the least recently used half of the
+    // unpinned ones goes.  Tables may be in use by launches in flight, so only behind a device-wide synchronisation -- which is
+    // not allowed while a stream of the process is capturing: then (and whenever the synchronisation fails) nothing is evicted
+    // and the cache grows until the next miss outside a capture.  Done BEFORE the new table is allocated.
+    if (g_orders.size() >= 1024 && !capturing) {
+        if (hipDeviceSynchronize() == hipSuccess) {
+            std::vector<uint64_t> ticks;
+            for (const auto &o : g_orders)
+                if (!o.pinned) ticks.push_back(o.last_use);
+            if (ticks.size() >= 2) {
+                std::nth_element(ticks.begin(), ticks.begin() + ticks.size() / 2, ticks.end());
+                const uint64_t cut = ticks[ticks.size() / 2];
+                std::vector<TileOrder> keep;
+                for (const auto &o : g_orders) {
+                    if (!o.pinned && o.last_use < cut) (void)hipFree(o.d_tab);
+                    else keep.push_back(o);
+                }
+                g_orders.swap(keep);
+            }
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     std::vector<std::vector<int2>> per(8);
     std::vector<int2> seq, sequ;          // sequ: the tiles of the first edge_cols columns (they go first on every XCD)
     const int64_t sm = (ntm + sgm - 1) / sgm, sn = (ntn + sgn - 1) / sgn;
@@ -726,23 +474,6 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
             }
         }
     }
-    if (mixed_slots >= 8 && (tri == 0 || tri == 1)) {
-        // mixed tiles: the last partial round of every XCD's list as 32x32 quarters (a diagonal tile of the trapezoid has no
-        // upper-right quarter), when that round is at most mixed_pct % full and lies behind the urgent tiles
-        const size_t ps = (size_t)(mixed_slots / 8), nu = sequ.size();
-        for (int x = 0; x < 8; x++) {
-            std::vector<int2> &v = per[x];
-            const size_t len = v.size(), r = len % ps, urgent = nu / 8 + ((size_t)x < nu % 8 ? 1 : 0);
-            if (len < ps || r == 0 || r * 100 > (size_t)mixed_pct * ps || len - r < urgent) continue;
-            std::vector<int2> tail(v.end() - r, v.end());
-            v.resize(len - r);
-            for (const int2 &t : tail)
-                for (int q = 0; q < 4; q++) {
-                    if (tri == 1 && t.x == t.y && q == 1) continue;
-                    v.push_back(make_int2(t.x | ((q + 1) << 24), t.y));
-                }
-        }
-    }
     size_t mx = 0;
     for (auto &v : per) mx = v.size() > mx ? v.size() : mx;
     std::vector<int2> flat(mx * 8, make_int2(-1, -1));
@@ -760,8 +491,6 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
     o.g_den = gs.den;
     o.g_base = gs.base;
     o.edge_cols = edge_cols;
-    o.mixed_slots = mixed_slots;
-    o.mixed_pct = mixed_pct;
     o.nedge = (int64_t)sequ.size();
     o.grid = (int64_t)flat.size();
     o.ntiles = 0;
@@ -775,42 +504,18 @@ static int tile_order(int64_t ntm, int64_t ntn, int tri, const int2 **tab, int64
         hipError_t e1 = hipMemcpyAsync(o.d_tab, flat.data(), flat.size() * sizeof(int2), hipMemcpyHostToDevice, up);
         hipError_t e2 = hipStreamSynchronize(up);
         hipStreamDestroy(up);
+        if (e1 != hipSuccess || e2 != hipSuccess) (void)hipFree(o.d_tab);
         GPT_HIP_CHECK(e1);
         GPT_HIP_CHECK(e2);
     }
-    // (a cap: the block-cyclic engines and the experiments behind options make a table per shape -- ADVICE r4.  Tables may be in use
-    // by launches in flight, so the oldest half goes only behind a device-wide synchronisation; rare by construction)
-    if (g_orders.size() >= 1024) {
-        GPT_HIP_CHECK(hipDeviceSynchronize());
-        for (size_t q = 0; q < 512; q++) hipFree(g_orders[q].d_tab);
-        g_orders.erase(g_orders.begin(), g_orders.begin() + 512);
-    }
+    o.last_use = ++g_orders_tick;
+    o.pinned = capturing;
     g_orders.push_back(o);
     *tab = o.d_tab;
     *grid = o.grid;
     if (ntiles) *ntiles = o.ntiles;
     if (nedge) *nedge = o.nedge;
     return GPT_OK;
-}
-
-// CUs the launches of a stream can use (a CU-masked stream: the bits of its mask), cached per stream: the tile loop sizes
-// its grid by them
-static int stream_cus(hipStream_t st, int ncu)
-{
-    static std::mutex mu;
-    static std::vector<std::pair<hipStream_t, int>> seen;
-    std::lock_guard<std::mutex> lk(mu);
-    for (const auto &p : seen)
-        if (p.first == st) return p.second;
-    uint32_t mask[16] = {0};
-    int cnt = 0;
-    if (st != nullptr && hipExtStreamGetCUMask(st, 16, mask) == hipSuccess)
-        for (int i = 0; i < ncu && i < 512; i++) cnt += (mask[i / 32] >> (i % 32)) & 1u;
-    else (void)hipGetLastError();
-    if (cnt <= 0 || cnt > ncu) cnt = ncu;
-    if (seen.size() > 256) seen.clear();
-    seen.push_back(std::make_pair(st, cnt));
-    return cnt;
 }
 
 template <int BM, int BN, int WPS, int NSTAGE>
@@ -830,15 +535,15 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
     const int2 *order = nullptr;
     if (tri == 2) {                        // staircase: the tile list always comes from a table
         int64_t grid = 0;
-        GPT_TRY_RC(tile_order(ntm, ntn, 2, &order, &grid, seg_cols / BN, row_step / BM, &nreal));
+        GPT_TRY_RC(tile_order(ntm, ntn, 2, &order, &grid, seg_cols / BN, row_step / BM, &nreal, 0, nullptr, GridStair(), st));
         nwg = grid;
     } else if (tri == 3) {                 // grid staircase: likewise
         int64_t grid = 0;
-        GPT_TRY_RC(tile_order(ntm, ntn, 3, &order, &grid, seg_cols / BN, 0, &nreal, 0, nullptr, gs));
+        GPT_TRY_RC(tile_order(ntm, ntn, 3, &order, &grid, seg_cols / BN, 0, &nreal, 0, nullptr, gs, st));
         nwg = grid;
     } else if (nwg >= 512) {               // large launches only: small ones live in L2 anyway
         int64_t grid = 0;
-        GPT_TRY_RC(tile_order(ntm, ntn, tri, &order, &grid, 0, 0, &nreal, edge_cols_elems / BN, &nedge));
+        GPT_TRY_RC(tile_order(ntm, ntn, tri, &order, &grid, 0, 0, &nreal, edge_cols_elems / BN, &nedge, GridStair(), st));
         nwg = grid;
     }
     if (edge_cols_elems > 0 && (order == nullptr || !edge.word || nedge <= 0)) {
@@ -850,70 +555,6 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
     // update on the main stream asks for 8 KiB -> three workgroups per CU, leaving 40 KiB of LDS and over 40 % of the
     // register file on every CU to the high-priority panel stream (whose own GEMMs and TRSMs need 32 / 9 KiB).
     const size_t dyn = (BM == 64) ? (size_t)lds_pad : 0;
-    // Large ordered launches of the 64x64 kernel (the main stream's trailing updates, the staircases of the partitioned engines)
-    // CAN walk the table with a tile loop (gemm_nt_loop_kernel): as many workgroups as are resident at once on the stream's CUs,
-    // each taking every G-th tile.  GPT_GEMM_LOOP=<workgroups per CU> switches it on; OFF by default: measured slower (round 4,
-    // same-box A/B: N = 8192 4.40 -> 4.72 ms, N = 16384 27.6 -> 33.6 ms at 4 per CU, 88 VGPRs, no spill) -- the one-tile kernel's
-    // prologue is already hidden by the three other workgroups of its CU and by the hardware's own re-dispatch, while the loop
-    // adds a wait for the previous tile's stores in front of every tile's first barrier (stores count in vmcnt on gfx9).
-    // Mixed tiles (GPT_GEMM_MIXED=<percent>, off by default): see gemm_nt_mixed_kernel.  Plain and trapezoid launches of the
-    // 64x64 kernel with an order table and nobody waiting inside the kernel.
-    if constexpr (BM == 64 && NSTAGE == 2) if (order != nullptr && (tri == 0 || tri == 1) && !wait.word && nbatch == 1 && seg_cols == 0) {
-        static int pct = -1, ncu_m = 0;
-        if (pct < 0) {
-            pct = 0;
-            if (const char *e = getenv("GPT_GEMM_MIXED")) pct = atoi(e);
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu_m = prop.multiProcessorCount;
-            if (ncu_m <= 0) ncu_m = 256;
-        }
-        if (pct > 0) {
-            const int64_t slots = (int64_t)stream_cus(st, ncu_m) * 4;
-            const int2 *mo = nullptr;
-            int64_t grid = 0, nr = 0, ne = 0;
-            GPT_TRY_RC(tile_order(ntm, ntn, tri, &mo, &grid, 0, 0, &nr, edge_cols_elems / BN, &ne, GridStair(), slots, pct));
-            if (ev0 || ev1)
-                hipExtLaunchKernelGGL((gemm_nt_mixed_kernel<WPS>), dim3((unsigned)grid), dim3(256), dyn, st, ev0, ev1, 0, m, n, k, alpha, A, lda, B,
-                                      ldb, beta, C, ldc, mo, prio, edge.word, edge.value, (unsigned)(edge_cols_elems > 0 ? ne : nr),
-                                      (int)(edge_cols_elems / BN), tail.word, tail.value, tail.err);
-            else
-                hipLaunchKernelGGL((gemm_nt_mixed_kernel<WPS>), dim3((unsigned)grid), dim3(256), dyn, st, m, n, k, alpha, A, lda, B, ldb, beta, C,
-                                   ldc, mo, prio, edge.word, edge.value, (unsigned)(edge_cols_elems > 0 ? ne : nr),
-                                   (int)(edge_cols_elems / BN), tail.word, tail.value, tail.err);
-            GPT_LAUNCH_CHECK();
-            return GPT_OK;
-        }
-    }
-    if constexpr (BM == 64 && NSTAGE == 2) if (order != nullptr && !wait.word && nbatch == 1 && nwg >= 2048) {
-        static int per_cu = -1, ncu = 0;
-        if (per_cu < 0) {
-            per_cu = 0;
-            if (const char *e = getenv("GPT_GEMM_LOOP")) per_cu = atoi(e);
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-            if (ncu <= 0) ncu = 256;
-        }
-        if (per_cu > 0) {
-            int64_t G = (int64_t)stream_cus(st, ncu) * per_cu / 8 * 8;
-            if (G > nwg) G = nwg / 8 * 8;
-            if (G >= 8) {
-                if (ev0 || ev1)
-                    hipExtLaunchKernelGGL((gemm_nt_loop_kernel<BM, BN, WPS>), dim3((unsigned)G), dim3(256), dyn, st, ev0, ev1, 0, m, n, k, alpha,
-                                          A, lda, B, ldb, beta, C, ldc, order, nwg, seg_cols, bskip, prio, edge.word, edge.value,
-                                          (unsigned)(edge_cols_elems > 0 ? nedge : nreal), (int)(edge_cols_elems / BN), tail.word, tail.value,
-                                          tail.err);
-                else
-                    hipLaunchKernelGGL((gemm_nt_loop_kernel<BM, BN, WPS>), dim3((unsigned)G), dim3(256), dyn, st, m, n, k, alpha, A, lda, B,
-                                       ldb, beta, C, ldc, order, nwg, seg_cols, bskip, prio, edge.word, edge.value,
-                                       (unsigned)(edge_cols_elems > 0 ? nedge : nreal), (int)(edge_cols_elems / BN), tail.word, tail.value,
-                                       tail.err);
-                GPT_LAUNCH_CHECK();
-                return GPT_OK;
-            }
-        }
-    }
     // timing events (roofline line of bench.py) ride on the dispatch packet itself: separate hipEventRecord calls
     // would add two barrier packets per launch to the stream being measured
     if (ev0 || ev1)
@@ -926,25 +567,6 @@ static int gemm_launch_t(hipStream_t st, int64_t m, int64_t n, int64_t k, double
                            A, lda, B, ldb, beta, C, ldc, tri, ntm, ntn, nwg, order, seg_cols, bskip, prio, edge.word, edge.value,
                               (unsigned)(edge_cols_elems > 0 ? nedge : nreal), wait.word, wait.value, wait.err, (int)(edge_cols_elems / BN), bstride,
                               tail.word, tail.value, tail.err, bstride_b, bstride_c);
-    GPT_LAUNCH_CHECK();
-    return GPT_OK;
-}
-
-static int gemm_launch_persist(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha, const double *A,
-                               int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int tri)
-{
-    const int64_t ntm = (m + 127) / 128, ntn = (n + 127) / 128;
-    const int64_t ntiles = tri ? ntn * (ntn + 1) / 2 + (ntm - ntn) * ntn : ntm * ntn;
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GPT_E_HIP;
-        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    const int64_t G = ntiles < ncu ? ntiles : ncu;
-    hipLaunchKernelGGL(gemm_nt_persist_kernel, dim3((unsigned)G), dim3(256), 0, st, m, n, k, alpha, A, lda, B, ldb, beta,
-                       C, ldc, tri, ntn, ntiles);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }
@@ -1027,12 +649,13 @@ int launch_gemm_nt(hipStream_t st, int64_t m, int64_t n, int64_t k, double alpha
         gpt_set_error("gemm_nt: edge flags exist for the 64x64 / 32x32 kernels only");
         return GPT_E_ARG;
     }
-    if (tile == 129) return gemm_launch_t<128, 128, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0);
-    if (tile == 128) return gemm_launch_persist(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri);
-    // A 4-stage variant (gemm_launch_t<64, 64, 1, 4>, DMA three k-tiles ahead, counted vmcnt) was measured on the
-    // small panel updates (8064x128x128: 12 us either way): they are bound by launch + prologue latency, not by the
-    // DMA wait, so everything uses the 2-stage kernel.
-    if (force_tile == 65) return gemm_launch_t<64, 64, 1, 4>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, 0);
+    // (measured and removed: 128x128 tiles, one workgroup per CU, persistent or not -- 47 against 58 TFLOP/s in the main loop, round 1; a
+    // 4-stage 64x64 variant -- 41 against 48 TFLOP/s, round 3; a tile loop inside the launch and quarter tiles for a launch's last
+    // partial round -- rounds 4 and 5, NOTES_r04.md / NOTES_r05.md; the sources are in the history up to round 5's last commit)
+    if (tile != 64) {
+        gpt_set_error("gemm_nt: option tile takes 0 (by size), 32 or 64");
+        return GPT_E_ARG;
+    }
     return gemm_launch_t<64, 64, 2, 2>(st, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, lds_pad, ev0, ev1, 0, 0, 0, prio, edge, wait, edge_cols,
                                        nbatch, bstride, tail, bstride_b, bstride_c);
 }

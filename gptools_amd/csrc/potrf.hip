@@ -304,10 +304,13 @@ __device__ __forceinline__ void edge_wait(const unsigned *word, unsigned value, 
 
 // ws store of the storing wave.  PUBLISH: agent-scope (write-through) so that workgroups of the same launch on other
 // XCDs can read the value as soon as the block's flag is up (potf2_trsm_kernel); otherwise a plain store.
+// The publishing form is ONE explicit store instruction per call (what hipcc emits for a relaxed agent-scope atomic store on
+// gfx950: global_store_dwordx2 ... sc1): the store wave of potf2_body_la counts its stores per step in s_waitcnt vmcnt(N) below,
+// and an asm statement can be neither merged nor split nor dropped by the compiler.
 template <bool PUBLISH>
 __device__ __forceinline__ void ws_store(double *p, double v)
 {
-    if (PUBLISH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (PUBLISH) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
     else *p = v;
 }
 
@@ -993,6 +996,9 @@ __device__ __forceinline__ void potf2_body_la(double *__restrict__ A, int64_t ld
                     // apart, the last one 7 us behind the chain; profiles/r05_upd_stamps.txt).  Stores complete in issue order
                     // (vmcnt), so once step jb's 32 - 4 jb store instructions are issued, vmcnt <= 32 - 4 jb means that everything
                     // older -- step jb - 1 -- is in memory: its flag goes up then, and the last step drains.
+                    // (the count: 4 stores of inv(L_jb,jb) + 4 per packed block (j, jb), j = jb + 1 .. 7 -- ws_store<true> is one
+                    // instruction by construction)
+                    static_assert(NB16 == 8 && PD_NB == 128, "the vmcnt counts below are 4 * (8 - jb) stores per step of a 128-column block");
                     switch (jb) {
                     case 0: break;
                     case 1: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
@@ -1154,9 +1160,7 @@ __device__ __forceinline__ void strip_batch_issue(StripBatch &b, const double *_
     // often and the strips prefetch less: N = 8192 4.328 -> 4.360 ms, N = 4096 1.153 -> 1.164, same box)
     b.fn = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// HIST: x_j also stays in LDS (Xh[j], which doubles as the re-layout scratch) and hprog counts the steps (potf2_trsm_upd_kernel);
-// otherwise Xh[0] is the wave's scratch.  through: write x_j through to memory (somebody reads it before this kernel ends).
-// post(j): called when x_j has been stored (the producers' counter).
+// X: the wave's 16 x 16 re-layout scratch in LDS.  through: write x_j through to memory (somebody reads it before this kernel ends).
 struct StripCtx {
     const double *ws;
     const unsigned *flag;
@@ -1174,16 +1178,15 @@ struct StripCtx {
 #ifndef STRIP_PREFETCH_FROM
 #define STRIP_PREFETCH_FROM 1
 #endif
-template <int J, bool HIST, bool THROUGH, class Post>
+template <int J, bool THROUGH>
 __device__ __forceinline__ void strip_step(StripCtx &c, StripBatch &cur, StripBatch &nxt, f64x4 (&bt)[8], f64x4 &acc,
-                                           double (*Xh)[16][TP_SP], int *hprog, Post post)
+                                           double (*X)[TP_SP])
 {
     const int lane = c.lane, fr = c.fr, fk = c.fk;
     if (!c.have) {
         c.fl = pu_poll_ge<1>(c.flag, c.fl, c.flag_base, J + 1);      // (signed difference: an earlier launch's value lies below flag_base)
         strip_batch_issue<J>(cur, c.ws, c.flag, lane);
     }
-    double (*X)[TP_SP] = Xh[HIST ? J : 0];
     // accumulator (C layout) -> A operand through the scratch
 #pragma unroll
     for (int r = 0; r < 4; r++) X[fk + 4 * r][fr] = acc[r];
@@ -1202,7 +1205,6 @@ __device__ __forceinline__ void strip_step(StripCtx &c, StripBatch &cur, StripBa
         else *dst = res[r];
         X[fk + 4 * r][fr] = res[r];
     }
-    if (HIST) lds_post(hprog, J + 1);
     if constexpr (J + 1 < 8) {
         double xj[4];
 #pragma unroll
@@ -1219,29 +1221,27 @@ __device__ __forceinline__ void strip_step(StripCtx &c, StripBatch &cur, StripBa
                 bt[jp] = __builtin_amdgcn_mfma_f64_16x16x4f64(xj[kk], cur.lv[jp - J - 1][kk], bt[jp], 0, 0, 0);
         acc = bt[J + 1];
     }
-    post(J);
 }
-template <bool HIST, bool THROUGH, class Post>
-__device__ __forceinline__ void strip_substitution_t(StripCtx &c, f64x4 (&bt)[8], double (*Xh)[16][TP_SP], int *hprog, Post post)
+template <bool THROUGH>
+__device__ __forceinline__ void strip_substitution_t(StripCtx &c, f64x4 (&bt)[8], double (*X)[TP_SP])
 {
     StripBatch a, b;
     f64x4 acc = bt[0];
     c.have = false;
     c.fl = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(c.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    strip_step<0, HIST, THROUGH>(c, a, b, bt, acc, Xh, hprog, post);
-    strip_step<1, HIST, THROUGH>(c, b, a, bt, acc, Xh, hprog, post);
-    strip_step<2, HIST, THROUGH>(c, a, b, bt, acc, Xh, hprog, post);
-    strip_step<3, HIST, THROUGH>(c, b, a, bt, acc, Xh, hprog, post);
-    strip_step<4, HIST, THROUGH>(c, a, b, bt, acc, Xh, hprog, post);
-    strip_step<5, HIST, THROUGH>(c, b, a, bt, acc, Xh, hprog, post);
-    strip_step<6, HIST, THROUGH>(c, a, b, bt, acc, Xh, hprog, post);
-    strip_step<7, HIST, THROUGH>(c, b, a, bt, acc, Xh, hprog, post);
+    strip_step<0, THROUGH>(c, a, b, bt, acc, X);
+    strip_step<1, THROUGH>(c, b, a, bt, acc, X);
+    strip_step<2, THROUGH>(c, a, b, bt, acc, X);
+    strip_step<3, THROUGH>(c, b, a, bt, acc, X);
+    strip_step<4, THROUGH>(c, a, b, bt, acc, X);
+    strip_step<5, THROUGH>(c, b, a, bt, acc, X);
+    strip_step<6, THROUGH>(c, a, b, bt, acc, X);
+    strip_step<7, THROUGH>(c, b, a, bt, acc, X);
 }
-template <bool HIST, class Post>
-__device__ __forceinline__ void strip_substitution(StripCtx &c, f64x4 (&bt)[8], double (*Xh)[16][TP_SP], int *hprog, Post post)
+__device__ __forceinline__ void strip_substitution(StripCtx &c, f64x4 (&bt)[8], double (*X)[TP_SP])
 {
-    if (c.through) strip_substitution_t<HIST, true>(c, bt, Xh, hprog, post);
-    else strip_substitution_t<HIST, false>(c, bt, Xh, hprog, post);
+    if (c.through) strip_substitution_t<true>(c, bt, X);
+    else strip_substitution_t<false>(c, bt, X);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1308,502 +1308,14 @@ __global__ __launch_bounds__(PD_THREADS) void potf2_trsm_kernel(double *__restri
         sc.lane = lane;
         sc.fr = fr;
         sc.fk = fk;
-        typedef double XBlk[16][TP_SP];
-        strip_substitution<false>(sc, bt, reinterpret_cast<XBlk *>(&X[0][0]), nullptr, [](int) {});
+        strip_substitution(sc, bt, X);
     }
     if (edge) edge_signal(edge, edge_val, gridDim.x);
 }
 
-// ------------------------------------------------------------------------------------------------
-// potf2_trsm_upd_kernel (round 5, option "fuse_upd", OFF by default): the diagonal block, the TRSM of the rows below it AND the
-// leaf's rank-128 update of the next 128 / 256 columns in ONE launch -- the separate update launch on the chain of every leaf
-// (7-15 us) disappears for those columns.  Built because VERDICT r4 asked for it; bit-identical to the separate launch; measured
-// SLOWER (N = 4096: 1.16 -> 1.62 ms): behind the chain's last pivot block the update is a chain of memory hand-overs between CUs
-// (write-through store acknowledged after 2.6 us, count, poll, staging load 1.5 us, then the MFMAs) that costs 8-10 us where the
-// separate GEMM costs 7-8 (NOTES_r05.md section 1, profiles/r05_upd_stamps.txt).
-//   Workgroup 0: potf2_body_la / potf2_body, unchanged (publishes the packed workspace block by block).
-//   Workgroups 1..: 64 rows each.  Waves 0..3 ("strip waves", one per SIMD) run the substitution of potf2_trsm_kernel
-//     (strip_substitution) and also leave every x_j in LDS (the strip's "history"); waves 4..7 ("helpers", wave w + 4 on the
-//     SIMD of wave w) keep ALL UT tiles of the strip's rows of the columns [r1, r1 + 16 UT) (r1 = the first row below the
-//     diagonal block) in accumulators, started from C itself.  The B operand of that update is X1 = the solved rows
-//     [r1, r1 + 16 UT) -- other workgroups' results: their owners ("producers") write x_j through to memory as they always did,
-//     drain, and count themselves in a per-step word (flag[32 + j]); the four helper waves of every workgroup stage the
-//     16 UT x 16 block of x_s into LDS (two buffers, a quarter each, one block ahead of the update when it has arrived) and take
-//     4 UT MFMAs per wave against it.  No workgroup barrier after the prologue: strip -> helper and helper <-> helper hand-overs
-//     are counters in LDS (the potf2_body_la style), so the substitution is never held up by the exchange.
-//     (First build, round 4: operands straight from memory, 104 us per leaf.  Round 5 (a): lock-step exchange, three memory round
-//     trips per step; (b): lagged exchange behind two workgroup barriers per step, solve and update alternating; this is (c).)
-// Same sums in the same order as the separate launch (gemm.hip: accumulator from C, MFMA 2t+u of a 16-wide k-tile contracts
-// k = 8t + 2 (lane >> 4) + u, sign by negating one operand): the factor is bit-identical to the unfused schedule's.
-// Tiles above the diagonal (column tile > row tile of the strip) are computed like the others and never stored.
-// ------------------------------------------------------------------------------------------------
-#define PU_XS_PITCH 18
-#define PU_HIST (8 * 16 * TP_SP)                         // doubles of one strip's history: x_0 .. x_7, 16 x 16 each at pitch TP_SP
-#define PU_CONS_SMEM_DOUBLES (4 * PU_HIST + 2 * 256 * PU_XS_PITCH + 16)
-struct PuSync {
-    int hprog[4];        // strip wave w: x_0 .. x_{hprog - 1} are in its history
-    int stage_cnt[8];    // helper waves that have stored their part of the staged block of step s
-    int upd_cnt[8];      // helper waves that are through with the update of step s (its buffer may be overwritten)
-};
-
-// one step's update of a helper wave's UT tiles: A operand = the strip's x_s out of its history (negated), B operand = the
-// staged block of X1's x_s.  No validity test: a tile above the diagonal is computed like the others and never stored (a
-// branch per MFMA made hipcc keep two copies of the accumulators, 40 spilled registers).
-template <int TC>
-__device__ __forceinline__ void pu_update(f64x4 (&accU)[TC], const double (*Hs)[TP_SP], const double *Xsb, int fr, int fk)
-{
-    constexpr int G = (TC > 8) ? 8 : TC;                 // (operand pairs in groups of eight: 32 registers beside the accumulators)
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const f64x2 w = *reinterpret_cast<const f64x2 *>(&Hs[fr][8 * t + 2 * fk]);
-        const f64x2 xa = {-w[0], -w[1]};
-#pragma unroll
-        for (int q0 = 0; q0 < TC; q0 += G) {
-            f64x2 bf[G];
-#pragma unroll
-            for (int q = 0; q < G; q++) bf[q] = *reinterpret_cast<const f64x2 *>(Xsb + ((q0 + q) * 16 + fr) * PU_XS_PITCH + 8 * t + 2 * fk);
-#pragma unroll
-            for (int u = 0; u < 2; u++)
-#pragma unroll
-                for (int q = 0; q < G; q++) accU[q0 + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u], bf[q][u], accU[q0 + q], 0, 0, 0);
-        }
-    }
-}
-// The two kinds of wave are NOT in step with each other (no workgroup barrier after the prologue):
-//   strip waves 0..3: the substitution of potf2_trsm_kernel, every wave polling the chain's flag for itself (the next step's
-//     flag is requested while this step's fold runs); x_j also goes to the strip's history in LDS (hprog), and the producer
-//     strips count themselves in x1cnt[j] once their write-through stores are drained;
-//   helper waves 4..7: ALL update tiles of the strip of wave - 4.  Per step s, as soon as x1cnt[s] says the producers' x_s is
-//     in memory (~3 us behind the chain's flag s + 1: longer than a chain step, which is why nothing here waits for it in
-//     lock-step with the substitution -- the first build of this kernel did and ran 16 us per leaf behind the chain): the four
-//     helper waves load a quarter each of the 16 UT x 16 block into LDS (two buffers), count themselves (stage_cnt), and
-//     take their strip's 4 UT MFMAs against it.  The matrix pipe of SIMD w is shared by strip wave w and helper w + 4.
-template <int UT>
-__device__ __forceinline__ void trsm_upd_consumer(double *__restrict__ invd, int64_t m, double *__restrict__ B, int64_t ldb,
-                                                  unsigned *flag, unsigned flag_base, unsigned x1_base, unsigned *edge,
-                                                  unsigned edge_val, const unsigned *cwait_word, unsigned cwait_val,
-                                                  unsigned *cwait_err)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr int NB16 = PD_NB / 16;
-    constexpr int SW = 4;                                // strip waves per workgroup
-    constexpr int NSV = UT * 256 / 256;                  // staged doubles per helper thread and step
-    constexpr int XSB = 256 * PU_XS_PITCH;               // doubles of one staging buffer
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 15, fk = lane >> 4;
-    const bool helper = wave >= SW;
-    const int sw = wave & 3;
-    typedef double HBlk[16][TP_SP];
-    HBlk *H = reinterpret_cast<HBlk *>(smem + sw * PU_HIST);       // H[s] = x_s of this strip (a helper wave: its strip wave's)
-    double *Xs = smem + SW * PU_HIST;                              // [2][16 UT][PU_XS_PITCH]
-    PuSync *sy = reinterpret_cast<PuSync *>(Xs + 2 * XSB);
-    const int64_t strip = (int64_t)(blockIdx.x - 1) * SW + sw;
-    const int64_t row0 = strip * 16;
-    const bool active = row0 < m;
-    unsigned *x1cnt = flag + 32;                         // x1cnt[s]: producer strips that have posted step s; only ever counted up, by UT per
-                                                         // launch: x1_base = their common value when this launch starts (host's count)
-    if (tid < (int)(sizeof(PuSync) / sizeof(int))) reinterpret_cast<int *>(sy)[tid] = 0;
-    __syncthreads();
-
-    if (helper) {
-        // ================================ helper waves ================================
-        __builtin_amdgcn_s_setprio(1);
-        const int nvalid = (strip + 1 > UT) ? UT : (int)(strip + 1);      // tiles on or below the diagonal of the trailing matrix
-        double *Cn = B + row0 * ldb + PD_NB;             // tile q, element (fk + 4r, fr): Cn[(fk + 4r) ldb + 16 q + fr]
-        f64x4 accU[UT];
-        if (active) {
-            // the C tiles of the update were last written by the main stream's update of the columns this panel touches
-            if (cwait_word != nullptr && lane == 0) edge_poll<1, false>(cwait_word, cwait_val, cwait_err);
-            // accumulators from C (agent-scope loads: behind an in-kernel wait they must not hit a stale line, EdgeSig form (b))
-#pragma unroll
-            for (int q = 0; q < UT; q++) {
-                if (q < nvalid) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        accU[q][r] = __hip_atomic_load(Cn + (int64_t)(fk + 4 * r) * ldb + 16 * q + fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    accU[q] = f64x4{0.0, 0.0, 0.0, 0.0};
-                }
-            }
-        }
-        const int ht = tid - 256;                        // 0 .. 255 over the four helper waves
-        const unsigned ldb8 = (unsigned)ldb * 8u;        // (the launcher checks that these byte offsets fit 32 bits)
-        double sv[NSV];
-        auto block_load = [&](int s) {
-#pragma unroll
-            for (int q = 0; q < NSV; q++) {
-                // (uniform base + 32-bit byte offset: one address register per load)
-                const int idx = ht + q * 256;
-                const unsigned off = (unsigned)(idx >> 4) * ldb8 + (unsigned)(idx & 15) * 8u;
-                sv[q] = __hip_atomic_load(reinterpret_cast<const double *>(reinterpret_cast<const char *>(B + s * 16) + off),
-                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        };
-        auto cnt_load = [&](int s) -> unsigned {
-            return __hip_atomic_load(x1cnt + (s & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
-        PU_STAMP(0);
-        // Pipelined: the block of step s + 1 is requested BEFORE the update of step s when it has arrived by then (its counter was
-        // read one update earlier) -- a wave that is behind the producers, the normal case with 16 tiles, never waits for a load.
-        {
-            const unsigned c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)cnt_load(0));
-            pu_poll_ge<2>(x1cnt, c0, x1_base, UT);
-            block_load(0);
-        }
-        unsigned cn = cnt_load(1);                       // x1cnt[s + 1], requested one update ahead
-#pragma unroll 1
-        for (int s = 0; s < NB16; s++) {
-            PU_STAMP(1 + 3 * s);
-            double *Xsb = Xs + (s & 1) * XSB;
-            if (s >= 2) lds_wait_ge<false>(&sy->upd_cnt[s - 2], 4);          // everybody is through with this buffer's last block
-#pragma unroll
-            for (int q = 0; q < NSV; q++) {
-                const int idx = ht + q * 256;
-                Xsb[(idx >> 4) * PU_XS_PITCH + (idx & 15)] = sv[q];
-            }
-            asm volatile("" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(&sy->stage_cnt[s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            asm volatile("" ::: "memory");
-            const unsigned cnow = (unsigned)__builtin_amdgcn_readfirstlane((int)cn);
-            const bool pre = (s + 1 < NB16) && (int)(cnow - x1_base) >= UT;
-            if (pre) block_load(s + 1);
-            cn = cnt_load(s + 2);
-            lds_wait_ge<false>(&sy->stage_cnt[s], 4);
-            PU_STAMP(2 + 3 * s);
-            if (active) {
-                lds_wait_ge<false>(&sy->hprog[sw], s + 1);
-                pu_update<UT>(accU, H[s], Xsb, fr, fk);
-            }
-            PU_STAMP(3 + 3 * s);
-            asm volatile("" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(&sy->upd_cnt[s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            asm volatile("" ::: "memory");
-            if (s + 1 < NB16 && !pre) {
-                pu_poll_ge<2>(x1cnt + s + 1, cnow, x1_base, UT);
-                block_load(s + 1);
-            }
-        }
-        if (active) {
-#pragma unroll
-            for (int q = 0; q < UT; q++)
-                if (q < nvalid) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) Cn[(int64_t)(fk + 4 * r) * ldb + 16 * q + fr] = accU[q][r];
-                }
-        }
-        PU_STAMP(25);
-        if (edge) edge_signal(edge, edge_val, gridDim.x);
-        return;
-    }
-
-    // ================================ strip waves ================================
-    __builtin_amdgcn_s_setprio(2);
-    const bool producer = active && strip < UT;
-    f64x4 bt[NB16];
-    if (active) {
-#pragma unroll
-        for (int j = 0; j < NB16; j++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) bt[j][r] = B[(row0 + fk + 4 * r) * ldb + j * 16 + fr];
-    }
-    PU_STAMP(0);
-    if (active) {
-        StripCtx sc;
-        sc.ws = invd;
-        sc.flag = flag;
-        sc.flag_base = flag_base;
-        sc.Brow = B + row0 * ldb;
-        sc.ldb = ldb;
-        sc.through = (edge != nullptr) || producer;
-        sc.lane = lane;
-        sc.fr = fr;
-        sc.fk = fk;
-        strip_substitution<true>(sc, bt, H, &sy->hprog[sw], [&](int j) {
-            PU_STAMP(1 + j);
-            if (producer) {
-                // (stores count in vmcnt on gfx9: drained = x_j is in memory)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_fetch_add(x1cnt + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        });
-    }
-    if (edge) edge_signal(edge, edge_val, gridDim.x);
-}
-
-template <bool LA, int UT>
-__global__ __launch_bounds__(PD_THREADS) void potf2_trsm_upd_kernel(double *__restrict__ A, int64_t lda,
-                                                                    double *__restrict__ invd, int32_t *info,
-                                                                    int64_t info_col0, int64_t m, double *__restrict__ B,
-                                                                    int64_t ldb, unsigned *flag, unsigned flag_base,
-                                                                    unsigned x1_base, unsigned *edge, unsigned edge_val,
-                                                                    const unsigned *wait_word, unsigned wait_val,
-                                                                    unsigned *wait_err, const unsigned *cwait_word,
-                                                                    unsigned cwait_val, unsigned *cwait_err)
-{
-    edge_wait(wait_word, wait_val, wait_err);
-    if (blockIdx.x == 0) {
-        if (LA) potf2_body_la<true>(A, lda, invd, info, info_col0, flag, flag_base);
-        else potf2_body<true>(A, lda, invd, info, info_col0, flag, flag_base);
-        if (edge) edge_signal(edge, edge_val, gridDim.x);
-        return;
-    }
-    trsm_upd_consumer<UT>(invd, m, B, ldb, flag, flag_base, x1_base, edge, edge_val, cwait_word, cwait_val, cwait_err);
-}
-
-// ------------------------------------------------------------------------------------------------
-// potf2x2_trsm_kernel: a 256-COLUMN leaf in one launch -- the chain-bound end of a factorisation spends its time in
-// launches (diagonal block 21 us, TRSM tail 8, rank-128 update 13.5, the gaps between them), not in arithmetic.
-//   Workgroup 0:  L00 = chol(A00) (potf2_body, published block by block)            flags base+1 .. base+8
-//                 L10 = A10 L00^-T: sixteen rows per wave, blocked substitution on MFMA with L00 and the inverses of its
-//                 16x16 diagonal blocks still in LDS; written to A and, packed in B-operand order, to `l10pk`   flag base+9
-//                 A11 -= L10 L10^T (36 lower tiles over the eight waves, operands from LDS), assembled in LDS
-//                 L11 = chol(A11) (potf2_body<.., STAGED>)                              flags base+10 .. base+17
-//   Workgroups 1..: 128 rows of the panel below the 256x256 block each (16 per wave), as in potf2_trsm_kernel:
-//                 X0 = B0 L00^-T trailing the first pivot chain, B1 -= X0 L10^T once L10 is out (the packed L10 is
-//                 copied to the workgroup's LDS first: 64 blocks, read by all eight waves), X1 = B1 L11^-T trailing the
-//                 second chain.
-// One launch does what took two diagonal-block launches, two TRSMs and a rank-128 update; the rank-256 update of the
-// columns to the right follows as one GEMM.  Same flag protocol as potf2_trsm_kernel (workgroup 0 waits for nobody).
-// ------------------------------------------------------------------------------------------------
-#define PD_L10PK (64 * 256)     // doubles of the packed L10 (64 blocks of 16x16)
-
-// Steps 0..7 of the forward substitution of one 128-column block for the 16 rows of a consumer wave: `acc` enters as
-// the right-hand side of step 0 and the tiles bt[jt0 .. jt0+7] are the block's right-hand sides; X tiles go to B.
-__device__ __forceinline__ void consumer_phase(const double *__restrict__ ws, unsigned *flag, unsigned fb, int jt0,
-                                               f64x4 (&bt)[16], double (&xa)[8][4], double (*X)[TP_SP],
-                                               double *__restrict__ B, int64_t ldb, int64_t row0, bool active, int tid,
-                                               int lane, int fr, int fk)
-{
-    constexpr int NB16 = PD_NB / 16;
-    const double *lpk = ws + GPT_WS_LOFF;
-    f64x4 acc = bt[jt0];
-#pragma unroll
-    for (int j = 0; j < NB16; j++) {
-        if (tid == 0) {
-            while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - fb) < j + 1)
-                __builtin_amdgcn_s_sleep(1);
-        }
-        __syncthreads();
-        if (!active) continue;
-        double dv[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++)
-            dv[kk] = __hip_atomic_load(ws + j * 256 + kk * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int r = 0; r < 4; r++) X[fk + 4 * r][fr] = acc[r];
-        double av[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) av[kk] = X[fr][fk + 4 * kk];
-        f64x4 res = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) res = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], dv[kk], res, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            B[(row0 + fk + 4 * r) * ldb + (jt0 + j) * 16 + fr] = res[r];
-            X[fk + 4 * r][fr] = res[r];
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) xa[j][kk] = -X[fr][fk + 4 * kk];
-        if (j + 1 < NB16) {
-            acc = bt[jt0 + j + 1];
-#pragma unroll
-            for (int c = 0; c <= j; c++) {
-                double lv[4];
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++)
-                    lv[kk] = __hip_atomic_load(lpk + ((j + 1) * j / 2 + c) * 256 + kk * 64 + lane, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[c][kk], lv[kk], acc, 0, 0, 0);
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(PD_THREADS) void potf2x2_trsm_kernel(double *__restrict__ A, int64_t lda,
-                                                                  double *__restrict__ invd, int32_t *info,
-                                                                  int64_t info_col0, int64_t m,
-                                                                  double *__restrict__ l10pk, unsigned *flag,
-                                                                  unsigned flag_base)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 15, fk = lane >> 4;
-    constexpr int NB16 = PD_NB / 16;
-    if (blockIdx.x == 0) {
-        double (*S)[PD_PITCH] = reinterpret_cast<double (*)[PD_PITCH]>(smem);
-        typedef double TBuf[16][PD_TP];
-        TBuf *T = reinterpret_cast<TBuf *>(smem + PD_NB * PD_PITCH);
-        // ---- L00
-        potf2_body<true>(A, lda, invd, info, info_col0, flag, flag_base);
-        PD_STAMP(72);
-        // (potf2_body ends with a barrier: S = L00 row-major, T[j] = transposed inverses of its diagonal blocks)
-        // ---- L10 = A10 L00^-T, rows 16 wave .. 16 wave + 15.  The per-wave 16x16 re-layout scratch is a tile of S's
-        // dead upper triangle: (0, wave + 1) for waves 0..6, (1, 2) for wave 7.
-        double *A10 = A + (int64_t)PD_NB * lda;
-        const int xr = (wave < 7) ? 0 : 16, xc = (wave < 7) ? (wave + 1) * 16 : 32;
-        f64x4 xt[NB16];
-        double xa[NB16][4];
-#pragma unroll
-        for (int j = 0; j < NB16; j++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) xt[j][r] = A10[(int64_t)(16 * wave + fk + 4 * r) * lda + j * 16 + fr];
-        PD_STAMP(73);
-#pragma unroll
-        for (int j = 0; j < NB16; j++) {
-            f64x4 acc = xt[j];
-#pragma unroll
-            for (int c = 0; c < j; c++) {
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[c][kk], S[j * 16 + fr][c * 16 + fk + 4 * kk], acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; r++) S[xr + fk + 4 * r][xc + fr] = acc[r];
-            double av[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) av[kk] = S[xr + fr][xc + fk + 4 * kk];
-            f64x4 res = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) res = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], T[j][fk + 4 * kk][fr], res, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                A10[(int64_t)(16 * wave + fk + 4 * r) * lda + j * 16 + fr] = res[r];
-                S[xr + fk + 4 * r][xc + fr] = res[r];
-            }
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) xa[j][kk] = -S[xr + fr][xc + fk + 4 * kk];
-            xt[j] = res;
-        }
-        PD_STAMP(74);
-        // packed L10 for the consumers: block (row tile = wave, column block j), element (fr, fk + 4 kk) at [kk][lane]
-#pragma unroll
-        for (int j = 0; j < NB16; j++)
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++)
-                __hip_atomic_store(l10pk + ((wave * NB16 + j) * 256 + kk * 64 + lane), -xa[j][kk], __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        // EVERY wave drains its own stores before the barrier: a workgroup-scope barrier does not wait for global stores
-        // (the waves of a workgroup share the CU's L1), so the flag of wave 4 could overtake another wave's part of L10
-        // (seen: the consumers of the second launch of a factorisation read the previous leaf's block)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (write-through stores: drained = visible, no release fence needed)
-        __syncthreads();                            // ... and every wave is done with L00 / the inverses in LDS
-        if (wave == 4 && lane == 0) __hip_atomic_store(flag, flag_base + 9u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // ---- S <- L10 (rows 16 wave ..), then A11 -= L10 L10^T on the 36 lower tiles
-#pragma unroll
-        for (int j = 0; j < NB16; j++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) S[16 * wave + fk + 4 * r][j * 16 + fr] = xt[j][r];
-        double *A11 = A10 + PD_NB;
-        constexpr int NT = NB16 * (NB16 + 1) / 2, PERW = (NT + PD_WAVES - 1) / PD_WAVES;
-        f64x4 ct[PERW];
-        int tis[PERW], tjs[PERW];
-#pragma unroll
-        for (int q = 0; q < PERW; q++) {
-            const int t = wave + q * PD_WAVES;
-            tis[q] = 0;
-            tjs[q] = 0;
-            if (t < NT) {
-                tri_decode(t, tis[q], tjs[q]);
-#pragma unroll
-                for (int r = 0; r < 4; r++) ct[q][r] = A11[(int64_t)(tis[q] * 16 + fk + 4 * r) * lda + tjs[q] * 16 + fr];
-            }
-        }
-        PD_STAMP(75);
-        __syncthreads();                            // L10 complete in S
-        PD_STAMP(76);
-#pragma unroll
-        for (int q = 0; q < PERW; q++) {
-            const int t = wave + q * PD_WAVES;
-            if (t < NT) {
-                f64x4 c0 = ct[q], c1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int k = 0; k < NB16; k++) {
-                    double av[4], bv[4];
-#pragma unroll
-                    for (int kk = 0; kk < 4; kk++) {
-                        av[kk] = -S[tis[q] * 16 + fr][k * 16 + fk + 4 * kk];
-                        bv[kk] = S[tjs[q] * 16 + fr][k * 16 + fk + 4 * kk];
-                    }
-                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], c1, 0, 0, 0);
-                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], c1, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; r++) ct[q][r] = c0[r] + c1[r];
-            }
-        }
-        PD_STAMP(77);
-        __syncthreads();                            // every wave is done reading L10 from S
-#pragma unroll
-        for (int q = 0; q < PERW; q++) {
-            const int t = wave + q * PD_WAVES;
-            if (t < NT) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) S[tis[q] * 16 + fk + 4 * r][tjs[q] * 16 + fr] = ct[q][r];
-            }
-        }
-        __syncthreads();
-        PD_STAMP(78);
-        // ---- L11
-        potf2_body<true, true>(A11, lda, invd + GPT_WS_BLOCK, info, info_col0 + PD_NB, flag, flag_base + 9u);
-        PD_STAMP(79);
-        PD_STAMP_DUMP();
-        return;
-    }
-    // ---- consumers
-    double *Lq = smem;                                                          // packed L10, PD_L10PK doubles
-    double (*X)[TP_SP] = reinterpret_cast<double (*)[TP_SP]>(smem + PD_L10PK + wave * 16 * TP_SP);
-    double *B = A + (int64_t)2 * PD_NB * lda;
-    const int64_t row0 = ((int64_t)(blockIdx.x - 1) * PD_WAVES + wave) * 16;
-    const bool active = row0 < m;
-    f64x4 bt[2 * NB16];
-    double xa[NB16][4];
-    if (active) {
-#pragma unroll
-        for (int j = 0; j < 2 * NB16; j++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) bt[j][r] = B[(row0 + fk + 4 * r) * lda + j * 16 + fr];
-    }
-    consumer_phase(invd, flag, flag_base, 0, bt, xa, X, B, lda, row0, active, tid, lane, fr, fk);
-    // L10 (64 packed blocks) into this workgroup's LDS once it is out
-    if (tid == 0) {
-        while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - flag_base) < 9)
-            __builtin_amdgcn_s_sleep(1);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < PD_L10PK / PD_THREADS; h += 8) {
-        double v[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++)
-            v[q] = __hip_atomic_load(l10pk + (h + q) * PD_THREADS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int q = 0; q < 8; q++) Lq[(h + q) * PD_THREADS + tid] = v[q];
-    }
-    __syncthreads();
-    if (active) {
-        // B1 -= X0 L10^T: tile c of the second block takes the eight column blocks of X0 (xa = -X0 in A-operand form)
-#pragma unroll
-        for (int c = 0; c < NB16; c++) {
-            f64x4 a0 = bt[NB16 + c], a1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int k = 0; k < NB16; k++) {
-                const double *blk = Lq + (c * NB16 + k) * 256 + lane;
-                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k][0], blk[0], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k][1], blk[64], a1, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k][2], blk[128], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k][3], blk[192], a1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; r++) bt[NB16 + c][r] = a0[r] + a1[r];
-        }
-    }
-    consumer_phase(invd + GPT_WS_BLOCK, flag, flag_base + 9u, NB16, bt, xa, X, B, lda, row0, active, tid, lane, fr, fk);
-}
+// (Removed in round 6, sources in the history up to round 5's last commit: potf2_trsm_upd_kernel -- the leaf's rank-128 update of
+// the next 128 / 256 columns inside the leaf's launch, bit-identical and slower, NOTES_r05.md section 1 -- and potf2x2_trsm_kernel --
+// a 256-column leaf in one launch, round 2, slower than two 128-column leaves once the fused leaf kernel existed.)
 
 // The 135 KB of dynamic LDS the diagonal-block kernels ask for needs hipFuncAttributeMaxDynamicSharedMemorySize, which
 // is a property of the function ON ONE DEVICE: set once per (kernel, device), thread-safe (ll_batch and bench.py drive
@@ -1853,64 +1365,6 @@ int launch_potf2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int3
                                     wait.word, wait.value, wait.err);
     else hipLaunchKernelGGL(kern, dim3(grid), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base, m,
                             A + 128 * lda, lda, flag, flag_base, edge.word, edge.value, wait.word, wait.value, wait.err);
-    GPT_LAUNCH_CHECK();
-    return GPT_OK;
-}
-
-// The same with the leaf's update of the next `upd_cols` (128 or 256) columns inside the launch (potf2_trsm_upd_kernel; 64
-// rows per consumer workgroup).  flag[32..39] are the producers' counters, one per step: x1_base = their common value before
-// this launch; the launch raises each by upd_cols / 16.  cwait: the word the update's C tiles wait for (may be empty).
-int launch_potf2_trsm_upd(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
-                          unsigned *flag, unsigned flag_base, unsigned x1_base, int64_t upd_cols, hipEvent_t done,
-                          EdgeSig edge, EdgeSig wait, EdgeSig cwait)
-{
-    gpt_jitter(st);
-    if (!(upd_cols == 128 || upd_cols == 256) || m < upd_cols || m % 64 || lda >= (int64_t)1 << 21) {      // (32-bit byte offsets of the staged rows)
-        gpt_set_error("potf2_trsm_upd: bad shape (m=%lld, upd_cols=%lld)", (long long)m, (long long)upd_cols);
-        return GPT_E_ARG;
-    }
-    const bool la = potf2_lookahead();
-    size_t shmem = la ? PD_LA_SMEM_BYTES : (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
-    if (shmem < (size_t)PU_CONS_SMEM_DOUBLES * sizeof(double)) shmem = (size_t)PU_CONS_SMEM_DOUBLES * sizeof(double);
-    typedef void (*kern_t)(double *, int64_t, double *, int32_t *, int64_t, int64_t, double *, int64_t, unsigned *, unsigned,
-                           unsigned, unsigned *, unsigned, const unsigned *, unsigned, unsigned *, const unsigned *, unsigned,
-                           unsigned *);
-    kern_t kern;
-    int which;
-    if (upd_cols == 128) {
-        kern = la ? potf2_trsm_upd_kernel<true, 8> : potf2_trsm_upd_kernel<false, 8>;
-        which = la ? 5 : 6;
-    } else {
-        kern = la ? potf2_trsm_upd_kernel<true, 16> : potf2_trsm_upd_kernel<false, 16>;
-        which = la ? 7 : 8;
-    }
-    { int rc_ = ensure_big_lds(reinterpret_cast<const void *>(kern), which, shmem); if (rc_ != GPT_OK) return rc_; }
-    const unsigned grid = 1u + (unsigned)(m / 64);
-    if (done) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(PD_THREADS), shmem, st, nullptr, done, 0, A, lda, invd, info, info_base, m,
-                                    A + 128 * lda, lda, flag, flag_base, x1_base, edge.word, edge.value, wait.word, wait.value,
-                                    wait.err, cwait.word, cwait.value, cwait.err);
-    else hipLaunchKernelGGL(kern, dim3(grid), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base, m, A + 128 * lda, lda,
-                            flag, flag_base, x1_base, edge.word, edge.value, wait.word, wait.value, wait.err, cwait.word,
-                            cwait.value, cwait.err);
-    GPT_LAUNCH_CHECK();
-    return GPT_OK;
-}
-
-// 256-column leaf: diagonal blocks at A and A + 128 lda + 128, m rows below them; invd = the two blocks' workspaces;
-// l10pk = PD_L10PK doubles of scratch; the flag word advances by up to 17 (the caller counts 32 per launch).
-int launch_potf2x2_trsm(hipStream_t st, double *A, int64_t lda, double *invd, int32_t *info, int64_t info_base, int64_t m,
-                        double *l10pk, unsigned *flag, unsigned flag_base, hipEvent_t done)
-{
-    gpt_jitter(st);
-    size_t shmem = (size_t)(PD_NB * PD_PITCH + 8 * 16 * PD_TP) * sizeof(double);
-    const size_t cons = (size_t)(PD_L10PK + PD_WAVES * 16 * TP_SP) * sizeof(double);
-    if (cons > shmem) shmem = cons;
-    { int rc_ = ensure_big_lds(reinterpret_cast<const void *>(potf2x2_trsm_kernel), 2, shmem); if (rc_ != GPT_OK) return rc_; }
-    const unsigned grid = 1u + (unsigned)((m + 16 * PD_WAVES - 1) / (16 * PD_WAVES));
-    if (done) hipExtLaunchKernelGGL(potf2x2_trsm_kernel, dim3(grid), dim3(PD_THREADS), shmem, st, nullptr, done, 0, A, lda, invd,
-                                    info, info_base, m, l10pk, flag, flag_base);
-    else hipLaunchKernelGGL(potf2x2_trsm_kernel, dim3(grid), dim3(PD_THREADS), shmem, st, A, lda, invd, info, info_base, m,
-                            l10pk, flag, flag_base);
     GPT_LAUNCH_CHECK();
     return GPT_OK;
 }

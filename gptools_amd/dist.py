@@ -283,6 +283,228 @@ def _ptr(t, row, col):
     return t.data_ptr() + (row * t.stride(0) + col) * t.element_size()
 
 
+# ======================================================================================================
+# Compiled schedules (round 6): the step loop recorded once as an op list, replayed per evaluation
+# ======================================================================================================
+# What a rank does per evaluation -- which library kernels on which buffers, on which queue, in which order, which events and
+# which panel exchanges between them -- depends on (N, nb, world, rank, options) only.  ``PlanRecorder`` is a PanelOps that
+# executes nothing: driven ONCE through the engine's own step loop it yields the op list; ``CompiledPlan`` replays it
+#   * natively: one call of ``gpt_plan_run`` (csrc/api_plan.inc) per evaluation -- a C loop over fixed-size integer records, RCCL
+#     called directly from the library on the plan's own communication stream (product path, HipPanelOps), or
+#   * through a Python interpreter of the SAME list against any PanelOps + torch.distributed (the gloo / numpy tests, and the
+#     ranks-sharing-one-GPU tests, where RCCL cannot run).
+OP_RECORD, OP_WAIT, OP_KBUILD, OP_PAD, OP_COPY2D, OP_POTRF_PANEL, OP_TRINV, OP_GEMM, OP_STAIR, OP_SCALARS, OP_BCAST, OP_SCATTER, \
+    OP_ALLGATHER = range(13)
+PLAN_W = 16
+QUEUE_ID = {"main": 0, "panel": 1, "recv": 2, "comm": 3}
+
+
+def _f64_bits(x):
+    import struct
+    return struct.unpack("<q", struct.pack("<d", float(x)))[0]
+
+
+class _RecEvent(object):
+    __slots__ = ("rec", "idx")
+
+    def __init__(self, rec):
+        self.rec, self.idx = rec, rec.nevents
+        rec.nevents += 1
+
+    def record(self):
+        self.rec.emit(OP_RECORD, self.rec.cur, [self.idx])
+
+    def wait(self):
+        self.rec.emit(OP_WAIT, self.rec.cur, [self.idx])
+
+
+class _RecQueue(object):
+    __slots__ = ("rec", "q", "prev")
+
+    def __init__(self, rec, q):
+        self.rec, self.q = rec, q
+
+    def __enter__(self):
+        self.prev, self.rec.cur = self.rec.cur, self.q
+        return self
+
+    def __exit__(self, *exc):
+        self.rec.cur = self.prev
+        return False
+
+
+class PlanRecorder(PanelOps):
+    """A PanelOps that records instead of executing.  ``ops``: list of ``(opcode, queue name, ints, py)`` -- ``ints`` is the native
+    record (addresses, sizes, bit patterns of doubles: include/gpt_hip.h "compiled schedules"), ``py`` what the Python interpreter
+    hands to the real ops object."""
+
+    def __init__(self, device):
+        self.device = device
+        self.ops, self.nevents, self.cur = [], 0, "main"
+
+    def emit(self, opcode, q, ints, py=None):
+        assert len(ints) <= PLAN_W - 2
+        self.ops.append((opcode, q, [int(v) for v in ints], py))
+
+    def queue(self, q):
+        return _RecQueue(self, q)
+
+    def new_event(self):
+        return _RecEvent(self)
+
+    def new_timing_event(self):
+        return None
+
+    def synchronize(self):
+        pass
+
+    # -- dense ops (the per-evaluation inputs of the K builder -- kernel id, hyperparameters, noise variance, loading -- are NOT
+    #    recorded: they are arguments of every replay)
+    def kbuild_block(self, kernel_id, params, X, n, r0, r1, c0, c1, err_y, noise_var, diag_add, out, ld):
+        self.emit(OP_KBUILD, "main", [r0, r1, c0, c1, out, ld], (r0, r1, c0, c1, out, ld))
+
+    def pad_block(self, A, lj, c0, nb, N, NP, y, big, row_shift=0):
+        self.emit(OP_PAD, "main", [_ptr(A, 0, lj * nb) + row_shift * A.stride(0) * 8, A.stride(0), c0, nb, N, NP, y.data_ptr(),
+                                   _f64_bits(big)], (A, lj, c0, nb, N, NP, y, big, row_shift))
+
+    def copy2d(self, dst, src, q="panel"):
+        assert dst.shape == src.shape and dst.stride(1) == 1 and src.stride(1) == 1
+        self.emit(OP_COPY2D, q, [src.shape[0], src.shape[1], src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0)], (dst, src))
+
+    def potrf_panel(self, m, nb, A, lda, invd, info, info_base):
+        self.emit(OP_POTRF_PANEL, "panel", [m, nb, A, lda, invd.data_ptr(), info.data_ptr(), info_base],
+                  (m, nb, A, lda, invd, info, info_base))
+
+    def trinv(self, nb, L, ldl, invd, W, ldw, q="panel"):
+        self.emit(OP_TRINV, q, [nb, L, ldl, invd.data_ptr(), W, ldw], (nb, L, ldl, invd, W, ldw))
+
+    def gemm_nt(self, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri, q="main"):
+        self.emit(OP_GEMM, q, [m, n, k, _f64_bits(alpha), A, lda, B, ldb, _f64_bits(beta), C, ldc, tri],
+                  (m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri))
+
+    def gemm_nt_stair(self, m, nseg, seg_cols, k, alpha, A, lda, B, ldb, b_stride, row_step, beta, C, ldc, q="main"):
+        self.emit(OP_STAIR, q, [m, nseg, seg_cols, k, _f64_bits(alpha), A, lda, B, ldb, b_stride, row_step, _f64_bits(beta), C, ldc],
+                  (m, nseg, seg_cols, k, alpha, A, lda, B, ldb, b_stride, row_step, beta, C, ldc))
+
+    def panel_scalars(self, buf, w, zrow, red, q="panel"):
+        self.emit(OP_SCALARS, q, [buf.data_ptr(), buf.stride(0), w, zrow, red.data_ptr()], (buf, w, zrow, red))
+
+    # -- the panel exchange: [issuing queue records "ready"] [comm stream waits for it] [collective(s)] [comm stream records
+    #    "arrived"]; the returned handle's wait() is a wait for "arrived" on whatever queue is current then
+    def exchange(self, buf, src, world, grank, scatter_gather):
+        ready, arrived = _RecEvent(self), _RecEvent(self)
+        issuing = self.cur
+        ready.record()
+        self.emit(OP_WAIT, "comm", [ready.idx])
+        rows = buf.shape[0]
+        if scatter_gather:
+            cnt = (rows // world) * buf.shape[1]
+            self.emit(OP_SCATTER, "comm", [buf.data_ptr(), cnt, src], (buf, src, issuing, arrived.idx))
+            self.emit(OP_ALLGATHER, "comm", [buf.data_ptr(), cnt], None)
+        else:
+            self.emit(OP_BCAST, "comm", [buf.data_ptr(), buf.numel(), src], (buf, src, issuing, arrived.idx))
+        self.emit(OP_RECORD, "comm", [arrived.idx])
+        return [arrived]
+
+
+class CompiledPlan(object):
+    """The op list of one rank's evaluation and its two executors (see above)."""
+
+    def __init__(self, recorder):
+        self.ops = recorder.ops
+        self.nevents = recorder.nevents
+        self.handle = None
+        self._keep = None
+
+    # ---- native ----
+    def build_native(self, hip_ops, X, n, err, nranks, rank, comm_group, with_comm):
+        lib = hip_ops.lib
+        arr = np.zeros((len(self.ops), PLAN_W), dtype=np.int64)
+        for i, (opcode, q, ints, _) in enumerate(self.ops):
+            arr[i, 0], arr[i, 1] = opcode, QUEUE_ID[q]
+            arr[i, 2:2 + len(ints)] = ints
+        import ctypes as C
+        ctxs = (C.c_void_p * 3)(hip_ops.ctx_main.handle, hip_ops.ctx_panel.handle, hip_ops.ctx_recv.handle)
+        out = C.c_void_p()
+        _lib.check(lib.gpt_plan_create(3, ctxs, arr.ctypes.data_as(C.POINTER(C.c_int64)), len(self.ops), self.nevents, X.data_ptr(),
+                                       n.data_ptr(), int(X.shape[1]), err.data_ptr(), C.byref(out)))
+        self.handle, self.lib = out, lib
+        self._keep = (X, n, err)
+        if with_comm:
+            # the communicator's id: made on rank 0, handed round through the job's own process group
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                buf = (C.c_char * 128)()
+                _lib.check(lib.gpt_plan_unique_id(buf))
+                uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            if nranks > 1:
+                dev_uid = uid.to(hip_ops.device) if dist.get_backend(comm_group) == "nccl" else uid
+                dist.broadcast(dev_uid, src=dist.get_global_rank(comm_group, 0) if comm_group is not None else 0, group=comm_group)
+                uid = dev_uid.cpu()
+            raw = bytes(uid.numpy().tobytes())
+            _lib.check(lib.gpt_plan_set_comm(self.handle, nranks, rank, C.c_char_p(raw)))
+        return self
+
+    def run_native(self, kernel_id, params, noise_var, diag_add):
+        params = _lib.f64(params)
+        _lib.check(self.lib.gpt_plan_run(self.handle, int(kernel_id), _lib.dptr(params), len(params), float(noise_var), float(diag_add)))
+        return self.lib.gpt_plan_last_enqueue_ms(self.handle)
+
+    def close(self):
+        if self.handle is not None:
+            self.lib.gpt_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- Python interpreter of the same list ----
+    def run_python(self, ops, engine, kernel_id, params, noise_var, diag_add):
+        events = [ops.new_event() for _ in range(self.nevents)]
+        works = {}
+        for opcode, q, ints, py in self.ops:
+            if q == "comm":
+                # torch.distributed orders a collective behind the stream that is current when it is issued and hands back work
+                # objects: "ready" / the comm stream's own waits have no counterpart, "arrived" is the work objects
+                if opcode in (OP_BCAST, OP_SCATTER):
+                    buf, src, issuing, arrived = py
+                    with ops.queue(issuing):
+                        works[arrived] = engine._exchange_now(buf, src, scatter_gather=(opcode == OP_SCATTER))
+                continue
+            with ops.queue(q):
+                if opcode == OP_RECORD:
+                    events[ints[0]].record()
+                elif opcode == OP_WAIT:
+                    if ints[0] in works:
+                        for w in works.pop(ints[0]):
+                            if w is not None:
+                                w.wait()
+                    else:
+                        events[ints[0]].wait()
+                elif opcode == OP_KBUILD:
+                    r0, r1, c0, c1, out, ld = py
+                    ops.kbuild_block(kernel_id, params, engine.X, engine.n, r0, r1, c0, c1, engine.err, noise_var, diag_add, out, ld)
+                elif opcode == OP_PAD:
+                    ops.pad_block(*py)
+                elif opcode == OP_COPY2D:
+                    ops.copy2d(py[0], py[1], q=q)
+                elif opcode == OP_POTRF_PANEL:
+                    ops.potrf_panel(*py)
+                elif opcode == OP_TRINV:
+                    ops.trinv(*py, q=q)
+                elif opcode == OP_GEMM:
+                    ops.gemm_nt(*py, q=q)
+                elif opcode == OP_STAIR:
+                    ops.gemm_nt_stair(*py, q=q)
+                elif opcode == OP_SCALARS:
+                    ops.panel_scalars(*py, q=q)
+                else:
+                    raise ValueError("unknown opcode %r" % (opcode,))
+
+
 class _Arrival(object):
     """One row chunk of a panel becoming readable on this rank: the exchange's work handle (None when no collective was
     issued) and, on the owner, the event after the kernels that produced it.  ``wait()`` orders the current queue
@@ -315,7 +537,7 @@ class DistributedLML(object):
 
     def __init__(self, X, n, nb=512, group=None, ops=None, device=None, lookahead=True, layout=None,
                  schedule="bcast", exchange="bcast", sag_min_bytes=8 << 20, owner_first=None, inv_trsm=True,
-                 inv_min_rows=8192):
+                 inv_min_rows=8192, compiled=None):
         if nb <= 0 or nb % 128:
             raise ValueError("nb must be a positive multiple of 128")
         self.group = group
@@ -385,6 +607,25 @@ class DistributedLML(object):
         self._h_out = torch.from_numpy(_lib.pinned_empty((3,), min_bytes=0)) if on_gpu else None
         self.timings = {}
         self.trace = False          # record the device-timeline position of every step (timings["steps_ms"])
+        # compiled: how an evaluation is driven.  "native": the step loop recorded once, replayed by gpt_plan_run (C loop, RCCL
+        # called from the library); "python": the same op list through the Python interpreter (any ops, torch.distributed);
+        # False: the step loop itself issues every operation (what rounds 1-5 did; still what a traced evaluation does).
+        # None: "native" with the product ops when the ranks can have a RCCL communicator of their own (one rank, or an
+        # "nccl" process group = one GPU per rank), else "python".  GPT_DIST_COMPILED=0 / native / python overrides.
+        env = os.environ.get("GPT_DIST_COMPILED")
+        if env is not None:
+            compiled = False if env == "0" else env
+        if compiled is None:
+            rccl_ok = isinstance(ops, HipPanelOps) and (not dist.is_initialized() or dist.get_world_size(group) == 1
+                                                        or dist.get_backend(group) == "nccl")
+            compiled = "native" if (rccl_ok and layout is None) else "python"
+        if compiled not in (False, "native", "python"):
+            raise ValueError("compiled must be None, False, 'native' or 'python'")
+        if compiled == "native" and not isinstance(ops, HipPanelOps):
+            raise ValueError("compiled='native' needs the product ops (HipPanelOps)")
+        self.compiled = compiled
+        self._plans = {}
+        self._rec = None
 
     # ------------------------------------------------------------------------------------------
     def _assemble(self, kernel_id, params, noise_var, diag_add):
@@ -409,20 +650,28 @@ class DistributedLML(object):
         gsrc = dist.get_global_rank(group, src) if group is not None else src
         return dist.broadcast(buf, src=gsrc, group=group, async_op=async_op)
 
+    def _use_scatter_gather(self, buf):
+        return (self.exchange == "scatter_gather" and buf.shape[0] % self.world == 0
+                and buf.numel() * buf.element_size() >= self.sag_min_bytes)
+
     def _exchange(self, buf, src, group=None, tag=None):
-        """Start moving the contiguous rows ``buf`` from rank ``src`` to everyone; returns the list of work handles to
-        wait for (empty when no collective is needed).  scatter + all-gather: the root's links each carry 1/world of
-        the rows, then every link carries the all-gather; a broadcast moves the whole chunk along one path.  ``tag`` = (panel, first row) is not used here
+        """Start moving the contiguous rows ``buf`` from rank ``src`` to everyone; returns the list of handles to wait for
+        (empty when no collective is needed).  scatter + all-gather: the root's links each carry 1/world of the rows, then
+        every link carries the all-gather; a broadcast moves the whole chunk along one path.  While the step loop is being
+        RECORDED (compiled schedules) the exchange becomes ops of the list.  ``tag`` = (panel, first row) is not used here
         (scratch/sim_ranks.py overrides this method and needs to know what is being moved)."""
         if not self._collectives_on():
             return []
+        if self._rec is not None:
+            return self._rec.exchange(buf, src, self.world, self.grank, self._use_scatter_gather(buf))
+        return self._exchange_now(buf, src, self._use_scatter_gather(buf), group)
+
+    def _exchange_now(self, buf, src, scatter_gather, group=None):
         W = self.world
-        rows = buf.shape[0]
-        if (self.exchange == "scatter_gather" and rows % W == 0
-                and buf.numel() * buf.element_size() >= self.sag_min_bytes):
+        if scatter_gather:
             group = self.group if group is None else group
             gsrc = dist.get_global_rank(group, src) if group is not None else src
-            c = rows // W
+            c = buf.shape[0] // W
             pieces = [buf[r * c:(r + 1) * c] for r in range(W)]
             mine = pieces[self.grank]
             w1 = dist.scatter(mine, scatter_list=pieces if self.grank == src else None, src=gsrc, group=group,
@@ -501,8 +750,8 @@ class DistributedLML(object):
         self.ops.gemm_nt_stair(self.NP - J0 * nb, len(Js), nb, nb, -1.0, _ptr(buf, off, 0), nb, _ptr(buf, off, 0), nb,
                                W * nb, W * nb, 1.0, _ptr(A, J0 * nb, (J0 // W) * nb), A.stride(0), q="main")
 
-    def _begin(self, kernel_id, params, y, err_y, noise_var, diag_factor):
-        """Common head of both schedules: upload y / err_y, build the local block columns (main queue)."""
+    def _upload(self, y, err_y):
+        """Per-evaluation host traffic and resets, on the main queue: y | err_y up, info and the scalar accumulators to zero."""
         ops, N = self.ops, self.N
         y = np.ascontiguousarray(y, dtype=np.float64)
         err_y = np.array(np.broadcast_to(err_y, (N,)), dtype=np.float64)
@@ -519,7 +768,12 @@ class DistributedLML(object):
                 self.err[:N] = torch.from_numpy(err_y)
             self.info.zero_()
             self.red.zero_()
-            self._t0 = ops.new_timing_event() if self.trace else None
+
+    def _begin(self, kernel_id, params, noise_var, diag_factor):
+        """Head of the schedule (recorded in a compiled plan): build the local block columns on the main queue."""
+        ops = self.ops
+        with ops.queue("main"):
+            self._t0 = ops.new_timing_event() if (self.trace and self._rec is None) else None
             if self._t0 is not None:
                 self._t0.record()
             self._assemble(kernel_id, params, noise_var, diag_factor * sys.float_info.epsilon)
@@ -583,12 +837,43 @@ class DistributedLML(object):
                        next (k+2) first.
         Edges: "urgent" (column k+2 is up to date with panel k) main -> panel, "done" (step k no longer reads its
         buffer) main -> panel before that buffer is staged / received into again, "arrived" panel -> main."""
-        ops = self.ops
         t_host0 = time.perf_counter()
+        self._upload(y, err_y)
+        if self.compiled and not self.trace:
+            diag_add = diag_factor * sys.float_info.epsilon
+            key = (self.compiled, self.exchange, self.lookahead, self.owner_first, self.inv_trsm, self.inv_min_rows, self.sag_min_bytes,
+                   self._collectives_on())
+            plan = self._plans.get(key)
+            if plan is None:
+                # walk the step loop once against the recorder (nothing runs), then build the executor
+                real, rec = self.ops, PlanRecorder(self.device)
+                self.ops = self._rec = rec
+                try:
+                    self._schedule(None, None, 0.0, 0.0)
+                finally:
+                    self.ops, self._rec = real, None
+                plan = CompiledPlan(rec)
+                if self.compiled == "native":
+                    plan.build_native(real, self.X, self.n, self.err, self.world if self._collectives_on() else 1,
+                                      self.grank if self._collectives_on() else 0, self.group, with_comm=self._collectives_on())
+                self._plans[key] = plan
+                self.timings["plan_ops"] = len(plan.ops)
+            if self.compiled == "native":
+                self.timings["native_enqueue_ms"] = plan.run_native(kernel_id, params, noise_var, diag_add)
+            else:
+                plan.run_python(self.ops, self, kernel_id, params, noise_var, diag_add)
+            return self._finish(t_host0)
+        self._schedule(kernel_id, params, noise_var, diag_factor)
+        return self._finish(t_host0)
+
+    def _schedule(self, kernel_id, params, noise_var, diag_factor):
+        """The step loop of the whole-panel schedule (see _fit_bcast): issues the operations -- or, against a PlanRecorder, lists
+        them."""
+        ops = self.ops
         nb, NP, world, rank, NBUF = self.nb, self.NP, self.world, self.rank, self.NBUF
         nblk = self.nblk
         owner = lambda J: J % world == rank
-        ev_asm = self._begin(kernel_id, params, y, err_y, noise_var, diag_factor)
+        ev_asm = self._begin(kernel_id, params, noise_var, diag_factor)
         ev_urg, ev_done = {}, {}
 
         def wait_all(ws):
@@ -659,7 +944,6 @@ class DistributedLML(object):
                         self._factor_staged(nxt, nbuf)
                     pending = self._exchange(nbuf[:NP - nxt * nb], nxt % world, tag=(nxt, 0))
                     self._accumulate_scalars()
-        return self._finish(t_host0)
 
 
 # ======================================================================================================

@@ -122,19 +122,18 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
  *   "graph"        0/1: replay the factorisation from a captured hipGraph
  *   "timing"       0/1: record per-phase HIP events (gpt_last_timings)
  *   "profile_gemm" 0/1: HIP-event timing of each large GEMM launch (gpt_gemm_profile_read)
- *   "tile"         0 auto, 32, 64, 65 (4-stage), 128 (persistent), 129: force the GEMM macro-tile
+ *   "tile"         0 by launch size (default), 32, 64: force the GEMM macro-tile (bit-identical results either way)
  *   "debug_poison" 0/1 (test aid): gpt_ll_grad fills its scratch matrices with NaN before use
  *   "edge_test_stall" 1 (test aid): the next evaluation's first flag is withheld once, so that the bounded wait, the repeat on
  *                  event edges and the switch of the process to event edges can be tested
- *   measured and off by default: "ramp", "inner", "inner_rows", "leaf256", "defer_rows", "late_rows",
- *   "early_rows", "nb_early", "nb_switch_rows", "late_pad", "late_pad_rows"; round 5 (NOTES_r05.md; both bit-identical to the
- *   default schedule and slower): "fuse_upd" / "fuse_upd_rows" (the leaf's rank-128 update of the next 128 / 256 columns inside
- *   the leaf's launch, potf2_trsm_upd_kernel), "pair_rows" (panels in pairs: one rank-2w trailing update per pair, the near
- *   update on a second main stream)
+ *   measured and off by default: "ramp", "inner", "inner_rows", "defer_rows", "late_rows",
+ *   "early_rows", "nb_early", "nb_switch_rows", "late_pad", "late_pad_rows".
+ *   Removed in round 6 with the code behind them (each lost its A/B twice; NOTES_r04.md / NOTES_r05.md have the numbers, the
+ *   history up to round 5's last commit the sources): "fuse_upd" / "fuse_upd_rows", "pair_rows", "leaf256", "tile" = 65 / 128 / 129,
+ *   the environment switches GPT_GEMM_LOOP and GPT_GEMM_MIXED.  gpt_ctx_set_option refuses unknown keys.
  * Environment: GPT_RESERVE_CUS (CUs the main stream leaves to the panel stream, default 32), GPT_TILE_ORDER
  * ("rows,cols,mode": supertile shape and deal of the GEMM's XCD-aware tile order, default 64,8,1), GPT_GRAD_TIMING,
  * GPT_EDGE_FLAGS=0 (event edges only: set it for jobs that share one GPU between several processes), GPT_GEMM_SMALL (64x64-tile count under which a GEMM launch uses 32x32 tiles, 512),
- * GPT_GEMM_MIXED=<percent> (measured, off: quarter tiles for the last partial round of a large GEMM launch),
  * GPT_JITTER (test aid: random delay kernels in front of every dense launch), GPT_ALPHA_NARROW (measurement aid: gpt_get_alpha
  * by 128-wide substitution steps instead of the 512-wide block inverses), GPT_POTF2_LA=0 (the 128-column diagonal-block kernels
  * with the lock-step body of rounds 1-3 instead of the look-ahead body; results agree to rounding, not bit for bit). */
@@ -326,6 +325,9 @@ int gpt_last_timings(gpt_ctx *ctx, double *out_ms, int n);
  * out3[0] = algorithmic flops (2k per computed element of C, lower trapezoid for SYRK-style launches),
  * out3[1] = summed launch durations in ms, out3[2] = number of launches. */
 int gpt_gemm_profile_read(gpt_ctx *ctx, double *out3);
+/* The same with out4[3] = the launches' ALGORITHMIC bytes (16 B per computed element of C -- read and written once -- plus the
+ * operand panel once, 8 k max(m, n)): what bench.py's roofline sets the measured HBM traffic of the same launches against. */
+int gpt_gemm_profile_read4(gpt_ctx *ctx, double *out4);
 
 /* Standalone dense kernels on host matrices (used by parity tests and the roofline bench). */
 int gpt_potrf_host(gpt_ctx *ctx, double *A, int64_t N);                 /* in place, lower */
@@ -422,6 +424,31 @@ int gpt_dev_copy2d_on(gpt_ctx *ctx, void *stream, int64_t rows, int64_t cols, co
 int gpt_dev_pad_block(gpt_ctx *ctx, double *dA, int64_t lda, int64_t c0, int64_t nb, int64_t n_valid, int64_t n_pad,
                       const double *d_y, double big);
 int gpt_dev_panel_scalars(gpt_ctx *ctx, const double *dP, int64_t ldp, int64_t w, int64_t zrow, double *d_acc);
+
+/* ---- compiled schedules of the partitioned engines (round 6) ------------------------------------------------------------
+ * The one-process-per-GPU block-cyclic Cholesky of gptools_amd/dist.py issues ~1000 operations per rank and evaluation; which
+ * ones, on which buffers, in which order is static per (N, nb, world, rank).  The Python layer records its step loop once as an
+ * op list -- GPT_PLAN_W = 16 int64 per op: [opcode, queue, a0 .. a13], doubles as their bit patterns, queues 0 = main, 1 = panel,
+ * 2 = recv (the contexts given here, in this order), 3 = the plan's own communication stream -- and every evaluation is then one
+ * gpt_plan_run: a C loop over the list, RCCL (dlopen'ed librccl) called directly for the panel exchange.  Opcodes (csrc/api_plan.inc):
+ *   0 record event a0 | 1 wait event a0 | 2 K block (r0, r1, c0, c1, out, ld) | 3 pad block (ptr, lda, c0, nb, N, NP, y, big) |
+ *   4 copy2d (rows, cols, src, lds, dst, ldd) | 5 potrf_panel (m, nb, A, lda, invd, info, info_base) | 6 trinv (nb, L, ldl, invd, W, ldw) |
+ *   7 gemm_nt (m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri) | 8 gemm_nt_stair (m, nseg, seg_cols, k, alpha, A, lda, B, ldb,
+ *   b_stride, row_step, beta, C, ldc) | 9 panel_scalars (buf, ld, w, zrow, red) | 10 broadcast (buf, count, root) |
+ *   11 scatter (buf, count per rank, root) | 12 all-gather in place (buf, count per rank).
+ * dX (N x D float64), dn (N x D int32), d_err (N float64) are the device arrays the K-block ops read; the per-evaluation inputs
+ * are arguments of gpt_plan_run.  gpt_plan_set_comm is collective over the ranks (ncclCommInitRank; the 128-byte id comes from
+ * gpt_plan_unique_id on rank 0 and travels by whatever means the caller has); without it the communication ops are skipped
+ * (single rank).  The caller keeps the buffers alive and synchronises the contexts' streams itself. */
+#define GPT_PLAN_W 16
+typedef struct gpt_plan gpt_plan;
+int gpt_plan_unique_id(void *out128);
+int gpt_plan_create(int nctx, gpt_ctx **ctxs, const int64_t *ops, int64_t nops, int nevents, const void *dX, const void *dn, int D,
+                    const void *d_err, gpt_plan **out);
+int gpt_plan_set_comm(gpt_plan *plan, int nranks, int rank, const void *unique_id128);
+int gpt_plan_run(gpt_plan *plan, int kernel_id, const double *params, int nparams, double noise_var, double diag_add);
+double gpt_plan_last_enqueue_ms(gpt_plan *plan);          /* host time gpt_plan_run spent enqueueing, last call */
+int gpt_plan_destroy(gpt_plan *plan);
 
 #ifdef __cplusplus
 }

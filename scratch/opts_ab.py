@@ -12,7 +12,7 @@ kernel, N, d, deriv = bench.WORKLOADS[wl]
 X, n, y, err, params = bench.synth(kernel, N, d, deriv)
 ctx.set_data(X, n)
 DEF = {"nb_outer": 0, "nb_early": 0, "nb_switch_rows": 4608, "fuse_rows64": 2048, "fuse_rows32": 2048, "fuse_rows16": 0, "inner": 0, "inner_rows": 4608, "purg_rows_flags": 0,
-       "merge_urgent": 1, "tail_wait": 0, "fuse_upd": 0, "pair_rows": 0, "ramp": 0, "fuse_trsm": 8192, "purg_rows": 6144, "late_pad": 0, "late_pad_rows": 4608, "gemm_pad": 1024, "head_wait_wgs": 33, "panel_prio": 2, "urgent_prio": 0, "urgent_split": 0}
+       "merge_urgent": 1, "tail_wait": 0, "fuse_upd": 0, "pair_rows": 0, "ramp": 0, "fuse_trsm": 8192, "purg_rows": 6144, "late_pad": 0, "late_pad_rows": 4608, "gemm_pad": 1024, "head_wait_wgs": 33, "panel_prio": 2, "urgent_prio": 0, "urgent_split": 0, "merge_min_tiles": 512, "early_urgent": 0}
 best = [1e9] * len(sets); wall = [1e9] * len(sets); res = [None] * len(sets)
 for rnd in range(5):
     for i, s in enumerate(sets):

@@ -303,7 +303,7 @@ def test_oracle_restatement_is_clean_under_asan_and_ubsan():
 def test_every_context_option_is_documented_in_the_header():
     """Every key gpt_ctx_set_option accepts appears (quoted) in the option list of include/gpt_hip.h -- the C ABI's only documentation."""
     import re
-    keys = re.findall(r'strcmp\(key, "([a-z0-9_]+)"\)', open(os.path.join(ROOT, "gptools_amd", "csrc", "api.hip")).read())
+    keys = re.findall(r'strcmp\(key, "([a-z0-9_]+)"\)', open(os.path.join(ROOT, "gptools_amd", "csrc", "api_context.inc")).read())
     hdr = open(os.path.join(ROOT, "include", "gpt_hip.h")).read()
     assert len(keys) >= 30
     missing = [k for k in keys if '"%s"' % k not in hdr]

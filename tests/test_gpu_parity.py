@@ -746,12 +746,17 @@ def test_dense_kernels_against_numpy(ctx):
     rs = np.random.RandomState(11)
     for (m, n, k) in ((64, 64, 64), (200, 130, 70), (640, 384, 256), (1024, 1024, 512)):
         A, B, C0 = rs.randn(m, k), rs.randn(n, k), rs.randn(m, n)
-        for tile in (64, 128):
+        res = {}
+        for tile in (64, 32, 0):
             ctx.set_option("tile", tile)
             got = ctx.gemm_nt_host(-1.0, A, B, 1.0, C0)
             np.testing.assert_allclose(got, C0 - A.dot(B.T), rtol=0, atol=1e-11 * k)
+            res[tile] = got
             got = ctx.gemm_nt_host(2.0, A, B, 0.0, C0)
             np.testing.assert_allclose(got, 2.0 * A.dot(B.T), rtol=0, atol=1e-11 * k)
+        # (64x64 and 32x32 tiles: the same sums in the same order -- what lets the library pick the tile by launch size)
+        np.testing.assert_array_equal(res[64], res[32])
+        np.testing.assert_array_equal(res[64], res[0])
     ctx.set_option("tile", 0)
     for N in (1, 17, 128, 129, 640, 1500):
         A = rs.randn(N, N)
@@ -847,10 +852,10 @@ def test_single_gpu_schedule_under_stream_jitter(ctx):
 
 
 def test_schedule_options_agree_with_default(ctx, oracle):
-    """The schedule variants kept behind options (NOTES_r02.md) -- the 256-column leaf kernel
-    (potf2x2_trsm_kernel: two diagonal blocks, the block between them and the TRSM consumers in one launch), left-looking
-    panels, the deferred rest, the panel-stream urgent update on / off, variable panel widths -- factor the same matrix:
-    ll / log|K| within 1e-11 of the default schedule and of the CPU oracle, at a size with several panels and a ragged end."""
+    """The schedule variants kept behind options (NOTES_r02.md) -- left-looking panels, the deferred rest,
+    the panel-stream urgent update on / off, variable panel widths, event edges, the consumer workgroup sizes of the fused
+    leaf kernel, the unfused leaf -- factor the same matrix: ll / log|K| within 1e-11 of the default schedule and of the CPU
+    oracle, at a size with several panels and a ragged end; the variants that only regroup the same sums, bit for bit."""
     N, d = 3000, 3
     X, n, y = c3_inputs(N, d)
     p = np.array([1.0, 0.3, 0.3, 0.3])
@@ -859,23 +864,20 @@ def test_schedule_options_agree_with_default(ctx, oracle):
     ctx.set_data(X, n)
     base = ctx.fit(1, p, 0.0, y, err, 1e2 * EPS)
     assert abs(base[0] - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"])
-    variants = ({"leaf256": 1}, {"leaf256": 1, "nb_outer": 256}, {"leaf256": 1, "nb_outer": 512}, {"inner": 1}, {"inner": 2},
+    variants = ({"nb_outer": 256}, {"nb_outer": 512}, {"inner": 1}, {"inner": 2},
                 {"defer_rows": 4608}, {"purg_rows": 0}, {"purg_rows": 1024}, {"nb_early": 512, "nb_switch_rows": 1500},
-                {"leaf256": 1, "purg_rows": 1024, "defer_rows": 4608},
+                {"purg_rows": 1024, "defer_rows": 4608},
                 # a 128-wide first panel is factored before the rest of K is built: the panel stream's first update beyond
                 # the head columns has to wait for the build (it once did not: "8064-th leading minor ...")
                 {"ramp": 1, "purg_rows": 1024}, {"ramp": 1, "purg_rows": 0}, {"edge_flags": 0}, {"edge_flags": 0, "ramp": 1, "purg_rows": 512},
-                # round 5: 128-row consumer workgroups everywhere / 64-row ones everywhere, the in-launch leaf update
-                # (potf2_trsm_upd_kernel) on flag and on event edges, panel pairs (rank-2w trailing updates on two main streams)
-                {"fuse_rows64": 0}, {"fuse_rows64": 8192}, {"fuse_upd": 1, "fuse_upd_rows": 8192}, {"fuse_upd": 1, "edge_flags": 0},
-                {"fuse_upd": 1, "nb_outer": 256}, {"pair_rows": 1}, {"pair_rows": 1024, "nb_outer": 256}, {"pair_rows": 1, "fuse_upd": 1},
-                # ... 64-row workgroups where the default has 32-row ones, 32-row ones everywhere, 16-row ones, a mix
-                {"fuse_rows32": 0}, {"fuse_rows32": 8192}, {"fuse_rows16": 8192}, {"fuse_rows32": 3000, "fuse_rows16": 1000, "fuse_rows64": 5000})
-    defaults = {"leaf256": 0, "nb_outer": 0, "inner": 0, "defer_rows": 0, "purg_rows": 6144, "nb_early": 0, "nb_switch_rows": 4608,
-                "ramp": 0, "edge_flags": 1, "fuse_rows64": 2048, "fuse_rows32": 2048, "fuse_rows16": 0, "fuse_upd": 0, "fuse_upd_rows": 4096,
-                "pair_rows": 0}
-    # (the round-5 variants are bit-identical to the default schedule by construction: same sums in the same order)
-    exact = ("fuse_rows64", "fuse_rows32", "fuse_rows16", "fuse_upd", "pair_rows")
+                # 128-row consumer workgroups everywhere / 64-row ones everywhere / where the default has 32-row ones, 32-row ones
+                # everywhere, 16-row ones, a mix; the unfused leaf (diagonal-block kernel + panel TRSM)
+                {"fuse_rows64": 0}, {"fuse_rows64": 8192}, {"fuse_rows32": 0}, {"fuse_rows32": 8192}, {"fuse_rows16": 8192},
+                {"fuse_rows32": 3000, "fuse_rows16": 1000, "fuse_rows64": 5000}, {"fuse_trsm": 0}, {"merge_urgent": 0})
+    defaults = {"nb_outer": 0, "inner": 0, "defer_rows": 0, "purg_rows": 6144, "nb_early": 0, "nb_switch_rows": 4608,
+                "ramp": 0, "edge_flags": 1, "fuse_rows64": 2048, "fuse_rows32": 2048, "fuse_rows16": 0, "fuse_trsm": 8192, "merge_urgent": 1}
+    # (bit-identical to the default schedule by construction: same sums in the same order)
+    exact = ("fuse_rows64", "fuse_rows32", "fuse_rows16", "merge_urgent")
     try:
         for v in variants:
             for k_, d_ in defaults.items():
@@ -886,29 +888,58 @@ def test_schedule_options_agree_with_default(ctx, oracle):
                 got = ctx.fit(1, p, 0.0, y, err, 1e2 * EPS)
                 assert abs(got[0] - base[0]) <= 1e-11 * abs(base[0]), v
                 assert abs(got[1] - base[1]) <= 1e-12 * abs(base[1]), v
-                if all(k_ in exact or k_ == "fuse_upd_rows" for k_ in v):
+                if all(k_ in exact for k_ in v):
                     assert got == base, v
     finally:
         for k_, d_ in defaults.items():
             ctx.set_option(k_, d_)
-    # the 256-column leaf kernel on dense matrices of awkward sizes against LAPACK
+    # options that were removed with the code behind them (round 6) are refused, not ignored
+    for gone in ("fuse_upd", "pair_rows", "leaf256"):
+        with pytest.raises(Exception):
+            ctx.set_option(gone, 1)
+    with pytest.raises(Exception):
+        ctx.set_option("tile", 128)
+    # dense matrices of awkward sizes against LAPACK, and the position of a failing pivot
     rs = np.random.RandomState(7)
     try:
-        ctx.set_option("leaf256", 1)
         for Nd in (255, 256, 300, 640, 1000):
             for nb in (256, 384):
                 ctx.set_option("nb_outer", nb)
                 A = rs.randn(Nd, Nd)
                 A = A.dot(A.T) + Nd * np.eye(Nd)
                 np.testing.assert_allclose(np.tril(ctx.potrf_host(A)), np.linalg.cholesky(A), rtol=1e-11, atol=1e-11)
-        with pytest.raises(np.linalg.LinAlgError) as ei:      # not positive definite inside the second block of a 256-column leaf
+        with pytest.raises(np.linalg.LinAlgError) as ei:      # not positive definite inside the second 128-column leaf
             A = np.eye(300)
             A[200, 200] = -1.0
             ctx.potrf_host(A)
         assert "201-th leading minor" in str(ei.value)
     finally:
-        ctx.set_option("leaf256", 0)
         ctx.set_option("nb_outer", 0)
+
+
+def test_fused_leaf_publication_is_repeatable_and_matches_the_unfused_leaf(ctx):
+    """The fused diagonal-block + TRSM kernel publishes the packed workspace block by block with PIPELINED write-through stores:
+    flag jb goes up once `s_waitcnt vmcnt(32 - 4 jb)` says that step jb - 1's stores are in memory (potrf.hip, store wave; the
+    store count per step is fixed by explicit store instructions and a static_assert -- ADVICE r5).  A flag raised early would let
+    a consumer read a stale inverse block or packed block: timing-dependent, so the same factorisation is repeated many times --
+    every repetition must return the bits of the first -- at sizes with 32-, 64- and 128-row consumer workgroups, and must agree
+    with the UNFUSED leaf (potf2_diag_kernel + trsm_panel_kernel: no in-launch publication at all) to rounding."""
+    for N, d, reps in ((1500, 2, 150), (2600, 3, 100), (5000, 3, 40)):
+        X, n, y = c3_inputs(N, d)
+        p = np.concatenate(([1.0], 0.3 * np.ones(d)))
+        err = 0.05 * np.ones(N)
+        ctx.set_data(X, n)
+        try:
+            ctx.set_option("fuse_trsm", 0)
+            plain = ctx.fit(1, p, 0.0, y, err, 1e2 * EPS)
+        finally:
+            ctx.set_option("fuse_trsm", 8192)
+        first = ctx.fit(1, p, 0.0, y, err, 1e2 * EPS)
+        assert abs(first[0] - plain[0]) <= 1e-11 * abs(plain[0]) and abs(first[1] - plain[1]) <= 1e-12 * abs(plain[1]), N
+        L0 = ctx.get_L(N)
+        for rep in range(reps):
+            assert ctx.fit(1, p, 0.0, y, err, 1e2 * EPS) == first, (N, rep)
+        np.testing.assert_array_equal(ctx.get_L(N), L0)
 
 
 def test_panel_inverse_and_gemm_solve_against_numpy():
@@ -1111,6 +1142,45 @@ def test_distributed_plan_on_one_gpu(ctx, oracle):
         assert ll2 == ll
         del plan                # (its streams go with it: every plan owns two library contexts)
         gc.collect()
+
+
+def test_compiled_schedule_native_replay_matches_the_step_loop(ctx, oracle):
+    """Compiled schedules: the 1-D engine's step loop recorded once as an op list and replayed by gpt_plan_run (a C
+    loop over the list, csrc/api_plan.inc), by the Python interpreter of the same list, and the step loop issuing every operation
+    itself give the same bits -- same kernels on the same buffers in the same order -- and agree with the oracle; a second
+    evaluation with other hyperparameters reuses the plan (only the K-block ops see them); look-ahead off and the
+    explicit-inverse route for tall panels are plans of their own."""
+    from gptools_amd.dist import DistributedLML, HipPanelOps
+    X, n, y = c3_inputs(2300, 3)
+    p = np.array([1.0, 0.3, 0.3, 0.3])
+    err = 0.05 * np.ones(2300)
+    ref = oracle.fit("m52", p, X, n, y, err, chol="scipy")
+    ref2 = oracle.fit("m52", 1.1 * p, X, n, y, err, chol="scipy")
+    ops = HipPanelOps(0)
+    for nb, kw in ((256, {}), (512, {"inv_min_rows": 0}), (128, {"lookahead": False})):
+        got = {}
+        for mode in ("native", "python", False):
+            plan = DistributedLML(X, n, nb=nb, ops=ops, compiled=mode, **kw)
+            assert plan.compiled == mode
+            got[mode] = (plan.fit(1, p, y, err), plan.fit(1, 1.1 * p, y, err), plan.fit(1, p, y, err))
+            if mode:
+                assert len(plan._plans) == 1 and plan.timings["plan_ops"] > 20
+            if mode == "native":
+                assert 0.0 < plan.timings["native_enqueue_ms"] < 200.0
+            del plan
+            gc.collect()
+        assert got["native"] == got["python"] == got[False], (nb, kw, got)
+        a, b, c_ = got["native"]
+        assert a == c_
+        assert abs(a[0] - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"]) and abs(a[1] - ref["logdet_half"]) <= 1e-10 * abs(ref["logdet_half"])
+        assert abs(b[0] - ref2["ll_data"]) <= 1e-9 * abs(ref2["ll_data"])
+    # not positive definite: reported through the plan like through the step loop
+    Xd = X.copy()
+    Xd[1] = Xd[0]
+    nd = np.zeros_like(n)
+    plan = DistributedLML(Xd, nd, nb=256, ops=ops, compiled="native")
+    with pytest.raises(np.linalg.LinAlgError):
+        plan.fit(0, p, y, 0.0, diag_factor=0.0)
 
 
 def test_replicated_random_starts_two_ranks_one_gpu():
