@@ -496,11 +496,11 @@ def main():
         # product: it rides on every INSTR_EVERY-th step of a round (steps 0, 4, 8, ...), `roofline.sampled_steps` says how many.
         INSTR_EVERY = 4
         MIN_TIMED_S = float(os.environ.get("GPT_BENCH_MIN_TIMED_S", "1.0"))
-        alpha_host = np.empty(N)
+        alpha_box = [None]
 
         def step_full():
             r_ = ctx.fit(KID[kernel], params, 0.0, y, err, diag_add)
-            alpha_host[:] = ctx.get_alpha(N)                    # (a host copy: the fit's own synchronisation covered the transfer)
+            alpha_box[0] = ctx.get_alpha(N)                     # (a host copy: the fit's own synchronisation covered the transfer)
             return r_
 
         def timed_rounds(step_fn, instrument, min_s):
@@ -550,7 +550,7 @@ def main():
                                  "ms_per_step_min": 1e3 * min(rounds) / args.steps, "ms_per_step_max": 1e3 * max(rounds) / args.steps,
                                  "note": "each round = exactly --steps full evaluations between barrier + synchronize; ms_per_step and "
                                          "value are the median round's"}
-        alpha_eager = alpha_host.copy()
+        alpha_eager = alpha_box[0].copy()
         # sibling: the evaluation without alpha (what update_hyperparameters costs in the MAP loop, which never reads alpha);
         # executed flops = potrf + the forward half of potrs
         ctx.set_option("eager_alpha", 0)

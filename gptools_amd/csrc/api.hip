@@ -133,6 +133,10 @@ struct gpt_ctx {
     bool binv2_valid = false;          // SLOT_BINV2 those of its 1024x1024 diagonal blocks (solves with very few rows)
     bool binv3_valid = false;          // SLOT_BINV3 those of its 2048x2048 diagonal blocks (the same, large factors)
     int64_t eager_alpha = 0;           // 1: every evaluation also enqueues alpha = L^-T z behind the factorisation (no second host round trip)
+    int64_t binv_early = 0;            // this factorisation: the 512-wide inverses of the diagonal blocks [0, binv_early) were enqueued on the
+                                       // main stream under the last panel (enqueue_early_block_inverses); e_binv_early follows them there
+    hipEvent_t e_binv_early = nullptr;
+    bool want_early_binv = false;      // set by factor_and_ll around potrf_run for an eager evaluation
     // (all three are always built for the whole padded order, floor(NP / width) blocks, whatever extent the caller needs:
     // gpt_ll_grad and the solves ask for different extents at N = 512 k - 128, and a valid flag says nothing about how far)
     unsigned alpha_counter = 0;        // value of the step counter of the wide back-substitution (d_edge[40], only ever raised)

@@ -684,6 +684,26 @@ __global__ __launch_bounds__(512) void gemv_t_sub_kernel(int64_t ncols, const do
 
 // Blocks [0, nwide / 512) of  L^T x = w : U = the strip of the blocks' inverse transposes (block j at rows [512 j, 512 j + 512),
 // row stride 512), w (in: right-hand side, already updated by every block right of nwide; consumed) and x (out) distinct.
+// alpha_init_kernel: w = z (the augmented row of the factor, n entries) padded with zeros to np, x = 0: one launch where a memset
+// and a device-to-device copy of the runtime were two (~5 us each on the eager alpha's critical path)
+__global__ __launch_bounds__(256) void alpha_init_kernel(int64_t n, int64_t np, const double *__restrict__ z, double *__restrict__ w,
+                                                         double *__restrict__ x)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < np) {
+        w[i] = i < n ? z[i] : 0.0;
+        x[i] = 0.0;
+    }
+}
+int launch_alpha_init(hipStream_t st, int64_t n, int64_t np, const double *z, double *w, double *x)
+{
+    hipLaunchKernelGGL(alpha_init_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, n, np, z, w, x);
+    GPT_LAUNCH_CHECK();
+    return GPT_OK;
+}
+
+// (Round 6 also let every step write its piece of x to the pinned host buffer of the eager alpha -- no device-to-host copy behind the
+// last step: same-box A/B 0.2795 against 0.2795 ms of alpha per evaluation; removed.)
 int launch_trsv_lt_wide(hipStream_t st, int64_t nwide, const double *L, int64_t ldl, const double *U, double *w, double *x)
 {
     if (nwide % TW_NB) {

@@ -308,6 +308,31 @@ def test_g11_high_derivative_orders(g, golden, oracle):
     assert_close(got, G[key + "k"], rtol=1e-9, atol_scale=1e-13, msg=key)
 
 
+def test_g13_orders_13_to_16_against_mpmath(g, golden, oracle):
+    """Combined derivative orders 13 .. 16 of a pair on the device (GPT_RQ_MAXORD = 16) against the independent 90-digit values of
+    tests/golden/gen_g13_mpmath.py (multivariate Taylor arithmetic in mpmath; ADVICE r5: orders above 12 were held to the oracle
+    only, which shares the device's regrouped sums): rational-quadratic, general-order Matern (nu = 0.6 .. 25, close points) and
+    the product SE * RQ, 1e-9 relative; the oracle agrees with the same values to 1e-11 (CPU suite)."""
+    G = golden("g13_high_orders_mpmath")
+    for ci in range(int(G["ncases"])):
+        key = "c%d_" % ci
+        name, p = str(G[key + "kernel"]), G[key + "params"]
+        d = G[key + "Xi"].shape[1]
+        if name == "rq":
+            k = g.RationalQuadraticKernel(num_dim=d, initial_params=list(p), param_bounds=[(0.0, 1e3)] * (d + 2))
+        elif name == "matern":
+            k = g.MaternKernel(num_dim=d, initial_params=list(p), param_bounds=[(0.0, 1e3)] * (d + 2))
+        else:
+            k = (g.SquaredExponentialKernel(num_dim=d, initial_params=list(p[:1 + d]), param_bounds=[(0.0, 1e3)] * (d + 1)) *
+                 g.RationalQuadraticKernel(num_dim=d, initial_params=list(p[1 + d:]), param_bounds=[(0.0, 1e3)] * (d + 2)))
+        got = k(G[key + "Xi"], G[key + "Xj"], G[key + "ni"], G[key + "nj"])
+        assert_close(got, G[key + "k"], rtol=1e-9, atol_scale=0.0, msg=key + name)
+    # one order beyond the limit is refused, not computed
+    k = g.RationalQuadraticKernel(num_dim=2, initial_params=[1.0, 1.5, 0.5, 0.5], param_bounds=[(0.0, 1e3)] * 4)
+    with pytest.raises(ValueError):
+        k(np.array([[0.1, 0.2]]), np.array([[0.3, 0.5]]), np.array([[9, 0]]), np.array([[0, 8]]))
+
+
 @pytest.mark.parametrize("d", [1, 2, 3])
 def test_g10_matern_general_nu_pairs(g, golden, oracle, d):
     """General-order MaternKernel on the device (kpair.hpp matern_pair: Temme's K_nu, closed-form derivatives, the

@@ -305,3 +305,24 @@ def test_g12_ll_grid_and_samples(oracle, golden, kern):
         if not noise:
             np.testing.assert_allclose(cov, G["samp_%s_pred_cov" % kern], rtol=0, atol=1e-11)
             np.testing.assert_allclose(mean, G["samp_%s_pred_mean" % kern], rtol=0, atol=1e-10)
+
+
+def test_g13_orders_13_to_16_against_mpmath(oracle, golden):
+    """Combined derivative orders 13 .. 16 of a pair -- the device builder's limit is 16, the reference can be run to 12 (g11) --
+    against an independent 90-digit evaluation (tests/golden/gen_g13_mpmath.py: multivariate Taylor arithmetic around the pair's
+    tau, outer-function coefficients from mpmath's numerical differentiation; shares neither the regrouped Faa di Bruno sums nor
+    the closed forms of f^(m) with this restatement).  Rational-quadratic incl. alpha < 1 and close points, general-order Matern
+    at nu = 0.6 / 3.2 / 7.5 / 25 incl. close points (cancellation in the alternating sums at high order)."""
+    G = golden("g13_high_orders_mpmath")
+    seen = 0
+    for ci in range(int(G["ncases"])):
+        key = "c%d_" % ci
+        name = str(G[key + "kernel"])
+        if name == "prod":
+            continue                                  # (the product rule runs on the device: GPU suite)
+        ni, nj = G[key + "ni"], G[key + "nj"]
+        assert (ni.sum(1) + nj.sum(1)).min() >= 13 and (ni.sum(1) + nj.sum(1)).max() == 16
+        got = oracle.kpairs(name, G[key + "params"], G[key + "Xi"], G[key + "Xj"], ni, nj)
+        assert_close(got, G[key + "k"], rtol=1e-11, atol_scale=0.0, msg=key + name)
+        seen += len(got)
+    assert seen >= 40
