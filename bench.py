@@ -777,10 +777,15 @@ def main():
                     g_ = tuple(int(v) for v in layout[4:].split("x"))
                     plans[name] = GridLML(X, n, g_, nb=nb_, ops=ops)
                 return plans[name]
-            key = "1d@%d" % nb_
+            # "1d+<exchange>[+native]": with "+native" the rank's step loop is replayed by gpt_plan_run (compiled schedule, RCCL
+            # called from the library on the plan's own communicator); without it the same op list goes through the Python
+            # interpreter and torch.distributed.  World size 1 always takes the native replay (no communicator involved).
+            parts_ = layout.split("+")
+            native_ = (len(parts_) > 2 and parts_[2] == "native") or world == 1
+            key = "1d%s@%d" % ("+native" if native_ else "", nb_)
             if key not in plans:
-                plans[key] = DistributedLML(X, n, nb=nb_, ops=ops)
-            plans[key].exchange = layout.split("+")[1]
+                plans[key] = DistributedLML(X, n, nb=nb_, ops=ops, compiled="native" if native_ else "python")
+            plans[key].exchange = parts_[1]
             return plans[key]
 
         def step():
@@ -833,8 +838,8 @@ def main():
             if layout.startswith("grid"):
                 return "2-D block-cyclic (nb=%s) over a %s process grid: diagonal block -> inverse down the process column -> row " \
                        "slices by GEMM -> row broadcast + column exchange over RCCL" % (nb_, layout[4:])
-            return "1-D block-cyclic block columns (nb=%s) over %d ranks, whole panels over RCCL (%s)" % (
-                nb_, world, layout.split("+")[1])
+            return "1-D block-cyclic block columns (nb=%s) over %d ranks, whole panels over RCCL (%s)%s" % (
+                nb_, world, layout.split("+")[1], ", compiled schedule replayed by gpt_plan_run" if (layout.endswith("+native") or world == 1) else "")
         for _ in range(args.warmup):
             ll, ld = step()
         per, (ll, ld) = timed(args.steps, profile=True)
@@ -861,7 +866,10 @@ def main():
         if os.environ.get("GPT_BENCH_FAKE_HANG"):        # (test hook for the watchdog: scratch/README.md)
             time.sleep(3600)
         grids_ = {1: [(1, 1)], 2: [(2, 1), (1, 2)], 4: [(2, 2), (4, 1)], 8: [(2, 4), (4, 2)]}.get(world, [])
-        combos = ["1d+scatter_gather@%d" % nb0] + ["grid%dx%d@%d" % (g_[0], g_[1], nb0) for g_ in grids_]
+        # (the native replay with its own RCCL communicator has run at world size 1 only: on more ranks it is a LEG -- under the
+        # watchdog like everything after the first timed region -- and becomes the line only if it completes and is faster)
+        combos = ["1d+scatter_gather@%d" % nb0] + (["1d+bcast+native@%d" % nb0, "1d+scatter_gather+native@%d" % nb0] if (world > 1 and os.environ.get("GPT_BENCH_BACKEND", "nccl") == "nccl") else []) \
+            + ["grid%dx%d@%d" % (g_[0], g_[1], nb0) for g_ in grids_]
         if not args.nb:
             combos += ["1d+bcast@384", "1d+bcast@256"] + ["grid%dx%d@256" % g_ for g_ in grids_[:1]]
         if args.schedule:

@@ -132,6 +132,8 @@ struct gpt_ctx {
     bool binv_valid = false;           // SLOT_BINV holds the inverses of the 512x512 diagonal blocks of the resident factor
     bool binv2_valid = false;          // SLOT_BINV2 those of its 1024x1024 diagonal blocks (solves with very few rows)
     bool binv3_valid = false;          // SLOT_BINV3 those of its 2048x2048 diagonal blocks (the same, large factors)
+    int64_t dev_gemm_pad = 0;          // dummy LDS (bytes) per workgroup of the device API's GEMM launches on this context (gpt_dev_gemm_nt*):
+                                       // a residency cap for the partitioned engines' trailing updates, see "dev_gemm_pad" in gpt_hip.h
     int64_t eager_alpha = 0;           // 1: every evaluation also enqueues alpha = L^-T z behind the factorisation (no second host round trip)
     int64_t binv_early = 0;            // this factorisation: the 512-wide inverses of the diagonal blocks [0, binv_early) were enqueued on the
                                        // main stream under the last panel (enqueue_early_block_inverses); e_binv_early follows them there

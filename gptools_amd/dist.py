@@ -194,6 +194,12 @@ class HipPanelOps(PanelOps):
         self._stream = {"main": self.main_stream, "panel": self.panel_stream, "recv": self.recv_stream}
         for c in self._ctx.values():
             c.set_option("lookahead", 0)
+        # Residency cap of the main queue's trailing updates (context option dev_gemm_pad, GPT_DIST_MAIN_PAD bytes of dummy LDS per
+        # workgroup; 24576 = two workgroups of the update per CU instead of five).  Isolated -- one trapezoid update, the chain of one
+        # panel looping beside it -- the cap is free for the update and takes the chain from 1.95 x to 1.43 x its stand-alone time
+        # (profiles/r06_chain_contention.txt); IN the engines it loses: the staircase updates run 10 % slower with
+        # it (C4 at world size 1: 218 -> 242 ms) and the converged 8-rank replay model goes from 44.2 to 45.1 ms.  Off by default.
+        self.ctx_main.set_option("dev_gemm_pad", int(os.environ.get("GPT_DIST_MAIN_PAD", "0")))
         # everything the panel context launches sits on the chain and shares CUs with the main context's trailing update:
         # its GEMM main loops keep a raised wave priority (gemm.hip; the TRSM / fused kernels carry theirs themselves)
         self.ctx_panel.set_option("gemm_prio", int(os.environ.get("GPT_DIST_PANEL_PRIO", "2")))

@@ -119,6 +119,11 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
  *   "helper_tf"    assumed rate of the helper stream (0.1 TFLOP/s per 24 CUs, 45) that takes a slice of the large trailing
  *                  updates on the reserved CUs when n > "helper_min_n" (12288); 0 = off
  *   "gemm_pad"     bytes of dummy dynamic LDS of the main-stream GEMM (residency cap)
+ *   "dev_gemm_pad" the same for the device API's GEMM launches on this context (gpt_dev_gemm_nt, _stair, _gridstair), 0 = none
+ *                  (default).  Measured in round 6 (profiles/r06_chain_contention.txt): with 24576 (two workgroups of a trailing
+ *                  update per CU instead of five) an isolated m = 16384, k = 512 update keeps its rate (48.7 against 48.9 TFLOP/s)
+ *                  and the serial chain beside it runs at 1.43 x its stand-alone time instead of 1.95 x -- but the partitioned
+ *                  engines' staircase updates lose 10 % with it and the modelled 8-rank time does not improve: off
  *   "graph"        0/1: replay the factorisation from a captured hipGraph
  *   "timing"       0/1: record per-phase HIP events (gpt_last_timings)
  *   "profile_gemm" 0/1: HIP-event timing of each large GEMM launch (gpt_gemm_profile_read)

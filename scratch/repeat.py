@@ -1,6 +1,6 @@
-"""Repeatability of the round-5 leaf kernels: the same evaluation N times must return the same bits every time (flag timing,
+"""Repeatability of the leaf kernels (round 5; round 6: the explicit publication stores, the eager alpha on the tail stream): the same evaluation N times must return the same bits every time (flag timing,
 pipelined publication and the strips' batch overlap may not leak into the numbers), at sizes that cover the 64-row and the 128-row
-consumer workgroups, with and without the in-launch update / panel pairs.  timeout 600 python scratch/r05_repeat.py [reps]"""
+consumer workgroups, timeout 600 python scratch/repeat.py [reps]"""
 import sys, numpy as np
 sys.path.insert(0, '/root/repo')
 from gptools_amd import _lib
@@ -14,8 +14,8 @@ for (kid, N, d) in ((0, 700, 2), (1, 2047, 3), (0, 3000, 2), (1, 5000, 3), (1, 8
         n[3 * N // 4:, 0] = 1
     y = np.sin(X.sum(1)) + 0.05 * rs.randn(N); err = 0.05 * np.ones(N); p = np.concatenate(([1.0], 0.3 * np.ones(d)))
     ctx.set_data(X, n)
-    for opts in ({}, {"fuse_upd": 1}, {"pair_rows": 1}, {"fuse_rows64": 8192, "fuse_rows32": 0}, {"fuse_rows32": 8192}, {"fuse_rows16": 8192}):
-        for k_, v_ in (("fuse_upd", 0), ("pair_rows", 0), ("fuse_rows64", 2048), ("fuse_rows32", 2048), ("fuse_rows16", 0)):
+    for opts in ({}, {"eager_alpha": 1}, {"fuse_rows64": 8192, "fuse_rows32": 0}, {"fuse_rows32": 8192}, {"fuse_rows16": 8192}):
+        for k_, v_ in (("eager_alpha", 0), ("fuse_rows64", 2048), ("fuse_rows32", 2048), ("fuse_rows16", 0)):
             ctx.set_option(k_, opts.get(k_, v_))
         r = reps if not opts else max(reps // 6, 20)
         first = ctx.fit(kid, p, 0.0, y, err, 2.2e-14)

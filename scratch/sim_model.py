@@ -84,7 +84,7 @@ class ModelRank(DistributedLML):
         return DistributedLML._begin(self, *a, **kw)
 
 
-rec = Recorder(X, n, nb=NB, ops=ops, schedule="bcast")
+rec = Recorder(X, n, nb=NB, ops=ops, schedule="bcast", compiled=False)
 rec.saved = {}
 ll_ref, ld_ref = rec.fit(kid, params, y, err)
 panels = rec.saved
@@ -94,7 +94,7 @@ torch.cuda.empty_cache()
 plans = []
 for r in range(W):
     ModelRank.NBUF = nblk
-    p = ModelRank(X, n, nb=NB, ops=ops, layout=(r, W), schedule="bcast", exchange="bcast", owner_first=bool(ofirst))      # (the row-chunked schedule left the product in round 4: scratch/attic)
+    p = ModelRank(X, n, nb=NB, ops=ops, layout=(r, W), schedule="bcast", exchange="bcast", owner_first=bool(ofirst), compiled=False)      # (the row-chunked schedule left the product in round 4: scratch/attic)
     p.force_collectives = True
     p.t0_dev = torch.zeros(1, dtype=torch.int64, device="cuda")
     p.arrive, p.produced = {}, {}
