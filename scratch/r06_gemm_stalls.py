@@ -10,7 +10,7 @@ def load(d):
     rows = list(csv.DictReader(open(f[0])))
     acc = collections.defaultdict(float); disp = set(); dur = 0.0; seen = set()
     for r in rows:
-        if 'gemm_nt_kernel' not in r['Kernel_Name'] or '64, 64' not in r['Kernel_Name'] or int(r['Grid_Size']) < 54528:
+        if 'gemm_nt_kernel' not in r['Kernel_Name'] or '64, 64' not in r['Kernel_Name'] or int(r["Grid_Size"]) < 54528:
             continue        # the >= 1 GFLOP launches of the 64x64-tile kernel (213 workgroups x 256 threads and up)
         acc[r['Counter_Name']] += float(r['Counter_Value'])
         if r['Dispatch_Id'] not in seen:
