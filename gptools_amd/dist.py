@@ -616,15 +616,16 @@ class DistributedLML(object):
         # compiled: how an evaluation is driven.  "native": the step loop recorded once, replayed by gpt_plan_run (C loop, RCCL
         # called from the library); "python": the same op list through the Python interpreter (any ops, torch.distributed);
         # False: the step loop itself issues every operation (what rounds 1-5 did; still what a traced evaluation does).
-        # None: "native" with the product ops when the ranks can have a RCCL communicator of their own (one rank, or an
-        # "nccl" process group = one GPU per rank), else "python".  GPT_DIST_COMPILED=0 / native / python overrides.
+        # None: "native" with the product ops on ONE rank (no communicator of the plan's own is involved beyond a 1-rank one), else
+        # "python".  The native replay on several ranks -- RCCL called from the library on the plan's own communicator -- has never
+        # run on more than one GPU (this build had none): it is opt-in (compiled="native", GPT_DIST_COMPILED=native; bench.py tries it
+        # as a leg under its watchdog) until it has.  GPT_DIST_COMPILED=0 / native / python overrides.
         env = os.environ.get("GPT_DIST_COMPILED")
         if env is not None:
             compiled = False if env == "0" else env
         if compiled is None:
-            rccl_ok = isinstance(ops, HipPanelOps) and (not dist.is_initialized() or dist.get_world_size(group) == 1
-                                                        or dist.get_backend(group) == "nccl")
-            compiled = "native" if (rccl_ok and layout is None) else "python"
+            one_rank = not dist.is_initialized() or dist.get_world_size(group) == 1
+            compiled = "native" if (isinstance(ops, HipPanelOps) and one_rank and layout is None) else "python"
         if compiled not in (False, "native", "python"):
             raise ValueError("compiled must be None, False, 'native' or 'python'")
         if compiled == "native" and not isinstance(ops, HipPanelOps):
