@@ -152,6 +152,10 @@ def _run(world, N, d, nb, kernel_id, lookahead, bad=False, plan_kw=None):
 _WHOLE = {"schedule": "bcast"}
 _WHOLE_INV = {"schedule": "bcast", "inv_min_rows": 0}        # rows below the diagonal block by inverse + GEMM
 _WHOLE_SAG = {"schedule": "bcast", "exchange": "scatter_gather", "sag_min_bytes": 0}
+# (default on CPU ops: the step loop is recorded once as an op list and every evaluation replays it through the Python interpreter of
+# that list -- the list gpt_plan_run replays natively on a GPU; compiled=False: the step loop issues every operation itself)
+_WHOLE_DIRECT = {"schedule": "bcast", "compiled": False}
+_WHOLE_SAG_DIRECT = {"schedule": "bcast", "exchange": "scatter_gather", "sag_min_bytes": 0, "compiled": False}
 
 
 @pytest.mark.parametrize("world,N,d,nb,kid,lookahead,plan_kw", [
@@ -163,6 +167,8 @@ _WHOLE_SAG = {"schedule": "bcast", "exchange": "scatter_gather", "sag_min_bytes"
     (3, 700, 3, 128, 1, True, _WHOLE_INV),
     (2, 700, 3, 128, 1, False, _WHOLE_INV),
     (8, 1900, 2, 128, 0, True, _WHOLE_INV),
+    (3, 500, 2, 128, 0, True, _WHOLE_DIRECT),
+    (2, 700, 3, 128, 1, True, _WHOLE_SAG_DIRECT),
 ])
 def test_distributed_fit_matches_single_process_oracle(world, N, d, nb, kid, lookahead, plan_kw):
     from oracle import oracle as O
@@ -282,3 +288,56 @@ def test_replicas_single_process_is_plain_map():
     assert replicas.world_size() == 1
     assert replicas.shared({"a": 1}) == {"a": 1}
     assert replicas.distributed_map(lambda v: v * v, [1, 2, 3]) == [1, 4, 9]
+
+
+def test_recorded_op_list_is_static_and_encodes_what_the_interpreter_runs():
+    """Compiled schedules, host side (no GPU, no process group: one rank, numpy ops): the recorder's integer records -- what
+    gpt_plan_run replays -- carry the same operands as the Python arguments the interpreter hands to the ops object (addresses,
+    sizes, the bit patterns of alpha / beta), events are recorded before they are waited for, every record fits GPT_PLAN_W, a second
+    recording yields the same list, and replaying the list reproduces the step loop's result bit for bit."""
+    import struct
+    from gptools_amd import dist as D
+    X, n, y = _inputs(900, 2)
+    p = np.array([1.0, 0.3, 0.3])
+    res = {}
+    for mode in ("python", False):
+        plan = D.DistributedLML(X, n, nb=128, ops=_numpy_ops(), compiled=mode, inv_min_rows=256)
+        res[mode] = (plan.fit(0, p, y, 0.05), plan.fit(0, 1.2 * p, y, 0.05))
+        if mode:
+            (cp,) = plan._plans.values()
+            lists = [cp.ops]
+            rec = D.PlanRecorder(plan.device)
+            real, plan.ops, plan._rec = plan.ops, rec, rec
+            try:
+                plan._schedule(None, None, 0.0, 0.0)
+            finally:
+                plan.ops, plan._rec = real, None
+            lists.append(rec.ops)
+            assert [(o[0], o[1], o[2]) for o in lists[0]] == [(o[0], o[1], o[2]) for o in lists[1]]
+            recorded = set()
+            f64 = lambda bits: struct.unpack("<d", struct.pack("<q", bits))[0]
+            kinds = set()
+            for opcode, q, ints, py in cp.ops:
+                assert len(ints) <= D.PLAN_W - 2 and q in D.QUEUE_ID
+                kinds.add(opcode)
+                if opcode == D.OP_RECORD:
+                    recorded.add(ints[0])
+                elif opcode == D.OP_WAIT:
+                    assert ints[0] in recorded
+                elif opcode == D.OP_GEMM:
+                    m, n_, k, alpha, A, lda, B, ldb, beta, C, ldc, tri = py
+                    assert ints == [m, n_, k, ints[3], A, lda, B, ldb, ints[8], C, ldc, tri]
+                    assert f64(ints[3]) == alpha and f64(ints[8]) == beta
+                elif opcode == D.OP_STAIR:
+                    assert f64(ints[4]) == py[4] and f64(ints[11]) == py[11] and ints[5] == py[5] and ints[12] == py[12]
+                elif opcode == D.OP_COPY2D:
+                    dst, src = py
+                    assert ints == [src.shape[0], src.shape[1], src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0)]
+                elif opcode == D.OP_POTRF_PANEL:
+                    assert ints[:4] == list(py[:4]) and ints[4] == py[4].data_ptr() and ints[5] == py[5].data_ptr() and ints[6] == py[6]
+                elif opcode == D.OP_KBUILD:
+                    assert ints == list(py)
+                elif opcode == D.OP_SCALARS:
+                    assert ints == [py[0].data_ptr(), py[0].stride(0), py[1], py[2], py[3].data_ptr()]
+            assert {D.OP_KBUILD, D.OP_PAD, D.OP_COPY2D, D.OP_POTRF_PANEL, D.OP_TRINV, D.OP_GEMM, D.OP_STAIR, D.OP_SCALARS} <= kinds
+    assert res["python"] == res[False]
