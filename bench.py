@@ -493,8 +493,9 @@ def main():
         # MEDIAN round's, min / max / all rounds are reported.
         # The bench's own instrumentation -- HIP events on every >= 1-GFLOP GEMM launch of the main stream (`roofline`) and around
         # the K-build / factorisation phases -- costs 0.13 ms per C3 step (3 %; scratch/instr_ab.py) and is not part of the
-        # product: it rides on every INSTR_EVERY-th step of a round (steps 0, 4, 8, ...), `roofline.sampled_steps` says how many.
-        INSTR_EVERY = 4
+        # product: it rides on every INSTR_EVERY-th step of a round (steps 0, 10, ...: with rounds repeated to a second there are tens of
+        # instrumented steps either way), `roofline.sampled_steps` says how many.
+        INSTR_EVERY = 10
         MIN_TIMED_S = float(os.environ.get("GPT_BENCH_MIN_TIMED_S", "1.0"))
         alpha_box = [None]
 
