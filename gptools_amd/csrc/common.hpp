@@ -190,7 +190,8 @@ int launch_logdet_dot(hipStream_t st, const double *A, int64_t lda, int64_t n, c
                       double *out4, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, unsigned *edge_err = nullptr);
 int launch_extract_lower(hipStream_t st, const double *A, int64_t lda, int64_t n, double *out, int64_t ldo);
 int launch_trsv_lt(hipStream_t st, int64_t n, const double *L, int64_t ldl, const double *invd, double *x, int64_t b_lo = 0);
-int launch_trsv_lt_wide(hipStream_t st, int64_t nwide, const double *L, int64_t ldl, const double *U, double *w, double *x);
+int launch_trsv_lt_wide(hipStream_t st, int64_t nwide, const double *L, int64_t ldl, const double *U, double *w, double *x,
+                        const double *w0 = nullptr);
 int launch_alpha_init(hipStream_t st, int64_t n, int64_t np, const double *z, double *w, double *x);
 int launch_gemv_n(hipStream_t st, int64_t m, int64_t n, const double *A, int64_t lda, const double *x, double *y);
 int launch_trinv512(hipStream_t st, int64_t nblk, const double *L, int64_t ldl, const double *invd, double *U, double *W);

@@ -648,8 +648,10 @@ int launch_trinv512(hipStream_t st, int64_t nblk, const double *L, int64_t ldl, 
 // workgroups fill the chip four times sooner.  Lane = (column, row mod 4); the eight waves split the 512 rows, sixteen loads in flight
 // per lane (a load instruction covers four rows of 128 bytes); the 32 partial sums of a column meet in LDS in a fixed order.
 #define TW_NB 512
+// w_in: where the vector being updated is READ (w itself, or -- the first step of an eager alpha -- the augmented row z of the factor:
+// w = z - M^T x then initialises w in passing and no init kernel sits in front of the substitution)
 __global__ __launch_bounds__(512) void gemv_t_sub_kernel(int64_t ncols, const double *__restrict__ M, int64_t ldm,
-                                                         const double *__restrict__ x, double *__restrict__ w)
+                                                         const double *__restrict__ x, double *__restrict__ w, const double *__restrict__ w_in)
 {
     __shared__ double xs[TW_NB];
     __shared__ double part[32][17];
@@ -678,7 +680,7 @@ __global__ __launch_bounds__(512) void gemv_t_sub_kernel(int64_t ncols, const do
         double t = 0.0;
 #pragma unroll
         for (int q = 0; q < 32; q++) t += part[q][tid];
-        w[col] -= t;
+        w[col] = w_in[col] - t;
     }
 }
 
@@ -704,19 +706,27 @@ int launch_alpha_init(hipStream_t st, int64_t n, int64_t np, const double *z, do
 
 // (Round 6 also let every step write its piece of x to the pinned host buffer of the eager alpha -- no device-to-host copy behind the
 // last step: same-box A/B 0.2795 against 0.2795 ms of alpha per evaluation; removed.)
-int launch_trsv_lt_wide(hipStream_t st, int64_t nwide, const double *L, int64_t ldl, const double *U, double *w, double *x)
+int launch_trsv_lt_wide(hipStream_t st, int64_t nwide, const double *L, int64_t ldl, const double *U, double *w, double *x, const double *w0)
 {
+    // w0 (may be null): the right-hand side is still where it was produced (the augmented row of the factor) and w is uninitialised:
+    // the first step reads w0 and its update writes w = w0 - ..., so that no copy / init kernel precedes the first step
     if (nwide % TW_NB) {
         gpt_set_error("trsv_lt_wide: the extent must be a multiple of %d", TW_NB);
+        return GPT_E_ARG;
+    }
+    if (w0 && nwide < 2 * TW_NB) {
+        gpt_set_error("trsv_lt_wide: w0 needs at least two blocks");
         return GPT_E_ARG;
     }
     // (Round 4 also built a one-launch step -- update of step j and block solve of step j - 1 in one kernel, the eight workgroups that
     // own the next block's columns dispatched first and handing over through a counter: 0.36 against 0.26 ms at n = 8192 with the
     // inverses cached, and its wait was the one unbounded spin of the library.  Removed in round 5.)
+    const double *wsrc = w0 ? w0 : w;
     for (int64_t j0 = nwide - TW_NB; j0 >= 0; j0 -= TW_NB) {
-        GPT_TRY_RC_SOLVE(launch_gemv_n(st, TW_NB, TW_NB, U + j0 * TW_NB, TW_NB, w + j0, x + j0));
+        GPT_TRY_RC_SOLVE(launch_gemv_n(st, TW_NB, TW_NB, U + j0 * TW_NB, TW_NB, wsrc + j0, x + j0));
         if (j0 > 0)
-            hipLaunchKernelGGL(gemv_t_sub_kernel, dim3((unsigned)(j0 / 16)), dim3(512), 0, st, j0, L + j0 * ldl, ldl, x + j0, w);
+            hipLaunchKernelGGL(gemv_t_sub_kernel, dim3((unsigned)(j0 / 16)), dim3(512), 0, st, j0, L + j0 * ldl, ldl, x + j0, w, wsrc);
+        wsrc = w;
     }
     GPT_LAUNCH_CHECK();
     return GPT_OK;
