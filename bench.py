@@ -493,9 +493,9 @@ def main():
         # MEDIAN round's, min / max / all rounds are reported.
         # The bench's own instrumentation -- HIP events on every >= 1-GFLOP GEMM launch of the main stream (`roofline`) and around
         # the K-build / factorisation phases -- costs 0.13 ms per C3 step (3 %; scratch/instr_ab.py) and is not part of the
-        # product: it rides on every INSTR_EVERY-th step of a round (steps 0, 10, ...: with rounds repeated to a second there are tens of
-        # instrumented steps either way), `roofline.sampled_steps` says how many.
-        INSTR_EVERY = 10
+        # product: it rides on the FIRST step of every INSTR_ROUNDS-th round (with rounds repeated to a second that is 6-11
+        # instrumented steps = 100-180 timed launches), `roofline.sampled_steps` says how many.
+        INSTR_ROUNDS = 2
         MIN_TIMED_S = float(os.environ.get("GPT_BENCH_MIN_TIMED_S", "1.0"))
         alpha_box = [None]
 
@@ -512,7 +512,7 @@ def main():
                 barrier()
                 t0_ = time.perf_counter()
                 for i_ in range(args.steps):
-                    instr_ = instrument and (i_ % INSTR_EVERY == 0)
+                    instr_ = instrument and i_ == 0 and (len(rounds_) % INSTR_ROUNDS == 0)
                     if instr_:
                         ctx.set_option("profile_gemm", 1)
                         ctx.set_option("timing", 1)
@@ -602,7 +602,7 @@ def main():
                     roof["traffic_algorithmic_bytes"] = tj_["algorithmic_bytes_per_launch"]
                     roof["traffic_file"] = os.path.relpath(tf_[-1], ROOT)
                     roof["traffic_note"] = tj_.get("note")
-        extra["methodology"] = {"version": 6, "instrumented_every": INSTR_EVERY,
+        extra["methodology"] = {"version": 6, "instrumented": "the first step of every %d-th round" % INSTR_ROUNDS,
                                 "ms_per_step_instrumented": 1e3 * sum(t_instr) / max(len(t_instr), 1),
                                 "ms_per_step_plain": (1e3 * sum(t_plain) / len(t_plain)) if t_plain else None,
                                 "note": "version 6 (round 6): a step computes and returns alpha (full compute_K_L_alpha_ll, full LAPACK flop "
