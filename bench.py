@@ -622,7 +622,7 @@ def main():
                                         X=X, y=y, err_y=err, n=n)
             gp_._ctx_obj, gp_._ctx_pool, gp_._data_on_device = ctx, ([[ctx2, -1]] if ctx2 is not None else []), True
             ctx.set_option("profile_gemm", 0)      # (what a user of the plugin API runs: no bench events at all; the timed loop
-            ctx.set_option("timing", 0)            #  above carries them on every 4th step, ~0.03 ms per step on average)
+            ctx.set_option("timing", 0)            #  above carries them on one step per two rounds)
             for _ in range(2):
                 v_ = gp_.update_hyperparameters(params)
             eg_ = ctx.edge_count
