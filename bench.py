@@ -774,9 +774,11 @@ def main():
             layout, nb_ = name.split("@")
             nb_ = int(nb_)
             if layout.startswith("grid"):
+                # "grid<Pr>x<Pc>[+native]": as below -- "+native" = gpt_plan_run with the plan's own five RCCL communicators
                 if name not in plans:
-                    g_ = tuple(int(v) for v in layout[4:].split("x"))
-                    plans[name] = GridLML(X, n, g_, nb=nb_, ops=ops)
+                    gparts_ = layout[4:].split("+")
+                    g_ = tuple(int(v) for v in gparts_[0].split("x"))
+                    plans[name] = GridLML(X, n, g_, nb=nb_, ops=ops, compiled="native" if (len(gparts_) > 1 or world == 1) else "python")
                 return plans[name]
             # "1d+<exchange>[+native]": with "+native" the rank's step loop is replayed by gpt_plan_run (compiled schedule, RCCL
             # called from the library on the plan's own communicator); without it the same op list goes through the Python
@@ -870,7 +872,8 @@ def main():
         # (the native replay with its own RCCL communicator has run at world size 1 only: on more ranks it is a LEG -- under the
         # watchdog like everything after the first timed region -- and becomes the line only if it completes and is faster)
         combos = ["1d+scatter_gather@%d" % nb0] + (["1d+bcast+native@%d" % nb0, "1d+scatter_gather+native@%d" % nb0] if (world > 1 and os.environ.get("GPT_BENCH_BACKEND", "nccl") == "nccl") else []) \
-            + ["grid%dx%d@%d" % (g_[0], g_[1], nb0) for g_ in grids_]
+            + ["grid%dx%d@%d" % (g_[0], g_[1], nb0) for g_ in grids_] \
+            + (["grid%dx%d+native@%d" % (g_[0], g_[1], nb0) for g_ in grids_[:1]] if (world > 1 and os.environ.get("GPT_BENCH_BACKEND", "nccl") == "nccl") else [])
         if not args.nb:
             combos += ["1d+bcast@384", "1d+bcast@256"] + ["grid%dx%d@256" % g_ for g_ in grids_[:1]]
         if args.schedule:

@@ -64,6 +64,7 @@ SIGNATURES = {
     "gpt_plan_unique_id": (C.c_int, [_vp]),
     "gpt_plan_create": (C.c_int, [C.c_int, C.POINTER(_vp), C.POINTER(_i64), _i64, C.c_int, _vp, _vp, C.c_int, _vp, C.POINTER(_vp)]),
     "gpt_plan_set_comm": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "gpt_plan_set_channel": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
     "gpt_plan_run": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double, C.c_double]),
     "gpt_plan_last_enqueue_ms": (C.c_double, [_vp]),
     "gpt_plan_destroy": (C.c_int, [_vp]),

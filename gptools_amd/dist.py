@@ -300,9 +300,11 @@ def _ptr(t, row, col):
 #   * through a Python interpreter of the SAME list against any PanelOps + torch.distributed (the gloo / numpy tests, and the
 #     ranks-sharing-one-GPU tests, where RCCL cannot run).
 OP_RECORD, OP_WAIT, OP_KBUILD, OP_PAD, OP_COPY2D, OP_POTRF_PANEL, OP_TRINV, OP_GEMM, OP_STAIR, OP_SCALARS, OP_BCAST, OP_SCATTER, \
-    OP_ALLGATHER = range(13)
-PLAN_W = 16
-QUEUE_ID = {"main": 0, "panel": 1, "recv": 2, "comm": 3}
+    OP_ALLGATHER, OP_KRECT, OP_ROWSUMSQ, OP_GRIDSTAIR = range(16)
+PLAN_W = 20
+PLAN_CHANNELS = 8
+# queues: the three contexts, then the communication channels ("comm" = channel 0: the 1-D engine's only one, the grid's whole-grid one)
+QUEUE_ID = dict({"main": 0, "panel": 1, "recv": 2, "comm": 3}, **{"comm%d" % c: 3 + c for c in range(1, PLAN_CHANNELS)})
 
 
 def _f64_bits(x):
@@ -311,17 +313,41 @@ def _f64_bits(x):
 
 
 class _RecEvent(object):
-    __slots__ = ("rec", "idx")
+    """An event of a recorded schedule.  The recorder keeps a vector clock per context queue (in-order streams in every
+    executor) and the clock an event was recorded at: a wait whose event is already behind the waiting queue -- recorded on that
+    queue itself, waited for before, or ordered through an event the queue waited for since -- is NOT emitted (a third of the
+    2-D engine's waits; each one is a hipStreamWaitEvent per evaluation).  An exchange's "arrived" event is a clock component of its
+    own: the channel queues are not assumed to complete in order (gloo's asynchronous operations do not)."""
+    __slots__ = ("rec", "idx", "vec")
 
     def __init__(self, rec):
-        self.rec, self.idx = rec, rec.nevents
+        self.rec, self.idx, self.vec = rec, rec.nevents, None
         rec.nevents += 1
 
     def record(self):
-        self.rec.emit(OP_RECORD, self.rec.cur, [self.idx])
+        rec, q = self.rec, self.rec.cur
+        clk = rec.clock.setdefault(q, {})
+        clk[q] = clk.get(q, 0) + 1
+        self.vec = dict(clk)
+        rec.emit(OP_RECORD, q, [self.idx])
+
+    def arrived_after(self, ready):
+        """(recorded by a channel queue behind ``ready``)"""
+        self.vec = dict(ready.vec)
+        self.vec[("arrived", self.idx)] = 1
 
     def wait(self):
-        self.rec.emit(OP_WAIT, self.rec.cur, [self.idx])
+        rec, q = self.rec, self.rec.cur
+        if self.vec is None:
+            raise RuntimeError("a recorded schedule waits for an event before recording it")
+        clk = rec.clock.setdefault(q, {})
+        if all(clk.get(k, 0) >= v for k, v in self.vec.items()):
+            rec.pruned += 1
+            return
+        for k, v in self.vec.items():
+            if clk.get(k, 0) < v:
+                clk[k] = v
+        rec.emit(OP_WAIT, q, [self.idx])
 
 
 class _RecQueue(object):
@@ -347,6 +373,7 @@ class PlanRecorder(PanelOps):
     def __init__(self, device):
         self.device = device
         self.ops, self.nevents, self.cur = [], 0, "main"
+        self.clock, self.pruned = {}, 0         # vector clock per context queue; waits not emitted (see _RecEvent)
 
     def emit(self, opcode, q, ints, py=None):
         assert len(ints) <= PLAN_W - 2
@@ -395,6 +422,28 @@ class PlanRecorder(PanelOps):
     def panel_scalars(self, buf, w, zrow, red, q="panel"):
         self.emit(OP_SCALARS, q, [buf.data_ptr(), buf.stride(0), w, zrow, red.data_ptr()], (buf, w, zrow, red))
 
+    def kbuild_rect(self, kernel_id, params, Xi, ni, r0, r1, Xj, nj, c0, c1, out, ld):
+        self.emit(OP_KRECT, "main", [Xi.data_ptr(), ni.data_ptr(), r0, r1, c0, c1, out, ld], (Xi, ni, r0, r1, Xj, nj, c0, c1, out, ld))
+
+    def row_sumsq(self, row, red, q="panel"):
+        self.emit(OP_ROWSUMSQ, q, [row.data_ptr(), row.numel(), red.data_ptr() + 8], (row, red))
+
+    def gemm_nt_gridstair(self, m, nseg, seg_cols, k, alpha, A, lda, B, ldb, off, num, den, base, beta, C, ldc, q="main"):
+        self.emit(OP_GRIDSTAIR, q, [m, nseg, seg_cols, k, _f64_bits(alpha), A, lda, B, ldb, off, num, den, base, _f64_bits(beta), C, ldc],
+                  (m, nseg, seg_cols, k, alpha, A, lda, B, ldb, off, num, den, base, beta, C, ldc))
+
+    # -- a broadcast on communication channel ``channel`` (a queue name, "comm" / "comm1" ...), root = rank inside that channel's
+    #    communicator; ``what`` is handed to the engine's ``_plan_collective`` by the Python interpreter
+    def bcast(self, buf, root, channel, what):
+        ready, arrived = _RecEvent(self), _RecEvent(self)
+        issuing = self.cur
+        ready.record()
+        self.emit(OP_WAIT, channel, [ready.idx])
+        self.emit(OP_BCAST, channel, [buf.data_ptr(), buf.numel(), root], (buf, what, issuing, arrived.idx))
+        self.emit(OP_RECORD, channel, [arrived.idx])
+        arrived.arrived_after(ready)
+        return [arrived]
+
     # -- the panel exchange: [issuing queue records "ready"] [comm stream waits for it] [collective(s)] [comm stream records
     #    "arrived"]; the returned handle's wait() is a wait for "arrived" on whatever queue is current then
     def exchange(self, buf, src, world, grank, scatter_gather):
@@ -410,6 +459,7 @@ class PlanRecorder(PanelOps):
         else:
             self.emit(OP_BCAST, "comm", [buf.data_ptr(), buf.numel(), src], (buf, src, issuing, arrived.idx))
         self.emit(OP_RECORD, "comm", [arrived.idx])
+        arrived.arrived_after(ready)
         return [arrived]
 
 
@@ -417,13 +467,18 @@ class CompiledPlan(object):
     """The op list of one rank's evaluation and its two executors (see above)."""
 
     def __init__(self, recorder):
-        self.ops = recorder.ops
+        # (records of events nobody waits for -- their waits were all pruned, or the step loop keeps them for a later step that
+        # never comes -- are dropped: one hipEventRecord less per evaluation each)
+        waited = {o[2][0] for o in recorder.ops if o[0] == OP_WAIT}
+        self.ops = [o for o in recorder.ops if not (o[0] == OP_RECORD and o[2][0] not in waited)]
         self.nevents = recorder.nevents
         self.handle = None
         self._keep = None
 
     # ---- native ----
-    def build_native(self, hip_ops, X, n, err, nranks, rank, comm_group, with_comm):
+    def build_native(self, hip_ops, X, n, err, channels):
+        """``channels``: [(channel index, ranks in it, this rank's position, the torch process group that carries the id)] -- every
+        rank lists its channels in the same order (each ``gpt_plan_set_channel`` is collective over that channel's ranks)."""
         lib = hip_ops.lib
         arr = np.zeros((len(self.ops), PLAN_W), dtype=np.int64)
         for i, (opcode, q, ints, _) in enumerate(self.ops):
@@ -436,19 +491,19 @@ class CompiledPlan(object):
                                        n.data_ptr(), int(X.shape[1]), err.data_ptr(), C.byref(out)))
         self.handle, self.lib = out, lib
         self._keep = (X, n, err)
-        if with_comm:
-            # the communicator's id: made on rank 0, handed round through the job's own process group
+        for ch, nranks, rank, group in channels:
+            # the communicator's id: made on the channel's rank 0, handed round through the job's own process group
             uid = torch.zeros(128, dtype=torch.uint8)
             if rank == 0:
                 buf = (C.c_char * 128)()
                 _lib.check(lib.gpt_plan_unique_id(buf))
                 uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
             if nranks > 1:
-                dev_uid = uid.to(hip_ops.device) if dist.get_backend(comm_group) == "nccl" else uid
-                dist.broadcast(dev_uid, src=dist.get_global_rank(comm_group, 0) if comm_group is not None else 0, group=comm_group)
+                dev_uid = uid.to(hip_ops.device) if dist.get_backend(group) == "nccl" else uid
+                dist.broadcast(dev_uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
                 uid = dev_uid.cpu()
             raw = bytes(uid.numpy().tobytes())
-            _lib.check(lib.gpt_plan_set_comm(self.handle, nranks, rank, C.c_char_p(raw)))
+            _lib.check(lib.gpt_plan_set_channel(self.handle, int(ch), int(nranks), int(rank), C.c_char_p(raw)))
         return self
 
     def run_native(self, kernel_id, params, noise_var, diag_add):
@@ -469,46 +524,70 @@ class CompiledPlan(object):
 
     # ---- Python interpreter of the same list ----
     def run_python(self, ops, engine, kernel_id, params, noise_var, diag_add):
-        events = [ops.new_event() for _ in range(self.nevents)]
+        events = [None] * self.nevents
         works = {}
-        for opcode, q, ints, py in self.ops:
-            if q == "comm":
-                # torch.distributed orders a collective behind the stream that is current when it is issued and hands back work
-                # objects: "ready" / the comm stream's own waits have no counterpart, "arrived" is the work objects
-                if opcode in (OP_BCAST, OP_SCATTER):
-                    buf, src, issuing, arrived = py
-                    with ops.queue(issuing):
-                        works[arrived] = engine._exchange_now(buf, src, scatter_gather=(opcode == OP_SCATTER))
-                continue
-            with ops.queue(q):
-                if opcode == OP_RECORD:
-                    events[ints[0]].record()
-                elif opcode == OP_WAIT:
+        state = [None, None]                 # the queue that is current, its context manager
+
+        def switch(q):
+            # (entering a queue = making its stream current: done when the queue CHANGES, not per op -- the list keeps runs of
+            # operations on one queue together)
+            if q != state[0]:
+                if state[1] is not None:
+                    state[1].__exit__(None, None, None)
+                state[0], state[1] = q, ops.queue(q)
+                state[1].__enter__()
+
+        try:
+            for opcode, q, ints, py in self.ops:
+                if QUEUE_ID[q] >= 3:
+                    # torch.distributed orders a collective behind the stream that is current when it is issued and hands back work
+                    # objects: "ready" / the channel stream's own waits have no counterpart, "arrived" is the work objects
+                    if opcode in (OP_BCAST, OP_SCATTER):
+                        buf, what, issuing, arrived = py
+                        switch(issuing)
+                        works[arrived] = engine._plan_collective(opcode, buf, what)
+                    continue
+                switch(q)
+                if opcode == OP_WAIT:
                     if ints[0] in works:
-                        for w in works.pop(ints[0]):
+                        # (an arrival may be waited for from several queues: the handles stay)
+                        for w in works[ints[0]]:
                             if w is not None:
                                 w.wait()
-                    else:
+                    elif events[ints[0]] is not None:
                         events[ints[0]].wait()
+                    # (else: "ready" of an exchange the engine's _plan_collective did not issue, or an "arrived" nobody recorded)
+                elif opcode == OP_RECORD:
+                    e = events[ints[0]] = ops.new_event()
+                    e.record()
+                elif opcode == OP_GEMM:
+                    ops.gemm_nt(*py, q=q)
+                elif opcode == OP_COPY2D:
+                    ops.copy2d(py[0], py[1], q=q)
+                elif opcode == OP_GRIDSTAIR:
+                    ops.gemm_nt_gridstair(*py, q=q)
+                elif opcode == OP_STAIR:
+                    ops.gemm_nt_stair(*py, q=q)
                 elif opcode == OP_KBUILD:
                     r0, r1, c0, c1, out, ld = py
                     ops.kbuild_block(kernel_id, params, engine.X, engine.n, r0, r1, c0, c1, engine.err, noise_var, diag_add, out, ld)
+                elif opcode == OP_KRECT:
+                    ops.kbuild_rect(kernel_id, params, *py)
                 elif opcode == OP_PAD:
                     ops.pad_block(*py)
-                elif opcode == OP_COPY2D:
-                    ops.copy2d(py[0], py[1], q=q)
                 elif opcode == OP_POTRF_PANEL:
                     ops.potrf_panel(*py)
                 elif opcode == OP_TRINV:
                     ops.trinv(*py, q=q)
-                elif opcode == OP_GEMM:
-                    ops.gemm_nt(*py, q=q)
-                elif opcode == OP_STAIR:
-                    ops.gemm_nt_stair(*py, q=q)
                 elif opcode == OP_SCALARS:
                     ops.panel_scalars(*py, q=q)
+                elif opcode == OP_ROWSUMSQ:
+                    ops.row_sumsq(*py, q=q)
                 else:
                     raise ValueError("unknown opcode %r" % (opcode,))
+        finally:
+            if state[1] is not None:
+                state[1].__exit__(None, None, None)
 
 
 class _Arrival(object):
@@ -689,6 +768,10 @@ class DistributedLML(object):
             return [w1, w2]
         return [self._bcast(buf, src, async_op=True, group=group)]
 
+    def _plan_collective(self, opcode, buf, src):
+        """(Python interpreter of a compiled schedule) issue the recorded exchange; returns the work handles."""
+        return self._exchange_now(buf, src, scatter_gather=(opcode == OP_SCATTER))
+
     def _allreduce(self, t, op):
         dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX, group=self.group)
 
@@ -861,8 +944,8 @@ class DistributedLML(object):
                     self.ops, self._rec = real, None
                 plan = CompiledPlan(rec)
                 if self.compiled == "native":
-                    plan.build_native(real, self.X, self.n, self.err, self.world if self._collectives_on() else 1,
-                                      self.grank if self._collectives_on() else 0, self.group, with_comm=self._collectives_on())
+                    plan.build_native(real, self.X, self.n, self.err,
+                                      [(0, self.world, self.grank, self.group)] if self._collectives_on() else [])
                 self._plans[key] = plan
                 self.timings["plan_ops"] = len(plan.ops)
             if self.compiled == "native":
@@ -1001,7 +1084,10 @@ class GridLML(object):
     """
     NBUF = 4
 
-    def __init__(self, X, n, grid, nb=512, group=None, ops=None, device=None, lookahead=True, layout=None):
+    # communication channels of a compiled schedule (queue names of the op list): what moves on which communicator
+    CHANNEL = {"H": "comm", "R": "comm1", "R0": "comm2", "W": "comm3", "C": "comm4"}
+
+    def __init__(self, X, n, grid, nb=512, group=None, ops=None, device=None, lookahead=True, layout=None, compiled=None):
         if nb <= 0 or nb % 128:
             raise ValueError("nb must be a positive multiple of 128")
         self.Pr, self.Pc = int(grid[0]), int(grid[1])
@@ -1093,6 +1179,23 @@ class GridLML(object):
         self._h_out = torch.from_numpy(_lib.pinned_empty((3,), min_bytes=0)) if on_gpu else None
         self.timings = {}
         self.trace = False
+        # compiled: as for DistributedLML -- "native" (gpt_plan_run replays the recorded op list, RCCL from the library: five
+        # communicators per rank), "python" (the same list through the Python interpreter + torch.distributed) or False (the step
+        # loop issues every operation; what a traced evaluation and the single-GPU model of scratch/ do).  None: "native" with the
+        # product ops on one rank, "python" on several (the native replay has not run on more than one GPU), False for a model.
+        env = os.environ.get("GPT_DIST_COMPILED")
+        if env is not None and layout is None:
+            compiled = False if env == "0" else env
+        if compiled is None:
+            one_rank = not inited or dist.get_world_size(group) == 1
+            compiled = False if layout is not None else ("native" if (isinstance(ops, HipPanelOps) and one_rank) else "python")
+        if compiled not in (False, "native", "python"):
+            raise ValueError("compiled must be None, False, 'native' or 'python'")
+        if compiled == "native" and not isinstance(ops, HipPanelOps):
+            raise ValueError("compiled='native' needs the product ops (HipPanelOps)")
+        self.compiled = compiled
+        self._plans = {}
+        self._rec = None
 
     # ---- index helpers ---------------------------------------------------------------------------
     def li_ge(self, I0):
@@ -1117,8 +1220,33 @@ class GridLML(object):
         (the model needs to know; the product path does not)."""
         if not self._on(size) or buf.numel() == 0:
             return []
+        if self._rec is not None:
+            # (recording a compiled schedule: the broadcast becomes ops of the list; root = position inside the communicator --
+            # process rows are ordered by column, process columns by row, the whole grid row-major)
+            root = {"W": src[0], "C": src[0], "R": src[1], "R0": src[1], "H": src[0] * self.Pc + src[1]}[kind]
+            return self._rec.bcast(buf, root, self.CHANNEL[kind], (kind, src))
         gsrc = self._ranks[src[0] * self.Pc + src[1]]
         return [dist.broadcast(buf, src=gsrc, group=group, async_op=True)]
+
+    def _plan_collective(self, opcode, buf, what):
+        """(Python interpreter of a compiled schedule) issue the recorded broadcast; returns the work handles."""
+        kind, src = what
+        group = {"H": self.group, "R": self.g_row, "R0": self.g_row0, "W": self.g_colw, "C": self.g_colx}[kind]
+        gsrc = self._ranks[src[0] * self.Pc + src[1]]
+        return [dist.broadcast(buf, src=gsrc, group=group, async_op=True)]
+
+    def _channels(self):
+        """The communicators of a native plan: (channel, ranks, own position, torch group carrying the id), in an order every
+        rank shares."""
+        if self._model or not dist.is_initialized():
+            return []
+        out = []
+        for kind, size, pos, group in (("H", self.world, self.rank, self.group), ("R", self.Pc, self.pc, self.g_row),
+                                       ("R0", self.Pc, self.pc, self.g_row0), ("W", self.Pr, self.pr, self.g_colw),
+                                       ("C", self.Pr, self.pr, self.g_colx)):
+            if self._on(size):
+                out.append((QUEUE_ID[self.CHANNEL[kind]] - 3, size, pos, group))
+        return out
 
     def _allreduce(self, t, op):
         dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX, group=self.group)
@@ -1153,10 +1281,36 @@ class GridLML(object):
         if kernel_id in (_lib.KERNEL_RQ, _lib.KERNEL_MATERN) and 2 * self._n_maxsum > 16:
             raise ValueError("RationalQuadratic / Matern kernel: derivative orders of a pair sum to %d, the device builder "
                              "supports 16" % (2 * self._n_maxsum))
-        ops, N, nb, NP, nblk, NBUF = self.ops, self.N, self.nb, self.NP, self.nblk, self.NBUF
-        Pr, Pc, pr, pc = self.Pr, self.Pc, self.pr, self.pc
-        A, ld = self.A, self.A.stride(0)
         t_host0 = time.perf_counter()
+        self._upload(y, err_y)
+        if self.compiled and not self.trace:
+            key = (self.compiled, self.lookahead)
+            plan = self._plans.get(key)
+            if plan is None:
+                # walk the step loop once against the recorder (nothing runs), then build the executor
+                real, rec = self.ops, PlanRecorder(self.device)
+                self.ops = self._rec = rec
+                try:
+                    self._schedule(None, None, 0.0, 0.0)
+                finally:
+                    self.ops, self._rec = real, None
+                plan = CompiledPlan(rec)
+                if self.compiled == "native":
+                    plan.build_native(real, self.X, self.n, self.err, self._channels())
+                self._plans[key] = plan
+                self.timings["plan_ops"] = len(plan.ops)
+            diag_add = diag_factor * sys.float_info.epsilon
+            if self.compiled == "native":
+                self.timings["native_enqueue_ms"] = plan.run_native(kernel_id, params, noise_var, diag_add)
+            else:
+                plan.run_python(self.ops, self, kernel_id, params, noise_var, diag_add)
+            return self._finish(t_host0)
+        self._schedule(kernel_id, params, noise_var, diag_factor)
+        return self._finish(t_host0)
+
+    def _upload(self, y, err_y):
+        """Per-evaluation host traffic and resets, on the main queue: y | err_y up, info and the scalar accumulators to zero."""
+        ops, N = self.ops, self.N
         y = np.ascontiguousarray(y, dtype=np.float64)
         err_y = np.array(np.broadcast_to(err_y, (N,)), dtype=np.float64)
         with ops.queue("main"):
@@ -1172,7 +1326,14 @@ class GridLML(object):
             self.red.zero_()
             self.red_b.zero_()          # (HERE, on the main queue in front of ev_asm: zeroed on the default stream it raced with the
                                         #  bulk queue's accumulation -- one evaluation in 72 lost part of z.z under queue jitter)
-            self._t0 = ops.new_timing_event() if self.trace else None
+
+    def _schedule(self, kernel_id, params, noise_var, diag_factor):
+        """The step loop (class docstring): issues the operations -- or, against a PlanRecorder, lists them."""
+        ops, N, nb, NP, nblk, NBUF = self.ops, self.N, self.nb, self.NP, self.nblk, self.NBUF
+        Pr, Pc, pr, pc = self.Pr, self.Pc, self.pr, self.pc
+        A, ld = self.A, self.A.stride(0)
+        with ops.queue("main"):
+            self._t0 = ops.new_timing_event() if (self.trace and self._rec is None) else None
             if self._t0 is not None:
                 self._t0.record()
             self._assemble(kernel_id, params, noise_var, diag_factor * sys.float_info.epsilon)
@@ -1403,9 +1564,15 @@ class GridLML(object):
             for d in (arr_W, arr_H, arr_R0, arr_R, arr_C, ev_urg, ev_done, ev_ch, ev_bk):
                 d.pop(k - NBUF - 2, None)
         with ops.queue(BK):
-            self._ev_bulk_end = ops.new_event()
-            self._ev_bulk_end.record()
-        return self._finish(t_host0)
+            ev_bulk_end = ops.new_event()
+            ev_bulk_end.record()
+        # the reduction of _finish runs on the chain queue: behind the bulk queue's last accumulation and the receive sides of
+        # the broadcasts nobody on this rank read
+        with ops.queue(CH):
+            for w_ in self._late:
+                w_.wait()
+            self._late = []
+            ev_bulk_end.wait()
 
     def _mark(self, k, tag):
         if self._t0 is not None:
@@ -1417,10 +1584,6 @@ class GridLML(object):
         ops, N = self.ops, self.N
         self.timings["host_enqueue_s"] = time.perf_counter() - t_host0
         with ops.queue("panel"):
-            for w_ in getattr(self, "_late", []):
-                w_.wait()
-            self._late = []
-            self._ev_bulk_end.wait()
             red = self.red
             red[:2] += self.red_b[:2]
             red[2] = self.info.to(torch.float64)[0]

@@ -433,24 +433,33 @@ int gpt_dev_panel_scalars(gpt_ctx *ctx, const double *dP, int64_t ldp, int64_t w
 /* ---- compiled schedules of the partitioned engines (round 6) ------------------------------------------------------------
  * The one-process-per-GPU block-cyclic Cholesky of gptools_amd/dist.py issues ~1000 operations per rank and evaluation; which
  * ones, on which buffers, in which order is static per (N, nb, world, rank).  The Python layer records its step loop once as an
- * op list -- GPT_PLAN_W = 16 int64 per op: [opcode, queue, a0 .. a13], doubles as their bit patterns, queues 0 = main, 1 = panel,
- * 2 = recv (the contexts given here, in this order), 3 = the plan's own communication stream -- and every evaluation is then one
- * gpt_plan_run: a C loop over the list, RCCL (dlopen'ed librccl) called directly for the panel exchange.  Opcodes (csrc/api_plan.inc):
+ * op list -- GPT_PLAN_W = 20 int64 per op: [opcode, queue, a0 .. a17], doubles as their bit patterns, queues 0 = main, 1 = panel,
+ * 2 = recv (the contexts given here, in this order), 3 + c = the stream of the plan's communication channel c -- and every
+ * evaluation is then one gpt_plan_run: a C loop over the list, RCCL (dlopen'ed librccl) called directly for the panel exchanges.
+ * Opcodes (csrc/api_plan.inc):
  *   0 record event a0 | 1 wait event a0 | 2 K block (r0, r1, c0, c1, out, ld) | 3 pad block (ptr, lda, c0, nb, N, NP, y, big) |
  *   4 copy2d (rows, cols, src, lds, dst, ldd) | 5 potrf_panel (m, nb, A, lda, invd, info, info_base) | 6 trinv (nb, L, ldl, invd, W, ldw) |
  *   7 gemm_nt (m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, tri) | 8 gemm_nt_stair (m, nseg, seg_cols, k, alpha, A, lda, B, ldb,
  *   b_stride, row_step, beta, C, ldc) | 9 panel_scalars (buf, ld, w, zrow, red) | 10 broadcast (buf, count, root) |
- *   11 scatter (buf, count per rank, root) | 12 all-gather in place (buf, count per rank).
+ *   11 scatter (buf, count per rank, root) | 12 all-gather in place (buf, count per rank) | 13 K rectangle (Xi, ni, r0, r1, c0, c1,
+ *   out, ld: rows from the caller's own row table, no diagonal terms) | 14 row_sumsq (row, count, out) | 15 gemm_nt_gridstair (m,
+ *   nseg, seg_cols, k, alpha, A, lda, B, ldb, off, num, den, base, beta, C, ldc).  Collectives (10-12) sit on a channel queue,
+ *   kernels on a context queue, events on either.
  * dX (N x D float64), dn (N x D int32), d_err (N float64) are the device arrays the K-block ops read; the per-evaluation inputs
- * are arguments of gpt_plan_run.  gpt_plan_set_comm is collective over the ranks (ncclCommInitRank; the 128-byte id comes from
- * gpt_plan_unique_id on rank 0 and travels by whatever means the caller has); without it the communication ops are skipped
- * (single rank).  The caller keeps the buffers alive and synchronises the contexts' streams itself. */
-#define GPT_PLAN_W 16
+ * are arguments of gpt_plan_run.  A CHANNEL is one communicator + one high-priority stream (up to GPT_PLAN_CHANNELS; the 1-D
+ * engine has one over all ranks, the 2-D engine five: process row x 2, process column x 2, the whole grid): gpt_plan_set_channel
+ * is collective over the channel's ranks (ncclCommInitRank; the 128-byte id comes from gpt_plan_unique_id on the channel's rank 0
+ * and travels by whatever means the caller has; every rank sets its channels in the same order); root / rank are positions in
+ * that communicator.  gpt_plan_set_comm = channel 0.  The ops of a channel without a communicator are skipped (single rank).
+ * The caller keeps the buffers alive and synchronises the contexts' streams itself. */
+#define GPT_PLAN_W 20
+#define GPT_PLAN_CHANNELS 8
 typedef struct gpt_plan gpt_plan;
 int gpt_plan_unique_id(void *out128);
 int gpt_plan_create(int nctx, gpt_ctx **ctxs, const int64_t *ops, int64_t nops, int nevents, const void *dX, const void *dn, int D,
                     const void *d_err, gpt_plan **out);
 int gpt_plan_set_comm(gpt_plan *plan, int nranks, int rank, const void *unique_id128);
+int gpt_plan_set_channel(gpt_plan *plan, int channel, int nranks, int rank, const void *unique_id128);
 int gpt_plan_run(gpt_plan *plan, int kernel_id, const double *params, int nparams, double noise_var, double diag_add);
 double gpt_plan_last_enqueue_ms(gpt_plan *plan);          /* host time gpt_plan_run spent enqueueing, last call */
 int gpt_plan_destroy(gpt_plan *plan);

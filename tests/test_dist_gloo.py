@@ -99,6 +99,78 @@ def _inputs(N, d, seed=4):
     return X, n, y
 
 
+def test_grid_recorded_op_list_is_static_and_replays_bit_identically():
+    """The 2-D engine's compiled schedule, host side (one rank, numpy ops, no process group): two recordings give the same list,
+    every wait follows its record, every record fits GPT_PLAN_W, the records of the grid-only ops (K rectangle, row_sumsq,
+    gemm_nt_gridstair) carry the operands the interpreter hands to the ops object, and the replay reproduces the step loop's result
+    bit for bit.  With the collectives switched on for a rank placed in a 2 x 4 grid (a model rank: nothing is sent) the list holds
+    the five channels' broadcasts, each between a wait for "ready" and a record of "arrived" on its channel's queue."""
+    import struct
+    from gptools_amd import dist as D
+    X, n, y = _inputs(900, 2)
+    p = np.array([1.0, 0.3, 0.3])
+    res = {}
+    f64 = lambda bits: struct.unpack("<d", struct.pack("<q", bits))[0]
+    for mode in ("python", False):
+        plan = D.GridLML(X, n, (1, 1), nb=128, ops=_numpy_ops(), compiled=mode)
+        res[mode] = (plan.fit(0, p, y, 0.05), plan.fit(0, 1.2 * p, y, 0.05))
+        if not mode:
+            continue
+        (cp,) = plan._plans.values()
+        rec = D.PlanRecorder(plan.device)
+        real, plan.ops, plan._rec = plan.ops, rec, rec
+        try:
+            plan._schedule(None, None, 0.0, 0.0)
+        finally:
+            plan.ops, plan._rec = real, None
+        assert [(o[0], o[1], o[2]) for o in cp.ops] == [(o[0], o[1], o[2]) for o in D.CompiledPlan(rec).ops]
+        assert rec.pruned > 0 and len(cp.ops) < len(rec.ops)       # waits already implied / records nobody waits for: not in the list
+        recorded, kinds = set(), set()
+        for opcode, q, ints, py in cp.ops:
+            assert len(ints) <= D.PLAN_W - 2 and q in D.QUEUE_ID
+            kinds.add(opcode)
+            if opcode == D.OP_RECORD:
+                recorded.add(ints[0])
+            elif opcode == D.OP_WAIT:
+                assert ints[0] in recorded
+            elif opcode == D.OP_GRIDSTAIR:
+                assert [f64(v) if i in (4, 13) else v for i, v in enumerate(ints)] == list(py)
+            elif opcode == D.OP_ROWSUMSQ:
+                assert ints == [py[0].data_ptr(), py[0].numel(), py[1].data_ptr() + 8]
+            elif opcode == D.OP_KRECT:
+                Xi, ni, r0, r1, Xj, nj, c0, c1, out, ld = py
+                assert ints == [Xi.data_ptr(), ni.data_ptr(), r0, r1, c0, c1, out, ld] and Xj is plan.X and nj is plan.n
+        assert {D.OP_KBUILD, D.OP_PAD, D.OP_POTRF_PANEL, D.OP_TRINV, D.OP_GEMM, D.OP_SCALARS, D.OP_ROWSUMSQ, D.OP_GRIDSTAIR} <= kinds
+    assert res["python"] == res[False]
+
+    class Placed(D.GridLML):            # rank 5 of a 2 x 4 grid, collectives "on", nothing sent
+        def _on(self, size):
+            return size > 1
+
+        def _allreduce(self, t, op):
+            pass
+
+    plan = Placed(X, n, (2, 4), nb=128, ops=_numpy_ops(), layout=5)
+    rec = D.PlanRecorder(plan.device)
+    real, plan.ops, plan._rec = plan.ops, rec, rec
+    try:
+        plan._schedule(None, None, 0.0, 0.0)
+    finally:
+        plan.ops, plan._rec = real, None
+    chans = {}
+    for i, (opcode, q, ints, py) in enumerate(rec.ops):
+        if opcode == D.OP_BCAST:
+            assert D.QUEUE_ID[q] >= 3 and rec.ops[i - 1][0] == D.OP_WAIT and rec.ops[i - 1][1] == q
+            assert rec.ops[i + 1][0] == D.OP_RECORD and rec.ops[i + 1][1] == q and rec.ops[i + 1][2] == [py[3]]
+            kind, src = py[1]
+            assert q == D.GridLML.CHANNEL[kind] and ints[1] == py[0].numel()
+            size = {"H": 8, "R": 4, "R0": 4, "W": 2, "C": 2}[kind]
+            assert 0 <= ints[2] < size
+            chans.setdefault(kind, 0)
+            chans[kind] += 1
+    assert set(chans) == {"H", "R", "R0", "W", "C"}, chans
+
+
 def _worker(rank, world, port, N, d, nb, kernel_id, lookahead, bad, q, plan_kw=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -187,6 +259,8 @@ def test_distributed_fit_matches_single_process_oracle(world, N, d, nb, kid, loo
     assert len({r[1] for r in out}) == 1                            # every rank reports the same numbers
 
 
+# (the grid engine records its step loop as an op list too -- default here: the Python interpreter of the list, the one
+# gpt_plan_run replays natively on a GPU with five RCCL communicators per rank; a trailing False: the step loop itself)
 @pytest.mark.parametrize("world,grid,N,d,nb,kid,lookahead", [
     (4, (2, 2), 1100, 3, 128, 1, True),      # 9 block rows / columns over 2 x 2, Matern52 with derivative rows
     (4, (2, 2), 1100, 3, 128, 1, False),
@@ -202,13 +276,18 @@ def test_distributed_fit_matches_single_process_oracle(world, N, d, nb, kid, loo
     (4, (2, 2), 1024, 2, 128, 0, True),      # N a multiple of nb: the augmented row opens a block row of its own
     (4, (4, 1), 1900, 2, 128, 0, True),      # nlc % (lcm / P_c) != 0 -- the exchange's staging piece in whole blocks
     (12, (4, 3), 2000, 2, 128, 0, True),     # the same with three process columns
+    (8, (4, 2), 1900, 2, 128, 0, (True, False)),      # the step loop issuing every operation itself (compiled=False)
+    (6, (2, 3), 1500, 2, 128, 1, (False, False)),
 ])
 def test_grid_fit_matches_single_process_oracle(world, grid, N, d, nb, kid, lookahead):
     """2-D block-cyclic layout (gptools_amd.dist.GridLML): every rank returns the oracle's ll / log-determinant
     (1e-9 / 1e-10), all ranks the same bits, the blocks of the lower triangle are covered exactly once, and a second
     evaluation with other hyperparameters reuses the buffers."""
     from oracle import oracle as O
-    out = _run(world, N, d, nb, kid, lookahead, plan_kw={"grid": grid})
+    plan_kw = {"grid": grid}
+    if isinstance(lookahead, tuple):
+        lookahead, plan_kw["compiled"] = lookahead
+    out = _run(world, N, d, nb, kid, lookahead, plan_kw=plan_kw)
     X, n, y = _inputs(N, d)
     p = np.concatenate(([1.0], 0.3 * np.ones(d)))
     ref = O.fit(kid, p, X, n, y, 0.05 * np.ones(N))
@@ -312,7 +391,7 @@ def test_recorded_op_list_is_static_and_encodes_what_the_interpreter_runs():
                 plan._schedule(None, None, 0.0, 0.0)
             finally:
                 plan.ops, plan._rec = real, None
-            lists.append(rec.ops)
+            lists.append(D.CompiledPlan(rec).ops)     # (the plan drops the records of events nobody waits for)
             assert [(o[0], o[1], o[2]) for o in lists[0]] == [(o[0], o[1], o[2]) for o in lists[1]]
             recorded = set()
             f64 = lambda bits: struct.unpack("<d", struct.pack("<q", bits))[0]

@@ -1208,6 +1208,76 @@ def test_compiled_schedule_native_replay_matches_the_step_loop(ctx, oracle):
         plan.fit(0, p, y, 0.0, diag_factor=0.0)
 
 
+def test_compiled_grid_schedule_native_replay_matches_the_step_loop(oracle):
+    """The 2-D engine's compiled schedule: GridLML's step loop recorded once and replayed by gpt_plan_run, by the Python interpreter
+    of the list and issued by the step loop itself -- same bits, equal to the oracle, at 1 x 1 (look-ahead on / off).  And for a
+    rank PLACED in a 2 x 4 / 4 x 2 / 2 x 3 grid (its schedule of a multi-rank job on the one GPU there is: the five channels'
+    broadcasts are in the list, nothing is sent, the receive buffers hold a constant): the rank's matrix after the evaluation is
+    bit-identical across the three drivers -- every grid-only op (K rectangle, row_sumsq, the grid staircase update with its
+    offsets) is encoded as the step loop issues it."""
+    import torch
+    from gptools_amd.dist import GridLML, HipPanelOps
+    X, n, y = c3_inputs(2300, 3)
+    p = np.array([1.0, 0.3, 0.3, 0.3])
+    err = 0.05 * np.ones(2300)
+    ref = oracle.fit("m52", p, X, n, y, err, chol="scipy")
+    ref2 = oracle.fit("m52", 1.1 * p, X, n, y, err, chol="scipy")
+    ops = HipPanelOps(0)
+    for nb, kw in ((256, {}), (128, {"lookahead": False})):
+        got = {}
+        for mode in ("native", "python", False):
+            plan = GridLML(X, n, (1, 1), nb=nb, ops=ops, compiled=mode, **kw)
+            assert plan.compiled == mode
+            got[mode] = (plan.fit(1, p, y, err), plan.fit(1, 1.1 * p, y, err), plan.fit(1, p, y, err))
+            if mode:
+                assert len(plan._plans) == 1 and plan.timings["plan_ops"] > 20
+            del plan
+            gc.collect()
+        assert got["native"] == got["python"] == got[False], (nb, kw, got)
+        a, b, c_ = got["native"]
+        assert a == c_
+        assert abs(a[0] - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"]) and abs(a[1] - ref["logdet_half"]) <= 1e-10 * abs(ref["logdet_half"])
+        assert abs(b[0] - ref2["ll_data"]) <= 1e-9 * abs(ref2["ll_data"])
+    assert GridLML(X, n, (1, 1), nb=256, ops=ops).compiled == "native"          # the default on one rank
+
+    class Placed(GridLML):
+        def _on(self, size):
+            return size > 1
+
+        def _xbcast(self, kind, k, buf, src, group, size):
+            return GridLML._xbcast(self, kind, k, buf, src, group, size) if self._rec is not None else []
+
+        def _plan_collective(self, opcode, buf, what):
+            return []
+
+        def _allreduce(self, t, op):
+            pass
+
+    for grid, rank in (((2, 4), 5), ((4, 2), 2), ((2, 3), 4)):
+        bits = {}
+        for mode in ("native", "python", False):
+            plan = Placed(X, n, grid, nb=128, ops=ops, layout=rank, compiled=mode)
+            for t in plan.R + plan.C + plan.H + plan.W + [q_ for ps in plan.piece for q_ in ps]:
+                t.fill_(1e-3)
+            plan.A.zero_()
+            for rep in range(2):
+                try:
+                    plan.fit(1, p, y, err)
+                except np.linalg.LinAlgError:
+                    pass
+                torch.cuda.synchronize()
+                bits[mode, rep] = (plan.A.view(torch.int64).clone(), plan.red.view(torch.int64).clone())
+            if mode:
+                (cp,) = plan._plans.values()
+                assert sum(1 for o in cp.ops if o[0] == 10) > 10        # the broadcasts are part of the list
+            del plan
+            gc.collect()
+        for rep in range(2):
+            for mode in ("python", False):
+                assert torch.equal(bits["native", rep][0], bits[mode, rep][0]), (grid, rank, mode, rep)
+                assert torch.equal(bits["native", rep][1], bits[mode, rep][1]), (grid, rank, mode, rep)
+
+
 def test_replicated_random_starts_two_ranks_one_gpu():
     """SURVEY 8f-2 / the reference's pool over random starts (gaussian_process.py:723-735): two gloo ranks, both on
     cuda:0, split four starts of optimize_hyperparameters; both return the same optimum, equal to the one a single
