@@ -139,6 +139,14 @@ struct gpt_ctx {
                                        // main stream under the last panel (enqueue_early_block_inverses); e_binv_early follows them there
     hipEvent_t e_binv_early = nullptr;
     bool want_early_binv = false;      // set by factor_and_ll around potrf_run for an eager evaluation
+    // Eager alpha with N a multiple of 512: the factor's last 128 columns hold only the augmented row and the padding.  alpha needs
+    // nothing of that leaf, so its pivot block (and the rank-128 updates that reach it) leave the panel stream: the substitution
+    // follows the last REAL leaf at once, the pad leaf and the reduction run beside it on the main stream (potrf_enqueue).
+    int64_t defer_pad = 1;             // option "defer_pad": 0 keeps the pad leaf on the panel stream (A/B)
+    bool defer_pad_leaf = false;       // in: set by factor_and_ll around potrf_run
+    bool pad_leaf_deferred = false;    // out: the pad leaf went to the main stream (the reduction must follow it there)
+    int pad_upd_n = 0;                 // leaves whose update of the pad block was held back, by first column
+    int64_t pad_upd_lc[8] = {0};
     // (all three are always built for the whole padded order, floor(NP / width) blocks, whatever extent the caller needs:
     // gpt_ll_grad and the solves ask for different extents at N = 512 k - 128, and a valid flag says nothing about how far)
     unsigned alpha_counter = 0;        // value of the step counter of the wide back-substitution (d_edge[40], only ever raised)

@@ -110,6 +110,9 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
  *   "eager_alpha"  1: every gpt_fit* also enqueues alpha = K_tot^-1 y behind its factorisation (the reference computes alpha in every
  *                  evaluation, gaussian_process.py:1462) and lands it in pinned memory under the call's own synchronisation;
  *                  gpt_get_alpha is then a host copy.  0 (default): alpha on first use (gpt_get_alpha, gpt_predict, gpt_ll_grad)
+ *   "defer_pad"    1 (default): an eager evaluation whose N is a multiple of 512 (>= 1024) factors the last 128 columns of the padded
+ *                  matrix -- the augmented row and the padding only -- on the main stream beside the substitution of alpha, which
+ *                  follows the last real leaf at once (same bits); 0: everything on the panel stream, alpha behind it
  *   "binv_launches" 1 (measurement aid): the 512-wide block inverses by rounds 2-4's recursion over 15 launches instead of the one
  *                  launch of trinv512_kernel (solve.hip); results agree to rounding
  *   "splitk"       gpt_predict with std / cov at few points: the GEMMs of a triangular solve with at most 128 right-hand sides

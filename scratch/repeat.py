@@ -8,7 +8,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 ctx = _lib.Context(0)
 rs = np.random.RandomState(5)
 bad = 0
-for (kid, N, d) in ((0, 700, 2), (1, 2047, 3), (0, 3000, 2), (1, 5000, 3), (1, 8192, 3)):
+for (kid, N, d) in ((0, 700, 2), (1, 2047, 3), (0, 3000, 2), (1, 4096, 3), (1, 5000, 3), (1, 8192, 3)):
     X = rs.rand(N, d); n = np.zeros((N, d), int)
     if kid == 1:
         n[3 * N // 4:, 0] = 1
@@ -21,9 +21,12 @@ for (kid, N, d) in ((0, 700, 2), (1, 2047, 3), (0, 3000, 2), (1, 5000, 3), (1, 8
         first = ctx.fit(kid, p, 0.0, y, err, 2.2e-14)
         L0 = np.tril(ctx.get_L(N)) if N <= 3000 else None
         diff = 0
+        a0 = ctx.get_alpha(N) if opts.get("eager_alpha") else None
         for it in range(r):
             got = ctx.fit(kid, p, 0.0, y, err, 2.2e-14)
             diff += got != first
+            if a0 is not None:          # (the eager alpha: with N a multiple of 512 its substitution runs beside the pad leaf)
+                diff += not np.array_equal(ctx.get_alpha(N), a0)
         if L0 is not None:
             diff += not np.array_equal(np.tril(ctx.get_L(N)), L0)
         print("N %5d kid %d %-22s %4d evaluations: %s" % (N, kid, opts or "(default)", r, "all identical" if diff == 0 else "%d DIFFER" % diff), flush=True)

@@ -2057,6 +2057,58 @@ def test_eager_alpha_and_the_one_launch_block_inverses(oracle, N):
         c.close()
 
 
+@pytest.mark.parametrize("N", [1024, 2048, 2560, 1920])
+def test_eager_alpha_pad_leaf_beside_the_substitution(oracle, N):
+    """Option defer_pad (default on; eager evaluations with N a multiple of 512): the last 128 columns of the padded factor -- the
+    augmented row and the padding -- are factored on the main stream beside alpha's substitution, which starts behind the last REAL
+    leaf.  Same bits as with everything on the panel stream: ll, alpha, L, a predict -- and, with the squared-exponential kernel, the
+    analytic gradient (gpt_ll_grad inverts the WHOLE padded factor, pad block included); a failed pivot and non-finite data are still
+    reported; N = 1920 (not a multiple of 512) takes the old route either way."""
+    from gptools_amd import _lib
+    d = 2
+    X, n, y = c3_inputs(N, d)
+    p = np.array([1.0, 0.3, 0.3])
+    err = 0.05 * np.ones(N)
+    ref = oracle.fit("m52", p, X, n, y, err, chol="scipy")
+    rs = np.random.RandomState(N)
+    Xs, ns = rs.rand(50, d), np.zeros((50, d), dtype=np.int32)
+    c = _lib.Context(0)
+    try:
+        c.set_data(X, n)
+        c.set_option("eager_alpha", 1)
+        out = {}
+        for mode in (0, 1, 0, 1):
+            c.set_option("defer_pad", mode)
+            ll = c.fit(KID["m52"], p, 0.0, y, err, 1e2 * EPS)
+            got = (ll, c.get_alpha(N), c.get_L(N), c.predict(Xs, ns, 1)[1])
+            if mode in out:
+                for u, v in zip(out[mode], got):
+                    assert np.array_equal(np.asarray(u), np.asarray(v))
+            out[mode] = got
+            with pytest.raises(np.linalg.LinAlgError):
+                c.fit(KID["m52"], p, 0.0, y, 0.0 * err, -2.0)          # K - 2 I: not positive definite
+            ybad = y.copy()
+            ybad[N // 2] = np.inf
+            with pytest.raises(np.linalg.LinAlgError):
+                c.fit(KID["m52"], p, 0.0, ybad, err, 1e2 * EPS)        # non-finite data: the augmented row's pivot fails
+            with pytest.raises(np.linalg.LinAlgError):
+                c.fit(KID["m52"], p, 0.0, 1e160 * y, err, 1e2 * EPS)   # z.z overflows the pad pivot
+        for u, v in zip(out[0], out[1]):
+            assert np.array_equal(np.asarray(u), np.asarray(v))
+        assert abs(out[1][0][0] - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"])
+        np.testing.assert_allclose(out[1][1], ref["alpha"], rtol=0, atol=2e-7 * np.abs(ref["alpha"]).max())
+        n0 = np.zeros_like(n)
+        c.set_data(X, n0)
+        grads = []
+        for mode in (0, 1):
+            c.set_option("defer_pad", mode)
+            ll = c.fit(KID["se"], p, 0.0, y, err, 1e2 * EPS)
+            grads.append((ll, c.ll_grad([0, 0, 0], [0, 1, 2])))
+        assert grads[0][0] == grads[1][0] and np.array_equal(grads[0][1], grads[1][1])
+    finally:
+        c.close()
+
+
 def test_block_inverse_extents_fit_predict_then_gradient(g):
     """at N = 512 k - 128 the solves (predict with std) and gpt_ll_grad ask for block inverses over different
     extents; fit -> predict(std) -> ll_grad must give the gradient ll_grad gives straight after the fit."""
