@@ -1,5 +1,5 @@
 """option defer_pad (the pad leaf beside the substitution of an eager alpha) on / off, same process: time, bits of ll / alpha / L"""
-import sys, time, numpy as np
+import os, sys, time, numpy as np
 sys.path.insert(0, "/root/repo")
 from gptools_amd import _lib
 import bench
@@ -8,8 +8,9 @@ for wl in sys.argv[1:] or ["c3", "c2"]:
     X, n, y, err, params = bench.synth(kernel, N, d, deriv)
     ctx = _lib.Context(0); ctx.set_data(X, n)
     ctx.set_option("eager_alpha", 1)
+    OPT = os.environ.get("AB_OPT", "defer_pad")
     def run(defer, reps=40):
-        ctx.set_option("defer_pad", defer)
+        ctx.set_option(OPT, defer)
         for _ in range(5): ctx.fit(bench.KID[kernel], params, 0.0, y, err, 2.2e-14); ctx.get_alpha(N)
         ts = []
         for r in range(8):
@@ -21,6 +22,6 @@ for wl in sys.argv[1:] or ["c3", "c2"]:
         return np.median(ts) * 1e3, min(ts) * 1e3, res, a, ctx.get_L(N)
     for rep in range(3):
         m0, b0, r0, a0, L0 = run(0); m1, b1, r1, a1, L1 = run(1)
-        print("%s defer_pad 0: %.4f (min %.4f)  1: %.4f (min %.4f) ms  gain %.1f us  ll equal %s alpha equal %s L equal %s"
-              % (wl, m0, b0, m1, b1, (m0 - m1) * 1e3, r0 == r1, np.array_equal(a0, a1), np.array_equal(L0, L1)), flush=True)
+        print(("%s " + OPT + " 0: %.4f (min %.4f)  1: %.4f (min %.4f) ms  gain %.1f us  ll equal %s alpha equal %s (max diff %.1e) L equal %s")
+              % (wl, m0, b0, m1, b1, (m0 - m1) * 1e3, r0 == r1, np.array_equal(a0, a1), np.abs(a0 - a1).max(), np.array_equal(L0, L1)), flush=True)
     del ctx
