@@ -9,6 +9,7 @@ for wl in sys.argv[1:] or ["c3", "c2"]:
     ctx = _lib.Context(0); ctx.set_data(X, n)
     ctx.set_option("eager_alpha", 1)
     OPT = os.environ.get("AB_OPT", "defer_pad")
+    V0, V1 = (int(v) for v in os.environ.get("AB_VALS", "0,1").split(","))
     def run(defer, reps=40):
         ctx.set_option(OPT, defer)
         for _ in range(5): ctx.fit(bench.KID[kernel], params, 0.0, y, err, 2.2e-14); ctx.get_alpha(N)
@@ -21,7 +22,7 @@ for wl in sys.argv[1:] or ["c3", "c2"]:
             ts.append((time.perf_counter() - t0) / reps)
         return np.median(ts) * 1e3, min(ts) * 1e3, res, a, ctx.get_L(N)
     for rep in range(3):
-        m0, b0, r0, a0, L0 = run(0); m1, b1, r1, a1, L1 = run(1)
-        print(("%s " + OPT + " 0: %.4f (min %.4f)  1: %.4f (min %.4f) ms  gain %.1f us  ll equal %s alpha equal %s (max diff %.1e) L equal %s")
+        m0, b0, r0, a0, L0 = run(V0); m1, b1, r1, a1, L1 = run(V1)
+        print(("%s " + OPT + " " + str(V0) + ": %.4f (min %.4f)  " + str(V1) + ": %.4f (min %.4f) ms  gain %.1f us  ll equal %s alpha equal %s (max diff %.1e) L equal %s")
               % (wl, m0, b0, m1, b1, (m0 - m1) * 1e3, r0 == r1, np.array_equal(a0, a1), np.abs(a0 - a1).max(), np.array_equal(L0, L1)), flush=True)
     del ctx
