@@ -41,6 +41,6 @@ timeout 200 python scratch/predict_bench.py c3 64 256 1024 > $O/predict.txt 2>&1
 timeout 300 python scratch/c5_map_grad.py 16384 > $O/c5_map_gradient.txt 2>&1
 timeout 600 python scratch/fuzz_fit.py 240 > $O/fuzz.txt 2>&1
 timeout 300 python scratch/repeat.py 100 > $O/repeat.txt 2>&1
-(timeout 400 python scratch/pad_ab.py c3 c2; AB_OPT=eager_alpha timeout 300 python scratch/pad_ab.py c3) 2>&1 | grep -v amdgpu.ids > $O/pad_ab.txt
+timeout 400 python scratch/pad_ab.py c3 c2 2>&1 | grep -v amdgpu.ids > $O/pad_ab.txt
 bash scratch/trace_fit.sh c3 6 eager_alpha=1 > /dev/null 2>&1; cp gpurun_out/tl/timeline.txt $O/timeline_c3_eager.txt
 tail -3 $O/pytest_gpu.txt
