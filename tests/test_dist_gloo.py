@@ -99,6 +99,58 @@ def _inputs(N, d, seed=4):
     return X, n, y
 
 
+def test_recorder_prunes_only_the_waits_its_vector_clocks_imply():
+    """PlanRecorder's wait pruning (host side): a wait is dropped when the event was recorded on the waiting queue itself, when the
+    queue has waited for it before, or when it is ordered behind the event through another event it waited for since; NOT when
+    only the order of a communication channel would imply it (two exchanges on one channel may complete out of order under gloo:
+    an "arrived" is a clock component of its own); a wait before the record is an error."""
+    import torch
+    from gptools_amd import dist as D
+    rec = D.PlanRecorder(torch.device("cpu"))
+    waits = lambda: [(o[1], o[2][0]) for o in rec.ops if o[0] == D.OP_WAIT and D.QUEUE_ID[o[1]] < 3]
+    e1, e2, e3 = rec.new_event(), rec.new_event(), rec.new_event()
+    with rec.queue("main"):
+        e1.record()
+        e1.wait()                                    # own queue: nothing
+    assert waits() == []
+    with rec.queue("panel"):
+        e1.wait()
+        e1.wait()                                    # again: nothing
+        e2.record()
+    assert waits() == [("panel", e1.idx)]
+    with rec.queue("recv"):
+        e2.wait()
+        e1.wait()                                    # behind e2, which is behind e1: nothing
+    assert waits() == [("panel", e1.idx), ("recv", e2.idx)]
+    with rec.queue("main"):
+        e3.record()
+    with rec.queue("recv"):
+        e3.wait()                                    # a later record of the main queue: needed
+    assert waits()[-1] == ("recv", e3.idx) and rec.pruned == 3
+    # two exchanges on one channel: waiting for the second does not stand for the first
+    buf = torch.zeros(4, dtype=torch.float64)
+    with rec.queue("panel"):
+        (x1,) = rec.bcast(buf, 0, "comm1", ("R", (0, 0)))
+        (x2,) = rec.bcast(buf, 0, "comm1", ("R", (0, 0)))
+    with rec.queue("main"):
+        x2.wait()
+        n0 = len(waits())
+        x1.wait()
+        assert len(waits()) == n0 + 1
+        x1.wait()                                    # ... but a second wait for the same arrival does
+        assert len(waits()) == n0 + 1
+    with rec.queue("recv"):
+        fresh = rec.new_event()
+        with pytest.raises(RuntimeError):
+            fresh.wait()
+    # the plan drops the records nobody waits for (e1 .. e3 are all waited for; "fresh" never was recorded)
+    e4 = rec.new_event()
+    with rec.queue("main"):
+        e4.record()
+    cp = D.CompiledPlan(rec)
+    assert [o[2][0] for o in cp.ops if o[0] == D.OP_RECORD and o[1] == "main"] == [e1.idx, e3.idx]
+
+
 def test_grid_recorded_op_list_is_static_and_replays_bit_identically():
     """The 2-D engine's compiled schedule, host side (one rank, numpy ops, no process group): two recordings give the same list,
     every wait follows its record, every record fits GPT_PLAN_W, the records of the grid-only ops (K rectangle, row_sumsq,
