@@ -2097,6 +2097,15 @@ def test_eager_alpha_pad_leaf_beside_the_substitution(oracle, N):
             assert np.array_equal(np.asarray(u), np.asarray(v))
         assert abs(out[1][0][0] - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"])
         np.testing.assert_allclose(out[1][1], ref["alpha"], rtol=0, atol=2e-7 * np.abs(ref["alpha"]).max())
+        # the event schedule (flag edges off): the pad leaf moves there too, same bits with and without
+        c.set_option("edge_flags", 0)
+        ev = []
+        for mode in (0, 1):
+            c.set_option("defer_pad", mode)
+            ev.append((c.fit(KID["m52"], p, 0.0, y, err, 1e2 * EPS), c.get_alpha(N), c.get_L(N)))
+        assert ev[0][0] == ev[1][0] and np.array_equal(ev[0][1], ev[1][1]) and np.array_equal(ev[0][2], ev[1][2])
+        assert abs(ev[1][0][0] - ref["ll_data"]) <= 1e-9 * abs(ref["ll_data"])
+        c.set_option("edge_flags", 1)
         n0 = np.zeros_like(n)
         c.set_data(X, n0)
         grads = []
