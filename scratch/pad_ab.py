@@ -10,7 +10,7 @@ for wl in sys.argv[1:] or ["c3", "c2"]:
     ctx.set_option("eager_alpha", 1)
     OPT = os.environ.get("AB_OPT", "defer_pad")
     V0, V1 = (int(v) for v in os.environ.get("AB_VALS", "0,1").split(","))
-    def run(defer, reps=40):
+    def run(defer, reps=(40 if N <= 8192 else 6 if N <= 16384 else 2)):
         ctx.set_option(OPT, defer)
         for _ in range(5): ctx.fit(bench.KID[kernel], params, 0.0, y, err, 2.2e-14); ctx.get_alpha(N)
         ts = []
