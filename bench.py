@@ -367,6 +367,8 @@ def main():
     ap.add_argument("--no-ref", action="store_true", help="N>1: skip the single-GPU run of the same workload on rank 0")
     ap.add_argument("--schedule", default=None, help="N>1: fix the layout (1d+bcast, 1d+scatter_gather, grid2x4, ...) instead of tuning")
     ap.add_argument("--no-probe", action="store_true", help="N>1: skip the step trace and the link probes after the timed region")
+    ap.add_argument("--ctx-opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="N=1: a gpt_ctx_set_option pair for the timed context (scratch/prof_r06.sh traces with tail_wait=0)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1:
@@ -436,6 +438,10 @@ def main():
         ctx2 = None if args.no_batched else _lib.Context(local_rank)
         if args.nb:
             ctx.set_option("nb_outer", args.nb)
+        for kv_ in args.ctx_opt:
+            ctx.set_option(kv_.split("=")[0], int(kv_.split("=")[1]))
+        if args.ctx_opt:
+            extra["ctx_opt"] = list(args.ctx_opt)
         ctx.set_option("timing", 1)
         ctx.set_data(X, n)
 
@@ -573,7 +579,11 @@ def main():
                     "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                     "frac_events": ach / FP64_MFMA_PEAK_TFLOPS,
                     "launch_population": "the >= 1 GFLOP launches of the timed steps' own schedule (flag edges: urgent + rest merged, one "
-                                         "launch per panel), HIP events on the dispatch packets of the main stream",
+                                         "launch per panel), HIP events on the dispatch packets of the main stream; in the instrumented "
+                                         "steps (one per two rounds) the main stream's wait for the next panel is a kernel of its own -- "
+                                         "the other steps let the update's last workgroup wait (option tail_wait), which a timed launch "
+                                         "would report as its own duration (the library drops it while profile_gemm is on; the committed "
+                                         "kernel trace is taken with --ctx-opt tail_wait=0 for the same reason)",
                     "launches_per_step": gcount / max(n_instr, 1), "sampled_steps": n_instr,
                     "avg_launch_us": gms * 1e3 / gcount, "flops_per_launch": gflops_alg / gcount,
                     "algorithmic_bytes": gbytes / gcount, "traffic_unit": "bytes/launch"}

@@ -67,9 +67,10 @@ struct gpt_ctx {
     unsigned edge_seq = 0;                 // value of the last edge raised (monotonic over the context's life)
     int64_t merge_min_tiles = 512;         // ... while the merged launch has at least this many 64x64 tiles (>= 512: it needs an order table)
     int64_t purg_rows_flags = 0;           // purg_rows while flag edges + merged launches are in use
-    int64_t tail_wait = 1;                 // 1: the main stream's last launch of a panel awaits the NEXT panel's flag at its end (gemm.hip "tail wait"):
-                                           //    no 5-us wait kernel between two trailing updates.  Round 4 measured it the same (4.459 / 4.471 ms at N = 8192);
-                                           //    at round 6's schedule: C3 -2 ... -47 us in six same-process A/Bs (mean 19), C2 -11 ... -18 us -- on.
+    int64_t tail_wait = 1;                 // 1: the main stream's last launch of a panel awaits the NEXT panel's flag at its end (gemm.hip "tail wait"): no
+                                           //    wait kernel between two trailing updates.  Round 4 measured it the same as 0 (4.459 / 4.471 ms at N = 8192); at
+                                           //    round 6's schedule: C3 -2 ... -47 us in six same-process A/Bs (mean 19), C2 -11 ... -18 us -- on.  The gain sits in
+                                           //    the launches that DO wait (1-6 GFLOP: only-large or only-small launches gain nothing); not while launches are timed.
     int64_t merge_urgent = 1;              // 1: with flag edges, urgent + rest of a panel are ONE launch (urgent tiles first, partial flag)
     int64_t edge_flags = 1;                // 1: those two edges of the look-ahead may be flag words instead of events (see EvalScope)
     bool flags_now = false;                // ... and ARE, in the evaluation in progress (set by EvalScope)

@@ -106,7 +106,8 @@ int gpt_ctx_destroy(gpt_ctx *ctx);
  *   "merge_min_tiles" smallest merged trailing update, in 64x64 tiles (512: the launch needs an order table)
  *   "purg_rows_flags" "purg_rows" while flag edges and merged launches are in use (0: never -- measured)
  *   "tail_wait"    1 (default since round 6): the main stream's last launch of a panel awaits the NEXT panel's flag at its end instead of
- *                  a wait kernel in front of the next launch (C3 -19 us, C2 -15 us); 0: the wait kernel
+ *                  a wait kernel in front of the next launch (C3 -19 us, C2 -15 us); not while "profile_gemm" times the launches (a
+ *                  launch that waits at its end reports the wait as its duration); 0: always the wait kernel
  *   "alpha_invalidate" (measurement aid) the next gpt_get_alpha recomputes alpha
  *   "eager_alpha"  1: every gpt_fit* also enqueues alpha = K_tot^-1 y behind its factorisation (the reference computes alpha in every
  *                  evaluation, gaussian_process.py:1462) and lands it in pinned memory under the call's own synchronisation;

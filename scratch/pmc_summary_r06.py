@@ -41,7 +41,12 @@ bigd = [int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in kt
 avg_us = sum(bigd) / len(bigd) * 1e-3
 tr = {"round": rnd, "kernel": "gemm_nt_kernel<64,64>",
       "launch_filter": "main-stream queue, Grid_Size_X >= %d threads (the >= 1 GFLOP trailing updates of the flag schedule)" % MIN_GRID,
-      "dispatches": len(bigd), "avg_launch_us": avg_us, "trace_file": "profiles/r%02d_bench_c3_N8192_rocprof_summary.txt" % rnd}
+      "dispatches": len(bigd), "avg_launch_us": avg_us, "trace_file": "profiles/r%02d_bench_c3_N8192_rocprof_summary.txt" % rnd,
+      "traced_command": "python3 bench.py --steps 5 --warmup 2 --no-cpu --no-batched --no-predict --no-gp-api --ctx-opt tail_wait=0 "
+                        "(scratch/prof_r06.sh): the timed schedule with the main stream's wait for the next panel in a kernel of its own -- by default "
+                        "the update's last workgroup waits (tail_wait), and a trace would count that wait, 20-50 us in the launches of the transition "
+                        "to the chain-bound end, as the GEMM's duration; bench.py's own instrumented steps do the same (the library drops the tail "
+                        "wait while profile_gemm times the launches)"}
 if bl and bl.get("roofline"):
     tr["flops_per_launch"] = bl["roofline"]["flops_per_launch"]
     tr["events_avg_launch_us_same_run"] = bl["roofline"]["avg_launch_us"]

@@ -5,7 +5,10 @@ TAG=${ROUND_TAG:-r06/prof}
 mkdir -p "$R/gpurun_out/$TAG"
 OUT="$R/gpurun_out/$TAG"
 cd /tmp && export TMPDIR=/tmp
-B="--steps 5 --warmup 2 --no-cpu --no-batched --no-predict --no-gp-api"
+# tail_wait=0: a kernel trace cannot tell a launch's wait from its work -- with the default (the update's last workgroup awaits the next
+# panel's flag) the launches of the transition report 20-50 us of waiting as their own duration; the traced run keeps the wait in a kernel
+# of its own, which is also what the bench's own instrumented steps do (the library drops the tail wait while profile_gemm times launches)
+B="--steps 5 --warmup 2 --no-cpu --no-batched --no-predict --no-gp-api --ctx-opt tail_wait=0"
 # (1) kernel trace + stats of the bench command itself: flag schedule, merged launches -- the timed population
 GPT_BENCH_MIN_TIMED_S=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 $R/bench.py $B > "$OUT/trace.log" 2>&1
 # (2) the shapes of that population (unprofiled evaluation, flag schedule)
