@@ -456,7 +456,8 @@ int gpt_dev_panel_scalars(gpt_ctx *ctx, const double *dP, int64_t ldp, int64_t w
  * is collective over the channel's ranks (ncclCommInitRank; the 128-byte id comes from gpt_plan_unique_id on the channel's rank 0
  * and travels by whatever means the caller has; every rank sets its channels in the same order); root / rank are positions in
  * that communicator.  gpt_plan_set_comm = channel 0.  The ops of a channel without a communicator are skipped (single rank).
- * The caller keeps the buffers alive and synchronises the contexts' streams itself. */
+ * The caller keeps the buffers alive and synchronises the contexts' streams itself.  (Environment GPT_PLAN_PROFILE=1: gpt_plan_run prints
+ * its host time per opcode to stderr.) */
 #define GPT_PLAN_W 20
 #define GPT_PLAN_CHANNELS 8
 typedef struct gpt_plan gpt_plan;
