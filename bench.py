@@ -881,9 +881,13 @@ def main():
         grids_ = {1: [(1, 1)], 2: [(2, 1), (1, 2)], 4: [(2, 2), (4, 1)], 8: [(2, 4), (4, 2)]}.get(world, [])
         # (the native replay with its own RCCL communicator has run at world size 1 only: on more ranks it is a LEG -- under the
         # watchdog like everything after the first timed region -- and becomes the line only if it completes and is faster)
-        combos = ["1d+scatter_gather@%d" % nb0] + (["1d+bcast+native@%d" % nb0, "1d+scatter_gather+native@%d" % nb0] if (world > 1 and os.environ.get("GPT_BENCH_BACKEND", "nccl") == "nccl") else []) \
+        # They are OPT-IN (GPT_BENCH_NATIVE_LEGS=1, or --schedule 1d+bcast+native): a hang of an untried path the watchdog can end, a
+        # crash it cannot -- and at 8 ranks an evaluation is GPU-bound (45 ms against 2-6 ms of host enqueue either way), so the native
+        # replay has nothing to add to THIS number on a first run on hardware.
+        native_legs = (world > 1 and os.environ.get("GPT_BENCH_BACKEND", "nccl") == "nccl" and bool(os.environ.get("GPT_BENCH_NATIVE_LEGS")))
+        combos = ["1d+scatter_gather@%d" % nb0] + (["1d+bcast+native@%d" % nb0, "1d+scatter_gather+native@%d" % nb0] if native_legs else []) \
             + ["grid%dx%d@%d" % (g_[0], g_[1], nb0) for g_ in grids_] \
-            + (["grid%dx%d+native@%d" % (g_[0], g_[1], nb0) for g_ in grids_[:1]] if (world > 1 and os.environ.get("GPT_BENCH_BACKEND", "nccl") == "nccl") else [])
+            + (["grid%dx%d+native@%d" % (g_[0], g_[1], nb0) for g_ in grids_[:1]] if native_legs else [])
         if not args.nb:
             combos += ["1d+bcast@384", "1d+bcast@256"] + ["grid%dx%d@256" % g_ for g_ in grids_[:1]]
         if args.schedule:
