@@ -861,12 +861,34 @@ def test_single_gpu_schedule_under_stream_jitter(ctx):
         "    c.set_data(X, n)\n"
         "    for rep in range(reps):\n"
         "        ll, ld = c.fit(1, np.concatenate(([1.0], 0.3 * np.ones(d))), 0.0, y, 0.05 * np.ones(N), 1e2 * sys.float_info.epsilon)\n"
-        "        print('RESULT', N, repr(ll), repr(ld))\n") % (ROOT, os.path.join(ROOT, "tests"))
+        "        print('RESULT', N, repr(ll), repr(ld))\n"
+        # an eager evaluation whose N is a multiple of 512: the pad leaf and the reduction on the main stream, alpha's substitution
+        # behind the last real leaf on the panel stream (option defer_pad), the early block inverses in between
+        "import hashlib\n"
+        "c.set_option('eager_alpha', 1)\n"
+        "X, n, y = c3_inputs(4096, 2)\n"
+        "c.set_data(X, n)\n"
+        "for rep in range(5):\n"
+        "    ll, ld = c.fit(1, np.array([1.0, 0.3, 0.3]), 0.0, y, 0.05 * np.ones(4096), 1e2 * sys.float_info.epsilon)\n"
+        "    print('EAGER', repr(ll), repr(ld), hashlib.sha1(c.get_alpha(4096).tobytes()).hexdigest())\n") % (ROOT, os.path.join(ROOT, "tests"))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GPT_JITTER="120"), stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     got = [l.split()[1:] for l in out.stdout.splitlines() if l.startswith("RESULT")]
     assert len(got) == 8
+    import hashlib
+    eager = [l.split()[1:] for l in out.stdout.splitlines() if l.startswith("EAGER")]
+    assert len(eager) == 5
+    X, n, y = c3_inputs(4096, 2)
+    ctx.set_data(X, n)
+    ctx.set_option("eager_alpha", 1)
+    try:
+        ll, ld = ctx.fit(1, np.array([1.0, 0.3, 0.3]), 0.0, y, 0.05 * np.ones(4096), 1e2 * EPS)
+        digest = hashlib.sha1(ctx.get_alpha(4096).tobytes()).hexdigest()
+    finally:
+        ctx.set_option("eager_alpha", 0)
+    for e_ in eager:
+        assert float(e_[0]) == ll and float(e_[1]) == ld and e_[2] == digest, (e_, ll, ld, digest)
     for N, d in ((3000, 3), (12800, 2)):
         X, n, y = c3_inputs(N, d)
         ctx.set_data(X, n)
