@@ -1078,7 +1078,11 @@ class GridLML(object):
     the bulk transfers.)
     ``z = L^-1 y`` rides along as the augmented row N and is summed where its pieces come to rest; one
     all-reduce of (sum log L_ii, z.z, info) ends the evaluation.  ``fit`` returns the same ``(ll_data, logdet_half)`` on every
-    rank.  ``grid = (1, W)`` is the 1-D block-column layout, ``(W, 1)`` a block-row layout.  UNMEASURED ON MORE THAN ONE GPU:
+    rank.  ``grid = (1, W)`` is the 1-D block-column layout, ``(W, 1)`` a block-row layout.  ``compiled`` as for
+    :class:`DistributedLML`: the step loop below is recorded once per (look-ahead) as an op list and replayed by ``gpt_plan_run``
+    ("native": five RCCL channels per rank -- bulk rows / early block on the process row, inverse / column exchange on the process
+    column, head blocks on the whole grid) or by the Python interpreter of the list ("python"); False: the loop issues every
+    operation itself.  UNMEASURED ON MORE THAN ONE GPU:
     gloo worlds 2-8 on CPU (tests/test_dist_gloo.py), ranks sharing one GPU through the product ops, and the modelled 8-rank
     time of scratch/sim_model.py are what exists.
     """
